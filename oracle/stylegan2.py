@@ -1,0 +1,181 @@
+"""Oracle restatement of the in-tree StyleGAN2 networks (test infrastructure only).
+
+Follows maua/GAN/wrappers/inference/stylegan2.py.  Networks are plain
+functions over a ``dict[str, Tensor]`` whose keys equal the reference modules'
+``state_dict()`` keys (``bs.3.conv0.affine.weight`` ...), so a state dict
+exported from the reference can be fed in directly (that is how the layer-level
+goldens are checked).
+
+``nv_compat=False`` (default) reproduces the in-tree behaviour, quirks included
+(SURVEY.md Q2-Q4): no kernel flip on up-layers, ``x @ w`` in the non-linear FC
+branch, unscaled noise.
+"""
+from math import sqrt
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- structure
+def block_resolutions(img_resolution):
+    """stylegan2.py:399-402"""
+    return [2 ** i for i in range(2, int(np.log2(img_resolution)) + 1)]
+
+
+def channels_dict(img_resolution, channel_base=32768, channel_max=512):
+    """stylegan2.py:403"""
+    return {r: min(channel_base // r, channel_max) for r in block_resolutions(img_resolution)}
+
+
+def num_ws(img_resolution):
+    """stylegan2.py:406-426: one w per conv layer plus one for the last toRGB."""
+    n = len(block_resolutions(img_resolution))
+    return 2 * n  # (2n - 1) convs + 1
+
+
+def layer_list(img_resolution, channel_base=32768, channel_max=512):
+    """The 2n-1 synthesis layers in execution order: (prefix, c_in, c_out, res, up)."""
+    ch = channels_dict(img_resolution, channel_base, channel_max)
+    out = []
+    for i, r in enumerate(block_resolutions(img_resolution)):
+        if r > 4:
+            out.append((f"bs.{i}.conv0", ch[r // 2], ch[r], r, 2))
+        out.append((f"bs.{i}.conv1", ch[r], ch[r], r, 1))
+    return out
+
+
+# ----------------------------------------------------------------------------- random init
+def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_base=32768, channel_max=512,
+                          generator=None):
+    """Draw parameters in the order the reference constructors draw them
+    (stylegan2.py:296-337 block, :221-227 layer, :263-265 toRGB, :43-44 FC), so that
+    ``torch.manual_seed(s); SynthesisNetwork(...)`` and this function with
+    ``torch.Generator().manual_seed(s)`` produce the same tensors."""
+    g = generator
+    ch = channels_dict(img_resolution, channel_base, channel_max)
+    f = ops.setup_filter([1, 3, 3, 1])
+    p = {}
+
+    def fc(prefix, fin, fout, bias_init):
+        p[prefix + ".weight"] = torch.randn([fout, fin], generator=g)
+        p[prefix + ".bias"] = torch.full([fout], float(bias_init))
+
+    def layer(prefix, cin, cout, res):
+        p[prefix + ".resample_filter"] = f.clone()
+        fc(prefix + ".affine", w_dim, cin, 1.0)
+        p[prefix + ".weight"] = torch.randn([cout, cin, 3, 3], generator=g)
+        p[prefix + ".noise_const"] = torch.randn([res, res], generator=g)
+        p[prefix + ".bias"] = torch.zeros([cout])
+
+    for i, r in enumerate(block_resolutions(img_resolution)):
+        cin = ch[r // 2] if r > 4 else 0
+        cout = ch[r]
+        p[f"bs.{i}.resample_filter"] = f.clone()
+        if cin == 0:
+            p[f"bs.{i}.const"] = torch.randn([cout, r, r], generator=g)
+        else:
+            layer(f"bs.{i}.conv0", cin, cout, r)
+        layer(f"bs.{i}.conv1", cout, cout, r)
+        fc(f"bs.{i}.torgb.affine", w_dim, cout, 1.0)
+        p[f"bs.{i}.torgb.weight"] = torch.randn([img_channels, cout, 1, 1], generator=g)
+        p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+    return p
+
+
+def init_mapping_params(z_dim=512, w_dim=512, num_layers=8, lr_multiplier=0.01, generator=None):
+    """stylegan2.py:140-159 with FullyConnectedLayer :43-44 (weight = randn / lr_multiplier)."""
+    p = {}
+    feats = [z_dim] + [w_dim] * num_layers
+    for i in range(num_layers):
+        p[f"fcs.{i}.weight"] = torch.randn([feats[i + 1], feats[i]], generator=generator) / lr_multiplier
+        p[f"fcs.{i}.bias"] = torch.zeros([feats[i + 1]])
+    p["w_avg"] = torch.zeros([w_dim])
+    return p
+
+
+# ----------------------------------------------------------------------------- layers
+def fully_connected(x, weight, bias, activation="linear", lr_multiplier=1.0, nv_compat=False):
+    """stylegan2.py:48-58.  Non-linear branch uses x @ w in-tree (Q3)."""
+    w = weight * (lr_multiplier / sqrt(weight.shape[1]))
+    b = bias
+    if b is not None and lr_multiplier != 1.0:
+        b = b * lr_multiplier
+    if activation == "linear":
+        return F.linear(x, w, b)
+    y = F.linear(x, w if nv_compat else w.T, None)
+    return ops.bias_act(y, b, act=activation)
+
+
+def mapping_network(p, z, truncation_psi=1.0, num_ws_=18, lr_multiplier=0.01, nv_compat=False):
+    """stylegan2.py:161-192 (c_dim == 0, truncation_cutoff None)."""
+    x = ops.normalize_2nd_moment(z)
+    i = 0
+    while f"fcs.{i}.weight" in p:
+        x = fully_connected(x, p[f"fcs.{i}.weight"], p[f"fcs.{i}.bias"], "lrelu", lr_multiplier, nv_compat)
+        i += 1
+    x = x.unsqueeze(1).repeat(1, num_ws_, 1)
+    if truncation_psi != 1:
+        x = p["w_avg"].lerp(x, truncation_psi)
+    return x
+
+
+def synthesis_layer(p, prefix, x, w, up=1, noise=None, noise_strength=1.0, gain=1.0, conv_clamp=256.0,
+                    nv_compat=False):
+    """stylegan2.py:229-251.  ``noise`` defaults to the layer's noise_const (noise_mode='const')."""
+    styles = fully_connected(w, p[prefix + ".affine.weight"], p[prefix + ".affine.bias"])
+    if noise is None:
+        noise = p[prefix + ".noise_const"]
+    noise = noise * noise_strength
+    x = ops.modulated_conv2d(x, p[prefix + ".weight"], styles, noise=noise, up=up, padding=1,
+                             resample_filter=p[prefix + ".resample_filter"], flip_weight=nv_compat)
+    return ops.bias_act(x, p[prefix + ".bias"], act="lrelu", gain=sqrt(2) * gain,
+                        clamp=None if conv_clamp is None else conv_clamp * gain)
+
+
+def torgb_layer(p, prefix, x, w, conv_clamp=256.0):
+    """stylegan2.py:268-272"""
+    cin = p[prefix + ".weight"].shape[1]
+    styles = fully_connected(w, p[prefix + ".affine.weight"], p[prefix + ".affine.bias"]) * (1 / sqrt(cin))
+    x = ops.modulated_conv2d(x, p[prefix + ".weight"], styles, demodulate=False)
+    return ops.bias_act(x, p[prefix + ".bias"], clamp=conv_clamp)
+
+
+def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False):
+    """stylegan2.py:429-436 + SynthesisBlock.forward :340-382 ('skip' architecture).
+
+    ``noise``: optional list, one [B|1,1,h,w] tensor per synthesis layer in
+    execution order (what StyleGAN2Synthesizer.forward installs, wrappers/stylegan2.py:85-100).
+    """
+    nblocks = 0
+    while f"bs.{nblocks}.conv1.weight" in p:
+        nblocks += 1
+    x = img = None
+    w_idx = 0
+    li = 0
+    feats = []
+    for i in range(nblocks):
+        def nz():
+            return None if noise is None or li >= len(noise) else noise[li]
+        if i == 0:
+            x = p["bs.0.const"].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+        else:
+            x = synthesis_layer(p, f"bs.{i}.conv0", x, ws[:, w_idx], up=2, noise=nz(),
+                                noise_strength=noise_strength, nv_compat=nv_compat)
+            feats.append(x)
+            w_idx += 1
+            li += 1
+        x = synthesis_layer(p, f"bs.{i}.conv1", x, ws[:, w_idx], up=1, noise=nz(),
+                            noise_strength=noise_strength, nv_compat=nv_compat)
+        feats.append(x)
+        w_idx += 1
+        li += 1
+        if img is not None:
+            img = ops.upsample2d(img, p[f"bs.{i}.resample_filter"])
+        y = torgb_layer(p, f"bs.{i}.torgb", x, ws[:, w_idx])
+        img = y if img is None else img + y
+    if return_features:
+        return img, feats
+    return img

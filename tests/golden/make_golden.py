@@ -1,0 +1,390 @@
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the authoring container (needs /root/reference; the GPU box only
+consumes the committed .npz files).  This script contains no reference code: it
+imports ``maua`` from /root/reference, calls its functions on seeded inputs and
+stores inputs + outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Third-party modules the reference imports at module scope but that are absent
+here (librosa, torchaudio, torchcubicspline, ...) are replaced by MagicMock
+stubs; none of the functions captured below calls into them.  The reference's
+only native file (efficient_quantile.cpp) is compiled from where it lies into
+oracle/_ref/ (see oracle/build_ref.py) and registered under its import name.
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+from math import sqrt
+from pathlib import Path
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = "/root/reference"
+sys.path.insert(0, str(REPO))
+
+ABSENT = {"librosa", "madmom", "torchaudio", "openunmix", "torchcubicspline", "torchtyping", "torch_geometric",
+          "kornia", "cv2", "resampy", "soundfile", "ffmpeg", "decord", "npy_append_array", "fire", "numba",
+          "matplotlib", "sklearn", "joblib", "resize_right", "medpy", "torchvision", "PIL", "glumpy", "pycuda"}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in ABSENT:
+            try:  # prefer the real module when the image has it
+                for f in sys.meta_path:
+                    if f is self:
+                        continue
+                    s = f.find_spec(name, path, target) if hasattr(f, "find_spec") else None
+                    if s is not None:
+                        return s
+            except Exception:
+                pass
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__name__ = spec.name
+        m.__spec__ = spec
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def import_reference():
+    sys.meta_path.insert(0, _StubFinder())
+    sys.path.insert(0, REF)
+    from oracle.build_ref import load_reference_quantile
+    ext = load_reference_quantile()
+    sys.modules[
+        "maua.audiovisual.audioreactive.selfsupervised.features.efficient_quantile.efficient_quantile"] = ext
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = HERE / f"{name}.npz"
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  keys={list(out)}")
+
+
+T = torch.tensor
+
+
+# --------------------------------------------------------------------------------------- ops
+def golden_ops():
+    from maua.GAN.wrappers.inference import ops as R
+
+    g = torch.Generator().manual_seed(100)
+    f = R.setup_filter([1, 3, 3, 1])
+    save("g01_setup_filter", f=f)
+
+    # G2 bias_act
+    x = torch.randn(2, 8, 16, 16, generator=g) * 3
+    b = torch.randn(8, generator=g)
+    out = {"x": x, "b": b}
+    for act in ["linear", "lrelu"]:
+        for gi, gain in enumerate([1.0, sqrt(2)]):
+            for ci, clamp in enumerate([None, 2.5]):
+                y = R.bias_act(x, b, act=act, gain=T(gain), clamp=None if clamp is None else T(clamp))
+                out[f"y_{act}_g{gi}_c{ci}"] = y
+    out["y_relu_default"] = R.bias_act(x, b, act="relu")
+    out["y_sigmoid_nobias"] = R.bias_act(x, None, act="sigmoid")
+    out["y_tanh"] = R.bias_act(x, b, act="tanh")
+    out["y_swish"] = R.bias_act(x, b, act="swish")
+    out["y_lrelu_clamp256"] = R.bias_act(x * 100, b, act="lrelu", gain=T(sqrt(2)), clamp=T(256.0))
+    save("g02_bias_act", **out)
+
+    # G3 upfirdn2d
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    y_up = R.upfirdn2d(x, f, up=T(2), padding=T([2, 1, 2, 1]), gain=T(4))
+    x17 = torch.randn(2, 4, 17, 17, generator=g)
+    y_fir = R.upfirdn2d(x17, f, padding=T([1, 1, 1, 1]), gain=T(4))
+    y_down = R.upfirdn2d(x, f, down=T(2), padding=T([1, 1, 1, 1]))
+    y_crop = R.upfirdn2d(x, f, padding=T([2, -1, -1, 3]))
+    xr = torch.randn(1, 2, 5, 9, generator=g)
+    y_rect = R.upfirdn2d(xr, f, up=T(2), padding=T([2, 1, 2, 1]), gain=T(4))
+    save("g03_upfirdn2d", f=f, x=x, y_up=y_up, x17=x17, y_fir=y_fir, y_down=y_down, y_crop=y_crop, xr=xr,
+         y_rect=y_rect)
+
+    # G4 upsample2d
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    save("g04_upsample2d", f=f, x=x, y=R.upsample2d(x, f))
+
+    # G5 modulated_conv2d up=1
+    x = torch.randn(2, 8, 12, 12, generator=g)
+    w3 = torch.randn(6, 8, 3, 3, generator=g)
+    s = torch.randn(2, 8, generator=g) + 1
+    nz = torch.randn(2, 1, 12, 12, generator=g)
+    y_demod = R.modulated_conv2d(x, w3, s, noise=nz, up=T(1), padding=T(1))
+    y_demod_nonoise = R.modulated_conv2d(x, w3, s, up=T(1), padding=T(1))
+    w1 = torch.randn(3, 8, 1, 1, generator=g)
+    y_1x1 = R.modulated_conv2d(x, w1, s, demodulate=False)
+    save("g05_modconv_up1", x=x, w3=w3, s=s, noise=nz, y_demod=y_demod, y_demod_nonoise=y_demod_nonoise, w1=w1,
+         y_1x1=y_1x1)
+
+    # G6 up=2 composition (Q1): the in-tree branch ops.py:211-225 cannot execute (torch.max(t, 0) namedtuple),
+    # so compose the same calls by hand: weight regroup (:215-217), conv_transpose2d stride 2 pad 0 (:224),
+    # reference upfirdn2d with padding (1,1,1,1) and gain 4 (:225).
+    B, ci, co, h = 2, 8, 4, 8
+    x = torch.randn(B, ci, h, h, generator=g)
+    w3 = torch.randn(co, ci, 3, 3, generator=g)
+    s = torch.randn(B, ci, generator=g) + 1
+    nz = torch.randn(B, 1, 2 * h, 2 * h, generator=g)
+    w = w3.unsqueeze(0) * s[:, None, :, None, None]
+    w = w / ((w * w).sum((2, 3, 4)) + 1e-8).sqrt()[..., None, None, None]
+    wg = w.reshape(B * co, ci, 3, 3).reshape(B, co, ci, 3, 3).permute(0, 2, 1, 3, 4).reshape(B * ci, co, 3, 3)
+    t = torch.nn.functional.conv_transpose2d(x.reshape(1, B * ci, h, h), wg, stride=2, padding=0, groups=B)
+    y = R.upfirdn2d(t, f, padding=T([1, 1, 1, 1]), gain=T(4)).reshape(B, co, 2 * h, 2 * h) + nz
+    save("g06_modconv_up2", x=x, w3=w3, s=s, noise=nz, f=f, y=y)
+
+    # G7 normalize_2nd_moment
+    z = torch.randn(4, 16, generator=g)
+    save("g07_norm2nd", z=z, y=R.normalize_2nd_moment(z))
+
+
+# --------------------------------------------------------------------------------------- modules
+def golden_modules():
+    from maua.GAN.wrappers.inference import stylegan2 as S
+
+    # FullyConnectedLayer linear + MappingNetwork (small) incl. truncation
+    torch.manual_seed(7)
+    fc = S.FullyConnectedLayer(16, 24, bias_init=1)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 16, generator=g)
+    save("g07_fc_linear", x=x, weight=fc.weight, bias=fc.bias, y=fc(x))
+
+    torch.manual_seed(9)
+    m = S.MappingNetwork(16, 0, 16, 6, num_layers=2)
+    m.w_avg.copy_(torch.randn(16, generator=g))
+    z = torch.randn(5, 16, generator=g)
+    sd = {k: v for k, v in m.state_dict().items()}
+    save("g07_mapping", z=z, y_psi1=m(z, None), y_psi07=m(z, None, truncation_psi=0.7),
+         **{k.replace(".", "__"): v for k, v in sd.items()})
+
+    # full-size mapping init parity: seed -> state dict checksum + a forward
+    torch.manual_seed(11)
+    m = S.MappingNetwork(512, 0, 512, 18)
+    z = torch.randn(2, 512, generator=g)
+    w = m(z, None)
+    save("g07_mapping512", z=z, w=w[:, 0], w0_sum=np.float64(m.fcs[0].weight.double().sum().item()),
+         w7_sum=np.float64(m.fcs[7].weight.double().sum().item()))
+
+    # G8 SynthesisLayer up=1 + ToRGBLayer with exported params
+    torch.manual_seed(12)
+    lay = S.SynthesisLayer(8, 6, w_dim=16, resolution=12, conv_clamp=256.0)
+    lay.padding = T(1)
+    lay.up = T(1)
+    lay.bias.data.copy_(torch.randn(6, generator=g))
+    x = torch.randn(2, 8, 12, 12, generator=g)
+    w = torch.randn(2, 16, generator=g)
+    y = lay(x, w)
+    save("g08_synth_layer", x=x, w=w, y=y, **{k.replace(".", "__"): v for k, v in lay.state_dict().items()})
+
+    torch.manual_seed(13)
+    rgb = S.ToRGBLayer(8, 3, w_dim=16, conv_clamp=256.0)
+    rgb.bias.data.copy_(torch.randn(3, generator=g))
+    y = rgb(x, w)
+    save("g08_torgb", x=x, w=w, y=y, **{k.replace(".", "__"): v for k, v in rgb.state_dict().items()})
+
+    # constructor draw order: reference SynthesisNetwork(16, 32, 3, channel_base=256, channel_max=16) under a seed
+    torch.manual_seed(21)
+    net = S.SynthesisNetwork(w_dim=16, img_resolution=32, img_channels=3, channel_base=256, channel_max=16)
+    sd = net.state_dict()
+    save("g08_synth_init", **{k.replace(".", "__"): v for k, v in sd.items()})
+    torch.manual_seed(22)
+    net = S.SynthesisNetwork(w_dim=512, img_resolution=1024, img_channels=3)
+    sums = {k.replace(".", "__"): np.float64(v.double().sum().item()) for k, v in net.state_dict().items()}
+    sums["num_ws"] = np.int64(net.num_ws)
+    save("g08_synth_init1024_sums", **sums)
+
+
+# --------------------------------------------------------------------------------------- audio
+def synth_audio(n, sr, seed):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64) / sr
+    u = torch.rand(n, generator=g, dtype=torch.float64)
+    nz = torch.randn(n, generator=g, dtype=torch.float64)
+    click = ((2 * t) % 1 < 0.05).double()
+    a = 0.3 * torch.sin(2 * np.pi * 220 * t) + 0.2 * (u - 0.5) * click + 0.01 * nz
+    return a.float()
+
+
+def golden_audio():
+    from maua.audiovisual.audioreactive.selfsupervised.features import audio as FA
+    from maua.audiovisual.audioreactive.selfsupervised.features import processing as FP
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import beat, convert, spectral
+    from maua.audiovisual.audioreactive.selfsupervised.features.efficient_quantile import quantile
+
+    sr = 30720
+    a = synth_audio(4 * sr, sr, 1234)  # 4 s -> 120 frames
+    D = spectral.stft(a)
+    S1 = spectral.spectrogram(a, power=1)
+    basis = spectral.mel(sr, 2048, fmax=11025.0)
+    M = spectral.melspectrogram(a, sr, fmax=11025.0)
+    db = convert.power_to_db(M)
+    env = beat.onset_strength(a, sr)
+    # keep fixtures small: store audio as f32 (480 KB) once, spectra as column samples
+    cols = np.array([0, 1, 2, 17, 59, 118, 119, 120])
+    save("g09_audio_clip", audio=a, sr=np.int64(sr))
+    save("g09_stft", cols=cols, D_re=D.real[:, cols], D_im=D.imag[:, cols], n_cols=np.int64(D.shape[1]),
+         S1_cols=S1[:, cols[:-1]], S1_shape=np.array(S1.shape))
+    save("g09_mel", basis_rowsum=basis.sum(1), basis_colsum=basis.sum(0), basis_rows=basis[[0, 1, 63, 127]],
+         M_cols=M[:, cols[:-1]], db_cols=db[:, cols[:-1]], db_max=db.max(), env=env,
+         mel_f=spectral.mel_frequencies(130, fmin=0.0, fmax=11025.0))
+
+    # G10 hpss + istft, 1 s clip
+    a1 = a[:sr].contiguous()
+    D1 = spectral.stft(a1)
+    Hh, Hp = spectral.hpss(D1, margin=8.0)
+    H1, P1 = spectral.hpss(D1, margin=1.0)
+    perc = FA.percussive(a1)
+    harm = FA.harmonic(a1)
+    mag = D1.abs()
+    med_t = FP.median_filter2d(mag[None, None], k=(1, 31), p=(15, 15, 0, 0)).squeeze()
+    med_f = FP.median_filter2d(mag[None, None], k=(31, 1), p=(0, 0, 15, 15)).squeeze()
+    save("g10_hpss", n=np.int64(sr), med_t=med_t.half(), med_f=med_f.half(), med_t_f32_cols=med_t[:, [0, 7, 30]],
+         med_f_f32_cols=med_f[:, [0, 7, 30]], Hp_re=Hp.real[:, [0, 7, 30]], Hp_im=Hp.imag[:, [0, 7, 30]],
+         Hh_re=Hh.real[:, [0, 7, 30]], Hh_im=Hh.imag[:, [0, 7, 30]], P1_re=P1.real[:, [0, 7, 30]],
+         H1_re=H1.real[:, [0, 7, 30]], perc=perc, harm=harm)
+    ons = FA.onsets(a, sr)
+    rms = FA.rms(a, sr)
+    save("g10_onsets_rms", onsets=ons, rms=rms)
+
+    # G11 envelope post-processing
+    g = torch.Generator().manual_seed(5)
+    e = torch.rand(200, generator=g)
+    e2 = torch.rand(200, 3, generator=g)
+    e4 = torch.rand(40, 2, 3, 4, generator=g)
+    short = torch.rand(6, 2, generator=g)
+    out = {"e": e, "e2": e2, "e4": e4, "short": short}
+    for sg in [1, 2, 5]:
+        out[f"p_circ_s{sg}"] = FP.gaussian_filter(e, sg)
+        out[f"p_refl_s{sg}"] = FP.gaussian_filter(e, sg, mode="reflect")
+    out["p_2d_s2"] = FP.gaussian_filter(e2, 2)
+    out["p_4d_s1"] = FP.gaussian_filter(e4, 1)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        out["p_short_s2"] = FP.gaussian_filter(short, 2)  # radius 8 > n_frames 6 -> fallback branch
+    out["p_normalize"] = FP.normalize(e2)
+    out["p_standardize"] = FP.standardize(e)
+    qs = [0.025, 0.25, 0.5, 0.75, 0.975]
+    big = torch.randn(100001, generator=g)
+    out["q_small"] = np.array([quantile(e, q).item() for q in qs], dtype=np.float32)
+    out["q_big"] = np.array([quantile(big, q).item() for q in qs], dtype=np.float32)
+    out["big_seed_check"] = big[:4]
+    withnan = e.clone()
+    withnan[::7] = float("nan")
+    out["q_nan"] = np.array([quantile(withnan, q).item() for q in qs], dtype=np.float32)
+    save("g11_processing", **out)
+
+    sig = sys.modules["maua.audiovisual.audioreactive.signal"]
+    out = {"e": e, "e2": e2}
+    out["s_circ_s2"] = sig.gaussian_filter(e, 2)
+    out["s_causal0_s2"] = sig.gaussian_filter(e, 2, causal=0)
+    out["s_causal05_s2"] = sig.gaussian_filter(e, 2, causal=0.5)
+    out["s_refl_s5"] = sig.gaussian_filter(e2, 5, mode="reflect")
+    out["s_percentile_clip95"] = sig.percentile_clip(e.clone(), 95)
+    out["s_percentile_clip80_2d"] = sig.percentile_clip(e2.clone(), 80)
+    out["s_percentile_50"] = np.float32(sig.percentile(e, 50))
+    out["s_percentile_95"] = np.float32(sig.percentile(e, 95))
+    out["s_resample_1d"] = sig.resample(e, 333)
+    out["s_resample_2d"] = sig.resample(e2, 77)
+    out["s_normalize"] = sig.normalize(e2)
+    save("g11_signal", **out)
+
+    # salience_weighted (selfsupervised/mir.py:13-21) needs librosa at import -> stubbed module import works
+    from maua.audiovisual.audioreactive.selfsupervised import mir as SM
+    feat = SM.normalize(SM.salience_weighted(SM.gaussian_filter(ons, sigma=2)))
+    save("g11_salience", onsets=ons, feat=feat)
+
+
+# --------------------------------------------------------------------------------------- latents / noise / io
+def golden_latents():
+    lat = sys.modules.get("maua.audiovisual.audioreactive.latent")
+    if lat is None:
+        import maua.audiovisual.audioreactive  # noqa
+        lat = sys.modules["maua.audiovisual.audioreactive.latent"]
+    g = torch.Generator().manual_seed(31)
+    y = torch.randn(5, 3, 8, generator=g)
+    env = torch.rand(64, generator=g)
+    envs = torch.rand(64, 7, generator=g) + 0.1
+    out = {"y": y, "env": env, "envs": envs}
+    out["slerp_loops"] = lat.slerp_loops(y, 64, 2)
+    out["single_weighted"] = lat.single_weighted(y[0], y[1], env)
+    out["multi_weighted"] = lat.multi_weighted(y, envs.clone())
+    # select_modulo: also capture the int64 index vector (the "onset-bin assignment")
+    sig = sys.modules["maua.audiovisual.audioreactive.signal"]
+    low, high = torch.quantile(env, 0.25), torch.quantile(env, 0.75)
+    idx = (sig.normalize(env.clamp(low, high)) * (len(y) - 1)).round().long()
+    out["select_modulo_idx"] = idx
+    out["select_modulo"] = lat.select_modulo(y, env)
+    save("g12_latents", **out)
+
+    # natural cubic spline loops: torchcubicspline is un-vendored (setup.py:104, unpinned git dep); the natural
+    # cubic spline through given knots is unique, so the fixture is produced with scipy's CubicSpline("natural")
+    # on the knot/eval grids of latent.py:83-92 and selfsupervised/latent.py:7-13.
+    from scipy.interpolate import CubicSpline
+    yn = y.double().numpy()
+    Y = np.concatenate([yn] * 3 + [yn[:1]])
+    cs = CubicSpline(np.linspace(0, 1, len(Y)), Y, axis=0, bc_type="natural")
+    out_classic = cs(np.linspace(0, 1, 50))
+    Y2 = np.concatenate([yn, yn[:1]])
+    cs2 = CubicSpline(np.linspace(0, 1, len(Y2)), Y2, axis=0, bc_type="natural")
+    t_out = (torch.linspace(0, 2.5, 50) % 1).double().numpy()
+    out_self = cs2(t_out)
+    save("g12_spline", y=y, classic_size50_loops3=out_classic, selfsup_size50_loops2p5=out_self)
+
+    # seeds (wrappers/stylegan.py:58-69) — numpy MT19937 is available everywhere, store two rows as a cross-check
+    z = np.concatenate([np.random.RandomState(s).randn(1, 512) for s in [0, 1, 2, 7]])
+    save("g12_seeds", seeds=np.array([0, 1, 2, 7]), z=z[:, :8])
+
+
+def golden_noise():
+    from maua.audiovisual.audioreactive.selfsupervised import noise as N
+    rng = torch.Generator("cpu").manual_seed(42)
+    loop = N.Loop(rng, length=48, size=(8, 12), n_loops=2, sigma=5)
+    out = {"loop_noise": loop.noise, "loop_idx": loop.idx, "loop_y_0_16": loop.forward(0, 16),
+           "loop_y_40_8": loop.forward(40, 8)}
+    mod = torch.rand(48, 3, generator=rng)
+    bl = N.Blend(rng, 48, (8, 12), mod)
+    mu = N.Multiply(rng, 48, (8, 12), mod)
+    out.update(mod=mod, blend_noise=bl.noise, blend_y=bl.forward(8, 4), mul_noise=mu.noise, mul_y=mu.forward(8, 4))
+    avg = N.Average(loop, mu)
+    md = N.Modulate(loop, mu, mod)
+    sb = N.ScaleBias(md, 0.7, 0.1)
+    out.update(avg_y=avg.forward(8, 4), modulate_y=md.forward(8, 4), scalebias_y=sb.forward(8, 4))
+    save("g13_noise", **out)
+
+
+def golden_io():
+    from maua.ops import io as RIO
+    # edge values incl. exact .5 ties after *255
+    vals = torch.tensor([-0.2, 0.0, 0.5 / 255, 1.5 / 255, 2.5 / 255, 0.5, 127.5 / 255, 128.5 / 255, 1.0, 1.3,
+                         254.5 / 255, 0.999], dtype=torch.float32)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 4, 8, generator=g) * 1.2 - 0.1
+    img.view(-1)[: len(vals)] = vals
+    b = np.frombuffer(RIO.tensor2bytes(img), dtype=np.uint8).reshape(4, 8, 3)
+    save("g14_tensor2bytes", img=img, bytes=b)
+
+
+if __name__ == "__main__":
+    import_reference()
+    which = sys.argv[1:] or ["ops", "modules", "audio", "latents", "noise", "io"]
+    with torch.no_grad():
+        for w in which:
+            globals()[f"golden_{w}"]()
