@@ -1,0 +1,108 @@
+/* libmaua_hip.so — C ABI of the MI355X (gfx950) audio-reactive StyleGAN2 render path.
+ *
+ * This is the drop-in boundary.  The reference (maua-maua-maua/maua) has no compiled plugin
+ * interface in-tree; its innermost replaceable surface is the Python operator layer
+ * maua/GAN/wrappers/inference/ops.py (upstream equivalent: the CUDA plugins of
+ * nv/torch_utils/ops, bound through torch_utils.custom_ops.get_plugin).  Each entry point below
+ * names the reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types.  All tensor pointers are DEVICE pointers in the
+ *    address space of ctx's device; the caller owns every buffer it passes in, the library owns only
+ *    the context workspaces and the parameters uploaded with maua_synth_load().
+ *  - every call returns MAUA_OK (0) or a negative error; maua_last_error() returns a thread-local text.
+ *  - launches are asynchronous on the ctx stream; the only synchronising calls are maua_ctx_sync(),
+ *    maua_synth_load() (host->device upload) and the *_host helpers that say so.
+ *  - a ctx is confined to one host thread at a time; different ctxs are independent.
+ *  - dtype: MAUA_F32 (exact-f32 MFMA path, parity mode) or MAUA_BF16 (bf16 operands, f32 accumulate).
+ */
+#ifndef MAUA_HIP_H
+#define MAUA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAUA_OK 0
+#define MAUA_ERR (-1)
+
+enum maua_dtype { MAUA_F32 = 0, MAUA_BF16 = 1 };
+/* activation ids: reference ops.py:9-19 / :44-62 */
+enum maua_act {
+  MAUA_ACT_LINEAR = 0, MAUA_ACT_RELU = 1, MAUA_ACT_LRELU = 2, MAUA_ACT_TANH = 3, MAUA_ACT_SIGMOID = 4,
+  MAUA_ACT_ELU = 5, MAUA_ACT_SELU = 6, MAUA_ACT_SOFTPLUS = 7, MAUA_ACT_SWISH = 8
+};
+/* gaussian_filter padding modes: reference signal.py:108-157 (F.pad modes) */
+enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLICATE = 2 };
+
+typedef struct maua_ctx maua_ctx;
+typedef struct maua_synth maua_synth;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+const char* maua_version(void);
+const char* maua_last_error(void);
+/* stream: a hipStream_t (NULL = the device's default stream); pass torch's current stream handle. */
+int maua_ctx_create(int device, void* stream, maua_ctx** out);
+int maua_ctx_set_stream(maua_ctx* ctx, void* stream);
+int maua_ctx_sync(maua_ctx* ctx);
+void maua_ctx_destroy(maua_ctx* ctx);
+
+/* ---- B1: operator layer (NCHW contiguous, like the reference tensors) --------------------------- */
+/* replaces ops.py:65-84 bias_act (upstream plugin nv/torch_utils/ops/bias_act).
+ * y = clamp(act(x + b[c]) * gain); b may be NULL; clamp < 0 disables clamping. */
+int maua_bias_act(maua_ctx* ctx, const void* x, const float* b, void* y, int N, int C, int H, int W, int dtype,
+                  int act, float alpha, float gain, float clamp);
+/* replaces ops.py:87-114 upfirdn2d (upstream plugin nv/torch_utils/ops/upfirdn2d).
+ * f: [fh,fw] f32 2-D filter (correlation, no flip); gain multiplies f (caller passes the 2-D gain,
+ * i.e. reference gain**(f.ndim/2) already resolved).  Output size
+ * Ho = (H*up + py0 + py1 - fh) / down + 1 (likewise Wo); y must hold [N,C,Ho,Wo]. */
+int maua_upfirdn2d(maua_ctx* ctx, const void* x, const float* f, int fh, int fw, void* y, int N, int C, int H, int W,
+                   int dtype, int up, int down, int px0, int px1, int py0, int py1, float gain);
+/* replaces ops.py:146-186 modulated_conv2d + :189-233 conv2d_resample (+ optionally the bias_act that
+ * always follows it, stylegan2.py:238-250 / :270-271), fused.
+ * x [N,Ci,H,W], weight [Co,Ci,k,k] f32 (k = 1 or 3), styles [N,Ci] f32, noise [N|1,1,H*up,W*up] f32 or NULL
+ * (noise_batch_stride = 0 broadcasts), bias [Co] f32 or NULL, y [N,Co,H*up,W*up].
+ * up in {1,2}; for up == 2 the filter is the 4x4 [1,3,3,1] outer product /64 with gain 4 (ops.py:211-225).
+ * flip_weight = 1 gives the upstream-NVIDIA kernel flip.  act/gain/clamp as maua_bias_act;
+ * pass act = MAUA_ACT_LINEAR, gain = 1, clamp = -1, bias = NULL for the bare modulated_conv2d. */
+int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight, const float* styles, const float* noise,
+                   long noise_batch_stride, float noise_strength, const float* bias, void* y, int N, int Ci, int Co,
+                   int H, int W, int k, int up, int demodulate, int flip_weight, int act, float alpha, float gain,
+                   float clamp, int dtype);
+/* replaces render/ffmpeg.py:72 (.add(1).div(2)) + ops/io.py:47-70 tensor2bytes:
+ * u8 = round_half_even(clamp((x+1)/2, 0, 1) * 255), NCHW f32 [B,3,H,W] -> HWC u8 [B,H,W,3]. */
+int maua_pack_rgb8(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int H, int W);
+
+/* ---- B2: synthesis network (parameters uploaded once, batched forwards) ------------------------- */
+/* replaces inference/stylegan2.py:385-436 SynthesisNetwork(w_dim, img_resolution, img_channels=3,
+ * channel_base, channel_max), 'skip' architecture, conv_clamp 256.
+ * dtype: activation/operand type.  nv_compat: bit0 flip up-layer kernels (Q2), bit1 scale noise by
+ * the loaded noise_strength instead of 1 (Q4). */
+int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_base, int channel_max, int dtype,
+                      int nv_compat, maua_synth** out);
+void maua_synth_destroy(maua_synth* net);
+int maua_synth_num_ws(const maua_synth* net);
+int maua_synth_num_layers(const maua_synth* net);
+/* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug). */
+int maua_synth_set_option(maua_synth* net, const char* key, int value);
+/* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
+ * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.
+ * Synchronous.  Unknown names return MAUA_ERR ("resample_filter" buffers are accepted and checked). */
+int maua_synth_load(maua_synth* net, const char* name, const float* host_data, size_t count);
+/* replaces wrappers/stylegan2.py:65-102 StyleGAN2Synthesizer.forward + G_synth.forward(noise_mode="const").
+ * ws [B,num_ws,w_dim] f32; noise: NULL or array of num_layers pointers, entry l = f32 [B|1, h_l, w_l] (or NULL
+ * for that layer's noise_const), noise_batch_stride[l] in elements (0 = broadcast); img_out f32 [B,3,R,R]. */
+int maua_synth_forward(maua_synth* net, const float* ws, const float* const* noise, const long* noise_batch_stride,
+                       int B, float* img_out);
+/* same, plus the u8 pack fused behind it (render/ffmpeg.py:72 + ops/io.py:47-70); img_out may be NULL. */
+int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const* noise,
+                           const long* noise_batch_stride, int B, float* img_out, uint8_t* rgb8_out);
+/* debug/parity: copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
+int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAUA_HIP_H */

@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 kernels of libmaua_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/maua_hip.h"
+
+namespace maua {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, finite inputs (activations are clamped to +-256 upstream)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kDtype = MAUA_F32;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = MAUA_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// activation ids follow maua_act in the header (reference ops.py:44-62)
+__device__ __forceinline__ float activate(float x, int act, float alpha) {
+  switch (act) {
+    case MAUA_ACT_LINEAR: return x;
+    case MAUA_ACT_RELU: return x > 0.f ? x : 0.f;
+    case MAUA_ACT_LRELU: return x > 0.f ? x : x * alpha;
+    case MAUA_ACT_TANH: return tanhf(x);
+    case MAUA_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    case MAUA_ACT_ELU: return x > 0.f ? x : expm1f(x);
+    case MAUA_ACT_SELU: {
+      const float a = 1.6732632423543772848170429916717f, s = 1.0507009873554804934193349852946f;
+      return s * (x > 0.f ? x : a * expm1f(x));
+    }
+    case MAUA_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+    case MAUA_ACT_SWISH: return x / (1.f + expf(-x));
+  }
+  return x;
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(const std::string& msg);  // sets the thread-local error, returns MAUA_ERR
+#define MAUA_HIP_CHECK(expr)                                                                  \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return ::maua::fail(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+#define MAUA_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) return ::maua::fail(std::string(msg));           \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace maua
+
+struct maua_ctx {
+  int device;
+  hipStream_t stream;
+  // grow-only scratch arena for the operator-level entry points (layout conversion, prepared weights)
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace maua {
+// returns a 256-byte aligned carve-out of ctx's scratch arena; grows (synchronising) when too small
+int scratch_reserve(maua_ctx* ctx, size_t bytes);
+}

@@ -1,0 +1,67 @@
+// Internal launcher prototypes shared between the translation units of libmaua_hip.so.
+#pragma once
+#include "common.h"
+
+namespace maua {
+
+// ---- ops_kernels.hip
+int launch_pack_rgb8(hipStream_t stream, const float* img, uint8_t* out, int B, int H, int W);
+template <typename TI, typename TO>
+int launch_nchw_to_nhwc(hipStream_t s, const void* x, void* y, int N, int C, int HW, int Cp);
+template <typename TI, typename TO>
+int launch_nhwc_to_nchw(hipStream_t s, const void* x, void* y, int N, int C, int HW, int Cp);
+
+// ---- modconv.hip
+// Arguments of one fused modulated-convolution launch (3x3, up in {1,2}); all pointers device.
+struct ConvArgs {
+  const void* x;        // NHWC [B][H][W][Ci] (T)
+  long x_bstride;       // elements between samples (0: broadcast, e.g. the learned const input)
+  const void* w;        // [phases][9][Co][Ci] (T), phases = up*up
+  const float* s;       // [B][Ci] styles (input scale)
+  const float* d;       // [B][Co] demodulation coefficients or NULL
+  const float* noise;   // [B|1][Ho][Wo] or NULL
+  long noise_bstride;   // elements (0: broadcast)
+  float noise_strength;
+  const float* bias;    // [Co] or NULL
+  void* y;              // NHWC [B][Ho][Wo][Co] (T)
+  int B, H, W, Ci, Co, up;
+  int act;
+  float alpha, gain, clamp;
+};
+int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
+
+// weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
+int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
+                        int up, int flip, int Cop, int Cip);
+size_t prepped_weight_elems(int k, int up, int Cop, int Cip);
+
+// styles / demod / toRGB pre-modulation for a list of layers in one launch
+struct StyleLayer {
+  const float* affine_w;  // [Cin][w_dim]
+  const float* affine_b;  // [Cin]
+  const float* wsq;       // [Co][Cin] or NULL (no demod)
+  const float* wrgb;      // [3][Cin] or NULL
+  float* s;               // out [B][Cs]   (Cs >= Cin, padding written as 0)
+  float* d;               // out [B][Cd]   or NULL
+  float* wmod;            // out [B][3][Cin] or NULL
+  int w_index;            // which of the num_ws vectors feeds this layer
+  int Cin, Co, Cs, Cd;
+  float scale;            // 1 (conv) or 1/sqrt(Cin) (toRGB)
+};
+int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
+                  int w_dim, int B);
+
+// toRGB (1x1 modconv, no demod, + bias, clamp) + FIR-upsampled skip + add -> f32 planar image
+struct RgbArgs {
+  const void* x;      // NHWC [B][H][W][C] (T)
+  const float* wmod;  // [B][3][C]
+  const float* bias;  // [3]
+  const float* prev;  // [B][3][H/2][W/2] or NULL
+  float* out;         // [B][3][H][W]
+  int B, H, W, C;
+  float clamp;
+  float fir[16];      // 4x4 filter incl. gain 4 (upsample2d, ops.py:117-133)
+};
+int launch_torgb(hipStream_t stream, int dtype, const RgbArgs& a);
+
+}  // namespace maua

@@ -1,0 +1,385 @@
+// StyleGAN2 synthesis network object: parameters resident in HBM, one batched forward = a fixed sequence of
+// launches on the ctx stream (styles -> [conv0(up2) -> conv1 -> toRGB+skip] x blocks -> optional u8 pack).
+//
+// Replaces (reference): inference/stylegan2.py:385-436 SynthesisNetwork, :275-382 SynthesisBlock,
+// :195-251 SynthesisLayer, :254-272 ToRGBLayer; wrappers/stylegan2.py:85-102 (per-batch noise install).
+// Activations are NHWC in the network dtype (bf16 or f32); the RGB skip image stays f32 planar.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+using namespace maua;
+
+namespace {
+
+struct ConvLayer {
+  int block, which;  // which: 0 = conv0 (up 2), 1 = conv1
+  int Ci, Co, res, up, w_index;
+  float* affine_w = nullptr;  // [Ci][w_dim]
+  float* affine_b = nullptr;  // [Ci]
+  float* bias = nullptr;      // [Co]
+  float* noise_const = nullptr;  // [res][res]
+  float noise_strength = 0.f;    // loaded value (used under nv_compat bit1)
+  void* wt = nullptr;            // prepared weights
+  float* wsq = nullptr;          // [Co][Ci]
+  float* s = nullptr;            // [Bcap][Ci]
+  float* d = nullptr;            // [Bcap][Co]
+  void* feat = nullptr;          // keep_features buffer
+};
+struct RgbLayer {
+  int block, C, res, w_index;
+  float* affine_w = nullptr;
+  float* affine_b = nullptr;
+  float* wrgb = nullptr;  // [3][C]
+  float* bias = nullptr;  // [3]
+  float* s = nullptr;     // [Bcap][C]
+  float* wmod = nullptr;  // [Bcap][3][C]
+};
+
+template <typename T>
+int dev_alloc(T** p, size_t n) {
+  MAUA_HIP_CHECK(hipMalloc((void**)p, n * sizeof(T)));
+  return MAUA_OK;
+}
+
+}  // namespace
+
+struct maua_synth {
+  maua_ctx* ctx;
+  int res, w_dim, channel_base, channel_max, dtype, nv_compat;
+  int nblocks, num_ws;
+  size_t esize;
+  std::vector<ConvLayer> convs;
+  std::vector<RgbLayer> rgbs;
+  void* const_x = nullptr;  // NHWC [4][4][C0]
+  int keep_features = 0;
+  // workspace
+  int bcap = 0;
+  void* act[2] = {nullptr, nullptr};
+  float* img[2] = {nullptr, nullptr};
+  StyleLayer* style_table_dev = nullptr;
+  float fir[16];
+};
+
+static int channels_for(int res, int base, int maxc) { return std::min(base / res, maxc); }
+
+static int free_workspace(maua_synth* n) {
+  for (auto& c : n->convs) {
+    if (c.s) hipFree(c.s);
+    if (c.d) hipFree(c.d);
+    if (c.feat) hipFree(c.feat);
+    c.s = c.d = nullptr;
+    c.feat = nullptr;
+  }
+  for (auto& r : n->rgbs) {
+    if (r.s) hipFree(r.s);
+    if (r.wmod) hipFree(r.wmod);
+    r.s = r.wmod = nullptr;
+  }
+  for (int i = 0; i < 2; i++) {
+    if (n->act[i]) hipFree(n->act[i]);
+    if (n->img[i]) hipFree(n->img[i]);
+    n->act[i] = nullptr;
+    n->img[i] = nullptr;
+  }
+  if (n->style_table_dev) hipFree(n->style_table_dev);
+  n->style_table_dev = nullptr;
+  n->bcap = 0;
+  return MAUA_OK;
+}
+
+static int ensure_workspace(maua_synth* n, int B) {
+  if (B <= n->bcap) return MAUA_OK;
+  MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  free_workspace(n);
+  size_t max_act = 0;
+  for (auto& c : n->convs) {
+    MAUA_HIP_CHECK(hipMalloc((void**)&c.s, (size_t)B * c.Ci * sizeof(float)));
+    MAUA_HIP_CHECK(hipMalloc((void**)&c.d, (size_t)B * c.Co * sizeof(float)));
+    size_t e = (size_t)c.res * c.res * c.Co;
+    max_act = std::max(max_act, e);
+    if (n->keep_features) MAUA_HIP_CHECK(hipMalloc(&c.feat, (size_t)B * e * n->esize));
+  }
+  for (auto& r : n->rgbs) {
+    MAUA_HIP_CHECK(hipMalloc((void**)&r.s, (size_t)B * r.C * sizeof(float)));
+    MAUA_HIP_CHECK(hipMalloc((void**)&r.wmod, (size_t)B * 3 * r.C * sizeof(float)));
+  }
+  if (!n->keep_features)
+    for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->act[i], (size_t)B * max_act * n->esize));
+  for (int i = 0; i < 2; i++)
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->img[i], (size_t)B * 3 * n->res * n->res * sizeof(float)));
+  // style table
+  std::vector<StyleLayer> tab;
+  for (auto& c : n->convs) {
+    StyleLayer L{};
+    L.affine_w = c.affine_w; L.affine_b = c.affine_b; L.wsq = c.wsq; L.wrgb = nullptr;
+    L.s = c.s; L.d = c.d; L.wmod = nullptr; L.w_index = c.w_index;
+    L.Cin = c.Ci; L.Co = c.Co; L.Cs = c.Ci; L.Cd = c.Co; L.scale = 1.f;
+    tab.push_back(L);
+  }
+  for (auto& r : n->rgbs) {
+    StyleLayer L{};
+    L.affine_w = r.affine_w; L.affine_b = r.affine_b; L.wsq = nullptr; L.wrgb = r.wrgb;
+    L.s = r.s; L.d = nullptr; L.wmod = r.wmod; L.w_index = r.w_index;
+    L.Cin = r.C; L.Co = 3; L.Cs = r.C; L.Cd = 0; L.scale = 1.f / std::sqrt((float)r.C);
+    tab.push_back(L);
+  }
+  MAUA_HIP_CHECK(hipMalloc((void**)&n->style_table_dev, tab.size() * sizeof(StyleLayer)));
+  MAUA_HIP_CHECK(hipMemcpy(n->style_table_dev, tab.data(), tab.size() * sizeof(StyleLayer), hipMemcpyHostToDevice));
+  n->bcap = B;
+  return MAUA_OK;
+}
+
+extern "C" {
+
+int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_base, int channel_max, int dtype,
+                      int nv_compat, maua_synth** out) {
+  MAUA_REQUIRE(ctx && out, "maua_synth_create: NULL argument");
+  MAUA_REQUIRE(img_resolution >= 4 && (img_resolution & (img_resolution - 1)) == 0,
+               "maua_synth_create: img_resolution must be a power of two >= 4");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_synth_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(w_dim > 0 && w_dim <= 4096, "maua_synth_create: bad w_dim");
+  const int kc = dtype == MAUA_BF16 ? 32 : 16;
+  maua_synth* n = new maua_synth();
+  n->ctx = ctx; n->res = img_resolution; n->w_dim = w_dim; n->channel_base = channel_base;
+  n->channel_max = channel_max; n->dtype = dtype; n->nv_compat = nv_compat;
+  n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  int nb = 0;
+  for (int r = 4; r <= img_resolution; r *= 2) nb++;
+  n->nblocks = nb;
+  n->num_ws = 2 * nb;
+  int widx = 0;
+  for (int i = 0; i < nb; i++) {
+    int r = 4 << i;
+    int co = channels_for(r, channel_base, channel_max);
+    if (co % 32 != 0 || co % kc != 0) {
+      delete n;
+      return fail("maua_synth_create: channel counts must be multiples of 32");
+    }
+    if (i > 0) {
+      ConvLayer c{};
+      c.block = i; c.which = 0; c.Ci = channels_for(r / 2, channel_base, channel_max); c.Co = co; c.res = r; c.up = 2;
+      c.w_index = widx++;
+      n->convs.push_back(c);
+    }
+    ConvLayer c{};
+    c.block = i; c.which = 1; c.Ci = co; c.Co = co; c.res = r; c.up = 1; c.w_index = widx++;
+    n->convs.push_back(c);
+    RgbLayer g{};
+    g.block = i; g.C = co; g.res = r; g.w_index = widx;  // toRGB shares the next block's first w (stylegan2.py:431-433)
+    n->rgbs.push_back(g);
+  }
+  hipError_t e = hipSuccess;
+  auto A = [&](void** p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+    if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+  };
+  for (auto& c : n->convs) {
+    A((void**)&c.affine_w, (size_t)c.Ci * w_dim * 4);
+    A((void**)&c.affine_b, (size_t)c.Ci * 4);
+    A((void**)&c.bias, (size_t)c.Co * 4);
+    A((void**)&c.noise_const, (size_t)c.res * c.res * 4);
+    A(&c.wt, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
+    A((void**)&c.wsq, (size_t)c.Co * c.Ci * 4);
+  }
+  for (auto& g : n->rgbs) {
+    A((void**)&g.affine_w, (size_t)g.C * w_dim * 4);
+    A((void**)&g.affine_b, (size_t)g.C * 4);
+    A((void**)&g.wrgb, (size_t)3 * g.C * 4);
+    A((void**)&g.bias, 3 * 4);
+  }
+  A(&n->const_x, (size_t)16 * n->convs[0].Ci * n->esize);
+  if (e != hipSuccess) {
+    maua_synth_destroy(n);
+    return fail(std::string("maua_synth_create: hipMalloc: ") + hipGetErrorString(e));
+  }
+  const float g4[4] = {0.25f, 0.75f, 0.75f, 0.25f};  // upsample2d: f*gain(4) = outer(g4,g4)
+  for (int u = 0; u < 4; u++)
+    for (int v = 0; v < 4; v++) n->fir[u * 4 + v] = g4[u] * g4[v];
+  *out = n;
+  return MAUA_OK;
+}
+
+void maua_synth_destroy(maua_synth* n) {
+  if (!n) return;
+  hipStreamSynchronize(n->ctx->stream);
+  free_workspace(n);
+  for (auto& c : n->convs) {
+    hipFree(c.affine_w); hipFree(c.affine_b); hipFree(c.bias); hipFree(c.noise_const); hipFree(c.wt); hipFree(c.wsq);
+  }
+  for (auto& g : n->rgbs) {
+    hipFree(g.affine_w); hipFree(g.affine_b); hipFree(g.wrgb); hipFree(g.bias);
+  }
+  hipFree(n->const_x);
+  delete n;
+}
+
+int maua_synth_num_ws(const maua_synth* n) { return n ? n->num_ws : 0; }
+int maua_synth_num_layers(const maua_synth* n) { return n ? (int)n->convs.size() : 0; }
+
+int maua_synth_set_option(maua_synth* n, const char* key, int value) {
+  MAUA_REQUIRE(n && key, "maua_synth_set_option: NULL argument");
+  if (!strcmp(key, "keep_features")) {
+    if (n->keep_features != value) {
+      MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+      free_workspace(n);
+      n->keep_features = value;
+    }
+    return MAUA_OK;
+  }
+  return fail(std::string("maua_synth_set_option: unknown option ") + key);
+}
+
+static int upload(float* dst, const float* host, size_t count, size_t expect, const char* name) {
+  if (count != expect)
+    return fail(std::string("maua_synth_load: ") + name + ": expected " + std::to_string(expect) + " values, got " +
+                std::to_string(count));
+  MAUA_HIP_CHECK(hipMemcpy(dst, host, count * sizeof(float), hipMemcpyHostToDevice));
+  return MAUA_OK;
+}
+
+int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t count) {
+  MAUA_REQUIRE(n && name && host, "maua_synth_load: NULL argument");
+  std::string s(name);
+  int blk = -1, pos = 0;
+  if (sscanf(name, "bs.%d.%n", &blk, &pos) < 1 || blk < 0 || blk >= n->nblocks || pos == 0)
+    return fail("maua_synth_load: unknown parameter name: " + s);
+  std::string rest = s.substr(pos);
+  hipStream_t st = n->ctx->stream;
+  auto check_filter = [&]() -> int {
+    if (count != 16) return fail("maua_synth_load: " + s + ": only the 4x4 [1,3,3,1] resample filter is supported");
+    const float t[4] = {1, 3, 3, 1};
+    for (int u = 0; u < 4; u++)
+      for (int v = 0; v < 4; v++)
+        if (std::fabs(host[u * 4 + v] - t[u] * t[v] / 64.f) > 1e-6f)
+          return fail("maua_synth_load: " + s + ": only the 4x4 [1,3,3,1] resample filter is supported");
+    return MAUA_OK;
+  };
+  if (rest == "resample_filter") return check_filter();
+  if (rest == "const") {
+    if (blk != 0) return fail("maua_synth_load: only block 0 has a const input");
+    int C = n->convs[0].Ci;
+    if (count != (size_t)C * 16) return fail("maua_synth_load: bs.0.const: wrong size");
+    float* tmp;
+    MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+    int rc = n->dtype == MAUA_BF16 ? launch_nchw_to_nhwc<float, bf16_t>(st, tmp, n->const_x, 1, C, 16, C)
+                                   : launch_nchw_to_nhwc<float, float>(st, tmp, n->const_x, 1, C, 16, C);
+    hipStreamSynchronize(st);
+    hipFree(tmp);
+    return rc;
+  }
+  size_t dot = rest.find('.');
+  if (dot == std::string::npos) return fail("maua_synth_load: unknown parameter name: " + s);
+  std::string mod = rest.substr(0, dot), par = rest.substr(dot + 1);
+  if (mod == "torgb") {
+    RgbLayer& g = n->rgbs[blk];
+    if (par == "weight") return upload(g.wrgb, host, count, (size_t)3 * g.C, name);
+    if (par == "bias") return upload(g.bias, host, count, 3, name);
+    if (par == "affine.weight") return upload(g.affine_w, host, count, (size_t)g.C * n->w_dim, name);
+    if (par == "affine.bias") return upload(g.affine_b, host, count, g.C, name);
+    return fail("maua_synth_load: unknown parameter name: " + s);
+  }
+  ConvLayer* c = nullptr;
+  for (auto& cc : n->convs)
+    if (cc.block == blk && ((mod == "conv0" && cc.which == 0) || (mod == "conv1" && cc.which == 1))) c = &cc;
+  if (!c) return fail("maua_synth_load: unknown parameter name: " + s);
+  if (par == "resample_filter") return check_filter();
+  if (par == "bias") return upload(c->bias, host, count, c->Co, name);
+  if (par == "affine.weight") return upload(c->affine_w, host, count, (size_t)c->Ci * n->w_dim, name);
+  if (par == "affine.bias") return upload(c->affine_b, host, count, c->Ci, name);
+  if (par == "noise_const") return upload(c->noise_const, host, count, (size_t)c->res * c->res, name);
+  if (par == "noise_strength") {
+    if (count != 1) return fail("maua_synth_load: noise_strength is a scalar");
+    c->noise_strength = host[0];
+    return MAUA_OK;
+  }
+  if (par == "weight") {
+    size_t expect = (size_t)c->Co * c->Ci * 9;
+    if (count != expect) return fail("maua_synth_load: " + s + ": wrong size");
+    float* tmp;
+    MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+    int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, c->wsq, c->Co, c->Ci, 3, c->up,
+                                 (c->up == 2) ? (n->nv_compat & 1) : 0, c->Co, c->Ci);
+    hipStreamSynchronize(st);
+    hipFree(tmp);
+    return rc;
+  }
+  return fail("maua_synth_load: unknown parameter name: " + s);
+}
+
+int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* noise, const long* noise_bstride, int B,
+                           float* img_out, uint8_t* rgb8_out) {
+  MAUA_REQUIRE(n && ws, "maua_synth_forward: NULL argument");
+  MAUA_REQUIRE(B >= 0, "maua_synth_forward: negative batch");
+  MAUA_REQUIRE(img_out || rgb8_out, "maua_synth_forward: no output buffer");
+  if (B == 0) return MAUA_OK;
+  if (int rc = ensure_workspace(n, B)) return rc;
+  hipStream_t st = n->ctx->stream;
+  const int ntab = (int)(n->convs.size() + n->rgbs.size());
+  if (int rc = launch_styles(st, n->style_table_dev, ntab, ws, n->num_ws, n->w_dim, B)) return rc;
+
+  const void* x = n->const_x;
+  long x_bstride = 0;
+  int cur = 0;
+  const float* prev_img = nullptr;
+  int img_cur = 0;
+  size_t li = 0;
+  for (int blk = 0; blk < n->nblocks; blk++) {
+    const int nconv = blk == 0 ? 1 : 2;
+    for (int k = 0; k < nconv; k++, li++) {
+      ConvLayer& c = n->convs[li];
+      ConvArgs a{};
+      a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;
+      const float* nz = (noise && noise[li]) ? noise[li] : c.noise_const;
+      a.noise = nz;
+      a.noise_bstride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.res * c.res) : 0;
+      a.noise_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
+      a.bias = c.bias;
+      void* y = n->keep_features ? c.feat : n->act[cur];
+      a.y = y;
+      a.B = B; a.H = c.res / c.up; a.W = c.res / c.up; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
+      a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+      if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
+      x = y;
+      x_bstride = (long)c.res * c.res * c.Co;
+      cur ^= 1;
+    }
+    RgbLayer& g = n->rgbs[blk];
+    RgbArgs r{};
+    r.x = x; r.wmod = g.wmod; r.bias = g.bias; r.prev = prev_img;
+    const bool last = blk == n->nblocks - 1;
+    float* out = (last && img_out) ? img_out : n->img[img_cur];
+    r.out = out; r.B = B; r.H = g.res; r.W = g.res; r.C = g.C; r.clamp = 256.f;
+    memcpy(r.fir, n->fir, sizeof(r.fir));
+    if (int rc = launch_torgb(st, n->dtype, r)) return rc;
+    prev_img = out;
+    img_cur ^= 1;
+  }
+  if (rgb8_out) return launch_pack_rgb8(st, prev_img, rgb8_out, B, n->res, n->res);
+  return MAUA_OK;
+}
+
+int maua_synth_forward(maua_synth* n, const float* ws, const float* const* noise, const long* noise_bstride, int B,
+                       float* img_out) {
+  MAUA_REQUIRE(img_out, "maua_synth_forward: img_out is NULL");
+  return maua_synth_render_rgb8(n, ws, noise, noise_bstride, B, img_out, nullptr);
+}
+
+int maua_synth_get_feature(maua_synth* n, int layer, int B, float* out_nchw) {
+  MAUA_REQUIRE(n && out_nchw, "maua_synth_get_feature: NULL argument");
+  MAUA_REQUIRE(n->keep_features, "maua_synth_get_feature: enable with maua_synth_set_option(net, \"keep_features\", 1)");
+  MAUA_REQUIRE(layer >= 0 && layer < (int)n->convs.size(), "maua_synth_get_feature: no such layer");
+  MAUA_REQUIRE(B <= n->bcap, "maua_synth_get_feature: batch larger than the last forward");
+  ConvLayer& c = n->convs[layer];
+  hipStream_t st = n->ctx->stream;
+  if (n->dtype == MAUA_BF16) return launch_nhwc_to_nchw<bf16_t, float>(st, c.feat, out_nchw, B, c.Co, c.res * c.res, c.Co);
+  return launch_nhwc_to_nchw<float, float>(st, c.feat, out_nchw, B, c.Co, c.res * c.res, c.Co);
+}
+
+}  // extern "C"

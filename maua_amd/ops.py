@@ -1,0 +1,171 @@
+"""Operator layer with the reference's names and argument meaning, executed by libmaua_hip.so.
+
+Drop-in for maua/GAN/wrappers/inference/ops.py (reference): bias_act :65-84, upfirdn2d :87-114,
+upsample2d :117-133, normalize_2nd_moment :142-143, modulated_conv2d :146-186, conv2d_resample :189-233,
+setup_filter :236-256.  Scalars may be Python numbers or 0-dim tensors (the reference passes both).
+Tensors are NCHW; float32 and bfloat16 are supported.  Every op raises MauaHipError when the HIP
+library or device is missing — there is no CPU path here.
+"""
+import ctypes as C
+from math import sqrt
+
+import torch
+
+from . import _lib as L
+
+_DEFAULTS = {"linear": (0.0, 1.0), "relu": (0.0, sqrt(2)), "lrelu": (0.2, sqrt(2)), "tanh": (0.0, 1.0),
+             "sigmoid": (0.0, 1.0), "elu": (0.0, 1.0), "selu": (0.0, 1.0), "softplus": (0.0, 1.0),
+             "swish": (0.0, sqrt(2))}
+
+
+def _num(v):
+    return float(v.item()) if isinstance(v, torch.Tensor) else float(v)
+
+
+def _int(v):
+    return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+
+def setup_filter(f=(1, 3, 3, 1), device=None, normalize=True, gain=1, separable=None):
+    """ops.py:236-256 (host-side constant; 16 floats)."""
+    if f is None:
+        f = 1
+    f = torch.as_tensor(f, dtype=torch.float32)
+    if f.ndim == 0:
+        f = f[None]
+    if separable is None:
+        separable = f.ndim == 1 and f.numel() >= 8
+    if f.ndim == 1 and not separable:
+        f = torch.outer(f, f)
+    if normalize:
+        f = f / f.sum()
+    f = f * (_num(gain) ** (f.ndim / 2))
+    return f.to(device) if device is not None else f
+
+
+def bias_act(x, b=None, act="linear", alpha=None, gain=None, clamp=None):
+    if act not in L.ACTS:
+        raise ValueError(f"unknown activation {act!r}")
+    da, dg = _DEFAULTS[act]
+    alpha = da if alpha is None else _num(alpha)
+    gain = dg if gain is None else _num(gain)
+    clamp = -1.0 if clamp is None else _num(clamp)
+    x = L.dev_tensor(x)
+    if x.ndim != 4:
+        raise ValueError("bias_act expects an NCHW tensor")
+    n, c, h, w = x.shape
+    if b is not None:
+        b = L.dev_tensor(b, torch.float32)
+        if b.numel() != c:
+            raise ValueError("bias must have one entry per channel")
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_bias_act(L.ctx(x.device), L.ptr(x), L.ptr(b), L.ptr(y), n, c, h, w, L.dtype_id(x),
+                                  L.ACTS[act], C.c_float(alpha), C.c_float(gain), C.c_float(clamp)))
+    return y
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=(0, 0, 0, 0), gain=1):
+    x = L.dev_tensor(x)
+    n, c, h, w = x.shape
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32)
+    f = torch.as_tensor(f, dtype=torch.float32).cpu()
+    g = _num(gain) ** (f.ndim / 2)
+    if f.ndim == 1:  # separable: correlate with the outer product (same result as two 1-D passes)
+        f2, g = torch.outer(f, f), g * g
+    else:
+        f2 = f
+    up, down = _int(up), _int(down)
+    pad = [_int(p) for p in (padding.tolist() if isinstance(padding, torch.Tensor) else padding)]
+    if len(pad) == 2:
+        pad = [pad[0], pad[0], pad[1], pad[1]]
+    px0, px1, py0, py1 = pad
+    fh, fw = f2.shape
+    ho = (h * up + py0 + py1 - fh) // down + 1
+    wo = (w * up + px0 + px1 - fw) // down + 1
+    y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device)
+    fd = L.dev_tensor(f2, torch.float32)
+    L.check(L.lib().maua_upfirdn2d(L.ctx(x.device), L.ptr(x), L.ptr(fd), fh, fw, L.ptr(y), n, c, h, w, L.dtype_id(x),
+                                   up, down, px0, px1, py0, py1, C.c_float(g)))
+    return y
+
+
+def _get_filter_size(f):
+    return (1, 1) if f is None else (f.shape[-1], f.shape[0])
+
+
+def upsample2d(x, f, up=2, padding=0, gain=1):
+    up, padding = _int(up), _int(padding)
+    fw, fh = _get_filter_size(f)
+    p = (padding + (fw + up - 1) // 2, padding + (fw - up) // 2, padding + (fh + up - 1) // 2,
+         padding + (fh - up) // 2)
+    return upfirdn2d(x, f, up=up, padding=p, gain=_num(gain) * up * up)
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    """ops.py:142-143 — a [P,512] prologue of the mapper; plain torch on the caller's device."""
+    return x / ((x * x).mean(dim=dim, keepdim=True) + eps).sqrt()
+
+
+def _check_resample_filter(f):
+    if f is None:
+        return
+    ref = setup_filter([1, 3, 3, 1])
+    if tuple(f.shape) != (4, 4) or not torch.allclose(f.detach().cpu().float(), ref, atol=1e-6):
+        raise NotImplementedError("only the [1,3,3,1] resample filter of the reference networks is supported")
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=False, bias=None, act="linear", alpha=None, gain=None, clamp=None,
+                     noise_strength=1.0):
+    """ops.py:146-186.  Extra keyword arguments (bias/act/gain/clamp) fuse the bias_act that follows the
+    convolution in every SynthesisLayer; leave them at their defaults for the bare reference op."""
+    up, down, padding = _int(up), _int(down), _int(padding)
+    if down != 1:
+        raise NotImplementedError("down-sampling is not on the render path")
+    x = L.dev_tensor(x)
+    n, ci, h, w = x.shape
+    co, wci, kh, kw = weight.shape
+    if wci != ci or kh != kw or kh not in (1, 3):
+        raise ValueError("weight must be [Co, Ci, k, k] with k in (1, 3)")
+    if padding != kh // 2:
+        raise NotImplementedError("padding must be kernel_size // 2 ('same' convolution)")
+    if up not in (1, 2):
+        raise NotImplementedError("up must be 1 or 2")
+    if up == 2:
+        _check_resample_filter(resample_filter)
+    weight = L.dev_tensor(weight, torch.float32)
+    styles = L.dev_tensor(styles, torch.float32)
+    nstride = 0
+    if noise is not None:
+        noise = L.dev_tensor(noise, torch.float32)
+        if noise.numel() == h * up * w * up:
+            nstride = 0
+        elif noise.numel() == n * h * up * w * up:
+            nstride = h * up * w * up
+        else:
+            raise ValueError("noise must be [N|1, 1, H*up, W*up] (or [H*up, W*up])")
+    if bias is not None:
+        bias = L.dev_tensor(bias, torch.float32)
+    da, dg = _DEFAULTS[act]
+    alpha = da if alpha is None else _num(alpha)
+    gain = dg if gain is None else _num(gain)
+    clamp = -1.0 if clamp is None else _num(clamp)
+    y = torch.empty((n, co, h * up, w * up), dtype=x.dtype, device=x.device)
+    L.check(L.lib().maua_modconv2d(L.ctx(x.device), L.ptr(x), L.ptr(weight), L.ptr(styles), L.ptr(noise),
+                                   C.c_long(nstride), C.c_float(_num(noise_strength)), L.ptr(bias), L.ptr(y), n, ci,
+                                   co, h, w, kh, up, int(bool(demodulate)), int(bool(flip_weight)), L.ACTS[act],
+                                   C.c_float(alpha), C.c_float(gain), C.c_float(clamp), L.dtype_id(x)))
+    return y
+
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=False):
+    """ops.py:189-233 for groups == 1: an un-modulated convolution = modulated_conv2d with unit styles
+    and no demodulation."""
+    if _int(groups) != 1:
+        raise NotImplementedError("grouped conv2d_resample is an implementation detail of the reference's "
+                                  "modulated_conv2d; call modulated_conv2d instead")
+    x = L.dev_tensor(x)
+    styles = torch.ones((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    return modulated_conv2d(x, w, styles, up=up, down=down, padding=padding, resample_filter=f, demodulate=False,
+                            flip_weight=flip_weight)

@@ -1,0 +1,248 @@
+"""StyleGAN2 networks and maua's generator wrappers, executed by libmaua_hip.so.
+
+Module API drop-in (same class names, constructor arguments, attributes and forward kwargs):
+  * SynthesisNetwork / MappingNetwork   <- maua/GAN/wrappers/inference/stylegan2.py:116-192, :385-436
+  * StyleGAN2Mapper / StyleGAN2Synthesizer / StyleGAN2 <- maua/GAN/wrappers/stylegan.py:11-77,
+    maua/GAN/wrappers/stylegan2.py:22-102, :196-213; MauaGenerator.render <- maua/GAN/wrappers/__init__.py:52-99
+
+Parameters keep the reference's state_dict names, so a reference state dict loads unchanged.  Random
+initialisation draws from torch's CPU generator in the reference constructors' order, so
+``torch.manual_seed(s)`` gives the same weights as the reference's ``SynthesisNetwork`` under that seed.
+The forward pass is one C-ABI call per batch (maua_synth_forward); nothing here falls back to PyTorch math.
+"""
+import ctypes as C
+from math import sqrt
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------- structure / init
+def block_resolutions(img_resolution):
+    return [2 ** i for i in range(2, int(np.log2(img_resolution)) + 1)]
+
+
+def channels_dict(img_resolution, channel_base=32768, channel_max=512):
+    return {r: min(channel_base // r, channel_max) for r in block_resolutions(img_resolution)}
+
+
+def _randn(shape, generator):
+    return torch.randn(shape, generator=generator) if generator is not None else torch.randn(shape)
+
+
+def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_base=32768, channel_max=512,
+                          generator=None) -> Dict[str, torch.Tensor]:
+    """Same tensors, same draw order as the reference constructors (stylegan2.py:296-337, :221-227, :263-265)."""
+    ch = channels_dict(img_resolution, channel_base, channel_max)
+    f = ops.setup_filter([1, 3, 3, 1])
+    p = {}
+
+    def layer(prefix, cin, cout, res):
+        p[prefix + ".resample_filter"] = f.clone()
+        p[prefix + ".affine.weight"] = _randn([cin, w_dim], generator)
+        p[prefix + ".affine.bias"] = torch.ones([cin])
+        p[prefix + ".weight"] = _randn([cout, cin, 3, 3], generator)
+        p[prefix + ".noise_const"] = _randn([res, res], generator)
+        p[prefix + ".bias"] = torch.zeros([cout])
+
+    for i, r in enumerate(block_resolutions(img_resolution)):
+        cin = ch[r // 2] if r > 4 else 0
+        cout = ch[r]
+        p[f"bs.{i}.resample_filter"] = f.clone()
+        if cin == 0:
+            p[f"bs.{i}.const"] = _randn([cout, r, r], generator)
+        else:
+            layer(f"bs.{i}.conv0", cin, cout, r)
+        layer(f"bs.{i}.conv1", cout, cout, r)
+        p[f"bs.{i}.torgb.affine.weight"] = _randn([cout, w_dim], generator)
+        p[f"bs.{i}.torgb.affine.bias"] = torch.ones([cout])
+        p[f"bs.{i}.torgb.weight"] = _randn([img_channels, cout, 1, 1], generator)
+        p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+    return p
+
+
+class SynthesisNetwork(torch.nn.Module):
+    """inference/stylegan2.py:385-436.  ``dtype``: torch.bfloat16 (default, MFMA bf16 operands / f32 accumulate)
+    or torch.float32 (exact-f32 MFMA, parity mode)."""
+
+    def __init__(self, w_dim, img_resolution, img_channels=3, channel_base=32768, channel_max=512, num_fp16_res=0,
+                 dtype=torch.bfloat16, nv_compat=False, generator=None, **block_kwargs):
+        super().__init__()
+        if img_channels != 3:
+            raise NotImplementedError("img_channels must be 3")
+        if block_kwargs.get("architecture", "skip") != "skip":
+            raise NotImplementedError("only the 'skip' architecture (the reference default) is implemented")
+        self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.channel_base, self.channel_max = channel_base, channel_max
+        self.block_resolutions = block_resolutions(img_resolution)
+        self.num_ws = 2 * len(self.block_resolutions)
+        self.num_layers = 2 * len(self.block_resolutions) - 1
+        self.dtype, self.nv_compat = dtype, bool(nv_compat)
+        self._params = init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max, generator)
+        self._net = None  # device handle, created on first use
+        self._net_device = None
+        self._keep_features = False
+
+    # -- parameters ------------------------------------------------------------------------------------
+    def state_dict(self, *a, **k):
+        return dict(self._params)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params and not k.endswith("noise_strength")]
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing {missing[:4]}..., unexpected {unexpected[:4]}...")
+        for k, v in sd.items():
+            if k in self._params:
+                if tuple(v.shape) != tuple(self._params[k].shape):
+                    raise ValueError(f"{k}: shape {tuple(v.shape)} != {tuple(self._params[k].shape)}")
+                self._params[k] = v.detach().float().cpu().contiguous()
+            elif k.endswith("noise_strength"):
+                self._params[k] = v.detach().float().cpu().reshape(1)
+        self._destroy()
+
+    def layer_shapes(self):
+        """[(prefix, c_in, c_out, resolution, up)] for the synthesis layers in execution order."""
+        ch = channels_dict(self.img_resolution, self.channel_base, self.channel_max)
+        out = []
+        for i, r in enumerate(self.block_resolutions):
+            if r > 4:
+                out.append((f"bs.{i}.conv0", ch[r // 2], ch[r], r, 2))
+            out.append((f"bs.{i}.conv1", ch[r], ch[r], r, 1))
+        return out
+
+    # -- device object ---------------------------------------------------------------------------------
+    def _destroy(self):
+        if self._net is not None:
+            L.lib().maua_synth_destroy(self._net)
+            self._net = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _handle(self):
+        L.require_device()
+        dev = torch.cuda.current_device()
+        if self._net is None or self._net_device != dev:
+            self._destroy()
+            lib = L.lib()
+            net = C.c_void_p()
+            flags = 3 if self.nv_compat else 0
+            L.check(lib.maua_synth_create(L.ctx(dev), self.img_resolution, self.w_dim, self.channel_base,
+                                          self.channel_max, L.dtype_id(self.dtype), flags, C.byref(net)))
+            for k, v in self._params.items():
+                a = np.ascontiguousarray(v.numpy(), dtype=np.float32)
+                L.check(lib.maua_synth_load(net, k.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+            L.check(lib.maua_synth_set_option(net, b"keep_features", int(self._keep_features)))
+            self._net, self._net_device = net, dev
+        else:
+            L.ctx(dev)  # re-bind torch's current stream
+        return self._net
+
+    def keep_features(self, flag=True):
+        self._keep_features = bool(flag)
+        if self._net is not None:
+            L.check(L.lib().maua_synth_set_option(self._net, b"keep_features", int(flag)))
+
+    # -- forward ---------------------------------------------------------------------------------------
+    def _noise_args(self, noise, B):
+        if noise is None:
+            return None, None, []
+        n = self.num_layers
+        ptrs = (C.c_void_p * n)()
+        strides = (C.c_long * n)()
+        keep = []
+        shapes = self.layer_shapes()
+        for l in range(n):
+            t = noise[l] if l < len(noise) else None
+            if t is None:
+                ptrs[l], strides[l] = None, 0
+                continue
+            res = shapes[l][3]
+            t = L.dev_tensor(t, torch.float32)
+            if t.shape[-2:] != (res, res):  # wrappers/stylegan2.py:92-98: resize mismatching noise
+                t = torch.nn.functional.interpolate(t.reshape(-1, 1, *t.shape[-2:]), (res, res), mode="bicubic",
+                                                    align_corners=False).contiguous()
+            nb = t.numel() // (res * res)
+            if nb not in (1, B):
+                raise ValueError(f"noise{l}: batch {nb} does not match latents batch {B}")
+            keep.append(t)
+            ptrs[l], strides[l] = t.data_ptr(), (0 if nb == 1 else res * res)
+        return ptrs, strides, keep
+
+    def forward(self, ws, noise_mode="const", noise=None, out=None, rgb8_out=None):
+        """ws [B, num_ws, w_dim] -> img f32 [B, 3, R, R].  ``noise``: optional list of per-layer tensors
+        [B|1, 1, h, w] replacing the layers' noise_const for this call (what the reference's
+        StyleGAN2Synthesizer installs per batch).  ``rgb8_out``: optional uint8 [B, R, R, 3] buffer that
+        receives the packed frame (render/ffmpeg.py:72 + ops/io.py:47-70) in the same call."""
+        if noise_mode != "const":
+            raise NotImplementedError("noise_mode must be 'const' (the render path never uses 'random')")
+        net = self._handle()
+        ws = L.dev_tensor(ws, torch.float32)
+        B = ws.shape[0]
+        if tuple(ws.shape[1:]) != (self.num_ws, self.w_dim):
+            raise ValueError(f"ws must be [B, {self.num_ws}, {self.w_dim}], got {tuple(ws.shape)}")
+        R = self.img_resolution
+        if out is None and rgb8_out is None:
+            out = torch.empty((B, 3, R, R), dtype=torch.float32, device=ws.device)
+        ptrs, strides, keep = self._noise_args(noise, B)
+        L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
+        del keep
+        return out if out is not None else rgb8_out
+
+    def get_feature(self, layer, B):
+        shp = self.layer_shapes()[layer]
+        out = torch.empty((B, shp[2], shp[3], shp[3]), dtype=torch.float32, device="cuda")
+        L.check(L.lib().maua_synth_get_feature(self._handle(), layer, B, L.ptr(out)))
+        return out
+
+
+class MappingNetwork(torch.nn.Module):
+    """inference/stylegan2.py:116-192 (c_dim == 0).  A [P,512] x 8 plain-GEMM chain executed once per clip with
+    torch's library GEMMs on the HIP device (rocBLAS); in-tree semantics incl. the x @ w quirk."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, lr_multiplier=0.01, nv_compat=False,
+                 generator=None):
+        super().__init__()
+        if c_dim != 0:
+            raise NotImplementedError("class conditioning is not on the render path")
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
+        self.lr_multiplier, self.nv_compat = lr_multiplier, nv_compat
+        feats = [z_dim] + [w_dim] * num_layers
+        self._params = {}
+        for i in range(num_layers):
+            self._params[f"fcs.{i}.weight"] = _randn([feats[i + 1], feats[i]], generator) / lr_multiplier
+            self._params[f"fcs.{i}.bias"] = torch.zeros([feats[i + 1]])
+        self._params["w_avg"] = torch.zeros([w_dim])
+
+    def state_dict(self, *a, **k):
+        return dict(self._params)
+
+    def load_state_dict(self, sd, strict=True):
+        for k in self._params:
+            if k in sd:
+                self._params[k] = sd[k].detach().float().cpu()
+            elif strict:
+                raise KeyError(k)
+
+    def forward(self, z, c=None, truncation_psi=1.0, truncation_cutoff=None):
+        L.require_device()
+        x = L.dev_tensor(z, torch.float32)
+        x = ops.normalize_2nd_moment(x)
+        for i in range(self.num_layers):
+            w = self._params[f"fcs.{i}.weight"].to(x.device) * (self.lr_multiplier / sqrt(self._params[f"fcs.{i}.weight"].shape[1]))
+            b = self._params[f"fcs.{i}.bias"].to(x.device) * self.lr_multiplier
+            y = x @ (w.T if self.nv_compat else w)
+            x = ops.bias_act(y[:, :, None, None], b, act="lrelu")[:, :, 0, 0]
+        x = x.unsqueeze(1).repeat(1, self.num_ws, 1)
+        if truncation_psi != 1:
+            x = self._params["w_avg"].to(x.device).lerp(x, truncation_psi)
+        return x

@@ -78,7 +78,7 @@ def save(name, **arrays):
         out[k] = np.asarray(v)
     path = HERE / f"{name}.npz"
     np.savez_compressed(path, **out)
-    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  keys={list(out)}")
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  {len(out)} arrays")
 
 
 T = torch.tensor
@@ -308,8 +308,9 @@ def golden_audio():
 
     # salience_weighted (selfsupervised/mir.py:13-21) needs librosa at import -> stubbed module import works
     from maua.audiovisual.audioreactive.selfsupervised import mir as SM
-    feat = SM.normalize(SM.salience_weighted(SM.gaussian_filter(ons, sigma=2)))
-    save("g11_salience", onsets=ons, feat=feat)
+    env800 = torch.rand(800, 1, generator=g) ** 3  # long enough for the sigma=80 reflect padding (radius 320)
+    feat = SM.normalize(SM.salience_weighted(SM.gaussian_filter(env800, sigma=2)))
+    save("g11_salience", env=env800, feat=feat)
 
 
 # --------------------------------------------------------------------------------------- latents / noise / io

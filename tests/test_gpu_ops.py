@@ -1,0 +1,165 @@
+"""HIP operator layer (through the C ABI) vs the oracle and the reference-generated goldens.  GPU only."""
+from math import sqrt
+
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    import maua_amd.ops as m
+    return m
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) / max(1e-12, float(b.abs().max()))
+
+
+# tolerances: f32 path = exact-f32 MFMA, only summation order differs from the oracle -> 1e-5 relative to max|ref|
+# (1e-6 for elementwise ops); bf16 path = operands rounded to 8 mantissa bits -> 2e-2.
+F32_TOL, F32_EW_TOL, BF16_TOL = 1e-5, 1e-6, 2e-2
+
+
+def test_bias_act_golden(M, golden):
+    g = golden("g02_bias_act")
+    x, b = g["x"], g["b"]
+    for act in ["linear", "lrelu"]:
+        for gi, gain in enumerate([1.0, sqrt(2)]):
+            for ci, clamp in enumerate([None, 2.5]):
+                y = M.bias_act(x, b, act=act, gain=gain, clamp=clamp)
+                assert relerr(y, g[f"y_{act}_g{gi}_c{ci}"]) <= F32_EW_TOL
+    assert relerr(M.bias_act(x, b, act="relu"), g["y_relu_default"]) <= F32_EW_TOL
+    assert relerr(M.bias_act(x, None, act="sigmoid"), g["y_sigmoid_nobias"]) <= F32_EW_TOL
+    assert relerr(M.bias_act(x, b, act="tanh"), g["y_tanh"]) <= 2e-6
+    assert relerr(M.bias_act(x, b, act="swish"), g["y_swish"]) <= 2e-6
+    assert relerr(M.bias_act(x * 100, b, act="lrelu", gain=torch.tensor(sqrt(2)), clamp=torch.tensor(256.0)),
+                  g["y_lrelu_clamp256"]) <= F32_EW_TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 3, 5, 7), (1, 32, 64, 64), (3, 5, 16, 16)])
+@pytest.mark.parametrize("act", ["linear", "relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"])
+def test_bias_act_random(M, shape, act):
+    g = torch.Generator().manual_seed(hash((shape, act)) % 1000)
+    x = torch.randn(shape, generator=g) * 2
+    b = torch.randn(shape[1], generator=g)
+    assert relerr(M.bias_act(x, b, act=act, clamp=3.0), O.bias_act(x, b, act=act, clamp=3.0)) <= 3e-6
+    xb = x.bfloat16()
+    yb = M.bias_act(xb, b, act=act)
+    assert yb.dtype == torch.bfloat16
+    assert relerr(yb, O.bias_act(xb.float(), b, act=act)) <= 1e-2
+
+
+def test_bias_act_empty(M):
+    y = M.bias_act(torch.zeros(0, 4, 8, 8), torch.zeros(4))
+    assert y.shape == (0, 4, 8, 8)
+
+
+def test_upfirdn2d_golden(M, golden):
+    g = golden("g03_upfirdn2d")
+    f = g["f"]
+    assert relerr(M.upfirdn2d(g["x"], f, up=2, padding=(2, 1, 2, 1), gain=4), g["y_up"]) <= F32_TOL
+    assert relerr(M.upfirdn2d(g["x17"], f, padding=torch.tensor([1, 1, 1, 1]), gain=torch.tensor(4)), g["y_fir"]) <= F32_TOL
+    assert relerr(M.upfirdn2d(g["x"], f, down=2, padding=(1, 1, 1, 1)), g["y_down"]) <= F32_TOL
+    assert relerr(M.upfirdn2d(g["x"], f, padding=(2, -1, -1, 3)), g["y_crop"]) <= F32_TOL
+    assert relerr(M.upfirdn2d(g["xr"], f, up=2, padding=(2, 1, 2, 1), gain=4), g["y_rect"]) <= F32_TOL
+    g = golden("g04_upsample2d")
+    assert relerr(M.upsample2d(g["x"], g["f"]), g["y"]) <= F32_TOL
+
+
+@pytest.mark.parametrize("hw,up,down,pad", [((33, 70), 2, 1, (2, 1, 2, 1)), ((64, 64), 1, 2, (1, 1, 1, 1)),
+                                              ((7, 5), 3, 2, (4, 0, -1, 5)), ((130, 130), 2, 1, (2, 1, 2, 1)),
+                                              ((16, 16), 1, 1, (0, 0, 0, 0))])
+def test_upfirdn2d_random(M, hw, up, down, pad):
+    g = torch.Generator().manual_seed(sum(hw) + up + down)
+    x = torch.randn(2, 3, *hw, generator=g)
+    f = O.setup_filter([1, 3, 3, 1])
+    ref = O.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=up * up)
+    assert relerr(M.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=up * up), ref) <= F32_TOL
+    f5 = torch.randn(5, 3, generator=g)
+    if hw[0] * up + pad[2] + pad[3] >= 5:
+        ref = O.upfirdn2d(x, f5, up=up, down=down, padding=pad)
+        assert relerr(M.upfirdn2d(x, f5, up=up, down=down, padding=pad), ref) <= F32_TOL
+    yb = M.upfirdn2d(x.bfloat16(), f, up=up, down=down, padding=pad, gain=up * up)
+    assert relerr(yb, O.upfirdn2d(x.bfloat16().float(), f, up=up, down=down, padding=pad, gain=up * up)) <= 1e-2
+
+
+def test_modconv_golden(M, golden):
+    g = golden("g05_modconv_up1")
+    y = M.modulated_conv2d(g["x"], g["w3"], g["s"], noise=g["noise"], up=1, padding=1)
+    assert relerr(y, g["y_demod"]) <= F32_TOL
+    y = M.modulated_conv2d(g["x"], g["w3"], g["s"], up=torch.tensor(1), padding=torch.tensor(1))
+    assert relerr(y, g["y_demod_nonoise"]) <= F32_TOL
+    y = M.modulated_conv2d(g["x"], g["w1"], g["s"], demodulate=False)
+    assert relerr(y, g["y_1x1"]) <= F32_TOL
+    g = golden("g06_modconv_up2")
+    y = M.modulated_conv2d(g["x"], g["w3"], g["s"], noise=g["noise"], up=2, padding=1, resample_filter=g["f"])
+    assert relerr(y, g["y"]) <= F32_TOL
+
+
+CASES = [  # (B, Ci, Co, H, W, up)
+    (1, 32, 32, 16, 16, 1), (2, 64, 64, 32, 32, 1), (1, 128, 128, 16, 16, 1), (2, 256, 128, 8, 8, 2),
+    (1, 64, 32, 32, 32, 2), (3, 40, 24, 12, 20, 1), (1, 16, 96, 5, 7, 2), (2, 512, 512, 4, 4, 1),
+    (1, 32, 32, 64, 64, 1), (1, 128, 64, 33, 17, 2),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_modconv_random(M, case, dt):
+    B, ci, co, h, w, up = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, ci, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    s = torch.randn(B, ci, generator=g) + 1
+    nz = torch.randn(B, 1, h * up, w * up, generator=g)
+    bias = torch.randn(co, generator=g)
+    f = O.setup_filter([1, 3, 3, 1])
+    xin = x if dt == "f32" else x.bfloat16()
+    ref = O.modulated_conv2d(xin.float(), wt, s, noise=nz, up=up, padding=1, resample_filter=f)
+    ref = O.bias_act(ref, bias, act="lrelu", gain=sqrt(2), clamp=256.0)
+    y = M.modulated_conv2d(xin, wt, s, noise=nz, up=up, padding=1, resample_filter=f, bias=bias, act="lrelu",
+                           gain=sqrt(2), clamp=256.0)
+    assert relerr(y, ref) <= (F32_TOL if dt == "f32" else BF16_TOL)
+    # nv_compat flip and broadcast noise
+    if up == 2:
+        ref = O.modulated_conv2d(xin.float(), wt, s, noise=nz[:1], up=2, padding=1, resample_filter=f, flip_weight=True)
+        y = M.modulated_conv2d(xin, wt, s, noise=nz[:1], up=2, padding=1, resample_filter=f, flip_weight=True)
+        assert relerr(y, ref) <= (F32_TOL if dt == "f32" else BF16_TOL)
+
+
+def test_modconv_linearity_full_size(M):
+    """size-independent property at a BASELINE-size layer (1024^2, 32->32, bf16 is exercised in test_synth):
+    conv(x1 + x2) == conv(x1) + conv(x2) without demod/noise/bias (f32 path), on 512^2 to bound memory."""
+    g = torch.Generator().manual_seed(5)
+    x1 = torch.randn(1, 32, 512, 512, generator=g)
+    x2 = torch.randn(1, 32, 512, 512, generator=g)
+    wt = torch.randn(32, 32, 3, 3, generator=g) / 17
+    s = torch.rand(1, 32, generator=g) + 0.5
+    a = M.modulated_conv2d(x1, wt, s, padding=1, demodulate=False)
+    b = M.modulated_conv2d(x2, wt, s, padding=1, demodulate=False)
+    c = M.modulated_conv2d(x1 + x2, wt, s, padding=1, demodulate=False)
+    assert relerr(c, a + b) <= 1e-5
+
+
+def test_pack_rgb8(M, golden):
+    import ctypes as C
+    from maua_amd import _lib as L
+    g = golden("g14_tensor2bytes")
+    img = g["img"].cuda()
+    out = torch.empty((1, 4, 8, 3), dtype=torch.uint8, device="cuda")
+    # the golden is tensor2bytes(img) with value_range (0,1): feed 2*img-1 so that (x+1)/2 == img
+    L.check(L.lib().maua_pack_rgb8(L.ctx(), L.ptr((img * 2 - 1).contiguous()), L.ptr(out), 1, 4, 8))
+    diff = (out.cpu().int()[0] - g["bytes"].int()).abs()
+    assert int(diff.max()) <= 1  # 2*img-1 then (x+1)/2 may move an exact .5 tie by one ulp
+    exact = torch.tensor([[-1.0, 0.0, 1.0, 0.5, -0.5, 3.0, 1 / 255, 127 / 255 * 2 - 1]]).reshape(1, 1, 1, 8)
+    img = exact.repeat(1, 3, 1, 1).cuda().contiguous()
+    out = torch.empty((1, 1, 8, 3), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().maua_pack_rgb8(L.ctx(), L.ptr(img), L.ptr(out), 1, 1, 8))
+    want = ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)
+    assert torch.equal(out, want)
