@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Benchmark of the audio-reactive StyleGAN2 render hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): random-init 1024x1024 StyleGAN2 SynthesisNetwork (seed 0), bf16 operands /
+f32 accumulate, 3600-frame clip @30 fps (120 s of synthetic audio at 30 720 Hz), frames sharded by contiguous
+range over the ranks.  One "step" = one batch of B frames through the per-batch hot path of
+selfsupervised/sample.py:90-98 (reference): 17 index-addressed Loop noise maps -> StyleGAN2 synthesis forward ->
+(x+1)/2 -> u8 HWC pack.  Latents (spline-loop schedule blended by the onset envelope) and network weights are
+resident in HBM before the timed region, as the reference has them resident before its render loop.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+T_FRAMES, FPS, RES, W_DIM = 3600, 30, 1024, 512
+NOISE_SIZES = [4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024]  # patch.py:142-151
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
+    return ap.parse_args()
+
+
+def layer_table(net):
+    """per-launch algorithmic work of one forward (per frame): name, kernel group, GFLOP (tconv-minimal MACs*2,
+    SURVEY 8(a) table), algorithmic bytes (input read once + output written once)."""
+    rows = [("styles", "styles", 0.0, 0.0)]
+    shapes = net.layer_shapes()
+    li = 0
+    for i, r in enumerate(net.block_resolutions):
+        for _ in range(1 if i == 0 else 2):
+            pfx, ci, co, res, up = shapes[li]
+            li += 1
+            hin = res // up
+            gflop = 2 * hin * hin * 9 * ci * co / 1e9
+            byts = (hin * hin * ci + res * res * co) * 2 + res * res * 4  # bf16 in/out + f32 noise
+            grp = "modconv3x3<bn128>" if co % 128 == 0 else "modconv3x3<bn64>" if co % 64 == 0 else "modconv3x3<bn32>"
+            rows.append((pfx, grp, gflop, byts))
+        c = shapes[li - 1][2]
+        rows.append((f"bs.{i}.torgb", "torgb", 2 * r * r * c * 3 / 1e9, r * r * c * 2 + r * r * 12 + (r // 2) ** 2 * 12))
+    rows.append(("pack_rgb8", "pack_rgb8", 0.0, RES * RES * 15))
+    return rows
+
+
+def build_inputs(device, rank, world, seed=0):
+    """Everything that is resident in HBM before the render loop."""
+    from maua_amd.noise import Loop
+    from maua_amd.stylegan2 import SynthesisNetwork
+    from maua_amd import pipeline
+
+    net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(seed))
+    latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, net.num_ws, W_DIM)
+    rng = torch.Generator().manual_seed(42)
+    noise = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
+    return net, latents.to(device), noise, info
+
+
+def cpu_baseline(seconds):
+    """The oracle (CPU restatement of the reference, fp32, PyTorch-CPU convs composed like ops.py) on the same
+    workload, bounded: whole 1024^2 frames (B=1) until `seconds` of CPU time are spent (at least 1)."""
+    from oracle import noise as ON
+    from oracle import stylegan2 as OS
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = OS.init_synthesis_params(RES, generator=torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    ws = torch.randn(1, OS.num_ws(RES), W_DIM, generator=g)
+    planes = [torch.randn(3, s, s, generator=g) for s in NOISE_SIZES]
+    idx = torch.linspace(0, 4 * 2 * torch.pi, T_FRAMES)
+    n, t0 = 0, time.time()
+    with torch.no_grad():
+        while True:
+            noise = [ON.loop(pl, idx, n, 1, 5)[:, None] for pl in planes]
+            img = OS.synthesis_network(p, ws, noise=noise)
+            img.add(1).div(2).clamp(0, 1).mul(255).round().byte()
+            n += 1
+            if time.time() - t0 >= seconds:
+                break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} frame(s) of the same 1024x1024 workload (B=1, fp32 oracle: noise + synthesis + u8), {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (maua_amd has no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from maua_amd import _lib as L
+    from maua_amd import pipeline
+    net, latents, noise, info = build_inputs(device, rank, world)
+    B = a.batch
+    lo, hi = pipeline.frame_range(T_FRAMES, rank, world)
+    out_u8 = torch.empty((a.steps, B, RES, RES, 3), dtype=torch.uint8, device=device)
+    scratch_u8 = torch.empty((B, RES, RES, 3), dtype=torch.uint8, device=device)
+
+    def step(k, u8):
+        i = lo + (k * B) % max(1, (hi - lo) - B + 1)  # batches walk this rank's frame range
+        nz = [m.forward(i, B) for m in noise]
+        net(latents[i:i + B], noise=nz, rgb8_out=u8)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        step(k, scratch_u8)
+    h = net._handle()
+    lib = L.lib()
+    L.check(lib.maua_synth_set_option(h, b"profile", 1))
+    fence()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(k, out_u8[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-launch HIP-event durations recorded on the kernels' stream during the timed steps
+    cnt = C.c_int()
+    L.check(lib.maua_synth_get_profile(h, None, 0, C.byref(cnt)))
+    ms = (C.c_float * max(1, cnt.value))()
+    L.check(lib.maua_synth_get_profile(h, ms, cnt.value, C.byref(cnt)))
+    L.check(lib.maua_synth_set_option(h, b"profile", 0))
+
+    # final gather of the u8 frames to rank 0 (one RCCL gather over xGMI, not part of the per-step rate)
+    gather_ms = None
+    if dist is not None:
+        fence()
+        tg = time.perf_counter()
+        bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
+        dist.gather(out_u8, bufs, dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * B * a.steps
+        rows = layer_table(net)
+        per_fwd = len(rows)
+        groups = {}
+        nfwd = cnt.value // per_fwd if per_fwd else 0
+        for f in range(nfwd):
+            for j, (name, grp, gflop, byts) in enumerate(rows):
+                g = groups.setdefault(grp, {"ms": 0.0, "gflop": 0.0, "bytes": 0.0, "launches": 0})
+                g["ms"] += ms[f * per_fwd + j]
+                g["gflop"] += gflop * B
+                g["bytes"] += byts * B
+                g["launches"] += 1
+        dom = max((g for g in groups if g.startswith("modconv") or g == "torgb"), key=lambda g: groups[g]["ms"])
+        gd = groups[dom]
+        roof_all = {}
+        for gname, g in groups.items():
+            if g["ms"] <= 0:
+                continue
+            roof_all[gname] = {"ms_per_launch": g["ms"] / g["launches"], "launches_per_step": g["launches"] // max(1, nfwd),
+                               "tflops": g["gflop"] / g["ms"], "gbs": g["bytes"] / g["ms"] / 1e6,
+                               "share_of_gpu_time": g["ms"] / sum(x["ms"] for x in groups.values())}
+        if dom == "modconv3x3<bn128>":
+            ach = gd["gflop"] / gd["ms"]  # GFLOP/ms = TFLOP/s
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_BF16_PEAK_TF}
+        else:
+            ach = gd["bytes"] / gd["ms"] / 1e6
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+        roof.update({"kernel": dom, "avg_launch_ms": gd["ms"] / gd["launches"], "launches_timed": gd["launches"],
+                     "traffic": pipeline.measured_traffic(dom)})
+        res = {
+            "metric": "frames/sec (whole node), 1024x1024 StyleGAN2 audio-reactive render",
+            "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1024x1024 random-init StyleGAN2 (seed 0), 3600-frame clip @30fps "
+                                   "(120 s synthetic audio @30720 Hz), per step: 17 Loop noise maps + synthesis + u8 pack",
+                       "frames_per_step_per_gpu": B, "clip_frames": T_FRAMES, "frame_sharding": f"contiguous x{world}",
+                       "latents": info},
+            "roofline": roof, "kernels": roof_all, "gather_ms": gather_ms,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,8 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
 void maua_synth_destroy(maua_synth* net);
 int maua_synth_num_ws(const maua_synth* net);
 int maua_synth_num_layers(const maua_synth* net);
-/* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug). */
+/* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug);
+ * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward. */
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.
@@ -99,8 +100,27 @@ int maua_synth_forward(maua_synth* net, const float* ws, const float* const* noi
 /* same, plus the u8 pack fused behind it (render/ffmpeg.py:72 + ops/io.py:47-70); img_out may be NULL. */
 int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const* noise,
                            const long* noise_batch_stride, int B, float* img_out, uint8_t* rgb8_out);
+/* profile mode: per-launch durations (ms) of every forward since the last read, in launch order per forward:
+ * styles, then per block [conv0,] conv1, torgb, then pack_rgb8 if requested.  Synchronises on the last event;
+ * a call with ms_out != NULL resets the recording (ms_out == NULL only returns the count). */
+int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* count);
 /* debug/parity: copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
 int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
+
+/* ---- per-batch noise (selfsupervised patch) ----------------------------------------------------- */
+/* replaces selfsupervised/noise.py:42-53 Loop.forward(i, b): planes [3,h,w] f32 (the module's randn buffer),
+ * idx [T] f32 (= linspace(0, 2*pi*n_loops, T)), frames i0..i0+B-1 ->
+ * out[b] = sin(cos(idx[i0+b] + n0) / (sigma/50) + n1) * n2, divided by its per-frame RMS + eps(f32).  out [B,h,w]. */
+int maua_noise_loop(maua_ctx* ctx, const float* planes, const float* idx, int i0, int B, int h, int w, float sigma,
+                    float* out);
+/* replaces noise.py:11-24 Blend.forward (noise2 != NULL: sum_m noise[m]*mod[b,m] + sum_m noise2[m]*(1-mod[b,m]))
+ * and :27-39 Multiply.forward (noise2 == NULL).  noise/noise2 [M,h,w], mod [B,M] (rows i..i+B of the modulator). */
+int maua_noise_mix(maua_ctx* ctx, const float* noise, const float* noise2, const float* mod, int M, int B, int h,
+                   int w, float* out);
+/* replaces noise.py:56-63 Average (mode 0: (x+y)/2), :66-75 Modulate (mode 1: x*mod[b] + y*(1-mod[b]), mod [B]),
+ * :78-86 ScaleBias (mode 2: scale*x + bias).  x, y, out [B,h,w]. */
+int maua_noise_combine(maua_ctx* ctx, const float* x, const float* y, const float* mod, int mode, float scale,
+                       float bias, int B, int h, int w, float* out);
 
 #ifdef __cplusplus
 }

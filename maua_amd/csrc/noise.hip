@@ -1,0 +1,149 @@
+// Index-addressed noise modules of the selfsupervised patch (reference
+// maua/audiovisual/audioreactive/selfsupervised/noise.py): Loop :42-53, Blend :11-24, Multiply :27-39.
+// HBM-bound elementwise work with one per-frame reduction (RMS); two launches per call, deterministic
+// (fixed-order partial sums, no atomics).
+#include "common.h"
+#include "internal.h"
+
+namespace maua {
+
+constexpr int NZ_BLOCKS = 32;  // partial-sum blocks per frame
+
+__device__ __forceinline__ float loop_value(float idx, float n0, float n1, float n2, float sigma50) {
+  float freqs = cosf(idx + n0) / sigma50;       // noise.py:50
+  return sinf(freqs + n1) * n2;                 // noise.py:51
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += sh[i];
+  return t;  // valid in thread 0
+}
+
+// pass 1: partial[b][blk] = sum over the block's slice of out^2
+__global__ __launch_bounds__(256) void noise_loop_sumsq_kernel(const float* __restrict__ planes,
+                                                               const float* __restrict__ idx, int i0, int hw,
+                                                               float sigma50, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const int b = blockIdx.y;
+  const float id = idx[i0 + b];
+  float acc = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
+    acc += v * v;
+  }
+  float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = t;
+}
+
+// pass 2: out = value / (sqrt(mean) + eps)   (noise.py:52)
+__global__ __launch_bounds__(256) void noise_loop_write_kernel(const float* __restrict__ planes,
+                                                               const float* __restrict__ idx, int i0, int hw,
+                                                               float sigma50, const float* __restrict__ partial,
+                                                               int nparts, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  float tot = 0.f;
+  for (int i = 0; i < nparts; i++) tot += partial[b * nparts + i];  // fixed order, identical in every thread
+  const float denom = sqrtf(tot / (float)hw) + 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+  const float id = idx[i0 + b];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
+    out[(long)b * hw + p] = v / denom;
+  }
+}
+
+// Blend / Multiply: out[b,p] = sum_m noise[m,p] * mod[b,m]  (+ sum_m noise2[m,p] * (1 - mod[b,m]))
+__global__ __launch_bounds__(256) void noise_mix_kernel(const float* __restrict__ noise, const float* __restrict__ noise2,
+                                                        const float* __restrict__ mod, int M, int hw,
+                                                        float* __restrict__ out) {
+  extern __shared__ float ms[];
+  const int b = blockIdx.y;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) ms[m] = mod[(long)b * M + m];
+  __syncthreads();
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
+    float l = 0.f, r = 0.f;
+    for (int m = 0; m < M; m++) {
+      l += noise[(long)m * hw + p] * ms[m];
+      if (noise2) r += noise2[(long)m * hw + p] * (1.f - ms[m]);
+    }
+    out[(long)b * hw + p] = noise2 ? l + r : l;
+  }
+}
+
+// Average (mode 0), Modulate (mode 1), ScaleBias (mode 2)   (noise.py:56-86)
+__global__ __launch_bounds__(256) void noise_combine_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ mod, int mode, float scale,
+                                                            float bias, long hw, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const float m = (mode == 1) ? mod[b] : 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) {
+    long o = (long)b * hw + p;
+    float v;
+    if (mode == 0) v = (x[o] + y[o]) / 2.f;
+    else if (mode == 1) v = x[o] * m + y[o] * (1.f - m);
+    else v = scale * x[o] + bias;
+    out[o] = v;
+  }
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+int maua_noise_loop(maua_ctx* ctx, const float* planes, const float* idx, int i0, int B, int h, int w, float sigma,
+                    float* out) {
+  MAUA_REQUIRE(ctx, "maua_noise_loop: ctx is NULL");
+  if (B == 0 || h * w == 0) return MAUA_OK;
+  MAUA_REQUIRE(planes && idx && out, "maua_noise_loop: NULL argument");
+  MAUA_REQUIRE(sigma != 0.f, "maua_noise_loop: sigma must be non-zero");
+  const int hw = h * w;
+  const int nblk = std::min(NZ_BLOCKS, cdiv(hw, 256));
+  if (int rc = scratch_reserve(ctx, (size_t)B * nblk * sizeof(float))) return rc;
+  float* partial = (float*)ctx->scratch;
+  const float sigma50 = (float)((double)sigma / 50.0);
+  hipLaunchKernelGGL(noise_loop_sumsq_kernel, dim3(nblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, sigma50,
+                     partial);
+  MAUA_HIP_CHECK(hipGetLastError());
+  const int wblk = std::min(256, cdiv(hw, 256));
+  hipLaunchKernelGGL(noise_loop_write_kernel, dim3(wblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, sigma50,
+                     partial, nblk, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_noise_mix(maua_ctx* ctx, const float* noise, const float* noise2, const float* mod, int M, int B, int h,
+                   int w, float* out) {
+  MAUA_REQUIRE(ctx, "maua_noise_mix: ctx is NULL");
+  if (B == 0 || h * w == 0) return MAUA_OK;
+  MAUA_REQUIRE(noise && mod && out && M > 0, "maua_noise_mix: NULL argument");
+  const int hw = h * w;
+  hipLaunchKernelGGL(noise_mix_kernel, dim3(std::min(256, cdiv(hw, 256)), B), dim3(256), (size_t)M * sizeof(float),
+                     ctx->stream, noise, noise2, mod, M, hw, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_noise_combine(maua_ctx* ctx, const float* x, const float* y, const float* mod, int mode, float scale,
+                       float bias, int B, int h, int w, float* out) {
+  MAUA_REQUIRE(ctx, "maua_noise_combine: ctx is NULL");
+  if (B == 0 || h * w == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && out, "maua_noise_combine: NULL argument");
+  MAUA_REQUIRE(mode >= 0 && mode <= 2, "maua_noise_combine: mode must be 0 (average), 1 (modulate) or 2 (scale+bias)");
+  MAUA_REQUIRE(mode == 2 || y, "maua_noise_combine: y is NULL");
+  MAUA_REQUIRE(mode != 1 || mod, "maua_noise_combine: mod is NULL");
+  const long hw = (long)h * w;
+  hipLaunchKernelGGL(noise_combine_kernel, dim3((unsigned)std::min<long>(256, (hw + 255) / 256), B), dim3(256), 0,
+                     ctx->stream, x, y, mod, mode, scale, bias, hw, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // extern "C"

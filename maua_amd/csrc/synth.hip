@@ -57,6 +57,12 @@ struct maua_synth {
   std::vector<RgbLayer> rgbs;
   void* const_x = nullptr;  // NHWC [4][4][C0]
   int keep_features = 0;
+  // profile mode: HIP events recorded on the ctx stream around every launch of a forward
+  int profile = 0;
+  std::vector<hipEvent_t> ev;
+  std::vector<std::string> ev_names;
+  size_t ev_used = 0;
+  std::vector<size_t> ev_fwd_start;
   // workspace
   int bcap = 0;
   void* act[2] = {nullptr, nullptr};
@@ -64,6 +70,17 @@ struct maua_synth {
   StyleLayer* style_table_dev = nullptr;
   float fir[16];
 };
+
+static void prof_mark(maua_synth* n, const char* name) {
+  if (!n->profile || n->ev_used >= (1u << 16)) return;
+  if (n->ev_used == n->ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    n->ev.push_back(e);
+  }
+  hipEventRecord(n->ev[n->ev_used++], n->ctx->stream);
+  n->ev_names.push_back(name);
+}
 
 static int channels_for(int res, int base, int maxc) { return std::min(base / res, maxc); }
 
@@ -208,6 +225,7 @@ void maua_synth_destroy(maua_synth* n) {
   if (!n) return;
   hipStreamSynchronize(n->ctx->stream);
   free_workspace(n);
+  for (auto e : n->ev) hipEventDestroy(e);
   for (auto& c : n->convs) {
     hipFree(c.affine_w); hipFree(c.affine_b); hipFree(c.bias); hipFree(c.noise_const); hipFree(c.wt); hipFree(c.wsq);
   }
@@ -223,6 +241,13 @@ int maua_synth_num_layers(const maua_synth* n) { return n ? (int)n->convs.size()
 
 int maua_synth_set_option(maua_synth* n, const char* key, int value) {
   MAUA_REQUIRE(n && key, "maua_synth_set_option: NULL argument");
+  if (!strcmp(key, "profile")) {
+    n->profile = value;
+    n->ev_used = 0;
+    n->ev_names.clear();
+    n->ev_fwd_start.clear();
+    return MAUA_OK;
+  }
   if (!strcmp(key, "keep_features")) {
     if (n->keep_features != value) {
       MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
@@ -322,8 +347,12 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   if (int rc = ensure_workspace(n, B)) return rc;
   hipStream_t st = n->ctx->stream;
   const int ntab = (int)(n->convs.size() + n->rgbs.size());
+  // events accumulate across forwards until maua_synth_get_profile() reads and resets them
+  n->ev_fwd_start.push_back(n->ev_used);
+  prof_mark(n, "begin");
   if (int rc = launch_styles(st, n->style_table_dev, ntab, ws, n->num_ws, n->w_dim, B)) return rc;
 
+  prof_mark(n, "styles");
   const void* x = n->const_x;
   long x_bstride = 0;
   int cur = 0;
@@ -346,6 +375,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       a.B = B; a.H = c.res / c.up; a.W = c.res / c.up; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
       a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
       if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
+      prof_mark(n, c.which == 0 ? "conv0" : "conv1");
       x = y;
       x_bstride = (long)c.res * c.res * c.Co;
       cur ^= 1;
@@ -358,10 +388,33 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
     r.out = out; r.B = B; r.H = g.res; r.W = g.res; r.C = g.C; r.clamp = 256.f;
     memcpy(r.fir, n->fir, sizeof(r.fir));
     if (int rc = launch_torgb(st, n->dtype, r)) return rc;
+    prof_mark(n, "torgb");
     prev_img = out;
     img_cur ^= 1;
   }
-  if (rgb8_out) return launch_pack_rgb8(st, prev_img, rgb8_out, B, n->res, n->res);
+  if (rgb8_out) {
+    if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->res, n->res)) return rc;
+    prof_mark(n, "pack_rgb8");
+  }
+  return MAUA_OK;
+}
+
+int maua_synth_get_profile(maua_synth* n, float* ms_out, int capacity, int* count) {
+  MAUA_REQUIRE(n && count, "maua_synth_get_profile: NULL argument");
+  // one duration per launch; the "begin" marker of every recorded forward is skipped
+  int k = 0;
+  if (n->ev_used > 0) MAUA_HIP_CHECK(hipEventSynchronize(n->ev[n->ev_used - 1]));
+  for (size_t f = 0; f < n->ev_fwd_start.size(); f++) {
+    size_t lo = n->ev_fwd_start[f], hi = (f + 1 < n->ev_fwd_start.size()) ? n->ev_fwd_start[f + 1] : n->ev_used;
+    for (size_t i = lo; i + 1 < hi; i++, k++)
+      if (ms_out && k < capacity) MAUA_HIP_CHECK(hipEventElapsedTime(&ms_out[k], n->ev[i], n->ev[i + 1]));
+  }
+  *count = k;
+  if (ms_out) {  // reading resets the recording
+    n->ev_used = 0;
+    n->ev_names.clear();
+    n->ev_fwd_start.clear();
+  }
   return MAUA_OK;
 }
 

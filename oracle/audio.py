@@ -1,0 +1,246 @@
+"""Oracle restatement of the audio feature chain (test infrastructure only).
+
+Follows the reference's pure-torch librosa re-implementation:
+  maua/audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py (stft :10-21, istft :24-32,
+  spectrogram :59-62, melspectrogram :65-70, mel_frequencies :73-78, mel :81-110, magphase :113-117,
+  softmask :120-142, hpss :145-161), rosa/convert.py (power_to_db :7-12, hz_to_mel :15-40, mel_to_hz :43-66),
+  rosa/beat.py (onset_strength :10-23), rosa/helpers.py (sync_agg :4-21),
+  features/processing.py (gaussian_filter :11-49, normalize :53-56, standardize :59-62, median_filter2d :75-85),
+  features/audio.py (harmonic :13-17, percussive :20-24, onsets :27-28, rms :31-37),
+  selfsupervised/mir.py (salience_weighted :13-21).
+STFT framing / overlap-add are written out explicitly (numpy-style) instead of calling torch.stft, so that the
+frame <-> sample mapping the HIP kernels must reproduce is stated once, here.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import quantile as Q
+
+N_FFT, HOP = 2048, 1024
+
+
+def hann(n=N_FFT):
+    """torch.hann_window(n) (periodic): 0.5 - 0.5 cos(2 pi k / n)."""
+    k = torch.arange(n, dtype=torch.float64)
+    return (0.5 - 0.5 * torch.cos(2 * np.pi * k / n)).float()
+
+
+def frame_signal(y, n_fft=N_FFT, hop=HOP):
+    """center=True, reflect padding of n_fft//2 each side; frame f covers samples [f*hop - n_fft/2, f*hop + n_fft/2)."""
+    yp = F.pad(y[None, None], (n_fft // 2, n_fft // 2), mode="reflect")[0, 0]
+    n_frames = 1 + (yp.numel() - n_fft) // hop
+    return yp.unfold(0, n_fft, hop)[:n_frames]  # [frames, n_fft]
+
+
+def stft(y, n_fft=N_FFT, hop=HOP):
+    """spectral.py:10-21 -> complex64 [n_fft//2+1, 1 + len(y)//hop], unnormalised, periodic Hann."""
+    fr = frame_signal(y, n_fft, hop) * hann(n_fft)
+    return torch.fft.rfft(fr, dim=1).T.contiguous()
+
+
+def istft(spec, n_fft=N_FFT, hop=HOP, length=None):
+    """spectral.py:24-32 (torch.istft, center=True): windowed inverse frames overlap-added, divided by the
+    overlap-added squared window, centre padding removed, cut/padded to `length`."""
+    w = hann(n_fft)
+    frames = torch.fft.irfft(spec.T, n=n_fft, dim=1) * w  # [frames, n_fft]
+    n_frames = frames.shape[0]
+    total = n_fft + hop * (n_frames - 1)
+    y = torch.zeros(total)
+    env = torch.zeros(total)
+    w2 = w * w
+    for f in range(n_frames):
+        y[f * hop: f * hop + n_fft] += frames[f]
+        env[f * hop: f * hop + n_fft] += w2
+    start = n_fft // 2
+    end = total - n_fft // 2 if length is None else start + length
+    y, env = y[start:end], env[start:end]
+    y = y / env
+    if length is not None and y.numel() < length:
+        y = F.pad(y, (0, length - y.numel()))
+    return y
+
+
+def spectrogram(y, power=1):
+    """spectral.py:59-62 — drops the LAST stft column."""
+    return stft(y)[:, :-1].abs() ** power
+
+
+def hz_to_mel(f):
+    """convert.py:15-40 (Slaney)."""
+    f = torch.as_tensor(f, dtype=torch.float32)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    if f.ndim:
+        t = f >= min_log_hz
+        mels[t] = min_log_mel + torch.log(f[t] / min_log_hz) / logstep
+    elif f >= min_log_hz:
+        mels = min_log_mel + torch.log(f / min_log_hz) / logstep
+    return mels
+
+
+def mel_to_hz(mels):
+    """convert.py:43-66."""
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    if mels.ndim:
+        t = mels >= min_log_mel
+        freqs[t] = min_log_hz * torch.exp(logstep * (mels[t] - min_log_mel))
+    elif mels >= min_log_mel:
+        freqs = min_log_hz * torch.exp(logstep * (mels - min_log_mel))
+    return freqs
+
+
+def mel_frequencies(n_mels=128, fmin=0.0, fmax=11025.0):
+    """spectral.py:73-78."""
+    return mel_to_hz(torch.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels))
+
+
+def mel_basis(sr, n_fft=N_FFT, n_mels=128, fmin=0.0, fmax=None):
+    """spectral.py:81-110 — Slaney-normalised triangular filters [n_mels, n_fft//2+1]."""
+    if fmax is None:
+        fmax = float(sr) / 2
+    fftfreqs = torch.linspace(0, float(sr) / 2, 1 + n_fft // 2)
+    mel_f = mel_frequencies(n_mels + 2, fmin, fmax)
+    fdiff = torch.diff(mel_f)
+    ramps = mel_f.reshape(-1, 1) - fftfreqs
+    w = torch.zeros(n_mels, 1 + n_fft // 2)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = torch.maximum(torch.zeros(()), torch.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2: n_mels + 2] - mel_f[:n_mels])
+    return w * enorm[:, None]
+
+
+def melspectrogram(y, sr, power=2.0, fmax=None):
+    """spectral.py:65-70."""
+    return mel_basis(sr, fmax=fmax) @ spectrogram(y, power=power)
+
+
+def power_to_db(S, amin=1e-10, top_db=80.0):
+    """convert.py:7-12 (ref_value = 1)."""
+    log_spec = 10.0 * torch.log10(torch.clamp(S, min=amin))
+    log_spec = log_spec - 10.0 * torch.log10(torch.tensor(1.0))
+    return torch.maximum(log_spec, log_spec.max() - top_db)
+
+
+def onset_strength(y, sr, n_fft=N_FFT, hop=HOP):
+    """beat.py:10-23 — mean over mels of the rectified lag-1 dB difference, left-padded by
+    1 + n_fft // (2*hop) zeros and cropped to the spectrogram length."""
+    S = power_to_db(melspectrogram(y, sr, fmax=11025.0).abs())
+    d = torch.clamp(S[:, 1:] - S[:, :-1], min=0).mean(0)
+    pad_width = 1 + n_fft // (2 * hop)
+    return F.pad(d, (pad_width, 0))[: S.shape[1]]
+
+
+def median_filter2d(x, k, p):
+    """processing.py:75-85 — x [1,1,H,W]; reflect pad p = (l, r, t, b); median over a k[0] x k[1] window
+    (torch.median: lower of the two middle values for even counts; all windows here are odd)."""
+    x = F.pad(x, p, mode="reflect")
+    x = x.unfold(2, k[0], 1).unfold(3, k[1], 1)
+    return x.contiguous().view(x.size()[:4] + (-1,)).median(dim=-1)[0]
+
+
+def softmask(X, X_ref, power=2.0, split_zeros=False):
+    """spectral.py:120-142."""
+    Z = torch.maximum(X, X_ref)
+    bad = Z < torch.finfo(torch.float32).tiny
+    Z = torch.where(bad, torch.ones_like(Z), Z)
+    mask = (X / Z) ** power
+    ref = (X_ref / Z) ** power
+    mask = torch.where(bad, torch.full_like(mask, 0.5 if split_zeros else 0.0), mask / (mask + ref))
+    return mask
+
+
+def hpss(D, ks=31, power=2.0, margin=1.0):
+    """spectral.py:145-161 on a complex STFT: (harmonic, percussive) complex spectra."""
+    S = D.abs()
+    phase = torch.exp(1.0j * torch.angle(D))
+    harm = median_filter2d(S[None, None], (1, ks), (ks // 2, ks // 2, 0, 0))[0, 0]
+    perc = median_filter2d(S[None, None], (ks, 1), (0, 0, ks // 2, ks // 2))[0, 0]
+    split = margin == 1
+    mh = softmask(harm, perc * margin, power, split)
+    mp = softmask(perc, harm * margin, power, split)
+    return (S * mh) * phase, (S * mp) * phase
+
+
+def harmonic(audio, margin=8.0):
+    """audio.py:13-17"""
+    return istft(hpss(stft(audio), margin=margin)[0], length=len(audio))
+
+
+def percussive(audio, margin=8.0):
+    """audio.py:20-24"""
+    return istft(hpss(stft(audio), margin=margin)[1], length=len(audio))
+
+
+def normalize(x):
+    """processing.py:53-56"""
+    x = x - x.min()
+    return x / (x.max() + 1e-8)
+
+
+def onsets(audio, sr):
+    """audio.py:27-28 -> [T, 1]"""
+    return normalize(onset_strength(percussive(audio), sr).unsqueeze(-1))
+
+
+def rms(y, frame_length=N_FFT, hop=HOP):
+    """audio.py:31-37 -> [T, 1] (drops the last frame)."""
+    fr = frame_signal(y, frame_length, hop)[:-1]
+    return torch.sqrt(torch.mean(fr.abs() ** 2, dim=1)).unsqueeze(-1)
+
+
+def gaussian_filter(x, sigma, mode="circular", causal=None, classic=False):
+    """processing.py:11-49 (selfsupervised; ignores `causal`) and, with classic=True, signal.py:108-157
+    (right half of the kernel multiplied by `causal` if it is a Python float, by 0 for any other non-None value).
+    Filters along dim 0 independently per element."""
+    dim = x.ndim
+    n = x.shape[0]
+    while x.ndim < 3:
+        x = x[:, None]
+    radius = min(int(sigma * 4), 3 * len(x))
+    ch = x.shape[1]
+    k = torch.arange(-radius, radius + 1, dtype=torch.float32)
+    k = torch.exp(-0.5 / sigma ** 2 * k ** 2)
+    if classic and causal is not None:
+        k[radius + 1:] *= causal if isinstance(causal, float) else 0
+    k = k / k.sum()
+    k = k.view(1, 1, -1).repeat(ch, 1, 1)
+    if dim == 4:
+        t, c, h, w = x.shape
+        x = x.reshape(t, c, h * w)
+    x = x.transpose(0, 2)
+    if radius > n:
+        x = F.pad(x, (n, n), mode=mode)
+        x = F.pad(x, (radius - n, radius - n), mode="replicate")
+    else:
+        x = F.pad(x, (radius, radius), mode=mode)
+    x = F.conv1d(x, k, groups=ch).transpose(0, 2)
+    if dim == 4:
+        x = x.reshape(t, c, h, w)
+    if x.ndim > dim:
+        x = x.squeeze()
+    return x
+
+
+def standardize(x):
+    """processing.py:59-62 (C++ midpoint quantile with float32 q)."""
+    return normalize(torch.clamp(x, Q.quantile(x, 0.25), Q.quantile(x, 0.75) + 1e-10))
+
+
+def salience_weighted(env, short_sigma=5, long_sigma=80):
+    """selfsupervised/mir.py:13-21"""
+    if env.dim() > 1:
+        env = env.squeeze(1)
+    short = gaussian_filter(env, short_sigma, mode="reflect")
+    long = gaussian_filter(env, long_sigma, mode="reflect")
+    w = (short / long) ** 2 * env
+    return w.unsqueeze(1) if w.dim() < 2 else w

@@ -1,0 +1,30 @@
+"""Oracle restatement of the output/seed boundary (test infrastructure only)."""
+import numpy as np
+import torch
+
+
+def tensor2bytes(t):
+    """maua/ops/io.py:47-70 with value_range (0,1): [1,C,H,W] -> uint8 [H,W,C] (round half to even)."""
+    return t.squeeze(0).permute(1, 2, 0).clamp(0, 1).sub(0).div(1).mul(255).round().byte().cpu().numpy()
+
+
+def frames_to_u8(img):
+    """render/ffmpeg.py:72 (.add(1).div(2)) followed by tensor2bytes per frame: [B,3,H,W] -> [B,H,W,3] u8."""
+    return np.stack([tensor2bytes(f[None].add(1).div(2)) for f in img])
+
+
+def parse_seeds(seeds):
+    """maua/GAN/wrappers/stylegan.py:59-65: "a-b,c" -> ints, ranges end-exclusive."""
+    out = []
+    for s in seeds.split(","):
+        if "-" in s:
+            a, b = s.split("-")
+            out += list(range(int(a), int(b)))
+        else:
+            out.append(int(s))
+    return out
+
+
+def get_z_latents(seeds, z_dim=512):
+    """stylegan.py:66-69 — float64 [P, z_dim] from numpy's MT19937 RandomState(seed).randn."""
+    return torch.cat([torch.from_numpy(np.random.RandomState(s).randn(1, z_dim)) for s in parse_seeds(seeds)])

@@ -111,3 +111,173 @@ def test_synth_init_order(golden):
             continue
         s = p[k.replace("__", ".")].double().sum().item()
         assert abs(s - float(v)) <= 1e-9 * max(1.0, abs(float(v))), k
+
+
+# ------------------------------------------------------------------------------------------ audio chain
+from oracle import audio as A
+from oracle import io as OIO
+from oracle import latent as OL
+from oracle import noise as ON
+from oracle import quantile as OQ
+from oracle import signal as OSG
+
+
+def test_stft_mel_onset(golden):
+    a = golden("g09_audio_clip")["audio"]
+    sr = 30720
+    g = golden("g09_stft")
+    D = A.stft(a)
+    assert D.shape[1] == int(g["n_cols"]) == 1 + len(a) // 1024
+    cols = g["cols"].long()
+    close(D.real[:, cols], g["D_re"], 2e-6)
+    close(D.imag[:, cols], g["D_im"], 2e-6)
+    S1 = A.spectrogram(a)
+    assert list(S1.shape) == g["S1_shape"].tolist()  # frame count = N // 1024 (int-exact)
+    close(S1[:, cols[:-1]], g["S1_cols"], 2e-6)
+    g = golden("g09_mel")
+    close(A.mel_frequencies(130), g["mel_f"], 1e-6)
+    basis = A.mel_basis(sr, fmax=11025.0)
+    close(basis.sum(1), g["basis_rowsum"], 1e-5)
+    close(basis.sum(0), g["basis_colsum"], 1e-5)
+    close(basis[[0, 1, 63, 127]], g["basis_rows"], 1e-6)
+    M = A.melspectrogram(a, sr, fmax=11025.0)
+    close(M[:, cols[:-1]], g["M_cols"], 1e-5)
+    db = A.power_to_db(M)
+    close(db[:, cols[:-1]], g["db_cols"], 1e-5)
+    env = A.onset_strength(a, sr)
+    assert env.shape == g["env"].shape
+    assert float(env[0]) == 0.0 and float(env[1]) == 0.0  # the 2-frame left pad (bin <-> frame mapping)
+    close(env, g["env"], 2e-5)
+
+
+def test_hpss_istft_onsets_rms(golden):
+    a = golden("g09_audio_clip")["audio"]
+    g = golden("g10_hpss")
+    a1 = a[: int(g["n"])].contiguous()
+    D = A.stft(a1)
+    mag = D.abs()
+    med_t = A.median_filter2d(mag[None, None], (1, 31), (15, 15, 0, 0))[0, 0]
+    med_f = A.median_filter2d(mag[None, None], (31, 1), (0, 0, 15, 15))[0, 0]
+    close(med_t[:, [0, 7, 30]], g["med_t_f32_cols"], 2e-6)
+    close(med_f[:, [0, 7, 30]], g["med_f_f32_cols"], 2e-6)
+    close(med_t, g["med_t"].float(), 2e-3)  # stored as f16
+    Hh, Hp = A.hpss(D, margin=8.0)
+    close(Hp.real[:, [0, 7, 30]], g["Hp_re"], 1e-5)
+    close(Hp.imag[:, [0, 7, 30]], g["Hp_im"], 1e-5)
+    close(Hh.real[:, [0, 7, 30]], g["Hh_re"], 1e-5)
+    close(Hh.imag[:, [0, 7, 30]], g["Hh_im"], 1e-5)
+    H1, P1 = A.hpss(D, margin=1.0)
+    close(P1.real[:, [0, 7, 30]], g["P1_re"], 1e-5)
+    close(H1.real[:, [0, 7, 30]], g["H1_re"], 1e-5)
+    close(A.percussive(a1), g["perc"], 1e-5)
+    close(A.harmonic(a1), g["harm"], 1e-5)
+    g = golden("g10_onsets_rms")
+    close(A.onsets(a, 30720), g["onsets"], 5e-5)
+    close(A.rms(a), g["rms"], 1e-6)
+
+
+def test_processing(golden):
+    g = golden("g11_processing")
+    e, e2, e4, short = g["e"], g["e2"], g["e4"], g["short"]
+    for sg in [1, 2, 5]:
+        close(A.gaussian_filter(e, sg), g[f"p_circ_s{sg}"], 1e-6)
+        close(A.gaussian_filter(e, sg, mode="reflect"), g[f"p_refl_s{sg}"], 1e-6)
+    close(A.gaussian_filter(e2, 2), g["p_2d_s2"], 1e-6)
+    close(A.gaussian_filter(e4, 1), g["p_4d_s1"], 1e-6)
+    close(A.gaussian_filter(short, 2), g["p_short_s2"], 1e-6)
+    close(A.normalize(e2), g["p_normalize"], 1e-6)
+    close(A.standardize(e), g["p_standardize"], 1e-6)
+    g2 = golden("g11_salience")
+    close(A.normalize(A.salience_weighted(A.gaussian_filter(g2["env"], 2))), g2["feat"], 1e-5)
+
+
+def test_quantile_c_vs_reference(golden):
+    g = golden("g11_processing")
+    qs = [0.025, 0.25, 0.5, 0.75, 0.975]
+    e = g["e"]
+    big = torch.randn(100001, generator=torch.Generator().manual_seed(5))
+    # regenerate the 'big' vector the golden used: it followed e, e2, e4, short draws from the same generator
+    gg = torch.Generator().manual_seed(5)
+    torch.rand(200, generator=gg); torch.rand(200, 3, generator=gg); torch.rand(40, 2, 3, 4, generator=gg)
+    torch.rand(6, 2, generator=gg)
+    big = torch.randn(100001, generator=gg)
+    assert torch.equal(big[:4], g["big_seed_check"])
+    withnan = e.clone()
+    withnan[::7] = float("nan")
+    for i, q in enumerate(qs):
+        assert OQ.quantile(e, q).item() == g["q_small"][i].item()      # bit-exact (order statistics + midpoint)
+        assert OQ.quantile(big, q).item() == g["q_big"][i].item()
+        assert OQ.quantile(withnan, q).item() == g["q_nan"][i].item()
+    assert np.isnan(OQ.quantile(torch.tensor([float("nan")]), 0.5).item())
+    # float32-q rounding moves the order-statistic pair away from torch.quantile's at the tails
+    v, lo, hi = OQ.quantile_with_indices(big, 0.975)
+    assert (lo, hi) == (int(np.float64(np.float32(0.975)) * 100000), int(np.ceil(np.float64(np.float32(0.975)) * 100000)))
+
+
+def test_quantile_c_vs_built_reference():
+    from oracle.build_ref import load_reference_quantile
+    ext = load_reference_quantile()
+    if ext is None:
+        pytest.skip("oracle/_ref not built (reference not mounted)")
+    g = torch.Generator().manual_seed(77)
+    for n in [1, 2, 3, 10, 1001, 65536]:
+        x = torch.randn(n, generator=g)
+        for q in [0.0, 0.01, 0.025, 0.3, 0.5, 0.75, 0.975, 1.0]:
+            ref = ext._efficient_quantile(x, torch.FloatTensor([q]), True, 3).squeeze().item()
+            assert OQ.quantile(x, q).item() == ref, (n, q)
+
+
+def test_signal(golden):
+    g = golden("g11_signal")
+    e, e2 = g["e"], g["e2"]
+    close(OSG.gaussian_filter(e, 2), g["s_circ_s2"], 1e-6)
+    close(OSG.gaussian_filter(e, 2, causal=0), g["s_causal0_s2"], 1e-6)
+    close(OSG.gaussian_filter(e, 2, causal=0.5), g["s_causal05_s2"], 1e-6)
+    close(OSG.gaussian_filter(e2, 5, mode="reflect"), g["s_refl_s5"], 1e-6)
+    close(OSG.percentile_clip(e.clone(), 95), g["s_percentile_clip95"], 1e-6)
+    close(OSG.percentile_clip(e2.clone(), 80), g["s_percentile_clip80_2d"], 1e-6)
+    assert np.float32(OSG.percentile(e, 50)) == g["s_percentile_50"]  # k-th value: bit-exact
+    assert np.float32(OSG.percentile(e, 95)) == g["s_percentile_95"]
+    assert OSG.percentile_index(200, 50) == 1 + round(0.5 * 199) == 101  # half-even: 99.5 -> 100
+    close(OSG.resample(e, 333), g["s_resample_1d"], 1e-6)
+    close(OSG.resample(e2, 77), g["s_resample_2d"], 1e-6)
+    close(OSG.normalize(e2), g["s_normalize"], 1e-6)
+
+
+def test_latents(golden):
+    g = golden("g12_latents")
+    y, env, envs = g["y"], g["env"], g["envs"]
+    close(OL.slerp_loops(y, 64, 2), g["slerp_loops"], 2e-6)
+    close(OL.single_weighted(y[0], y[1], env), g["single_weighted"], 1e-6)
+    close(OL.multi_weighted(y, envs), g["multi_weighted"], 2e-6)
+    assert torch.equal(OL.select_modulo_indices(len(y), env), g["select_modulo_idx"])  # bit-exact indices
+    close(OL.select_modulo(y, env), g["select_modulo"], 1e-6)
+    g = golden("g12_spline")
+    close(OL.spline_loops(g["y"], 50, 3).double(), g["classic_size50_loops3"], 2e-6)
+    close(OL.spline_loop_latents(g["y"], 50, 2.5).double(), g["selfsup_size50_loops2p5"], 2e-6)
+    g = golden("g12_seeds")
+    z = OIO.get_z_latents("0-3,7")
+    assert z.dtype == torch.float64 and z.shape == (4, 512)
+    assert torch.equal(z[:, :8], g["z"])  # MT19937 values bit-exact
+    assert OIO.parse_seeds("0-3,7") == [0, 1, 2, 7]
+
+
+def test_noise(golden):
+    g = golden("g13_noise")
+    close(ON.loop(g["loop_noise"], g["loop_idx"], 0, 16, 5), g["loop_y_0_16"], 2e-6)
+    close(ON.loop(g["loop_noise"], g["loop_idx"], 40, 8, 5), g["loop_y_40_8"], 2e-6)
+    mod = g["mod"]
+    bl = ON.blend(g["blend_noise"], mod, 8, 4)
+    mu = ON.multiply(g["mul_noise"], mod, 8, 4)
+    close(bl, g["blend_y"], 2e-6)
+    close(mu, g["mul_y"], 2e-6)
+    lp = ON.loop(g["loop_noise"], g["loop_idx"], 8, 4, 5)
+    close(ON.average(lp, mu), g["avg_y"], 2e-6)
+    md = ON.modulate(lp, mu, mod, 8, 4)
+    close(md, g["modulate_y"], 2e-6)
+    close(ON.scale_bias(md, 0.7, 0.1), g["scalebias_y"], 2e-6)
+
+
+def test_tensor2bytes(golden):
+    g = golden("g14_tensor2bytes")
+    assert np.array_equal(OIO.tensor2bytes(g["img"]), g["bytes"].numpy())
