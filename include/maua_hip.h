@@ -107,6 +107,78 @@ int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* co
 /* debug/parity: copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
 int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
 
+/* ---- audio pre-pass (once per clip).  n_fft = 2048, hop = 1024, periodic Hann, centre/reflect padding ---- */
+/* Spectra are FRAME-major: spec[frame][bin] complex64 (re, im interleaved), 1025 bins. */
+int maua_stft_num_frames(int n_samples); /* 1 + n_samples / 1024 */
+/* replaces rosa/spectral.py:10-21 stft (torch.stft).  y [n_samples] f32 -> spec [frames][1025] complex. */
+int maua_stft(maua_ctx* ctx, const float* y, int n_samples, float* spec);
+/* replaces rosa/spectral.py:24-32 istft (torch.istft, center=True, length=...).  -> y [length] f32. */
+int maua_istft(maua_ctx* ctx, const float* spec, int n_frames, int length, float* y);
+/* |spec|**power over n complex values (rosa/spectral.py:59-62 spectrogram, :113-117 magphase). */
+int maua_magnitude(maua_ctx* ctx, const float* spec, long n, float power, float* mag);
+/* replaces processing.py:75-85 median_filter2d as hpss calls it: window 31, reflect padding 15, along time
+ * (axis 0, "harmonic") or along frequency (axis 1, "percussive") of mag [n_frames][n_bins]. */
+int maua_median31(maua_ctx* ctx, const float* mag, int n_frames, int n_bins, int axis, float* out);
+/* replaces rosa/spectral.py:145-161 hpss (+ :120-142 softmask): complex spec in, harmonic / percussive complex
+ * spectra out (either may be NULL). */
+int maua_hpss(maua_ctx* ctx, const float* spec, int n_frames, float margin, float power, float* harm_out,
+              float* perc_out);
+/* replaces rosa/spectral.py:65-70 melspectrogram(power=2): mel[m][f] = sum_k basis[m][k] |spec[f][k]|^2 for
+ * f < n_frames_used (the reference drops the last STFT column).  basis [n_mels][1025], mel [n_mels][n_frames_used]. */
+int maua_mel_power(maua_ctx* ctx, const float* spec, int n_frames_used, const float* basis, int n_mels, float* mel);
+/* replaces rosa/convert.py:7-12 power_to_db (in place on mel) + rosa/beat.py:13-21: env[f] = mean_m relu(dB lag-1
+ * difference), left-padded by pad_width zeros, cropped to T. */
+int maua_onset_from_mel(maua_ctx* ctx, float* mel_inout, int n_mels, int T, float amin, float top_db, int pad_width,
+                        float* env);
+/* replaces processing.py:53-56 normalize (eps = 1e-8) and signal.py:27-38 normalize (eps = 0):
+ * y = (x - min) / ((max - min) + eps) over all n elements. */
+int maua_normalize(maua_ctx* ctx, const float* x, long n, float eps, float* y);
+/* replaces features/audio.py:31-37 rms: out[f] = sqrt(mean(frame_f^2)), centred reflect-padded frames. */
+int maua_rms(maua_ctx* ctx, const float* y, int n_samples, int frame_length, int hop, int n_frames, float* out);
+/* replaces signal.py:108-157 / processing.py:11-49 gaussian_filter: depthwise correlation along axis 0 of
+ * x [T][C] with taps [2*radius+1] (built by the caller exactly as the reference builds its kernel), padding
+ * min(radius,T) samples with `mode` (maua_pad_mode) and the rest by replication.  x and y must not alias. */
+int maua_gaussian_filter1d(maua_ctx* ctx, const float* x, const float* taps, int radius, int T, long C, int mode,
+                           float* y);
+/* exact order statistics of the non-NaN (and, if mask != NULL, mask[i] != 0) elements of x[n]:
+ *  mode 0: midpoint quantile with float32 q — replaces efficient_quantile.cpp:86-206 as __init__.py:6-7 calls it;
+ *  mode 1: k-th smallest value, k 1-based — replaces signal.py:41-52 percentile's kthvalue;
+ *  mode 2: torch.quantile(x, q) (linear interpolation, float32 rank arithmetic) — latent.py:37.
+ * out3 (device) = {result, x_(lo), x_(hi)}; ranks2 (device, may be NULL) = {lo, hi} 0-based, -1 when empty. */
+int maua_order_stat(maua_ctx* ctx, const float* x, const uint8_t* mask, long n, int mode, float q, long k,
+                    float* out3, long long* ranks2);
+/* signal.py:69-76: mask[i] = x[i] > x[i+1] && x[i] > x[i-1] with neighbours clamped to the ends. */
+int maua_peak_mask(maua_ctx* ctx, const float* x, int n, uint8_t* mask);
+/* y = min(max(x, lo), hi + hi_add); lo = lo_dev[0] if lo_dev else lo_const; hi = hi_dev[0] (device scalars,
+ * e.g. from maua_order_stat).  processing.py:59-62 standardize, signal.py:78 percentile_clip. */
+int maua_clamp(maua_ctx* ctx, const float* x, const float* lo_dev, const float* hi_dev, float lo_const, float hi_add,
+               long n, float* y);
+
+/* ---- latent schedules (once per clip); tensors are [T][C] f32 with C = num_ws * w_dim ------------------- */
+/* replaces latent.py:83-92 spline_loops / selfsupervised/latent.py:7-13 spline_loop_latents (the spline itself:
+ * un-vendored torchcubicspline = natural cubic spline).  t_knots_host [n] and t_eval_host [T] are HOST f64 arrays
+ * (strictly increasing knots); y [n][C] and out [T][C] are device f32.  Synchronises once (uploads the grids). */
+int maua_spline_natural(maua_ctx* ctx, const double* t_knots_host, int n, const float* y, long C,
+                        const double* t_eval_host, int T, float* out);
+/* replaces latent.py:12-18 single_weighted: out[t] = a[t]*(1-env[t]) + b[t]*env[t]; a/b row strides in elements
+ * (0 broadcasts one [C] row over time). */
+int maua_latent_blend(maua_ctx* ctx, const float* a, long a_tstride, const float* b, long b_tstride, const float* env,
+                      int T, long C, float* out);
+/* replaces latent.py:21-31 multi_weighted: out[t] = sum_a (env[t][a]/sum_a' env[t][a']) * latents[a % n]. */
+int maua_weighted_sum(maua_ctx* ctx, const float* env, const float* latents, int T, int A, int n, long C, float* out);
+/* latent.py:38-40: idx = int64(round_half_even(x * scale)) — the onset-bin assignment (bit-exact). */
+int maua_scale_round_index(maua_ctx* ctx, const float* x, float scale, long n, long long* idx);
+/* latent.py:41: out[t] = src[idx[t]] (rows of C floats). */
+int maua_gather_rows(maua_ctx* ctx, const float* src, const long long* idx, int n_rows, int T, long C, float* out);
+/* replaces signal.py:5-24 resample / F.interpolate(mode="linear", align_corners=False) along axis 0. */
+int maua_resample_linear(maua_ctx* ctx, const float* x, int n, long C, int size, float* out);
+/* replaces latent.py:54-65 slerp: y [n_seg+1][L][D], t [k] -> out [k][n_seg][L][D] (unit-normalised, Q9). */
+int maua_slerp(maua_ctx* ctx, const float* y, const float* t, int k, int n_seg, int L, int D, float* out);
+/* replaces selfsupervised/latent.py:57-78: merge `sequence` into layers [l0,l1) of latents [T][L][D] in place;
+ * mode 0 average, 1 modulate by mod[t], 2 overwrite. */
+int maua_latent_merge(maua_ctx* ctx, float* latents, const float* sequence, const float* mod, int mode, int T, int L,
+                      int D, int l0, int l1);
+
 /* ---- per-batch noise (selfsupervised patch) ----------------------------------------------------- */
 /* replaces selfsupervised/noise.py:42-53 Loop.forward(i, b): planes [3,h,w] f32 (the module's randn buffer),
  * idx [T] f32 (= linspace(0, 2*pi*n_loops, T)), frames i0..i0+B-1 ->

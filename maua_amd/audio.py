@@ -1,0 +1,304 @@
+"""Audio features on the HIP device (drop-in names for the reference's pure-torch librosa layer).
+
+  stft / istft / spectrogram / melspectrogram / mel / mel_frequencies / hpss / magphase
+      <- maua/audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py:10-161
+  power_to_db / hz_to_mel / mel_to_hz <- rosa/convert.py:7-66       onset_strength <- rosa/beat.py:10-23
+  harmonic / percussive / onsets / rms <- features/audio.py:13-37
+  gaussian_filter / normalize / standardize / median_filter2d <- features/processing.py:11-85
+  quantile <- features/efficient_quantile/__init__.py:6-7 (C++ efficient_quantile.cpp)
+  salience_weighted <- selfsupervised/mir.py:13-21
+
+Inputs may be CPU or device tensors; results live on the HIP device.  n_fft = 2048 / hop = 1024 (the only
+framing the reference's features use).  Every function goes through libmaua_hip.so; small constant tables (mel
+basis, Gaussian taps, linspace grids) are built on the host exactly as the reference builds them.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+N_FFT, HOP, N_BINS = 2048, 1024, 1025
+
+
+def _f32(t):
+    return L.dev_tensor(torch.as_tensor(t), torch.float32)
+
+
+def _check_framing(n_fft, hop_length):
+    if n_fft != N_FFT or hop_length != HOP:
+        raise NotImplementedError("the HIP STFT is specialised to n_fft=2048, hop_length=1024 (the reference features' framing)")
+
+
+# ------------------------------------------------------------------------------------------------ spectra
+def stft(y, n_fft=2048, hop_length=1024, center=True, window=None, pad_mode="reflect", return_complex=True):
+    """-> complex64 [1025, 1 + len(y)//1024] (a transposed view of the frame-major device buffer)."""
+    _check_framing(n_fft, hop_length)
+    if not center or pad_mode != "reflect":
+        raise NotImplementedError("center=True / reflect padding only")
+    y = _f32(y).reshape(-1)
+    frames = 1 + y.numel() // HOP
+    out = torch.empty((frames, N_BINS, 2), dtype=torch.float32, device=y.device)
+    L.check(L.lib().maua_stft(L.ctx(y.device), L.ptr(y), y.numel(), L.ptr(out)))
+    return torch.view_as_complex(out).T
+
+
+def _frame_major(spec):
+    """complex [1025, frames] (any strides) -> contiguous float view [frames, 1025, 2]."""
+    s = spec.T.contiguous() if spec.T.is_contiguous() is False else spec.T
+    return torch.view_as_real(s.contiguous())
+
+
+def istft(spec, n_fft=2048, hop_length=1024, center=True, window=None, length=None):
+    _check_framing(n_fft, hop_length)
+    spec = L.dev_tensor(spec, torch.complex64) if not spec.is_cuda else spec
+    buf = _frame_major(spec)
+    frames = buf.shape[0]
+    if length is None:
+        length = HOP * (frames - 1)
+    y = torch.empty((length,), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_istft(L.ctx(buf.device), L.ptr(buf), frames, int(length), L.ptr(y)))
+    return y
+
+
+def spectrogram(y, n_fft=2048, hop_length=1024, power=1, **_):
+    D = stft(y, n_fft, hop_length)[:, :-1]
+    buf = _frame_major(D)
+    mag = torch.empty(buf.shape[:2], dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_magnitude(L.ctx(buf.device), L.ptr(buf), C.c_long(mag.numel()), C.c_float(float(power)),
+                                   L.ptr(mag)))
+    return mag.T
+
+
+def magphase(D, power=1.0):
+    buf = _frame_major(D)
+    mag = torch.empty(buf.shape[:2], dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_magnitude(L.ctx(buf.device), L.ptr(buf), C.c_long(mag.numel()), C.c_float(1.0), L.ptr(mag)))
+    mag = mag.T
+    phase = torch.where(mag > 0, D / mag.clamp_min(1e-38), torch.ones_like(D))
+    return mag ** power, phase
+
+
+def hz_to_mel(frequencies, htk=False, device="cpu"):
+    """convert.py:15-40 (host constant math)."""
+    f = torch.as_tensor(frequencies, dtype=torch.float32)
+    if htk:
+        return 2595.0 * torch.log10(1.0 + f / 700.0)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    if f.ndim:
+        t = f >= min_log_hz
+        mels[t] = min_log_mel + torch.log(f[t] / min_log_hz) / logstep
+    elif f >= min_log_hz:
+        mels = min_log_mel + torch.log(f / min_log_hz) / logstep
+    return mels
+
+
+def mel_to_hz(mels, htk=False):
+    if htk:
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    if mels.ndim:
+        t = mels >= min_log_mel
+        freqs[t] = min_log_hz * torch.exp(logstep * (mels[t] - min_log_mel))
+    elif mels >= min_log_mel:
+        freqs = min_log_hz * torch.exp(logstep * (mels - min_log_mel))
+    return freqs
+
+
+def mel_frequencies(n_mels=128, fmin=0.0, fmax=11025.0, htk=False, device="cpu"):
+    return mel_to_hz(torch.linspace(hz_to_mel(fmin, htk), hz_to_mel(fmax, htk), n_mels), htk)
+
+
+def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, dtype=torch.float, device="cpu"):
+    """spectral.py:81-110 — [n_mels, 1 + n_fft//2] Slaney filterbank, a host-built constant."""
+    if fmax is None:
+        fmax = float(sr) / 2
+    fftfreqs = torch.linspace(0, float(sr) / 2, int(1 + n_fft // 2))
+    mel_f = mel_frequencies(n_mels + 2, fmin=fmin, fmax=fmax, htk=htk)
+    fdiff = torch.diff(mel_f)
+    ramps = mel_f.reshape(-1, 1) - fftfreqs
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    weights = torch.clamp(torch.minimum(lower, upper), min=0)
+    enorm = 2.0 / (mel_f[2: n_mels + 2] - mel_f[:n_mels])
+    return (weights * enorm[:, None]).to(dtype)
+
+
+def melspectrogram(y, sr, n_fft=2048, hop_length=1024, power=2.0, fmax=None, **_):
+    if power != 2.0:
+        raise NotImplementedError("power must be 2 (the onset path)")
+    D = stft(y, n_fft, hop_length)
+    buf = _frame_major(D)
+    T = buf.shape[0] - 1
+    basis = _f32(mel(sr, n_fft, fmax=fmax))
+    out = torch.empty((basis.shape[0], T), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_mel_power(L.ctx(buf.device), L.ptr(buf), T, L.ptr(basis), basis.shape[0], L.ptr(out)))
+    return out
+
+
+def power_to_db(magnitude, ref_value=1.0, amin=1e-10, top_db=80.0):
+    """convert.py:7-12 on a device tensor (elementwise + one max; runs in the onset kernel on the hot path —
+    this standalone form composes torch device ops for API parity)."""
+    m = _f32(magnitude)
+    log_spec = 10.0 * torch.log10(torch.clamp(m, min=amin)) - 10.0 * np.log10(max(amin, float(ref_value)))
+    if top_db is not None:
+        log_spec = torch.maximum(log_spec, log_spec.max() - top_db)
+    return log_spec
+
+
+def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None):
+    """beat.py:10-23 -> [T] on device."""
+    S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=11025.0)
+    n_mels, T = S.shape
+    env = torch.empty((T,), dtype=torch.float32, device=S.device)
+    pad_width = 1 + n_fft // (2 * hop_length)
+    L.check(L.lib().maua_onset_from_mel(L.ctx(S.device), L.ptr(S), n_mels, T, C.c_float(1e-10), C.c_float(80.0),
+                                        pad_width, L.ptr(env)))
+    return env
+
+
+def hpss(S, ks=31, power=2.0, margin=1.0):
+    """spectral.py:145-161 on a complex STFT [1025, frames] -> (harmonic, percussive) complex spectra."""
+    if ks != 31:
+        raise NotImplementedError("median window must be 31 (the reference default)")
+    if not torch.is_complex(S):
+        raise NotImplementedError("pass the complex STFT")
+    S = S if S.is_cuda else L.dev_tensor(S, torch.complex64)
+    buf = _frame_major(S)
+    frames = buf.shape[0]
+    if buf.shape[1] != N_BINS:
+        raise ValueError("expected 1025 frequency bins")
+    h = torch.empty_like(buf)
+    p = torch.empty_like(buf)
+    L.check(L.lib().maua_hpss(L.ctx(buf.device), L.ptr(buf), frames, C.c_float(float(margin)), C.c_float(float(power)),
+                              L.ptr(h), L.ptr(p)))
+    return torch.view_as_complex(h).T, torch.view_as_complex(p).T
+
+
+def median_filter2d(x, k=(3, 3), s=(1, 1), p=(1, 1, 1, 1), mode="reflect"):
+    """processing.py:75-85 for the two shapes hpss uses: k=(1,31),p=(15,15,0,0) and k=(31,1),p=(0,0,15,15);
+    x [1,1,bins,frames]."""
+    x = _f32(x)
+    if mode != "reflect" or tuple(s) != (1, 1):
+        raise NotImplementedError
+    bins, frames = x.shape[-2:]
+    fm = x.reshape(bins, frames).T.contiguous()  # frame-major
+    out = torch.empty_like(fm)
+    if tuple(k) == (1, 31) and tuple(p) == (15, 15, 0, 0):
+        axis = 0  # along time
+    elif tuple(k) == (31, 1) and tuple(p) == (0, 0, 15, 15):
+        axis = 1  # along frequency
+    else:
+        raise NotImplementedError("only the 31-tap harmonic / percussive medians of hpss")
+    L.check(L.lib().maua_median31(L.ctx(fm.device), L.ptr(fm), frames, bins, axis, L.ptr(out)))
+    return out.T.reshape(x.shape)
+
+
+def harmonic(audio, margin=8.0):
+    y = _f32(audio)
+    return istft(hpss(stft(y), margin=margin)[0], length=y.numel())
+
+
+def percussive(audio, margin=8.0):
+    y = _f32(audio)
+    return istft(hpss(stft(y), margin=margin)[1], length=y.numel())
+
+
+# ------------------------------------------------------------------------------------------------ envelopes
+def normalize(array, eps=1e-8):
+    """processing.py:53-56: (x - min) / (max(x - min) + 1e-8)."""
+    x = _f32(array)
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_normalize(L.ctx(x.device), L.ptr(x), C.c_long(x.numel()), C.c_float(eps), L.ptr(y)))
+    return y
+
+
+def onsets(audio, sr):
+    """features/audio.py:27-28 -> [T, 1]."""
+    return normalize(onset_strength(percussive(audio), sr).unsqueeze(-1))
+
+
+def rms(y, sr=None, frame_length=2048, hop_length=1024, center=True, pad_mode="reflect"):
+    """features/audio.py:31-37 -> [T, 1] (drops the last frame)."""
+    if not center or pad_mode != "reflect":
+        raise NotImplementedError
+    y = _f32(y).reshape(-1)
+    n_frames = (y.numel() + 2 * (frame_length // 2) - frame_length) // hop_length + 1 - 1
+    out = torch.empty((max(n_frames, 0),), dtype=torch.float32, device=y.device)
+    L.check(L.lib().maua_rms(L.ctx(y.device), L.ptr(y), y.numel(), frame_length, hop_length, n_frames, L.ptr(out)))
+    return out.unsqueeze(-1)
+
+
+def gaussian_taps(sigma, n_frames, causal=None, classic=False):
+    """The reference's kernel construction (signal.py:124-132 / processing.py:18-24), on the host."""
+    radius = min(int(sigma * 4), 3 * n_frames)
+    k = torch.arange(-radius, radius + 1, dtype=torch.float32)
+    k = torch.exp(-0.5 / sigma ** 2 * k ** 2)
+    if classic and causal is not None:
+        k[radius + 1:] *= causal if isinstance(causal, float) else 0
+    return k / k.sum(), radius
+
+
+def gaussian_filter(x, sigma, mode="circular", causal=None, _classic=False):
+    """processing.py:11-49 (ignores ``causal``, like the reference's selfsupervised version).  Filters along
+    dim 0; any trailing shape."""
+    x = _f32(x)
+    shape = x.shape
+    T = shape[0]
+    Cn = x.numel() // max(T, 1)
+    taps, radius = gaussian_taps(sigma, T, causal, _classic)
+    if radius > T:
+        print(f"WARNING: Gaussian filter radius ({int(sigma * 4)}) is larger than number of frames ({T}).\n\t "
+              f"Filter size has been lowered to ({radius}). You might want to consider lowering sigma ({sigma}).")
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_gaussian_filter1d(L.ctx(x.device), L.ptr(x), L.ptr(_f32(taps)), radius, T, C.c_long(Cn),
+                                           L.PAD_MODES[mode], L.ptr(y)))
+    return y
+
+
+def order_stat(x, mode, q=0.0, k=1, mask=None):
+    """device triple {result, x_(lo), x_(hi)} and int64 ranks {lo, hi}; see maua_order_stat in the header."""
+    x = _f32(x).reshape(-1)
+    out = torch.empty((3,), dtype=torch.float32, device=x.device)
+    ranks = torch.empty((2,), dtype=torch.int64, device=x.device)
+    if mask is not None:
+        mask = mask.to(device=x.device, dtype=torch.uint8).contiguous()
+    L.check(L.lib().maua_order_stat(L.ctx(x.device), L.ptr(x), L.ptr(mask), C.c_long(x.numel()), mode,
+                                    C.c_float(float(q)), C.c_long(int(k)), L.ptr(out), L.ptr(ranks)))
+    return out, ranks
+
+
+def quantile(tensor, q):
+    """efficient_quantile/__init__.py:6-7: midpoint quantile with a float32 q, NaNs ignored -> 0-dim tensor."""
+    return order_stat(tensor, 0, q=q)[0][0]
+
+
+def standardize(array):
+    """processing.py:59-62"""
+    x = _f32(array)
+    lo, _ = order_stat(x, 0, q=0.25)
+    hi, _ = order_stat(x, 0, q=0.75)
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_clamp(L.ctx(x.device), L.ptr(x), L.ptr(lo), L.ptr(hi), C.c_float(0), C.c_float(1e-10),
+                               C.c_long(x.numel()), L.ptr(y)))
+    return normalize(y)
+
+
+def salience_weighted(envelope, short_sigma=5, long_sigma=80):
+    """selfsupervised/mir.py:13-21 (three elementwise ops on a [T] envelope between two HIP filters)."""
+    e = _f32(envelope)
+    if e.dim() > 1:
+        e = e.squeeze(1)
+    short = gaussian_filter(e, short_sigma, mode="reflect")
+    long = gaussian_filter(e, long_sigma, mode="reflect")
+    w = (short / long) ** 2 * e
+    return w.unsqueeze(1) if w.dim() < 2 else w

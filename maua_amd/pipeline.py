@@ -39,7 +39,7 @@ def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4
     half = palette.shape[0] // 2
     low = latent.spline_loops(palette[:half], n_frames, n_loops)
     high = latent.spline_loops(palette[half:2 * half], n_frames, n_loops)
-    lat = low * (1 - env[:, None, None]) + high * env[:, None, None]
+    lat = latent.sequence_weighted(low, high, env)
     lat = audio.gaussian_filter(lat, 2)
     return lat.contiguous(), {"seeds": seeds, "schedule": f"spline_loops(n_loops={n_loops}) x2 blended by onsets, gaussian sigma=2"}
 

@@ -1,0 +1,54 @@
+"""Classic envelope post-processing on the HIP device (drop-in for maua/audiovisual/audioreactive/signal.py:
+resample :5-24, normalize :27-38, percentile :41-52, percentile_clip :55-81, gaussian_filter :108-157)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import audio as A
+
+
+def resample(x, size):
+    x = A._f32(x)
+    y = x.squeeze()
+    if y.ndim == 0:
+        y = y[None]
+    n = y.shape[0]
+    Cn = y.numel() // n
+    out = torch.empty((size, *y.shape[1:]), dtype=torch.float32, device=y.device)
+    L.check(L.lib().maua_resample_linear(L.ctx(y.device), L.ptr(y.contiguous()), n, C.c_long(Cn), int(size), L.ptr(out)))
+    return out.squeeze()
+
+
+def normalize(x):
+    return A.normalize(x, eps=0.0)
+
+
+def percentile(signal, p):
+    s = A._f32(signal).reshape(-1)
+    k = 1 + round(0.01 * float(p) * (s.numel() - 1))
+    return A.order_stat(s, 1, k=k)[0][0].item()
+
+
+def percentile_clip(signal, percent):
+    sig = A._f32(signal)
+    if sig.ndim < 2:
+        sig = sig.unsqueeze(1)
+    cols = []
+    for col in sig.unbind(1):
+        col = col.contiguous()
+        n = col.numel()
+        mask = torch.empty((n,), dtype=torch.uint8, device=col.device)
+        L.check(L.lib().maua_peak_mask(L.ctx(col.device), L.ptr(col), n, L.ptr(mask)))
+        n_peaks = int(mask.sum().item())  # host needs the count for the reference's k = 1 + round(p% * (n-1))
+        k = 1 + round(0.01 * float(percent) * (n_peaks - 1))
+        hi, _ = A.order_stat(col, 1, k=k, mask=mask)
+        y = torch.empty_like(col)
+        L.check(L.lib().maua_clamp(L.ctx(col.device), L.ptr(col), None, L.ptr(hi), C.c_float(0.0), C.c_float(0.0),
+                                   C.c_long(n), L.ptr(y)))
+        cols.append(y / y.max())
+    return torch.stack(cols, dim=1)
+
+
+def gaussian_filter(x, sigma, causal=None, mode="circular"):
+    return A.gaussian_filter(x, sigma, mode=mode, causal=causal, _classic=True)

@@ -65,6 +65,23 @@ def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_bas
     return p
 
 
+def parse_seeds(seeds):
+    """wrappers/stylegan.py:59-65: "a-b,c" -> ints (ranges end-exclusive)."""
+    out = []
+    for s in str(seeds).split(","):
+        if "-" in s:
+            a, b = s.split("-")
+            out += list(range(int(a), int(b)))
+        else:
+            out.append(int(s))
+    return out
+
+
+def get_z_latents(seeds, z_dim=512):
+    """wrappers/stylegan.py:58-69: float64 [P, z_dim] from numpy's MT19937 (host)."""
+    return torch.cat([torch.from_numpy(np.random.RandomState(s).randn(1, z_dim)) for s in parse_seeds(seeds)])
+
+
 class SynthesisNetwork(torch.nn.Module):
     """inference/stylegan2.py:385-436.  ``dtype``: torch.bfloat16 (default, MFMA bf16 operands / f32 accumulate)
     or torch.float32 (exact-f32 MFMA, parity mode)."""

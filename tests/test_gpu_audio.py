@@ -1,0 +1,219 @@
+"""HIP audio / envelope / latent / noise kernels (through the C ABI) vs the oracle and the goldens.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio as OA
+from oracle import latent as OL
+from oracle import noise as ON
+from oracle import quantile as OQ
+from oracle import signal as OS
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = a.detach().cpu()
+    b = b.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if torch.is_complex(b):
+        return float((a - b).abs().max()) / max(1e-20, float(b.abs().max()))
+    return float((a.double() - b.double()).abs().max()) / max(1e-20, float(b.abs().max()))
+
+
+@pytest.fixture(scope="module")
+def clip(golden):
+    return golden("g09_audio_clip")["audio"]
+
+
+def test_stft_istft(clip, golden):
+    import maua_amd.audio as A
+    D = A.stft(clip)
+    ref = OA.stft(clip)
+    assert D.shape == ref.shape == (1025, 1 + len(clip) // 1024)
+    assert rel(D, ref) <= 2e-6
+    g = golden("g09_stft")
+    cols = g["cols"].long()
+    assert rel(D.real.cpu()[:, cols], g["D_re"]) <= 2e-6
+    assert rel(D.imag.cpu()[:, cols], g["D_im"]) <= 2e-6
+    # round trip (size-independent property): istft(stft(y)) == y
+    y = A.istft(D, length=len(clip))
+    assert rel(y, clip) <= 2e-6
+    assert rel(A.istft(ref, length=len(clip)), OA.istft(ref, length=len(clip))) <= 2e-6
+    S1 = A.spectrogram(clip)
+    assert S1.shape == (1025, len(clip) // 1024)  # frame count int-exact
+    assert rel(S1, OA.spectrogram(clip)) <= 2e-6
+
+
+def test_stft_full_clip_properties():
+    """BASELINE size: 120 s @ 30720 Hz -> 3601 columns; Parseval per frame + linearity."""
+    import maua_amd.audio as A
+    from maua_amd.pipeline import synthetic_audio
+    y = synthetic_audio(3600 * 1024, 30720)
+    D = A.stft(y)
+    assert D.shape == (1025, 3601)
+    D2 = A.stft(2.5 * y)
+    assert rel(D2, 2.5 * D) <= 2e-6
+    # Parseval on an interior frame: sum |X_k|^2 (two-sided) == N * sum (w x)^2
+    f = 1777
+    fr = y[f * 1024 - 1024: f * 1024 + 1024] * OA.hann()
+    X = D[:, f].cpu()
+    two_sided = (X.abs() ** 2).sum() * 2 - X[0].abs() ** 2 - X[-1].abs() ** 2
+    assert abs(float(two_sided) - 2048 * float((fr.double() ** 2).sum())) <= 1e-4 * float(two_sided)
+    env = A.onset_strength(y, 30720)
+    assert env.shape == (3600,) and float(env[0]) == 0.0 and float(env[1]) == 0.0
+
+
+def test_mel_onset(clip, golden):
+    import maua_amd.audio as A
+    sr = 30720
+    assert rel(A.mel(sr, 2048, fmax=11025.0), OA.mel_basis(sr, fmax=11025.0)) <= 1e-6
+    M = A.melspectrogram(clip, sr, fmax=11025.0)
+    assert rel(M, OA.melspectrogram(clip, sr, fmax=11025.0)) <= 1e-5
+    env = A.onset_strength(clip, sr)
+    g = golden("g09_mel")
+    assert rel(env, g["env"]) <= 5e-5
+    assert float(env[0]) == 0.0 and float(env[1]) == 0.0
+
+
+def test_hpss_percussive_onsets_rms(clip, golden):
+    import maua_amd.audio as A
+    g = golden("g10_hpss")
+    a1 = clip[: int(g["n"])].contiguous()
+    D = OA.stft(a1)
+    mag = D.abs()
+    mt = A.median_filter2d(mag[None, None], k=(1, 31), p=(15, 15, 0, 0))[0, 0]
+    mf = A.median_filter2d(mag[None, None], k=(31, 1), p=(0, 0, 15, 15))[0, 0]
+    # medians select an input element: bit-exact
+    assert torch.equal(mt.cpu(), OA.median_filter2d(mag[None, None], (1, 31), (15, 15, 0, 0))[0, 0])
+    assert torch.equal(mf.cpu(), OA.median_filter2d(mag[None, None], (31, 1), (0, 0, 15, 15))[0, 0])
+    Hh, Hp = A.hpss(D, margin=8.0)
+    Rh, Rp = OA.hpss(D, margin=8.0)
+    assert rel(Hh, Rh) <= 1e-5 and rel(Hp, Rp) <= 1e-5
+    H1, P1 = A.hpss(D, margin=1.0)
+    R1h, R1p = OA.hpss(D, margin=1.0)
+    assert rel(H1, R1h) <= 1e-5 and rel(P1, R1p) <= 1e-5
+    assert rel(A.percussive(a1), g["perc"]) <= 2e-5
+    assert rel(A.harmonic(a1), g["harm"]) <= 2e-5
+    g2 = golden("g10_onsets_rms")
+    assert rel(A.onsets(clip, 30720), g2["onsets"]) <= 2e-4
+    assert rel(A.rms(clip), g2["rms"]) <= 2e-6
+
+
+def test_gaussian_normalize_quantile(golden):
+    import maua_amd.audio as A
+    g = golden("g11_processing")
+    e, e2, e4, short = g["e"], g["e2"], g["e4"], g["short"]
+    for sg in [1, 2, 5]:
+        assert rel(A.gaussian_filter(e, sg), g[f"p_circ_s{sg}"]) <= 2e-6
+        assert rel(A.gaussian_filter(e, sg, mode="reflect"), g[f"p_refl_s{sg}"]) <= 2e-6
+    assert rel(A.gaussian_filter(e2, 2), g["p_2d_s2"]) <= 2e-6
+    assert rel(A.gaussian_filter(e4, 1), g["p_4d_s1"]) <= 2e-6
+    assert rel(A.gaussian_filter(short, 2), g["p_short_s2"]) <= 2e-6  # short-sequence fallback branch
+    assert torch.equal(A.normalize(e2).cpu(), g["p_normalize"])        # exact: same IEEE ops
+    assert rel(A.standardize(e), g["p_standardize"]) <= 1e-6
+    qs = [0.025, 0.25, 0.5, 0.75, 0.975]
+    gg = torch.Generator().manual_seed(5)
+    torch.rand(200, generator=gg); torch.rand(200, 3, generator=gg); torch.rand(40, 2, 3, 4, generator=gg)
+    torch.rand(6, 2, generator=gg)
+    big = torch.randn(100001, generator=gg)
+    withnan = e.clone()
+    withnan[::7] = float("nan")
+    for i, q in enumerate(qs):
+        assert A.quantile(e, q).item() == g["q_small"][i].item()       # bit-exact
+        assert A.quantile(big, q).item() == g["q_big"][i].item()
+        assert A.quantile(withnan, q).item() == g["q_nan"][i].item()
+        _, ranks = A.order_stat(big, 0, q=q)
+        v, lo, hi = OQ.quantile_with_indices(big, q)
+        assert ranks.tolist() == [lo, hi]                               # order-statistic indices int-exact
+    assert np.isnan(A.quantile(torch.tensor([float("nan")]), 0.5).item())
+    g2 = golden("g11_salience")
+    assert rel(A.normalize(A.salience_weighted(A.gaussian_filter(g2["env"], 2))), g2["feat"]) <= 2e-5
+
+
+def test_quantile_full_size():
+    """C1-size input (3 686 400 samples): HIP radix select == C oracle, bit for bit."""
+    import maua_amd.audio as A
+    x = torch.randn(3600 * 1024, generator=torch.Generator().manual_seed(3))
+    for q in [0.025, 0.5, 0.975]:
+        v, lo, hi = OQ.quantile_with_indices(x, q)
+        out, ranks = A.order_stat(x, 0, q=q)
+        assert out[0].item() == v and ranks.tolist() == [lo, hi]
+
+
+def test_signal(golden):
+    import maua_amd.signal as S
+    g = golden("g11_signal")
+    e, e2 = g["e"], g["e2"]
+    assert rel(S.gaussian_filter(e, 2), g["s_circ_s2"]) <= 2e-6
+    assert rel(S.gaussian_filter(e, 2, causal=0), g["s_causal0_s2"]) <= 2e-6
+    assert rel(S.gaussian_filter(e, 2, causal=0.5), g["s_causal05_s2"]) <= 2e-6
+    assert rel(S.gaussian_filter(e2, 5, mode="reflect"), g["s_refl_s5"]) <= 2e-6
+    assert torch.equal(S.percentile_clip(e.clone(), 95).cpu(), g["s_percentile_clip95"])
+    assert torch.equal(S.percentile_clip(e2.clone(), 80).cpu(), g["s_percentile_clip80_2d"])
+    assert np.float32(S.percentile(e, 50)) == g["s_percentile_50"]     # k-th value bit-exact
+    assert np.float32(S.percentile(e, 95)) == g["s_percentile_95"]
+    assert rel(S.resample(e, 333), g["s_resample_1d"]) <= 1e-6
+    assert rel(S.resample(e2, 77), g["s_resample_2d"]) <= 1e-6
+    assert torch.equal(S.normalize(e2).cpu(), g["s_normalize"])
+
+
+def test_latents(golden):
+    import maua_amd.latent as LT
+    g = golden("g12_latents")
+    y, env, envs = g["y"], g["env"], g["envs"]
+    assert rel(LT.slerp_loops(y, 64, 2), g["slerp_loops"]) <= 1e-5
+    assert torch.equal(LT.single_weighted(y[0], y[1], env).cpu(), g["single_weighted"])
+    assert rel(LT.multi_weighted(y, envs), g["multi_weighted"]) <= 2e-6
+    assert torch.equal(LT.select_modulo_indices(len(y), env).cpu(), g["select_modulo_idx"])  # bit-exact indices
+    assert rel(LT.select_modulo(y, env), g["select_modulo"]) <= 2e-6
+    g = golden("g12_spline")
+    assert rel(LT.spline_loops(g["y"], 50, 3).double(), g["classic_size50_loops3"]) <= 2e-6
+    assert rel(LT.spline_loop_latents(g["y"], 50, 2.5).double(), g["selfsup_size50_loops2p5"]) <= 2e-6
+    # merges
+    gen = torch.Generator().manual_seed(1)
+    lat = torch.randn(40, 18, 16, generator=gen)
+    seq = torch.randn(40, 18, 16, generator=gen)
+    mod = torch.rand(40, generator=gen)
+    for mt, depth in [("average", "low"), ("modulate", "midhigh"), ("overwrite", "all")]:
+        got = LT.merge(lat.clone().cuda(), seq, mt, depth, mod)
+        assert rel(got, OL.merge(lat, seq, mt, depth, mod[:, None])) <= 1e-6
+
+
+def test_spline_full_size():
+    """C1-size schedule [3600,18,512]: spline passes through its knots and is periodic (loop property)."""
+    import maua_amd.latent as LT
+    pal = torch.randn(30, 18, 512, generator=torch.Generator().manual_seed(2))
+    out = LT.spline_loops(pal, 3600, 4)
+    assert out.shape == (3600, 18, 512)
+    assert rel(out[0], pal[0]) <= 1e-6 and rel(out[-1], pal[0]) <= 1e-6
+    ref = OL.spline_loops(pal[:, :2, :8], 3600, 4)
+    assert rel(out[:, :2, :8], ref) <= 2e-6
+
+
+def test_noise(golden):
+    import maua_amd.noise as N
+    g = golden("g13_noise")
+    loop = N.Loop(None, 48, (8, 12), n_loops=2, sigma=5, noise=g["loop_noise"])
+    assert rel(loop.idx, g["loop_idx"]) == 0
+    assert rel(loop.forward(0, 16), g["loop_y_0_16"]) <= 1e-5
+    assert rel(loop.forward(40, 8), g["loop_y_40_8"]) <= 1e-5
+    mod = g["mod"]
+    bl = N.Blend(None, 48, (8, 12), mod, noise=g["blend_noise"])
+    mu = N.Multiply(None, 48, (8, 12), mod, noise=g["mul_noise"])
+    assert rel(bl.forward(8, 4), g["blend_y"]) <= 2e-6
+    assert rel(mu.forward(8, 4), g["mul_y"]) <= 2e-6
+    assert rel(N.Average(loop, mu).forward(8, 4), g["avg_y"]) <= 1e-5
+    md = N.Modulate(loop, mu, mod)
+    assert rel(md.forward(8, 4), g["modulate_y"]) <= 1e-5
+    assert rel(N.ScaleBias(md, 0.7, 0.1).forward(8, 4), g["scalebias_y"]) <= 1e-5
+    # RNG parity: planes drawn from a CPU generator like the reference
+    rng = torch.Generator("cpu").manual_seed(42)
+    l2 = N.Loop(rng, 48, (8, 12), n_loops=2, sigma=5)
+    assert torch.equal(l2.noise, g["loop_noise"])
+    # full-size layer (1024x1024): per-frame RMS == 1 (normalisation property) and parity on a slice
+    big = N.Loop(torch.Generator().manual_seed(1), 3600, (1024, 1024), n_loops=4, sigma=5)
+    y = big.forward(1234, 2)
+    assert abs(float(y[0].square().mean().sqrt()) - 1.0) <= 1e-5
+    ref = ON.loop(big.noise, big.idx, 1234, 1, 5)
+    assert rel(y[:1], ref) <= 2e-5
