@@ -80,7 +80,8 @@ def cpu_baseline(seconds):
     workload, bounded: whole 1024^2 frames (B=1) until `seconds` of CPU time are spent (at least 1)."""
     from oracle import noise as ON
     from oracle import stylegan2 as OS
-    torch.set_num_threads(os.cpu_count() or 1)
+    # oneDNN convolutions stop scaling (and regress) far below the 256 hardware threads of the GPU box's host
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     p = OS.init_synthesis_params(RES, generator=torch.Generator().manual_seed(0))
     g = torch.Generator().manual_seed(1)
     ws = torch.randn(1, OS.num_ws(RES), W_DIM, generator=g)
