@@ -1,0 +1,31 @@
+"""The ``ar`` namespace patches use (maua/audiovisual/audioreactive/__init__.py): audio loading, features,
+envelope post-processing and latent builders, all executed on the HIP device."""
+import torch
+
+from ..audio import (gaussian_filter as _gf_selfsup, harmonic, hpss, istft, melspectrogram, onset_strength, percussive,  # noqa
+                     rms as _rms, spectrogram, stft)
+from ..audio_io import load_audio as _load
+from ..latent import (multi_weighted, select_modulo, single_weighted, slerp, slerp_loops, spline_loops,  # noqa
+                      tempo_loops)
+from ..signal import gaussian_filter, normalize, percentile, percentile_clip, resample  # noqa
+
+
+def load_audio(audio_file, offset=0, duration=-1, cache=True):
+    """audioreactive/audio.py:15-48 -> (audio tensor, sr, duration)."""
+    audio, sr = _load(audio_file, offset, None if duration in (-1, None) else duration)
+    return audio, sr, len(audio) / sr
+
+
+def onsets(audio, sr, type="rosa", prepercussive=4):
+    """audioreactive/mir.py:16-61.  type="rosa" semantics (HPSS -> mel onset strength -> percentile_clip(95)) at the
+    in-tree framing (n_fft 2048, hop 1024); type="mm" needs madmom (un-vendored) and is rejected."""
+    if type != "rosa":
+        raise NotImplementedError('onsets(type="mm") needs madmom, which the reference does not vendor; use type="rosa"')
+    a = torch.as_tensor(audio)
+    if prepercussive:
+        a = percussive(a, margin=float(prepercussive))
+    return percentile_clip(onset_strength(a, sr), 95).squeeze()
+
+
+def rms(audio, sr):
+    return _rms(torch.as_tensor(audio), sr).squeeze(-1)

@@ -1,0 +1,49 @@
+"""MauaPatch protocol (drop-in for maua/audiovisual/patches/base/__init__.py:7-44)."""
+import importlib
+import importlib.util
+import inspect
+from pathlib import Path
+
+import torch
+
+from ... import audioreactive as ar
+
+
+class MauaPatch:
+    def __init__(self, audio_file, fps=24, offset=0, duration=-1) -> None:
+        self.fps = fps
+        self.audio_file = audio_file
+        self.audio, self.sr, self.duration = ar.load_audio(audio_file, offset, duration)
+        self.audio = self.audio.numpy()
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.n_frames = round(self.duration * self.fps)  # Python round: half to even (base/__init__.py:16)
+
+    def process_audio(self):
+        pass
+
+    def force_output_size(self, video):
+        t, c, h, w = video.shape
+        if (w, h) != tuple(self.synthesizer.output_size):
+            raise NotImplementedError("post-render resampling (maua/ops/image.py:214-240) is not implemented yet")
+        return video
+
+
+def get_patch_from_file(filepath, class_name=None):
+    """base/__init__.py:28-44: first class in the file that extends MauaPatch (optionally by name).  Accepts a
+    dotted-module-style path like the reference or a real file path."""
+    module_name = filepath.replace(".py", "").replace("/", ".").lstrip(".")
+    try:  # the reference's way: the path doubles as a dotted module name relative to the working directory
+        module = importlib.import_module(module_name)
+    except ImportError:
+        p = Path(filepath)
+        if not p.exists():
+            raise
+        spec = importlib.util.spec_from_file_location(p.stem, p)  # a stand-alone user file (absolute imports)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        module_name = module.__name__
+    for _, cls in inspect.getmembers(module, inspect.isclass):
+        if cls.__module__ == module_name and issubclass(cls, MauaPatch) and (class_name is None or cls.__name__ == class_name):
+            return cls
+    raise Exception("Patch not found! Are you sure there is a class that extends MauaPatch in the file you specified "
+                    "and that the name you (might have) specified is correct?")

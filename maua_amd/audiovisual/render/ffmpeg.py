@@ -1,0 +1,30 @@
+"""FFMPEG renderer (drop-in for maua/audiovisual/render/ffmpeg.py:21-75): batch loop -> synthesizer -> packed u8
+frames -> VideoWriter.  The (x+1)/2 -> clamp -> u8 HWC conversion the reference does per frame on its writer thread
+(ops/io.py:47-70) happens inside the same C-ABI call as the synthesis (maua_synth_render_rgb8)."""
+import torch
+
+from ...pipeline import frame_range
+from ...video import VideoWriter
+from . import Renderer, batch_inputs, n_frames_of
+
+
+class FFMPEG(Renderer):
+    def __init__(self, output_file, fps=24, audio_file=None, audio_offset=0, audio_duration=None, ffmpeg_preset="medium",
+                 batch_size=16):
+        super().__init__()
+        self.output_file, self.fps, self.ffmpeg_preset = output_file, fps, ffmpeg_preset
+        self.audio_file, self.audio_offset, self.audio_duration = audio_file, audio_offset, audio_duration
+        self.batch_size = batch_size
+
+    def __call__(self, synthesizer, inputs, postprocess=None, fp16=True, rank=0, world=1):
+        T = n_frames_of(inputs)
+        lo, hi = frame_range(T, rank, world)
+        W, H = synthesizer.output_size
+        with VideoWriter(self.output_file if world == 1 else f"{self.output_file}.part{rank}", (W, H), self.fps,
+                         self.audio_file, self.audio_offset, self.audio_duration, self.ffmpeg_preset) as video:
+            for i in range(lo, hi, self.batch_size):
+                b = min(self.batch_size, hi - i)
+                u8 = torch.empty((b, H, W, 3), dtype=torch.uint8, device="cuda")
+                synthesizer(**batch_inputs(inputs, i, b), rgb8_out=u8)
+                video.write(u8)
+        return self.output_file

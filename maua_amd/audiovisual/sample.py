@@ -1,0 +1,165 @@
+"""Hop-aligned audio-reactive sampler (drop-in for
+maua/audiovisual/audioreactive/selfsupervised/sample.py:36-107 ``generate`` and patch.py:34-197 ``Patch``).
+
+Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  The feature set is the in-scope part
+of the reference's (SURVEY 8f N3 lists the rest): ``onsets`` and ``rms``; tempo / beat tracking (librosa) and
+Laplacian segmentation (torch_geometric) are un-vendored, so ``tempo`` is an argument and "segmentation" patches are
+not drawn.  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
+rank 0 with one RCCL gather at the end.
+
+    python -m maua_amd.audiovisual.sample --audio_file clip.wav --stylegan2_checkpoint None --downscale_factor 4
+"""
+import argparse
+import json
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import audio as A
+from .. import latent as LT
+from .. import noise as N
+from ..audio_io import load_audio
+from ..distributed import gather_frames, world_info
+from ..pipeline import frame_range
+from ..stylegan2 import StyleGAN2
+from ..video import VideoWriter
+
+AFEATFNS = ["rms", "onsets"]
+UNITFEATS = ["rms", "onsets"]
+ALLFEATS = UNITFEATS
+
+
+def retrieve_music_information(audio, sr):
+    """selfsupervised/mir.py:24-45 for the in-scope features: raw feature -> gaussian(2) -> salience -> normalize."""
+    raw = {"rms": A.rms(audio, sr), "onsets": A.onsets(audio, sr)}
+    return {k: A.normalize(A.salience_weighted(A.gaussian_filter(v, sigma=2))) for k, v in raw.items()}
+
+
+def random_choice(rng, options, weights=None):
+    p = torch.ones(len(options)) / len(options) if weights is None else torch.tensor(weights, dtype=torch.float) / np.sum(weights)
+    return options[p.multinomial(num_samples=1, generator=rng)]
+
+
+class Patch(torch.nn.Module):
+    """patch.py:34-197 restricted to in-scope sub-patch types ("feature", "loop")."""
+
+    def __init__(self, features, tempo, fps=24, seed=42, min_subpatches=2, max_subpatches=20, device="cuda"):
+        super().__init__()
+        rng = torch.Generator("cpu").manual_seed(seed)
+        self.seed, self.rng, self.fps, self.tempo = seed, rng, fps, tempo
+        self.features = features
+        self.length = features[list(features.keys())[0]].shape[0]
+        self.n_base_latents = torch.randint(3, 15, size=(), generator=rng).item()
+        self.sigma_base_noise = 1 + 9 * torch.rand((), generator=rng).item()
+        self.loops_base_noise = random_choice(rng, [1, 2, 4, 8, 16, 32, 64])
+        n = lambda: int(torch.randint(min_subpatches, max_subpatches, size=(), generator=rng))
+        self.latent_patches = [self.random_latent_patch() for _ in range(n())]
+        self.noise_patches = [self.random_noise_patch() for _ in range(n())]
+
+    def _common(self):
+        r = self.rng
+        return dict(loop_bars=random_choice(r, [4, 8, 16, 32], weights=[2, 2, 2, 1]), seq_feat=random_choice(r, ALLFEATS),
+                    seq_feat_weight=1, mod_feat=random_choice(r, UNITFEATS), mod_feat_weight=1,
+                    merge_type=random_choice(r, ["average", "modulate"], weights=[1, 3]),
+                    merge_depth=random_choice(r, ["low", "mid", "high", "lowmid", "midhigh", "all"], weights=[3, 3, 3, 2, 2, 1]))
+
+    def random_latent_patch(self):
+        return dict(patch_type=random_choice(self.rng, ["feature", "loop"]), segments=random_choice(self.rng, [2, 4, 6, 8, 12, 16]),
+                    **self._common())
+
+    def random_noise_patch(self):
+        return dict(patch_type=random_choice(self.rng, ["blend", "multiply", "loop"]), **self._common(), noise_mean=0, noise_std=1)
+
+    def forward(self, latent_palette, downscale_factor=1, aspect_ratio=1):
+        self.rng.manual_seed(self.seed)
+        base = torch.randperm(len(latent_palette), generator=self.rng)[: self.n_base_latents]
+        latents = LT.spline_loop_latents(latent_palette[base.to(latent_palette.device)], self.length).contiguous()
+        for sub in self.latent_patches:
+            latents = LT.latent_patch(self.rng, latents, latent_palette, {}, self.features, self.tempo, self.fps, **sub)
+        sizes = [4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024]
+        noise = [N.Loop(rng=self.rng, length=self.length,
+                        size=(round(aspect_ratio * s / downscale_factor), round(s / downscale_factor)),
+                        n_loops=self.loops_base_noise, sigma=self.sigma_base_noise) for s in sizes]
+        for sub in self.noise_patches:
+            noise = N.noise_patch(self.rng, noise, self.features, self.tempo, self.fps, **sub)
+        return latents, noise
+
+    def save(self, path):
+        Path(path).write_text(json.dumps(dict(seed=self.seed, latent_patches=self.latent_patches,
+                                              noise_patches=self.noise_patches, n_base_latents=self.n_base_latents,
+                                              sigma_base_noise=self.sigma_base_noise,
+                                              loops_base_noise=self.loops_base_noise), default=str))
+
+
+@torch.inference_mode()
+def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_file: Optional[str] = None,
+             seed: Optional[int] = None, latent_seeds: Optional[str] = None, fps: float = 30, audio_offset: float = 0,
+             audio_duration: Optional[float] = None, downscale_factor: float = 4, aspect_ratio: float = 1,
+             batch_size: int = 32, device: str = "cuda", tempo: float = 120.0, out_dir: str = "output",
+             reference_tail: bool = False, dtype=torch.bfloat16):
+    """sample.py:36-101.  ``reference_tail=True`` reproduces the reference loop's dropped tail."""
+    if aspect_ratio != 1:
+        raise NotImplementedError("aspect_ratio != 1 needs the feature-space resize hooks (N2)")
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31, size=()).item())
+    rank, world = world_info()
+    res = round(1024 / downscale_factor)
+    out_size = (res, res)
+    out_file = f"{out_dir}/{Path(audio_file).stem}_RandomPatches++_seed{seed}_{out_size[0]}x{out_size[1]}.mp4"
+    audio, sr = load_audio(audio_file, audio_offset, audio_duration, fps)
+    features = retrieve_music_information(audio, sr)
+    patch = Patch(features=features, tempo=tempo, seed=seed, fps=fps)
+    G = StyleGAN2(model_file=stylegan2_checkpoint, output_size=out_size, dtype=dtype,
+                  generator=torch.Generator().manual_seed(seed))
+    if latent_seeds is None:
+        z = torch.randn((180, 512), generator=torch.Generator().manual_seed(seed))
+        palette = G.mapper(z)
+    else:
+        palette = G.get_w_latents(latent_seeds)
+    latents, noise = patch.forward(palette, downscale_factor=1024 / res, aspect_ratio=aspect_ratio)
+    noise = noise[: G.synthesizer.G_synth.num_layers]
+    T = len(latents) - (len(latents) % batch_size if reference_tail else 0)
+    if reference_tail and len(latents) % batch_size == 0:
+        T -= batch_size  # range(0, len - B, B) never reaches the last full batch either
+    lo, hi = frame_range(T, rank, world)
+    local = torch.empty((hi - lo, res, res, 3), dtype=torch.uint8, device="cuda")
+    for i in range(lo, hi, batch_size):
+        b = min(batch_size, hi - i)
+        nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
+        G.synthesizer(latents=latents[i:i + b], rgb8_out=local[i - lo:i - lo + b], **nz)
+    frames = gather_frames(local, T, rank, world)  # one RCCL gather at the end (rank 0 receives)
+    if rank == 0:
+        wav = audio_file if str(audio_file).lower().endswith(".wav") else None
+        with VideoWriter(out_file, out_size, fps, wav, audio_offset, audio_duration) as video:
+            for i in range(0, T, 64):
+                video.write(frames[i:i + 64])
+        patch.save(out_file.replace(".mp4", ".json"))
+    return out_file, frames
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="argparse shim for the reference's fire.Fire(generate): same names/defaults")
+    ap.add_argument("--audio_file", required=True)
+    ap.add_argument("--stylegan2_checkpoint", default=None)
+    ap.add_argument("--patch_file", default=None)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--latent_seeds", default=None)
+    ap.add_argument("--fps", type=float, default=30)
+    ap.add_argument("--audio_offset", type=float, default=0)
+    ap.add_argument("--audio_duration", type=float, default=None)
+    ap.add_argument("--downscale_factor", type=float, default=4)
+    ap.add_argument("--aspect_ratio", type=float, default=1)
+    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--tempo", type=float, default=120.0)
+    ap.add_argument("--reference_tail", action="store_true")
+    a = ap.parse_args(argv)
+    from ..distributed import maybe_init_process_group
+    maybe_init_process_group()
+    return generate(**vars(a))[0]
+
+
+if __name__ == "__main__":
+    main()

@@ -263,3 +263,183 @@ class MappingNetwork(torch.nn.Module):
         if truncation_psi != 1:
             x = self._params["w_avg"].to(x.device).lerp(x, truncation_psi)
         return x
+
+
+# =================================================================================================== wrappers
+class MauaMapper(torch.nn.Module):
+    """maua/GAN/wrappers/__init__.py:20-22"""
+
+    def forward(self):
+        raise NotImplementedError()
+
+
+class MauaSynthesizer(torch.nn.Module):
+    """maua/GAN/wrappers/__init__.py:25-38"""
+    _hook_handles = []
+
+    def forward(self):
+        raise NotImplementedError()
+
+    def change_output_resolution(self):
+        raise NotImplementedError()
+
+    def refresh_model_hooks(self):
+        self._hook_handles = []
+
+
+def _state_dict_from_file(model_file, prefix):
+    """A torch-saved state dict (``.pt``) whose keys follow the reference's inference layout
+    ("synthesis.bs.0.conv1.weight", "mapping.fcs.0.weight" ...).  NVIDIA pickles / rosinality checkpoints
+    (maua/GAN/load.py) need the un-vendored nv package and are a SURVEY 8(f) N1 item."""
+    sd = torch.load(model_file, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    if not out:
+        raise ValueError(f"{model_file}: no '{prefix}*' keys; expected a state dict in the reference's inference layout")
+    return out
+
+
+class StyleGAN2Mapper(MauaMapper):
+    """maua/GAN/wrappers/stylegan.py:11-32 (StyleGANMapper) with the StyleGAN2 mapping network."""
+
+    def __init__(self, model_file=None, inference=False, generator=None):
+        super().__init__()
+        self.G_map = MappingNetwork(z_dim=512, c_dim=0, w_dim=512, num_ws=18, generator=generator)
+        if model_file is not None and model_file != "None":
+            sd = _state_dict_from_file(model_file, "mapping.")
+            self.G_map = MappingNetwork(512, 0, 512, _num_ws_from_sd(_state_dict_from_file(model_file, "synthesis.")))
+            self.G_map.load_state_dict(sd)
+        self.z_dim, self.c_dim = self.G_map.z_dim, self.G_map.c_dim
+        self.modulation_targets = {"latent_z": (self.z_dim,), "truncation": (1,)}
+
+    def forward(self, latent_z, class_conditioning=None, truncation=1.0):
+        return self.G_map.forward(latent_z, class_conditioning, truncation_psi=truncation)
+
+
+def _num_ws_from_sd(sd):
+    n = 0
+    while f"bs.{n}.conv1.weight" in sd:
+        n += 1
+    return 2 * n
+
+
+class StyleGAN2Synthesizer(MauaSynthesizer):
+    """maua/GAN/wrappers/stylegan2.py:22-102: same constructor, attributes (w_dim, num_ws, layer_names,
+    modulation_targets, output_size, G_synth) and forward kwargs.  Only the native output size is implemented
+    (the reference's resize hooks do not run on CPU and are a SURVEY 8(f) N2 item); geometric transforms likewise."""
+
+    def __init__(self, model_file=None, inference=False, output_size=None, strategy="stretch", layer=0,
+                 img_resolution=1024, dtype=torch.bfloat16, generator=None):
+        super().__init__()
+        if model_file is None or model_file == "None":
+            # The reference always builds the 1024 net and reaches other sizes through feature-space resize hooks
+            # (not implemented, N2).  A square power-of-two output_size selects a native random-init net instead.
+            if output_size is not None and output_size[0] == output_size[1] and output_size[0] >= 8 \
+                    and (output_size[0] & (output_size[0] - 1)) == 0:
+                img_resolution = int(output_size[0])
+            self.G_synth = SynthesisNetwork(w_dim=512, img_resolution=img_resolution, img_channels=3, dtype=dtype,
+                                            generator=generator)
+        else:
+            sd = _state_dict_from_file(model_file, "synthesis.")
+            res = 4 * 2 ** (_num_ws_from_sd(sd) // 2 - 1)
+            self.G_synth = SynthesisNetwork(w_dim=512, img_resolution=res, img_channels=3, dtype=dtype)
+            self.G_synth.load_state_dict(sd, strict=False)
+        R = self.G_synth.img_resolution
+        if output_size is None:
+            output_size = (R, R)
+        if tuple(output_size) != (R, R):
+            raise NotImplementedError(f"output_size {tuple(output_size)} != native {(R, R)}: feature-space resizing "
+                                      "(wrappers/stylegan2.py:104-151) is not implemented yet")
+        self.w_dim, self.num_ws = self.G_synth.w_dim, self.G_synth.num_ws
+        self.layer_names = [f"bs.{c // 2}.conv{1 if bs == 4 else c % 2}"
+                            for c, bs in enumerate(sorted(self.G_synth.block_resolutions * 2))]
+        self.modulation_targets = {"latent_w": (self.w_dim,), "latent_w_plus": (self.num_ws, self.w_dim),
+                                   "translation": (2,), "rotation": (1,)}
+        self.output_size = tuple(output_size)
+
+    def change_output_resolution(self, output_size, strategy, layer):
+        if tuple(output_size) != self.output_size:
+            raise NotImplementedError("feature-space resizing is not implemented yet")
+
+    def forward(self, latents, translation=None, translation_layer=7, zoom=None, zoom_layer=7, zoom_center=None,
+                rotation=None, rotation_layer=7, rotation_center=None, rgb8_out=None, **noise):
+        if translation is not None or zoom is not None or rotation is not None:
+            raise NotImplementedError("translation / zoom / rotation hooks (kornia) are not implemented yet")
+        # noise kwargs are consumed in dict order as layer 0..16 (wrappers/stylegan2.py:86-100)
+        nz = list(noise.values()) if noise else None
+        return self.G_synth.forward(latents, noise_mode="const", noise=nz, rgb8_out=rgb8_out)
+
+    def make_noise_pyramid(self, noise, layer_limit=8):
+        """wrappers/stylegan2.py:196-213: bicubic resize of a [T,1,h,w] base to each layer's size, / per-frame std
+        (a clip-level pre-pass; torch device ops)."""
+        noises = {}
+        shapes = self.G_synth.layer_shapes()
+        noise = L.dev_tensor(noise, torch.float32)
+        for l, layer in enumerate(self.layer_names[1:]):
+            if l > layer_limit:
+                continue
+            h = w = shapes[l][3]
+            n = torch.nn.functional.interpolate(noise, (h, w), mode="bicubic", align_corners=False)
+            noises[f"noise{l}"] = n / n.std((1, 2, 3), keepdim=True)
+        return noises
+
+
+class MauaGenerator(torch.nn.Module):
+    """maua/GAN/wrappers/__init__.py:41-99"""
+    MapperCls = None
+    SynthesizerCls = None
+
+    def __init__(self, mapper_kwargs={}, synthesizer_kwargs={}):
+        super().__init__()
+        self.mapper = self.__class__.MapperCls(**mapper_kwargs)
+        self.synthesizer = self.__class__.SynthesizerCls(**synthesizer_kwargs)
+
+    def render(self, inputs, batch_size=32, postprocess_fn=lambda x: x, device=None, fp16=True, batched=True,
+               verbose=False):
+        """Generator over frame batches in [0,1] (wrappers/__init__.py:52-99).  ``fp16`` is accepted for drop-in
+        compatibility; the compute type is the synthesizer's dtype (bf16 by default)."""
+        keys = list(inputs.keys())
+        T = len(inputs[keys[0]])
+        for i in range(0, T, batch_size):
+            batch = {k: inputs[k][i:i + batch_size] for k in keys}
+            frames = self.synthesizer.forward(**batch).add(1).div(2).clamp(0, 1)
+            frames = postprocess_fn(frames)
+            if batched:
+                yield frames
+            else:
+                for f in frames:
+                    yield f[None]
+
+
+class StyleGAN2(MauaGenerator):
+    """maua/GAN/wrappers/stylegan.py:39-77 + stylegan2.py StyleGAN2."""
+    MapperCls = StyleGAN2Mapper
+    SynthesizerCls = StyleGAN2Synthesizer
+
+    def __init__(self, model_file=None, inference=False, output_size=None, strategy="stretch", layer=0, **kw):
+        # construction order (mapper, then synthesizer) and the shared generator mirror MauaGenerator.__init__
+        super().__init__(mapper_kwargs=dict(model_file=model_file, inference=inference, generator=kw.get("generator")),
+                         synthesizer_kwargs=dict(model_file=model_file, inference=inference, output_size=output_size,
+                                                 strategy=strategy, layer=layer, **kw))
+        self.z_dim, self.c_dim = self.mapper.G_map.z_dim, self.mapper.G_map.c_dim
+        self.w_dim, self.num_ws = self.mapper.G_map.w_dim, self.synthesizer.num_ws
+        self.mapper.G_map.num_ws = self.num_ws
+        self.res = self.synthesizer.G_synth.img_resolution
+        self.model_file = model_file
+
+    def get_z_latents(self, seeds):
+        return get_z_latents(seeds, self.mapper.z_dim)
+
+    def get_w_latents(self, seeds, truncation=1):
+        return self.mapper(self.get_z_latents(seeds).float(), truncation=truncation)
+
+    def forward(self, z, *args, c=None, **kwargs):
+        return self.synthesizer(self.mapper(z, c))
+
+
+def get_generator_class(architecture):
+    """maua/GAN/wrappers/__init__.py:102-112"""
+    if architecture == "stylegan2":
+        return StyleGAN2
+    raise Exception(f"Architecture not found: {architecture}")

@@ -1,0 +1,77 @@
+"""BASELINE configs[0] plumbing on the GPU box: 32-frame 256x256 random-init render through the drop-in
+maua.audiovisual entry points (synthetic clip: the MP3 named by configs[0] is missing upstream)."""
+import json
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, n_frames):
+    from maua_amd.pipeline import synthetic_audio
+    sr = 30720
+    a = synthetic_audio(n_frames * 1024, sr)
+    pcm = (a.clamp(-1, 1) * 32767).short().numpy()
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+    return str(path)
+
+
+@pytest.fixture(scope="module")
+def wav(tmp_path_factory):
+    return _write_wav(tmp_path_factory.mktemp("audio") / "clip.wav", 32)
+
+
+@pytest.fixture(scope="module")
+def wav_long(tmp_path_factory):
+    # the sampler's salience weighting filters with sigma=80 (radius 320, reflect): like the reference it needs
+    # clips longer than 320 frames
+    return _write_wav(tmp_path_factory.mktemp("audio") / "clip352.wav", 352)
+
+
+def test_generate_from_patch_memmap_and_ffmpeg(wav, tmp_path, monkeypatch):
+    from maua_amd.audiovisual.generate import generate_audiovisal_from_patch, main
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    common = dict(audio_file=wav, model_file="None", patch_file="maua_amd/audiovisual/patches/examples/stylegan2.py",
+                  patch_name=None, fps=30, out_size=(256, 256), resize_strategy="pad-zero", resize_layer=0)
+    import os, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(repo)
+    os.symlink(os.path.join(repo, "maua_amd"), tmp_path / "maua_amd")
+    torch.manual_seed(0)
+    video, (audio, sr) = generate_audiovisal_from_patch(renderer="memmap", renderer_kwargs={}, **common)
+    assert video.shape == (32, 3, 256, 256) and video.dtype == np.uint8 and sr == 30720
+    assert video.std() > 1.0  # not a constant image
+    torch.manual_seed(0)
+    out = generate_audiovisal_from_patch(renderer="ffmpeg", renderer_kwargs=dict(output_file=str(tmp_path / "o.mp4")),
+                                         **common)[0]
+    import shutil
+    if not shutil.which("ffmpeg"):
+        meta = json.loads(open(out + ".json").read())
+        assert meta["frames"] == 32 and (meta["width"], meta["height"]) == (256, 256)
+        raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(32, 256, 256, 3)
+        # same seed, same frames: ffmpeg path (round-half-even pack) vs memmap path (truncating astype) differ <= 1
+        d = np.abs(raw.transpose(0, 3, 1, 2).astype(int) - np.asarray(video).astype(int))
+        assert d.max() <= 1
+
+
+def test_sample_generate(wav, wav_long, tmp_path):
+    """selfsupervised sampler at 256^2 (downscale 4), f32 parity mode."""
+    from maua_amd._lib import MauaHipError
+    from maua_amd.audiovisual.sample import generate
+    with pytest.raises(MauaHipError):  # 32 frames < reflect padding of the sigma=80 filter (torch raises too)
+        generate(wav, None, seed=5, out_dir=str(tmp_path))
+    wav = wav_long
+    out_file, frames = generate(wav, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path),
+                                dtype=torch.float32)
+    assert frames.shape == (352, 256, 256, 3) and frames.dtype == torch.uint8
+    meta = json.loads(open(out_file.replace(".mp4", ".json")).read())
+    assert meta["seed"] == 5 and len(meta["latent_patches"]) >= 2
+    # reference-tail mode drops the tail like sample.py:90 (352 frames, B=8 -> 344)
+    _, fr2 = generate(wav, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path),
+                      dtype=torch.float32, reference_tail=True)
+    assert fr2.shape[0] == 344 and torch.equal(fr2, frames[:344])
