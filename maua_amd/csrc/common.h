@@ -11,6 +11,7 @@ namespace maua {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // native 16-byte register quad (stays in VGPRs)
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 

@@ -49,7 +49,7 @@ struct StyleLayer {
   float scale;            // 1 (conv) or 1/sqrt(Cin) (toRGB)
 };
 int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
-                  int w_dim, int B);
+                  int w_dim, int B, int max_channels);
 
 // toRGB (1x1 modconv, no demod, + bias, clamp) + FIR-upsampled skip + add -> f32 planar image
 struct RgbArgs {

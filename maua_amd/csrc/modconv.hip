@@ -30,34 +30,33 @@ constexpr int RS = KCB + 16;  // LDS row stride in bytes
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-  __device__ static __forceinline__ void step(f32x16& acc, const uint4& a, const uint4& b) {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
                                                   0, 0);
   }
   // scale 8 bf16 by 8 f32 styles, round to nearest even
-  __device__ static __forceinline__ uint4 scale(const uint4& v, const float* sv) {
-    uint4 o;
-    o.x = pack2bf(bf2f((bf16_t)(v.x & 0xffff)) * sv[0], bf2f((bf16_t)(v.x >> 16)) * sv[1]);
-    o.y = pack2bf(bf2f((bf16_t)(v.y & 0xffff)) * sv[2], bf2f((bf16_t)(v.y >> 16)) * sv[3]);
-    o.z = pack2bf(bf2f((bf16_t)(v.z & 0xffff)) * sv[4], bf2f((bf16_t)(v.z >> 16)) * sv[5]);
-    o.w = pack2bf(bf2f((bf16_t)(v.w & 0xffff)) * sv[6], bf2f((bf16_t)(v.w >> 16)) * sv[7]);
+  __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[2 * k + 1]);
     return o;
   }
 };
 template <> struct Mma<float> {
   // lane half h holds k = 8j+4h+e (e = 0..3): MFMA e consumes element e of both operands, so A and B see the
   // same K permutation and the sum is over the same set of products.
-  __device__ static __forceinline__ void step(f32x16& acc, const uint4& a, const uint4& b) {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
     f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], acc, 0, 0, 0);
   }
-  __device__ static __forceinline__ uint4 scale(const uint4& v, const float* sv) {
+  __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
     f32x4 f = __builtin_bit_cast(f32x4, v);
     f[0] *= sv[0]; f[1] *= sv[1]; f[2] *= sv[2]; f[3] *= sv[3];
-    return __builtin_bit_cast(uint4, f);
+    return __builtin_bit_cast(u32x4, f);
   }
 };
 
@@ -70,12 +69,22 @@ struct ConvGeom {
   int phases;           // up*up
 };
 
+// Pipeline: the K loop is a sequence of stages (input-channel chunk c, tap group g).  While stage s is multiplied
+// out of LDS, the global loads of stage s+1 (weights, and the halo when a new chunk starts) are already in flight
+// into registers; they are written to LDS between the two barriers that separate the stages.
+// Accumulators are kept TRANSPOSED (MFMA called as W x X^T): a lane owns one pixel and 4-channel runs, so the
+// epilogue needs one noise value per lane, float4 demod/bias loads, packs 4 channels per LDS store, and the tile
+// leaves the workgroup as full 16-byte coalesced NHWC rows.
 template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int TG>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvArgs a, ConvGeom g) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BN = WAVES_N * WN * 32;
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   constexpr int KC = KCB / (int)sizeof(T);   // channels per K chunk
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte piece
+  constexpr int WREGS = (TG * BN * 4 + NT - 1) / NT;         // weight pieces per thread per stage
+  constexpr int HREGS = BM == 128 ? 4 : 7;                   // halo pieces per thread per chunk (max over tile shapes)
+  constexpr int ES = BN * (int)sizeof(T) + 16;               // epilogue tile row stride (bytes)
+  constexpr int PPP = BN * (int)sizeof(T) / 16;              // 16-byte pieces per output pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wt = smem + g.halo_px * RS;
@@ -88,11 +97,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   const int tile = blockIdx.x;
   const int tyi = tile / g.tiles_x, txi = tile - tyi * g.tiles_x;
   const int ty0 = tyi * g.th, tx0 = txi * tw;
-  const int n0 = blockIdx.y * BN;
-  const int b = blockIdx.z / g.phases, phase = blockIdx.z - b * g.phases;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.z * BN;        // virtual output channel n_v = phase * Co + co
+  const int CoV = a.Co * g.phases;
 
   const T* xb = reinterpret_cast<const T*>(a.x) + (long)b * a.x_bstride;
-  const T* wp = reinterpret_cast<const T*>(a.w) + (long)phase * 9 * a.Co * a.Ci;
+  const T* wp = reinterpret_cast<const T*>(a.w);
   const float* sb = a.s + (long)b * a.Ci;
 
   // per-lane fragment base offsets (bytes)
@@ -114,84 +124,161 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int q = tid & 3;  // which 16-byte piece of the 64-byte row this thread stages (NT % 4 == 0)
+  const int q = tid & 3;   // which 16-byte piece of a 64-byte row this thread stages (NT % 4 == 0)
+  const int rq = tid >> 2;  // first row / halo pixel this thread stages
 
-  for (int c0 = 0; c0 < a.Ci; c0 += KC) {
-    // styles of this thread's piece
-    float sv[EPC];
+  // halo pixel -> global offset (elements), -1 outside the image; fixed for the whole K loop
+  long hoff[HREGS];
 #pragma unroll
-    for (int e = 0; e < EPC; e++) sv[e] = sb[c0 + q * EPC + e];
-    __syncthreads();  // all waves done with the previous chunk's halo / weights
-    // ---- stage the (th+2) x (tw+2) input halo, scaled by the styles, zero outside the image
-    for (int p = tid >> 2; p < g.halo_px; p += NT / 4) {
+  for (int i = 0; i < HREGS; i++) {
+    int p = rq + i * (NT / 4);
+    hoff[i] = -1;
+    if (p < g.halo_px) {
       int py = (int)(((unsigned)p * g.inv_hw2) >> 20);
       int px = p - py * g.hw2;
       int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        v = *reinterpret_cast<const uint4*>(xb + ((long)gy * a.W + gx) * a.Ci + c0 + q * EPC);
-        v = Mma<T>::scale(v, sv);
-      }
-      *reinterpret_cast<uint4*>(halo + p * RS + q * 16) = v;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = ((long)gy * a.W + gx) * a.Ci + q * EPC;
     }
-    for (int tg = 0; tg < 9; tg += TG) {
-      if (tg > 0) __syncthreads();  // previous tap group consumed
-      // ---- stage TG taps of weights: rows (t, n) of KC channels
-      for (int row = tid >> 2; row < TG * BN; row += NT / 4) {
-        int t = row / BN, n = row - t * BN;
-        uint4 v = *reinterpret_cast<const uint4*>(wp + ((long)(tg + t) * a.Co + n0 + n) * a.Ci + c0 + q * EPC);
-        *reinterpret_cast<uint4*>(wt + row * RS + q * 16) = v;
-      }
+  }
+
+  // Prefetch registers.  No lambdas / runtime indices here: everything below is fully unrolled so that these arrays
+  // stay in VGPRs (a by-reference capture sent them to scratch and serialised the pipeline).
+  u32x4 wreg[WREGS], hreg[HREGS];
+  float sv[EPC];
+  const T* wrow[WREGS];  // per-thread weight row base for tap 0 / chunk 0 of this N tile (row -> (t, n) is fixed)
+  int wlds[WREGS];
+#pragma unroll
+  for (int i = 0; i < WREGS; i++) {
+    int row = rq + i * (NT / 4);
+    if (row >= TG * BN) row = TG * BN - 1;  // only when TG*BN*4 % NT != 0: duplicate a valid row, never stored
+    int t = row / BN, n = row - t * BN;
+    wrow[i] = wp + ((long)t * CoV + n0 + n) * a.Ci + q * EPC;
+    wlds[i] = row * RS + q * 16;
+  }
+  const long tap_stride = (long)CoV * a.Ci;
+
+#define MAUA_LOAD_W(C0, TG0)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < WREGS; i++)                                                      \
+      wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (long)(TG0) * tap_stride + (C0));
+#define MAUA_LOAD_H(C0)                                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int e = 0; e < EPC; e++) sv[e] = sb[(C0) + q * EPC + e];                       \
+    _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                  \
+      hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                                   \
+      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + (C0));                   \
+    }                                                                                                     \
+  }
+#define MAUA_STORE_W()                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < WREGS; i++) {                                                    \
+    if ((TG * BN * 4) % NT == 0 || rq + i * (NT / 4) < TG * BN)                                           \
+      *reinterpret_cast<u32x4*>(wt + wlds[i]) = wreg[i];                                                  \
+  }
+#define MAUA_STORE_H()                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                    \
+    int p = rq + i * (NT / 4);                                                                            \
+    if (p < g.halo_px) *reinterpret_cast<u32x4*>(halo + p * RS + q * 16) = Mma<T>::scale(hreg[i], sv);    \
+  }
+
+  constexpr int NG = 9 / TG;
+  const int n_chunks = a.Ci / KC;
+  MAUA_LOAD_W(0, 0)
+  MAUA_LOAD_H(0)
+  for (int c = 0; c < n_chunks; c++) {
+    const int c0 = c * KC;
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      __syncthreads();  // every wave is done reading the previous stage's LDS
+      if (gi == 0) MAUA_STORE_H()
+      MAUA_STORE_W()
       __syncthreads();
+      // next stage's global loads fly while this stage is multiplied
+      if (gi + 1 < NG) {
+        MAUA_LOAD_W(c0, (gi + 1) * TG)
+      } else if (c + 1 < n_chunks) {
+        MAUA_LOAD_W(c0 + KC, 0)
+        MAUA_LOAD_H(c0 + KC)
+      }
 #pragma unroll
       for (int t = 0; t < TG; t++) {
-        const int tap = tg + t;
+        const int tap = gi * TG + t;                       // compile-time after unrolling
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int tapoff = (dy * g.hw2 + dx) * RS;
 #pragma unroll
         for (int ks = 0; ks < KCB / 32; ks++) {
-          uint4 af[WM], bf[WN];
+          u32x4 af[WM], bf[WN];
 #pragma unroll
-          for (int i = 0; i < WM; i++) af[i] = *reinterpret_cast<const uint4*>(halo + offa[i] + tapoff + ks * 32);
+          for (int i = 0; i < WM; i++) af[i] = *reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + ks * 32);
 #pragma unroll
-          for (int j = 0; j < WN; j++) bf[j] = *reinterpret_cast<const uint4*>(wt + t * BN * RS + offb[j] + ks * 32);
+          for (int j = 0; j < WN; j++) bf[j] = *reinterpret_cast<const u32x4*>(wt + t * BN * RS + offb[j] + ks * 32);
 #pragma unroll
           for (int i = 0; i < WM; i++)
 #pragma unroll
-            for (int j = 0; j < WN; j++) Mma<T>::step(acc[i][j], af[i], bf[j]);
+            for (int j = 0; j < WN; j++) Mma<T>::step(acc[i][j], bf[j], af[i]);  // rows = channels, cols = pixels
         }
       }
     }
   }
+#undef MAUA_LOAD_W
+#undef MAUA_LOAD_H
+#undef MAUA_STORE_W
+#undef MAUA_STORE_H
 
-  // ---- epilogue: demod, noise, bias, activation, gain, clamp, store NHWC
+  // ---- epilogue: demod, noise, bias, activation, gain, clamp -> LDS tile [pixel][virtual channel] -> coalesced
+  // NHWC rows.  A virtual channel n_v decodes to (output parity, real channel): phase = n_v / Co, co = n_v % Co.
   const int Ho = a.H * a.up, Wo = a.W * a.up;
-  const int pa = phase / a.up, pb = phase - pa * a.up;  // output parity (row, col); 0,0 when up == 1
-  T* yb = reinterpret_cast<T*>(a.y) + (long)b * Ho * Wo * a.Co;
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
+  __syncthreads();  // main-loop LDS is dead from here on
+  char* epi = smem;
 #pragma unroll
-  for (int j = 0; j < WN; j++) {
-    const int n = n0 + (wn * WN + j) * 32 + r;
-    const float dv = a.d ? a.d[(long)b * a.Co + n] : 1.f;
-    const float bv = a.bias ? a.bias[n] : 0.f;
+  for (int i = 0; i < WM; i++) {
+    const int m = (wm * WM + i) * 32 + r;
+    const int ty = m >> g.tw_log2, tx = m & (tw - 1);
+    const int gy = ty0 + ty, gx = tx0 + tx;
+    const bool inside = gy < a.H && gx < a.W;
 #pragma unroll
-    for (int i = 0; i < WM; i++) {
+    for (int j = 0; j < WN; j++) {
 #pragma unroll
-      for (int e = 0; e < 16; e++) {
-        int m = (wm * WM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        int ty = m >> g.tw_log2, tx = m & (tw - 1);
-        int gy = ty0 + ty, gx = tx0 + tx;
-        if (ty < g.th && gy < a.H && gx < a.W) {
-          int oy = gy * a.up + pa, ox = gx * a.up + pb;
-          long pix = (long)oy * Wo + ox;
-          float v = acc[i][j][e] * dv;
-          if (nb) v += nb[pix] * a.noise_strength;
-          v = activate(v + bv, a.act, a.alpha);
-          v *= a.gain;
-          if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
-          Elem<T>::store(yb + pix * a.Co + n, v);
+      for (int qd = 0; qd < 4; qd++) {
+        const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive virtual channels (tile-local)
+        const int nv = n0 + nl;
+        const int ph = g.phases == 1 ? 0 : nv / a.Co;
+        const int co = nv - ph * a.Co;
+        const int pa = ph / a.up, pb = ph - pa * a.up;
+        float nz = 0.f;
+        if (nb && inside) nz = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb] * a.noise_strength;
+        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);
+        float v[4] = {acc[i][j][qd * 4 + 0] * dv.x + nz + bv.x, acc[i][j][qd * 4 + 1] * dv.y + nz + bv.y,
+                      acc[i][j][qd * 4 + 2] * dv.z + nz + bv.z, acc[i][j][qd * 4 + 3] * dv.w + nz + bv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float t = activate(v[k], a.act, a.alpha) * a.gain;
+          if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+          v[k] = t;
         }
+        char* dst = epi + m * ES + nl * (int)sizeof(T);
+        if constexpr (sizeof(T) == 2)
+          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+  }
+  __syncthreads();
+  char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ho * Wo * a.Co * (long)sizeof(T);
+  for (int p = tid; p < BM * PPP; p += NT) {
+    const int m = p / PPP, pc = p - m * PPP;
+    const int ty = m >> g.tw_log2, tx = m & (tw - 1);
+    const int gy = ty0 + ty, gx = tx0 + tx;
+    if (gy < a.H && gx < a.W) {
+      const int nv = n0 + pc * EPC;
+      const int ph = g.phases == 1 ? 0 : nv / a.Co;
+      const int co = nv - ph * a.Co;
+      const int pa = ph / a.up, pb = ph - pa * a.up;
+      const long pix = (long)(gy * a.up + pa) * Wo + gx * a.up + pb;
+      *reinterpret_cast<uint4*>(yb + (pix * a.Co + co) * (long)sizeof(T)) =
+          *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
     }
   }
 }
@@ -209,12 +296,18 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
   g.inv_hw2 = ((1u << 20) + g.hw2 - 1) / g.hw2;
   g.halo_px = (g.th + 2) * g.hw2;
   g.phases = a.up * a.up;
-  size_t smem = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
+  MAUA_REQUIRE(g.halo_px <= (BM == 128 ? 4 : 7) * (NT / 4), "modconv3x3: halo does not fit the prefetch registers");
+  size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
+  size_t smem_epi = (size_t)BM * (BN * sizeof(T) + 16);
+  size_t smem = std::max(smem_main, smem_epi);
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv3x3: LDS budget exceeded");
+  MAUA_REQUIRE(a.B <= 65535 && (a.Co * g.phases / BN) <= 65535, "modconv3x3: grid too large");
   auto kern = modconv3x3_kernel<T, WAVES_M, WAVES_N, WM, WN, TG>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  dim3 grid(g.tiles_x * tiles_y, a.Co / BN, a.B * g.phases);
+  // x = spatial tiles, y = sample, z = tile of virtual output channels (phase * Co + co): consecutive workgroups
+  // share one weight slice (L2-resident per XCD) while they stream different activation tiles
+  dim3 grid(g.tiles_x * tiles_y, a.B, a.Co * g.phases / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a, g);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
@@ -227,8 +320,9 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(a.Co % 32 == 0, "modconv3x3: Co must be a multiple of 32 (pad channels)");
   MAUA_REQUIRE(a.up == 1 || a.up == 2, "modconv3x3: up must be 1 or 2");
   if (a.B == 0) return MAUA_OK;
-  if (a.Co % 128 == 0) return launch_variant<T, 2, 2, 2, 2, 3>(stream, a);
-  if (a.Co % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9>(stream, a);
+  const int cov = a.Co * a.up * a.up;  // virtual output channels: up-layers carry their 4 parities in N
+  if (cov % 128 == 0) return launch_variant<T, 2, 2, 2, 2, 3>(stream, a);
+  if (cov % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9>(stream, a);
   return launch_variant<T, 4, 1, 2, 1, 9>(stream, a);
 }
 
@@ -239,7 +333,9 @@ int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight prep
-// f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (zero padded) and Wsq[co][ci] = sum_taps W^2.
+// f32 [Co][Ci][k][k] -> T [k*k][phases][Cop][Cip] (zero padded; the phase is part of a 'virtual' output-channel
+// index n_v = phase*Cop + co, so one workgroup can produce several output parities from one input halo) and
+// Wsq[co][ci] = sum_taps W^2.
 // up == 2 (k == 3): phase kernels from K = full_conv2d(flip(W), 4f), f = outer([1,3,3,1])/64.
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, T* __restrict__ wt,
@@ -286,7 +382,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
       for (int ky = 0; ky < 3; ky++)
         for (int kx = 0; kx < 3; kx++) {
           int ph = pa * 2 + pb, t = ky * 3 + kx;
-          Elem<T>::store(wt + ((long)ph * 9 + t) * plane + idx, K[2 * ky + 1 - pa][2 * kx + 1 - pb]);
+          Elem<T>::store(wt + ((long)t * 4 + ph) * plane + idx, K[2 * ky + 1 - pa][2 * kx + 1 - pb]);
         }
 }
 
@@ -311,63 +407,91 @@ int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt,
 }
 
 // ------------------------------------------------------------------------------------------------ styles / demod
-// One workgroup per (layer, sample).  Phase 1: s = affine(w) (stylegan2.py:48-58,:230,:269); phase 2: demod
-// coefficients (ops.py:168-171) or pre-modulated toRGB weights.
-__global__ __launch_bounds__(256) void styles_kernel(const StyleLayer* __restrict__ layers, const float* __restrict__ ws,
-                                                     int num_ws, int w_dim) {
+// Two launches per batch for ALL layers (17 conv + 9 toRGB at 1024^2): (1) s = affine(w) (stylegan2.py:48-58,:230,
+// :269), (2) demod coefficients (ops.py:168-171) / pre-modulated toRGB weights.  Tiny GEMVs: the only thing that
+// matters is parallelism, so the grid is (layer, sample, 64-output slice) and every wave keeps 4 independent
+// dot products in flight.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void styles_affine_kernel(const StyleLayer* __restrict__ layers,
+                                                            const float* __restrict__ ws, int num_ws, int w_dim) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wv = reinterpret_cast<float*>(smem);  // w_dim
-  float* ss = wv + w_dim;                      // Cin
   const StyleLayer L = layers[blockIdx.x];
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.z * 64;
+  if (c0 >= L.Cs) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* wsrc = ws + ((long)b * num_ws + L.w_index) * w_dim;
   for (int i = threadIdx.x; i < w_dim; i += blockDim.x) wv[i] = wsrc[i];
   __syncthreads();
   const float wgain = rsqrtf((float)w_dim);
-  for (int ci = wave; ci < L.Cs; ci += nw) {
-    float s = 0.f;
-    if (ci < L.Cin) {
-      const float* row = L.affine_w + (long)ci * w_dim;
-      float acc = 0.f;
-      for (int k = lane; k < w_dim; k += 64) acc += row[k] * wv[k];
+  for (int g = 0; g < 4; g++) {
+    const int ci0 = c0 + wave * 16 + g * 4;  // 4 outputs at a time
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < w_dim; k += 64) {
+      const float w = wv[k];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      s = (acc * wgain + L.affine_b[ci]) * L.scale;
+      for (int j = 0; j < 4; j++)
+        if (ci0 + j < L.Cin) acc[j] += L.affine_w[(long)(ci0 + j) * w_dim + k] * w;
     }
-    if (lane == 0) {
-      if (ci < L.Cin) ss[ci] = s;
-      L.s[(long)b * L.Cs + ci] = s;
-    }
-  }
-  __syncthreads();
-  if (L.d) {
-    for (int co = wave; co < L.Cd; co += nw) {
-      float dv = 0.f;
-      if (co < L.Co) {
-        const float* row = L.wsq + (long)co * L.Cin;
-        float acc = 0.f;
-        for (int k = lane; k < L.Cin; k += 64) acc += ss[k] * ss[k] * row[k];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        dv = rsqrtf(acc + 1e-8f);
-      }
-      if (lane == 0) L.d[(long)b * L.Cd + co] = dv;
-    }
-  }
-  if (L.wmod) {
-    for (int i = threadIdx.x; i < 3 * L.Cin; i += blockDim.x) {
-      int ci = i % L.Cin;
-      L.wmod[(long)b * 3 * L.Cin + i] = L.wrgb[i] * ss[ci];
+    for (int j = 0; j < 4; j++) {
+      const float t = wave_sum(acc[j]);
+      const int ci = ci0 + j;
+      if (lane == 0 && ci < L.Cs) L.s[(long)b * L.Cs + ci] = ci < L.Cin ? (t * wgain + L.affine_b[ci]) * L.scale : 0.f;
     }
   }
 }
 
+__global__ __launch_bounds__(256) void styles_demod_kernel(const StyleLayer* __restrict__ layers) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s2 = reinterpret_cast<float*>(smem);  // Cin: s (toRGB) or s^2 (conv)
+  const StyleLayer L = layers[blockIdx.x];
+  const int b = blockIdx.y, z = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (L.d) {
+    const int c0 = z * 64;
+    if (c0 >= L.Cd) return;
+    for (int i = threadIdx.x; i < L.Cin; i += blockDim.x) {
+      const float v = L.s[(long)b * L.Cs + i];
+      s2[i] = v * v;
+    }
+    __syncthreads();
+    for (int g = 0; g < 4; g++) {
+      const int co0 = c0 + wave * 16 + g * 4;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = lane; k < L.Cin; k += 64) {
+        const float v = s2[k];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (co0 + j < L.Co) acc[j] += v * L.wsq[(long)(co0 + j) * L.Cin + k];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float t = wave_sum(acc[j]);
+        const int co = co0 + j;
+        if (lane == 0 && co < L.Cd) L.d[(long)b * L.Cd + co] = co < L.Co ? rsqrtf(t + 1e-8f) : 0.f;
+      }
+    }
+  } else if (L.wmod) {
+    const int i = z * 256 + threadIdx.x;
+    if (i < 3 * L.Cin) L.wmod[(long)b * 3 * L.Cin + i] = L.wrgb[i] * L.s[(long)b * L.Cs + (i % L.Cin)];
+  }
+}
+
 int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
-                  int w_dim, int B) {
+                  int w_dim, int B, int max_channels) {
   if (B == 0 || n_layers == 0) return MAUA_OK;
-  size_t smem = (size_t)(w_dim + 1024) * sizeof(float);
-  hipLaunchKernelGGL(styles_kernel, dim3(n_layers, B), dim3(256), smem, stream, layers_dev, ws, num_ws, w_dim);
+  const int nz = cdiv(std::max(max_channels, 64), 64);
+  hipLaunchKernelGGL(styles_affine_kernel, dim3(n_layers, B, nz), dim3(256), (size_t)w_dim * sizeof(float), stream,
+                     layers_dev, ws, num_ws, w_dim);
+  const int nz2 = std::max(nz, cdiv(3 * max_channels, 256));
+  hipLaunchKernelGGL(styles_demod_kernel, dim3(n_layers, B, nz2), dim3(256), (size_t)max_channels * sizeof(float), stream,
+                     layers_dev);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
