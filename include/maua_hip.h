@@ -86,7 +86,9 @@ void maua_synth_destroy(maua_synth* net);
 int maua_synth_num_ws(const maua_synth* net);
 int maua_synth_num_layers(const maua_synth* net);
 /* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug);
- * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward. */
+ * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward;
+ * "use_hires" (default 1) / "fuse_torgb" (default 1) select the register-stationary high-resolution kernels and
+ * the toRGB fusion (0 = generic kernels everywhere, for A/B comparisons and parity tests). */
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.

@@ -30,6 +30,31 @@ struct ConvArgs {
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 
+// high-resolution specialisation (modconv_hires.hip): weights stationary in registers, persistent tile walk,
+// optional fused toRGB + skip on conv1 layers
+struct HiresArgs {
+  const void* x;        // NHWC bf16 [B][H][W][Ci]
+  const void* w;        // prepared weights [9][phases][Co][Ci] bf16
+  const float* s;       // [B][Ci]
+  const float* d;       // [B][Co] or NULL
+  const float* noise;   // [B|1][H*up][W*up] or NULL
+  long noise_bstride;
+  float noise_strength;
+  const float* bias;    // [Co] or NULL
+  void* y;              // NHWC bf16 [B][H*up][W*up][Co]
+  int B, H, W, Ci, Co, up, act;
+  float alpha, gain, clamp;
+  // fused toRGB (conv1 only; rgb_out == NULL disables)
+  const float* rgb_wmod;  // [B][3][Co]
+  const float* rgb_bias;  // [3]
+  const float* rgb_prev;  // [B][3][H/2][W/2] or NULL
+  float* rgb_out;         // [B][3][H][W]
+  float rgb_clamp;
+  float fir[16];
+};
+bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W);
+int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);
+
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
                         int up, int flip, int Cop, int Cip);

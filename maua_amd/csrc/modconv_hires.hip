@@ -1,0 +1,280 @@
+// High-resolution (few-channel, HBM-bound) modulated 3x3 convolution for gfx950: weights stationary in VGPRs.
+//
+// Same math as modconv.hip (reference ops.py:146-186,189-233,87-114,65-84 fused), specialised for the layers where
+// the activations, not the MACs, are the cost: 512^2 / 1024^2 with 32..64 channels.  At these shapes the whole
+// weight set of a wave's output slice is only 18..36 MFMA B-fragments, so it is loaded ONCE per workgroup into
+// registers — pre-multiplied by the sample's styles, which is the reference's own "w = weight * styles" — and the
+// workgroup then walks over spatial tiles of its sample: the only per-tile traffic is the input halo (prefetched
+// into registers while the previous tile is multiplied), the noise row and the output.  LDS holds just the halo
+// and the [pixel][channel] epilogue tile; B operands never touch LDS.
+//   <32,32,1>  b1024.conv1   tile 8x32 px, wave = 2 image rows x 32 channels
+//   <64,64,1>  b512.conv1    tile 4x32 px, wave = 2 image rows x one 32-channel half
+//   <64,32,2>  b1024.conv0   tile 4x32 input px, wave = one output parity (phase kernels of modconv.hip) x 32 ch
+// The conv1 variants optionally fuse the block's toRGB (stylegan2.py:268-272) + FIR-upsampled skip + add
+// (stylegan2.py:372-378) on the epilogue tile while it is still in LDS: the 1x1 conv then never re-reads x from HBM.
+#include "common.h"
+#include "internal.h"
+
+namespace maua {
+
+template <int CI, int CO, int UP>
+__global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(HiresArgs a) {
+  constexpr int P = UP * UP;                      // output parities
+  constexpr int NV = CO * P;                      // virtual output channels
+  constexpr int KS = CI / 16;                     // MFMA k-steps per tap
+  constexpr int NKS = 9 * KS;                     // B fragments per wave
+  constexpr int PIECES = CI * 2 / 16;             // 16-byte pieces per input pixel
+  constexpr int RSH = CI * 2 + 16;                // halo row stride (bytes), +16 keeps ds_read_b128 conflict-free
+  constexpr int TH = CI == 32 ? 8 : 4, TW = 32;   // tile (input grid)
+  constexpr int BM = TH * TW;
+  constexpr int HW2 = TW + 2, HALO_PX = (TH + 2) * HW2;
+  constexpr int HREGS = (HALO_PX * PIECES + 255) / 256;
+  constexpr int ES = NV * 2 + 16;                 // epilogue tile row stride
+  constexpr int PPP = NV * 2 / 16;                // 16-byte pieces per pixel of the epilogue tile
+  constexpr int MSW = (UP == 2) ? 4 : 2;          // image rows (M sub-tiles of 32 px) per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* epi = smem + HALO_PX * RSH;
+  float* wrgb = reinterpret_cast<float*>(epi + BM * ES);  // [3][CO] f32 (fused toRGB only)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * a.H * a.W * CI;
+  const float* sb = a.s + (long)b * CI;
+
+  // ---- role of this wave
+  int phase = 0, nsub = 0, ms0 = 0;
+  if constexpr (UP == 2) { phase = wave; }
+  else if constexpr (CO == 64) { nsub = wave & 1; ms0 = (wave >> 1) * 2; }
+  else { ms0 = wave * 2; }
+
+  // ---- B fragments: W[tap][phase][co][ci] * s[b][ci] -> bf16, resident for the whole kernel
+  u32x4 wf[NKS];
+  {
+    float sv[KS][8];
+#pragma unroll
+    for (int cs = 0; cs < KS; cs++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e];
+    const bf16_t* wbase = reinterpret_cast<const bf16_t*>(a.w);
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+      for (int cs = 0; cs < KS; cs++) {
+        const bf16_t* src = wbase + (((long)tap * P + phase) * CO + nsub * 32 + r) * CI + cs * 16 + 8 * h;
+        u32x4 v = *reinterpret_cast<const u32x4*>(src);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[cs][2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[cs][2 * k + 1]);
+        wf[tap * KS + cs] = o;
+      }
+  }
+  // per-lane epilogue constants: 4 quads of 4 consecutive channels
+  float4 dv[4], bv[4];
+#pragma unroll
+  for (int qd = 0; qd < 4; qd++) {
+    const int co = nsub * 32 + 8 * qd + 4 * h;
+    dv[qd] = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+    bv[qd] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (a.rgb_out)
+    for (int i = tid; i < 3 * CO; i += 256) wrgb[i] = a.rgb_wmod[(long)b * 3 * CO + i];
+
+  const int tiles_x = a.W / TW, n_tiles = tiles_x * (a.H / TH);
+  const int Ho = a.H * UP, Wo = a.W * UP;
+  const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
+  char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ho * Wo * CO * 2;
+
+  // halo staging: piece index -> (pixel, 16-byte piece)
+  const int q = tid % PIECES, rq = tid / PIECES;
+  u32x4 hreg[HREGS];
+#define MAUA_HIRES_LOAD_HALO(TILE)                                                               \
+  {                                                                                               \
+    const int tyi_ = (TILE) / tiles_x, txi_ = (TILE) - tyi_ * tiles_x;                            \
+    _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                          \
+      const int p = rq + i * (256 / PIECES);                                                      \
+      hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                            \
+      if (p < HALO_PX) {                                                                          \
+        const int py = p / HW2, px = p - py * HW2;                                                \
+        const int gy = tyi_ * TH - 1 + py, gx = txi_ * TW - 1 + px;                               \
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)                                           \
+          hreg[i] = *reinterpret_cast<const u32x4*>(xb + ((long)gy * a.W + gx) * CI + q * 8);     \
+      }                                                                                           \
+    }                                                                                             \
+  }
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) MAUA_HIRES_LOAD_HALO(tile)
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    __syncthreads();  // previous tile: MFMA reads of the halo and read-out of the epilogue tile are done
+#pragma unroll
+    for (int i = 0; i < HREGS; i++) {
+      const int p = rq + i * (256 / PIECES);
+      if (p < HALO_PX) *reinterpret_cast<u32x4*>(halo + p * RSH + q * 16) = hreg[i];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) MAUA_HIRES_LOAD_HALO(tile + (int)gridDim.x)  // flies during the MFMAs
+
+    // ---- multiply: two image rows (M sub-tiles) at a time share every B fragment
+#pragma unroll
+    for (int mp = 0; mp < MSW; mp += 2) {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      const int ms = ms0 + mp;
+      const char* abase = halo + ((ms + 1) * HW2 + (r + 1)) * RSH + h * 16;
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+        for (int cs = 0; cs < KS; cs++) {
+          const char* ap = abase + (dy * HW2 + dx) * RSH + cs * 32;
+          const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap);
+          const u32x4 a1 = *reinterpret_cast<const u32x4*>(ap + HW2 * RSH);
+          const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[tap * KS + cs]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, a0), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, a1), acc1, 0, 0, 0);
+        }
+      }
+      // ---- epilogue into the LDS tile: lane = pixel (ms or ms+1, r), 16 channels in 4 quads
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int m = (ms + half) * 32 + r;
+        const int gy = ty0 + ms + half, gx = tx0 + r;
+        const int pa = phase / UP, pb = phase - pa * UP;
+        float nz = 0.f;
+        if (nb) nz = nb[(long)(gy * UP + pa) * Wo + gx * UP + pb] * a.noise_strength;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float ac = half == 0 ? acc0[qd * 4 + k] : acc1[qd * 4 + k];
+            const float dd = k == 0 ? dv[qd].x : k == 1 ? dv[qd].y : k == 2 ? dv[qd].z : dv[qd].w;
+            const float bb = k == 0 ? bv[qd].x : k == 1 ? bv[qd].y : k == 2 ? bv[qd].z : bv[qd].w;
+            float t = ac * dd + nz + bb;
+            t = (t > 0.f ? t : t * a.alpha) * a.gain;   // lrelu (alpha = 1 gives linear)
+            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+            v[k] = t;
+          }
+          const int nv = phase * CO + nsub * 32 + 8 * qd + 4 * h;
+          *reinterpret_cast<uint2*>(epi + m * ES + nv * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- read-out: full 16-byte NHWC pieces
+    for (int p = tid; p < BM * PPP; p += 256) {
+      const int m = p / PPP, pc = p - m * PPP;
+      const int gy = ty0 + (m >> 5), gx = tx0 + (m & 31);
+      const int nv = pc * 8;
+      const int ph = nv / CO, co = nv - ph * CO;
+      const int pa = ph / UP, pb = ph - pa * UP;
+      const long pix = (long)(gy * UP + pa) * Wo + gx * UP + pb;
+      *reinterpret_cast<uint4*>(yb + (pix * CO + co) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
+    }
+    // ---- fused toRGB + upsampled skip (conv1 layers only): one pixel per thread (two threads at CO = 64)
+    if constexpr (UP == 1) {
+      if (a.rgb_out) {
+        constexpr int TPP = 256 / BM;             // threads per pixel (1 or 2)
+        constexpr int CPT = CO / TPP;             // channels per thread
+        const int m = tid / TPP, part = tid - m * TPP;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < CPT / 8; c8++) {
+          const int c = part * CPT + c8 * 8;
+          const uint4 v = *reinterpret_cast<const uint4*>(epi + m * ES + c * 2);
+          const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float lo = bf2f((bf16_t)(u[k] & 0xffff)), hi = bf2f((bf16_t)(u[k] >> 16));
+            r0 += lo * wrgb[c + 2 * k] + hi * wrgb[c + 2 * k + 1];
+            r1 += lo * wrgb[CO + c + 2 * k] + hi * wrgb[CO + c + 2 * k + 1];
+            r2 += lo * wrgb[2 * CO + c + 2 * k] + hi * wrgb[2 * CO + c + 2 * k + 1];
+          }
+        }
+        if constexpr (TPP == 2) {
+          r0 += __shfl_xor(r0, 1);
+          r1 += __shfl_xor(r1, 1);
+          r2 += __shfl_xor(r2, 1);
+        }
+        if (part == 0) {
+          const int y = ty0 + (m >> 5), x = tx0 + (m & 31);
+          float o3[3] = {r0 + a.rgb_bias[0], r1 + a.rgb_bias[1], r2 + a.rgb_bias[2]};
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
+          const long HWl = (long)a.H * a.W;
+          if (a.rgb_prev) {
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+            const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
+            float u3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int Y = y + u - 2;
+              if (Y < 0 || (Y & 1) || (Y >> 1) >= Hp) continue;
+#pragma unroll
+              for (int v = 0; v < 4; v++) {
+                const int X = x + v - 2;
+                if (X < 0 || (X & 1) || (X >> 1) >= Wp) continue;
+                const float f = a.fir[u * 4 + v];
+                const long o = (long)(Y >> 1) * Wp + (X >> 1);
+                u3[0] += pv[o] * f;
+                u3[1] += pv[(long)Hp * Wp + o] * f;
+                u3[2] += pv[2L * Hp * Wp + o] * f;
+              }
+            }
+            o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
+          }
+          float* ob = a.rgb_out + (long)b * 3 * HWl + (long)y * a.W + x;
+          ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+        }
+      }
+    }
+  }
+#undef MAUA_HIRES_LOAD_HALO
+}
+
+template <int CI, int CO, int UP>
+static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
+  constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
+  constexpr int HALO_PX = (TH + 2) * (TW + 2);
+  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + 3 * CO * sizeof(float);
+  auto kern = modconv_hires_kernel<CI, CO, UP>;
+  if (smem > 64 * 1024)
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  const int n_tiles = (a.W / TW) * (a.H / TH);
+  // persistent workgroups: ~2 per CU over all samples, each walks the tiles of ONE sample (its styles are baked
+  // into the register-resident weights)
+  int per_sample = std::max(1, std::min(n_tiles, (512 + a.B - 1) / a.B));
+  hipLaunchKernelGGL(kern, dim3(per_sample, a.B), dim3(256), smem, stream, a);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W) {
+  if (dtype != MAUA_BF16) return false;
+  const bool shape = (Ci == 32 && Co == 32 && up == 1) || (Ci == 64 && Co == 64 && up == 1) ||
+                     (Ci == 64 && Co == 32 && up == 2);
+  if (!shape) return false;
+  const int th = Ci == 32 ? 8 : 4;
+  return W % 32 == 0 && H % th == 0;
+}
+
+int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
+  if (a.B == 0) return MAUA_OK;
+  MAUA_REQUIRE(hires_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_hires: unsupported shape");
+  MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "modconv_hires: lrelu / linear only");
+  HiresArgs b = a;
+  if (a.act == MAUA_ACT_LINEAR) b.alpha = 1.f;
+  if (a.Ci == 32) return launch_hires_variant<32, 32, 1>(stream, b);
+  if (a.up == 1) return launch_hires_variant<64, 64, 1>(stream, b);
+  MAUA_REQUIRE(!a.rgb_out, "modconv_hires: toRGB fusion is for conv1 layers");
+  return launch_hires_variant<64, 32, 2>(stream, b);
+}
+
+}  // namespace maua

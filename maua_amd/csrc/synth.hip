@@ -57,6 +57,8 @@ struct maua_synth {
   std::vector<RgbLayer> rgbs;
   void* const_x = nullptr;  // NHWC [4][4][C0]
   int keep_features = 0;
+  int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
+  int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   // profile mode: HIP events recorded on the ctx stream around every launch of a forward
   int profile = 0;
   std::vector<hipEvent_t> ev;
@@ -248,6 +250,14 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->ev_fwd_start.clear();
     return MAUA_OK;
   }
+  if (!strcmp(key, "use_hires")) {
+    n->use_hires = value;
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "fuse_torgb")) {
+    n->fuse_torgb = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "keep_features")) {
     if (n->keep_features != value) {
       MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
@@ -363,35 +373,52 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   size_t li = 0;
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
+    RgbLayer& g = n->rgbs[blk];
+    const bool last = blk == n->nblocks - 1;
+    float* rgb_out = (last && img_out) ? img_out : n->img[img_cur];
+    bool rgb_fused = false;
     for (int k = 0; k < nconv; k++, li++) {
       ConvLayer& c = n->convs[li];
-      ConvArgs a{};
-      a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;
       const float* nz = (noise && noise[li]) ? noise[li] : c.noise_const;
-      a.noise = nz;
-      a.noise_bstride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.res * c.res) : 0;
-      a.noise_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
-      a.bias = c.bias;
+      const long nz_stride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.res * c.res) : 0;
+      const float nz_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
       void* y = n->keep_features ? c.feat : n->act[cur];
-      a.y = y;
-      a.B = B; a.H = c.res / c.up; a.W = c.res / c.up; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
-      a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
-      if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
+      const int hin = c.res / c.up;
+      if (n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, hin, hin)) {
+        HiresArgs a{};
+        a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
+        a.noise_strength = nz_strength; a.bias = c.bias; a.y = y;
+        a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
+        a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+        if (c.which == 1 && n->fuse_torgb) {  // conv1: the block's toRGB + skip rides on the epilogue tile
+          a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
+          memcpy(a.fir, n->fir, sizeof(a.fir));
+          rgb_fused = true;
+        }
+        if (int rc = launch_modconv_hires(st, a)) return rc;
+      } else {
+        ConvArgs a{};
+        a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;
+        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength;
+        a.bias = c.bias; a.y = y;
+        a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
+        a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+        if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
+      }
       prof_mark(n, c.which == 0 ? "conv0" : "conv1");
       x = y;
       x_bstride = (long)c.res * c.res * c.Co;
       cur ^= 1;
     }
-    RgbLayer& g = n->rgbs[blk];
-    RgbArgs r{};
-    r.x = x; r.wmod = g.wmod; r.bias = g.bias; r.prev = prev_img;
-    const bool last = blk == n->nblocks - 1;
-    float* out = (last && img_out) ? img_out : n->img[img_cur];
-    r.out = out; r.B = B; r.H = g.res; r.W = g.res; r.C = g.C; r.clamp = 256.f;
-    memcpy(r.fir, n->fir, sizeof(r.fir));
-    if (int rc = launch_torgb(st, n->dtype, r)) return rc;
-    prof_mark(n, "torgb");
-    prev_img = out;
+    if (!rgb_fused) {
+      RgbArgs r{};
+      r.x = x; r.wmod = g.wmod; r.bias = g.bias; r.prev = prev_img;
+      r.out = rgb_out; r.B = B; r.H = g.res; r.W = g.res; r.C = g.C; r.clamp = 256.f;
+      memcpy(r.fir, n->fir, sizeof(r.fir));
+      if (int rc = launch_torgb(st, n->dtype, r)) return rc;
+    }
+    prof_mark(n, "torgb");  // zero-length when fused into conv1
+    prev_img = rgb_out;
     img_cur ^= 1;
   }
   if (rgb8_out) {

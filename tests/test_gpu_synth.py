@@ -78,3 +78,42 @@ def test_synth_rgb8_and_determinism():
     # batch independence: frame 1 alone == frame 1 in the batch (frame-range sharding relies on it)
     img3 = net(ws[1:])
     assert torch.equal(img3[0], img[1])
+
+
+def test_hires_kernels_match_generic_and_oracle():
+    """The register-stationary high-resolution kernels (+ fused toRGB) must agree with the generic MFMA kernel
+    bit-for-bit in structure-independent terms: compare both against each other (bf16, tight) and the oracle."""
+    import ctypes as C
+    from maua_amd import _lib as L
+    from maua_amd.stylegan2 import SynthesisNetwork
+    # channel_base 8192 / max 64: 4..128 -> 64 ch, 256 -> 32 ch: exercises <64,64,1>, <64,32,2>, <32,32,1>
+    g = torch.Generator().manual_seed(4)
+    net = SynthesisNetwork(64, 256, 3, channel_base=8192, channel_max=64, dtype=torch.bfloat16, generator=g)
+    p = net.state_dict()
+    g2 = torch.Generator().manual_seed(5)
+    for k in p:
+        if k.endswith(".bias") and "affine" not in k:
+            p[k] = torch.randn(p[k].shape, generator=g2) * 0.1
+    net.load_state_dict(p)
+    B = 3
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    net.keep_features(True)
+    img_h = net(ws, noise=noise).cpu()
+    feats_h = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    h = net._handle()
+    L.check(L.lib().maua_synth_set_option(h, b"use_hires", 0))
+    img_g = net(ws, noise=noise).cpu()
+    feats_g = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    for l, (a, b) in enumerate(zip(feats_h, feats_g)):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert err <= 2e-2, f"layer {l}: hires vs generic {err}"   # both bf16; styles folded into W vs into x
+    rng = float(img_g.max() - img_g.min())
+    assert float((img_h - img_g).abs().max()) <= 2e-2 * rng
+    ref = OS.synthesis_network(p, ws, noise=noise)
+    assert psnr(img_h, ref) >= 40.0
+    # fused toRGB on/off gives the same image up to f32 summation order
+    L.check(L.lib().maua_synth_set_option(h, b"use_hires", 1))
+    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
+    img_nf = net(ws, noise=noise).cpu()
+    assert float((img_nf - img_h).abs().max()) <= 1e-4 * rng
