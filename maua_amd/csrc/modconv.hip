@@ -20,6 +20,8 @@
 // mode) per 32-byte K-step; both read identical 16-byte-per-lane LDS fragments.
 // LDS rows are 64 B of K + 16 B pad (80 B stride): ds_read_b128 fragment reads of 32 consecutive rows are
 // bank-conflict-free (5*i mod 16 is a bijection).
+#include <cstdlib>
+
 #include "common.h"
 #include "internal.h"
 
@@ -67,6 +69,7 @@ struct ConvGeom {
   unsigned inv_hw2;     // ceil(2^20 / hw2) for the halo pixel -> (row, col) split
   int halo_px;          // (th+2)*(tw+2)
   int phases;           // up*up
+  int dbg;              // profiling experiments only (MAUA_DBG env): bit0 weights / bit1 halo always from chunk 0
 };
 
 // Pipeline: the K loop is a sequence of stages (input-channel chunk c, tap group g).  While stage s is multiplied
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   constexpr int KC = KCB / (int)sizeof(T);   // channels per K chunk
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte piece
   constexpr int WREGS = (TG * BN * 4 + NT - 1) / NT;         // weight pieces per thread per stage
-  constexpr int HREGS = BM == 128 ? 4 : 7;                   // halo pieces per thread per chunk (max over tile shapes)
+  constexpr int HREGS = ((BM == 128 ? 204 : 396) * 4 + NT - 1) / NT;  // halo pieces per thread per chunk (max over tile shapes)
   constexpr int ES = BN * (int)sizeof(T) + 16;               // epilogue tile row stride (bytes)
   constexpr int PPP = BN * (int)sizeof(T) / 16;              // 16-byte pieces per output pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 
 #define MAUA_LOAD_W(C0, TG0)                                                                              \
   _Pragma("unroll") for (int i = 0; i < WREGS; i++)                                                      \
-      wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (long)(TG0) * tap_stride + (C0));
+      wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + ((g.dbg & 1) ? 0 : (long)(TG0) * tap_stride + (C0)));
 #define MAUA_LOAD_H(C0)                                                                                   \
   {                                                                                                       \
     _Pragma("unroll") for (int e = 0; e < EPC; e++) sv[e] = sb[(C0) + q * EPC + e];                       \
     _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                  \
       hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                                   \
-      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + (C0));                   \
+      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + ((g.dbg & 2) ? 0 : (C0))); \
     }                                                                                                     \
   }
 #define MAUA_STORE_W()                                                                                    \
@@ -296,7 +299,10 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
   g.inv_hw2 = ((1u << 20) + g.hw2 - 1) / g.hw2;
   g.halo_px = (g.th + 2) * g.hw2;
   g.phases = a.up * a.up;
-  MAUA_REQUIRE(g.halo_px <= (BM == 128 ? 4 : 7) * (NT / 4), "modconv3x3: halo does not fit the prefetch registers");
+  static const int dbg_env = getenv("MAUA_DBG") ? atoi(getenv("MAUA_DBG")) : 0;
+  g.dbg = dbg_env;
+  MAUA_REQUIRE(g.halo_px <= (((BM == 128 ? 204 : 396) * 4 + NT - 1) / NT) * (NT / 4),
+               "modconv3x3: halo does not fit the prefetch registers");
   size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
   size_t smem_epi = (size_t)BM * (BN * sizeof(T) + 16);
   size_t smem = std::max(smem_main, smem_epi);
@@ -321,7 +327,10 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(a.up == 1 || a.up == 2, "modconv3x3: up must be 1 or 2");
   if (a.B == 0) return MAUA_OK;
   const int cov = a.Co * a.up * a.up;  // virtual output channels: up-layers carry their 4 parities in N
-  if (cov % 128 == 0) return launch_variant<T, 2, 2, 2, 2, 3>(stream, a);
+  // 8 / 16 waves per workgroup: measured 1.15x over 4 waves at the same tile (more waves hide the two barriers
+  // per stage); the 256-pixel tile pays off once a sample has >= 16 of them
+  if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3>(stream, a);
+  if (cov % 128 == 0) return launch_variant<T, 2, 4, 2, 1, 3>(stream, a);
   if (cov % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9>(stream, a);
   return launch_variant<T, 4, 1, 2, 1, 9>(stream, a);
 }
