@@ -560,27 +560,27 @@ __global__ __launch_bounds__(256) void torgb_kernel(RgbArgs a, int lp_log2) {
       if (a.prev) {
         // upsample2d: zero-insert x2, pad (2,1,2,1), correlate with 4f
         const float* pv = a.prev + (long)b * 3 * Hp * Wp;
+        // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
+        // parity hits a real sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index
+        // u = 2*iy - y + 2 (same products, same u-major order as the 16-tap correlation)
+        const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
         float u3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          int Y = y + u - 2;
-          if (Y < 0 || (Y & 1)) continue;
-          int iy = Y >> 1;
-          if (iy >= Hp) continue;
+        for (int dy = 0; dy < 2; dy++) {
+          const int iy = iy0 + dy, u = 2 * iy - y + 2;
+          const bool oky = iy >= 0 && iy < Hp;
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            int X = x + v - 2;
-            if (X < 0 || (X & 1)) continue;
-            int ix = X >> 1;
-            if (ix >= Wp) continue;
-            float f = a.fir[u * 4 + v];
-            long o = (long)iy * Wp + ix;
+          for (int dx = 0; dx < 2; dx++) {
+            const int ix = ix0 + dx, v = 2 * ix - x + 2;
+            const bool ok = oky && ix >= 0 && ix < Wp;
+            const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
+                  const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+            const long o = ok ? (long)iy * Wp + ix : 0;
             u3[0] += pv[o] * f;
             u3[1] += pv[(long)Hp * Wp + o] * f;
             u3[2] += pv[2L * Hp * Wp + o] * f;
           }
         }
-        // reference order: img = upsample2d(img) + y
         o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
       }
       float* ob = a.out + (long)b * 3 * HW + p;

@@ -35,7 +35,6 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* epi = smem + HALO_PX * RSH;
-  float* wrgb = reinterpret_cast<float*>(epi + BM * ES);  // [3][CO] f32 (fused toRGB only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -79,8 +78,28 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
     dv[qd] = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
     bv[qd] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (a.rgb_out)
-    for (int i = tid; i < 3 * CO; i += 256) wrgb[i] = a.rgb_wmod[(long)b * 3 * CO + i];
+  // fused toRGB as one more MFMA: B rows 0..2 = bf16(hi) part of the pre-modulated RGB weights, rows 8..10 = the
+  // bf16 remainder (w = hi + lo to ~2^-17), everything else zero; rgb[c] = acc[row c] + acc[row 8+c], both of
+  // which land in the h == 0 lane of the pixel.
+  u32x4 rf[CO / 16];
+  if (a.rgb_out) {
+    const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
+#pragma unroll
+    for (int ks = 0; ks < CO / 16; ks++) {
+      u32x4 o = u32x4{0u, 0u, 0u, 0u};
+      if (c_rgb >= 0) {
+        const float* src = a.rgb_wmod + ((long)b * 3 + c_rgb) * CO + ks * 16 + 8 * h;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float w0 = src[2 * k], w1 = src[2 * k + 1];
+          const float h0 = bf2f(f2bf(w0)), h1 = bf2f(f2bf(w1));
+          if (r >= 8) { w0 -= h0; w1 -= h1; }
+          o[k] = pack2bf(w0, w1);
+        }
+      }
+      rf[ks] = o;
+    }
+  }
 
   const int tiles_x = a.W / TW, n_tiles = tiles_x * (a.H / TH);
   const int Ho = a.H * UP, Wo = a.W * UP;
@@ -177,61 +196,60 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
       const long pix = (long)(gy * UP + pa) * Wo + gx * UP + pb;
       *reinterpret_cast<uint4*>(yb + (pix * CO + co) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
     }
-    // ---- fused toRGB + upsampled skip (conv1 layers only): one pixel per thread (two threads at CO = 64)
+    // ---- fused toRGB + upsampled skip (conv1 layers only): [32 px x CO] x [CO x 3(+3)] on the matrix cores, the
+    // activated bf16 outputs are the A operand straight from the epilogue tile
     if constexpr (UP == 1) {
       if (a.rgb_out) {
-        constexpr int TPP = 256 / BM;             // threads per pixel (1 or 2)
-        constexpr int CPT = CO / TPP;             // channels per thread
-        const int m = tid / TPP, part = tid - m * TPP;
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        constexpr int ROWS_W = TH / 4;  // image rows per wave
 #pragma unroll
-        for (int c8 = 0; c8 < CPT / 8; c8++) {
-          const int c = part * CPT + c8 * 8;
-          const uint4 v = *reinterpret_cast<const uint4*>(epi + m * ES + c * 2);
-          const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+        for (int rw = 0; rw < ROWS_W; rw++) {
+          const int row = wave * ROWS_W + rw;
+          f32x16 racc;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const float lo = bf2f((bf16_t)(u[k] & 0xffff)), hi = bf2f((bf16_t)(u[k] >> 16));
-            r0 += lo * wrgb[c + 2 * k] + hi * wrgb[c + 2 * k + 1];
-            r1 += lo * wrgb[CO + c + 2 * k] + hi * wrgb[CO + c + 2 * k + 1];
-            r2 += lo * wrgb[2 * CO + c + 2 * k] + hi * wrgb[2 * CO + c + 2 * k + 1];
+          for (int e = 0; e < 16; e++) racc[e] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < CO / 16; ks++) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(epi + (row * 32 + r) * ES + (ks * 16 + 8 * h) * 2);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]),
+                                                           __builtin_bit_cast(bf16x8, av), racc, 0, 0, 0);
           }
-        }
-        if constexpr (TPP == 2) {
-          r0 += __shfl_xor(r0, 1);
-          r1 += __shfl_xor(r1, 1);
-          r2 += __shfl_xor(r2, 1);
-        }
-        if (part == 0) {
-          const int y = ty0 + (m >> 5), x = tx0 + (m & 31);
-          float o3[3] = {r0 + a.rgb_bias[0], r1 + a.rgb_bias[1], r2 + a.rgb_bias[2]};
+          if (h == 0) {
+            const int y = ty0 + row, x = tx0 + r;
+            float o3[3] = {racc[0] + racc[4] + a.rgb_bias[0], racc[1] + racc[5] + a.rgb_bias[1],
+                           racc[2] + racc[6] + a.rgb_bias[2]};
 #pragma unroll
-          for (int c = 0; c < 3; c++)
-            if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
-          const long HWl = (long)a.H * a.W;
-          if (a.rgb_prev) {
-            const int Hp = a.H >> 1, Wp = a.W >> 1;
-            const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
-            float u3[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < 3; c++)
+              if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
+            const long HWl = (long)a.H * a.W;
+            if (a.rgb_prev) {
+              const int Hp = a.H >> 1, Wp = a.W >> 1;
+              const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
+              // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
+              // parity hits a real sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index
+              // u = 2*iy - y + 2 (same products, same u-major order as the 16-tap correlation)
+              const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
+              float u3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int Y = y + u - 2;
-              if (Y < 0 || (Y & 1) || (Y >> 1) >= Hp) continue;
+              for (int dy = 0; dy < 2; dy++) {
+                const int iy = iy0 + dy, u = 2 * iy - y + 2;
+                const bool oky = iy >= 0 && iy < Hp;
 #pragma unroll
-              for (int v = 0; v < 4; v++) {
-                const int X = x + v - 2;
-                if (X < 0 || (X & 1) || (X >> 1) >= Wp) continue;
-                const float f = a.fir[u * 4 + v];
-                const long o = (long)(Y >> 1) * Wp + (X >> 1);
-                u3[0] += pv[o] * f;
-                u3[1] += pv[(long)Hp * Wp + o] * f;
-                u3[2] += pv[2L * Hp * Wp + o] * f;
+                for (int dx = 0; dx < 2; dx++) {
+                  const int ix = ix0 + dx, v = 2 * ix - x + 2;
+                  const bool ok = oky && ix >= 0 && ix < Wp;
+                  const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
+                  const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+                  const long o = ok ? (long)iy * Wp + ix : 0;
+                  u3[0] += pv[o] * f;
+                  u3[1] += pv[(long)Hp * Wp + o] * f;
+                  u3[2] += pv[2L * Hp * Wp + o] * f;
+                }
               }
+              o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
             }
-            o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
+            float* ob = a.rgb_out + (long)b * 3 * HWl + (long)y * a.W + x;
+            ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
           }
-          float* ob = a.rgb_out + (long)b * 3 * HWl + (long)y * a.W + x;
-          ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
         }
       }
     }
@@ -243,7 +261,7 @@ template <int CI, int CO, int UP>
 static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
   constexpr int HALO_PX = (TH + 2) * (TW + 2);
-  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + 3 * CO * sizeof(float);
+  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16);
   auto kern = modconv_hires_kernel<CI, CO, UP>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
