@@ -45,12 +45,14 @@ def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4
 
 
 def measured_traffic(kernel_name):
-    """HBM bytes per launch measured with rocprofv3 --pmc (profiles/traffic.json, written by
-    scripts/collect_traffic.py from the counter CSVs; corrections per MI355X_MICROARCH.md §HBM). None if absent."""
+    """HBM bytes per launch (at the bench's default batch of 16 frames per step) measured with rocprofv3 --pmc:
+    profiles/traffic.json, written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with
+    the corrections of MI355X_MICROARCH.md §HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  None if absent."""
     p = Path(__file__).resolve().parent.parent / "profiles" / "traffic.json"
     if not p.exists():
         return None
     try:
-        return json.loads(p.read_text()).get(kernel_name)
+        v = json.loads(p.read_text()).get(kernel_name)
+        return None if v is None else float(v["bytes_per_launch"])
     except Exception:
         return None

@@ -1,0 +1,69 @@
+"""Measured HBM traffic per kernel launch from rocprofv3 PMC counters (GPU box).
+
+Two separate passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md §rocprofv3 PMC
+slots), each `rocprofv3 --kernel-trace --pmc <counter>` over `bench.py --steps 4 --warmup 1 --no-cpu-baseline`.
+Corrections prescribed by MI355X_MICROARCH.md §HBM: counters are in KiB (x1024); on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled; WRITE_SIZE is taken
+as reported (uncalibrated).  Infinity-Cache hits are included in both (fabric-side counters).
+Writes profiles/traffic.json: {bench kernel name: {"bytes_per_launch": ..., "fetch_bytes": ..., "write_bytes": ...}}.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+
+
+def run(counter):
+    os.makedirs(OUT, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", OUT, "-o", counter, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
+    f = glob.glob(os.path.join(OUT, f"{counter}_counter_collection.csv"))[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def bench_name(k):
+    m = re.search(r"modconv3x3_kernel<unsigned short, (\d), (\d), (\d), (\d), (\d)>", k)
+    if m:
+        return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s>" % m.groups()
+    m = re.search(r"modconv_hires_kernel<(\d+), (\d+), (\d)>", k)
+    if m:
+        return "modconv_hires_kernel<%s,%s,%s>" % m.groups()
+    for n in ("torgb_kernel", "pack_rgb8_kernel", "styles_affine_kernel", "styles_demod_kernel",
+              "noise_loop_sumsq_kernel", "noise_loop_write_kernel"):
+        if n in k:
+            return n
+    return None
+
+
+def main():
+    fetch, write = run("FETCH_SIZE"), run("WRITE_SIZE")
+    out = {}
+    for k in fetch:
+        n = bench_name(k)
+        if n is None:
+            continue
+        f = 2.0 * 1024 * sum(fetch[k]) / len(fetch[k])
+        w = 1024 * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
+        out[n] = {"bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "launches_sampled": len(fetch[k]),
+                  "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane coalesced), KiB -> B; WRITE_SIZE as reported"}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
+    for n, v in sorted(out.items()):
+        print(f"{n:44s} {v['bytes_per_launch'] / 1e6:10.1f} MB/launch (fetch {v['fetch_bytes'] / 1e6:.1f}, write {v['write_bytes'] / 1e6:.1f})")
+
+
+if __name__ == "__main__":
+    main()
