@@ -140,6 +140,7 @@ def main():
 
     from maua_amd import _lib as L
     from maua_amd import pipeline
+    from maua_amd.noise import loop_batch
     net, latents, noise, info = build_inputs(device, rank, world)
     B = a.batch
     lo, hi = pipeline.frame_range(T_FRAMES, rank, world)
@@ -148,7 +149,7 @@ def main():
 
     def step(k, u8):
         i = lo + (k * B) % max(1, (hi - lo) - B + 1)  # batches walk this rank's frame range
-        nz = [m.forward(i, B) for m in noise]
+        nz = loop_batch(noise, i, B)  # 17 Loop modules, two launches
         net(latents[i:i + B], noise=nz, rgb8_out=u8)
 
     def fence():

@@ -187,6 +187,10 @@ int maua_latent_merge(maua_ctx* ctx, float* latents, const float* sequence, cons
  * out[b] = sin(cos(idx[i0+b] + n0) / (sigma/50) + n1) * n2, divided by its per-frame RMS + eps(f32).  out [B,h,w]. */
 int maua_noise_loop(maua_ctx* ctx, const float* planes, const float* idx, int i0, int B, int h, int w, float sigma,
                     float* out);
+/* the same for n Loop modules (one per synthesis layer) in two launches: host arrays of n device pointers / sizes;
+ * out[l] receives [B, h[l], w[l]].  What selfsupervised/sample.py:93-95 does per batch with 17 module calls. */
+int maua_noise_loop_batch(maua_ctx* ctx, int n, const float* const* planes, const float* const* idx, const int* h,
+                          const int* w, const float* sigma, int i0, int B, float* const* out);
 /* replaces noise.py:11-24 Blend.forward (noise2 != NULL: sum_m noise[m]*mod[b,m] + sum_m noise2[m]*(1-mod[b,m]))
  * and :27-39 Multiply.forward (noise2 == NULL).  noise/noise2 [M,h,w], mod [B,M] (rows i..i+B of the modulator). */
 int maua_noise_mix(maua_ctx* ctx, const float* noise, const float* noise2, const float* mod, int M, int B, int h,

@@ -58,6 +58,50 @@ __global__ __launch_bounds__(256) void noise_loop_write_kernel(const float* __re
   }
 }
 
+// All layers of a batch in two launches: the per-layer descriptors travel in the kernel arguments.
+constexpr int NZ_MAX_LAYERS = 24;
+struct NoiseBatch {
+  const float* planes[NZ_MAX_LAYERS];
+  const float* idx[NZ_MAX_LAYERS];
+  float* out[NZ_MAX_LAYERS];
+  int hw[NZ_MAX_LAYERS];
+  float sigma50[NZ_MAX_LAYERS];
+  int nparts[NZ_MAX_LAYERS];
+  int i0, B;
+};
+
+__global__ __launch_bounds__(256) void noise_loop_batch_sumsq_kernel(NoiseBatch nb, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const int l = blockIdx.z, b = blockIdx.y;
+  if ((int)blockIdx.x >= nb.nparts[l]) return;
+  const int hw = nb.hw[l];
+  const float* planes = nb.planes[l];
+  const float id = nb.idx[l][nb.i0 + b];
+  const float sigma50 = nb.sigma50[l];
+  float acc = 0.f;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += nb.nparts[l] * blockDim.x) {
+    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
+    acc += v * v;
+  }
+  float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[((long)l * nb.B + b) * NZ_BLOCKS + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void noise_loop_batch_write_kernel(NoiseBatch nb, const float* __restrict__ partial) {
+  const int l = blockIdx.z, b = blockIdx.y;
+  const int hw = nb.hw[l];
+  if ((long)blockIdx.x * blockDim.x >= hw) return;
+  float tot = 0.f;
+  for (int i = 0; i < nb.nparts[l]; i++) tot += partial[((long)l * nb.B + b) * NZ_BLOCKS + i];
+  const float denom = sqrtf(tot / (float)hw) + 1.1920928955078125e-07f;
+  const float* planes = nb.planes[l];
+  const float id = nb.idx[l][nb.i0 + b];
+  const float sigma50 = nb.sigma50[l];
+  float* out = nb.out[l] + (long)b * hw;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x)
+    out[p] = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50) / denom;
+}
+
 // Blend / Multiply: out[b,p] = sum_m noise[m,p] * mod[b,m]  (+ sum_m noise2[m,p] * (1 - mod[b,m]))
 __global__ __launch_bounds__(256) void noise_mix_kernel(const float* __restrict__ noise, const float* __restrict__ noise2,
                                                         const float* __restrict__ mod, int M, int hw,
@@ -115,6 +159,32 @@ int maua_noise_loop(maua_ctx* ctx, const float* planes, const float* idx, int i0
   const int wblk = std::min(256, cdiv(hw, 256));
   hipLaunchKernelGGL(noise_loop_write_kernel, dim3(wblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, sigma50,
                      partial, nblk, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_noise_loop_batch(maua_ctx* ctx, int n, const float* const* planes, const float* const* idx, const int* h,
+                          const int* w, const float* sigma, int i0, int B, float* const* out) {
+  MAUA_REQUIRE(ctx, "maua_noise_loop_batch: ctx is NULL");
+  if (B == 0 || n == 0) return MAUA_OK;
+  MAUA_REQUIRE(planes && idx && h && w && sigma && out, "maua_noise_loop_batch: NULL argument");
+  MAUA_REQUIRE(n <= NZ_MAX_LAYERS, "maua_noise_loop_batch: at most 24 layers per call");
+  NoiseBatch nb{};
+  int max_hw = 0;
+  for (int l = 0; l < n; l++) {
+    MAUA_REQUIRE(planes[l] && idx[l] && out[l] && sigma[l] != 0.f, "maua_noise_loop_batch: NULL layer argument");
+    nb.planes[l] = planes[l]; nb.idx[l] = idx[l]; nb.out[l] = out[l];
+    nb.hw[l] = h[l] * w[l];
+    nb.sigma50[l] = (float)((double)sigma[l] / 50.0);
+    nb.nparts[l] = std::min(NZ_BLOCKS, cdiv(nb.hw[l], 256));
+    max_hw = std::max(max_hw, nb.hw[l]);
+  }
+  nb.i0 = i0; nb.B = B;
+  if (int rc = scratch_reserve(ctx, (size_t)n * B * NZ_BLOCKS * sizeof(float))) return rc;
+  float* partial = (float*)ctx->scratch;
+  hipLaunchKernelGGL(noise_loop_batch_sumsq_kernel, dim3(NZ_BLOCKS, B, n), dim3(256), 0, ctx->stream, nb, partial);
+  hipLaunchKernelGGL(noise_loop_batch_write_kernel, dim3(std::min(256, cdiv(max_hw, 1024)), B, n), dim3(256), 0,
+                     ctx->stream, nb, partial);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

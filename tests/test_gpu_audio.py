@@ -207,6 +207,10 @@ def test_noise(golden):
     md = N.Modulate(loop, mu, mod)
     assert rel(md.forward(8, 4), g["modulate_y"]) <= 1e-5
     assert rel(N.ScaleBias(md, 0.7, 0.1).forward(8, 4), g["scalebias_y"]) <= 1e-5
+    # batched form == per-module form, bit for bit
+    mods = [N.Loop(torch.Generator().manual_seed(7 + k), 48, (sz, sz), n_loops=3, sigma=4 + k) for k, sz in enumerate([4, 8, 64, 130])]
+    for a_, b_ in zip(N.loop_batch(mods, 5, 6), [m.forward(5, 6) for m in mods]):
+        assert torch.equal(a_, b_)
     # RNG parity: planes drawn from a CPU generator like the reference
     rng = torch.Generator("cpu").manual_seed(42)
     l2 = N.Loop(rng, 48, (8, 12), n_loops=2, sigma=5)
