@@ -47,6 +47,8 @@ def kernel_of(ci, co, res, up):
     hin = res // up
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
+    if up == 2 and 32 <= hin <= 128:
+        return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     cov = co * up * up
     if cov % 128 == 0:
         return "modconv3x3_kernel<bf16,4,4,2,1,3>" if hin * hin >= 4096 else "modconv3x3_kernel<bf16,2,4,2,1,3>"
@@ -71,7 +73,12 @@ def layer_table(net):
             if kern.startswith("modconv_hires") and up == 1:  # + fused toRGB: img write + upsampled skip read
                 gflop += 2 * r * r * co * 3 / 1e9
                 byts += r * r * 12 + (r // 2) ** 2 * 12
-            rows.append((pfx, kern, gflop, byts))
+            if kern.startswith("tconv2"):  # two launches: MACs on the first, the output write on the second
+                t_bytes = (res + 1) * (res + 1) * co * 2
+                rows.append((pfx + ".tconv", kern, gflop, hin * hin * ci * 2 + t_bytes))
+                rows.append((pfx + ".upfir", "upfir_epilogue_kernel<bf16>", 0.0, t_bytes + res * res * co * 2 + res * res * 4))
+            else:
+                rows.append((pfx, kern, gflop, byts))
         c = shapes[li - 1][2]
         fused = kernel_of(c, c, r, 1).startswith("modconv_hires")
         rows.append((f"bs.{i}.torgb", "torgb(fused)" if fused else "torgb_kernel",

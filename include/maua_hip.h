@@ -87,7 +87,8 @@ int maua_synth_num_ws(const maua_synth* net);
 int maua_synth_num_layers(const maua_synth* net);
 /* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug);
  * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward;
- * "use_hires" (default 1) / "fuse_torgb" (default 1) select the register-stationary high-resolution kernels and
+ * "tconv_up" (default 1) runs up-layers as the minimal stride-2 transposed convolution + a FIR/epilogue pass
+ * (0 = four 3x3 phase kernels, 4x the MACs); "use_hires" (default 1) / "fuse_torgb" (default 1) select the register-stationary high-resolution kernels and
  * the toRGB fusion (0 = generic kernels everywhere, for A/B comparisons and parity tests). */
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
@@ -103,7 +104,8 @@ int maua_synth_forward(maua_synth* net, const float* ws, const float* const* noi
 int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const* noise,
                            const long* noise_batch_stride, int B, float* img_out, uint8_t* rgb8_out);
 /* profile mode: per-launch durations (ms) of every forward since the last read, in launch order per forward:
- * styles, then per block [conv0,] conv1, torgb, then pack_rgb8 if requested.  Synchronises on the last event;
+ * styles, then per block [conv0 (two entries — transposed conv, FIR pass — when it runs as tconv_up),] conv1, torgb,
+ * then pack_rgb8 if requested.  Synchronises on the last event;
  * a call with ms_out != NULL resets the recording (ms_out == NULL only returns the count). */
 int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* count);
 /* debug/parity: copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */

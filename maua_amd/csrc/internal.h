@@ -58,6 +58,27 @@ int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
                         int up, int flip, int Cop, int Cip);
+
+// modconv_tconv.hip: up-layer as the minimal stride-2 transposed convolution; writes the raw tensor
+// t [B][2H+1][2W+1][Co] (uses x, x_bstride, w (from launch_prep_tconv_weights), s, y, B, H, W, Ci, Co of ConvArgs)
+int launch_tconv2(hipStream_t stream, int dtype, const ConvArgs& a);
+int launch_prep_tconv_weights(hipStream_t stream, int dtype, const float* w, void* wt, int Co, int Ci, int flip);
+
+// second half of the minimal up-layer: out = act(d * FIR4x4(t) + noise + bias) (ops.py:225 upfirdn2d pad 1 gain 4,
+// then :184-185 noise and bias_act :65-84), t [B][2H+1][2W+1][Co] -> y [B][2H][2W][Co], both NHWC in dtype
+struct UpfirArgs {
+  const void* t;
+  void* y;
+  const float* d;      // [B][Co] or NULL
+  const float* noise;  // [B|1][2H][2W] or NULL
+  long noise_bstride;
+  float noise_strength;
+  const float* bias;   // [Co] or NULL
+  int B, H, W, Co;     // H, W = INPUT grid of the layer (output is 2H x 2W)
+  int act;
+  float alpha, gain, clamp;
+};
+int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a);
 size_t prepped_weight_elems(int k, int up, int Cop, int Cip);
 
 // styles / demod / toRGB pre-modulation for a list of layers in one launch

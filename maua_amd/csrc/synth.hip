@@ -24,7 +24,8 @@ struct ConvLayer {
   float* bias = nullptr;      // [Co]
   float* noise_const = nullptr;  // [res][res]
   float noise_strength = 0.f;    // loaded value (used under nv_compat bit1)
-  void* wt = nullptr;            // prepared weights
+  void* wt = nullptr;            // prepared weights (up-layers: 4 phase kernels, 9 taps each)
+  void* wt_t = nullptr;          // up-layers: transposed-conv class weights (minimal MACs; FIR done afterwards)
   float* wsq = nullptr;          // [Co][Ci]
   float* s = nullptr;            // [Bcap][Ci]
   float* d = nullptr;            // [Bcap][Co]
@@ -59,6 +60,8 @@ struct maua_synth {
   int keep_features = 0;
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
+  int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
+  void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
   // profile mode: HIP events recorded on the ctx stream around every launch of a forward
   int profile = 0;
   std::vector<hipEvent_t> ev;
@@ -107,6 +110,8 @@ static int free_workspace(maua_synth* n) {
   }
   if (n->style_table_dev) hipFree(n->style_table_dev);
   n->style_table_dev = nullptr;
+  if (n->tbuf) hipFree(n->tbuf);
+  n->tbuf = nullptr;
   n->bcap = 0;
   return MAUA_OK;
 }
@@ -129,6 +134,10 @@ static int ensure_workspace(maua_synth* n, int B) {
   }
   if (!n->keep_features)
     for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->act[i], (size_t)B * max_act * n->esize));
+  size_t max_t = 0;
+  for (auto& c : n->convs)
+    if (c.up == 2) max_t = std::max(max_t, (size_t)(c.res + 1) * (c.res + 1) * c.Co);
+  if (max_t) MAUA_HIP_CHECK(hipMalloc(&n->tbuf, (size_t)B * max_t * n->esize));
   for (int i = 0; i < 2; i++)
     MAUA_HIP_CHECK(hipMalloc((void**)&n->img[i], (size_t)B * 3 * n->res * n->res * sizeof(float)));
   // style table
@@ -203,6 +212,7 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
     A((void**)&c.bias, (size_t)c.Co * 4);
     A((void**)&c.noise_const, (size_t)c.res * c.res * 4);
     A(&c.wt, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
+    if (c.up == 2) A(&c.wt_t, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
     A((void**)&c.wsq, (size_t)c.Co * c.Ci * 4);
   }
   for (auto& g : n->rgbs) {
@@ -230,6 +240,7 @@ void maua_synth_destroy(maua_synth* n) {
   for (auto e : n->ev) hipEventDestroy(e);
   for (auto& c : n->convs) {
     hipFree(c.affine_w); hipFree(c.affine_b); hipFree(c.bias); hipFree(c.noise_const); hipFree(c.wt); hipFree(c.wsq);
+    if (c.wt_t) hipFree(c.wt_t);
   }
   for (auto& g : n->rgbs) {
     hipFree(g.affine_w); hipFree(g.affine_b); hipFree(g.wrgb); hipFree(g.bias);
@@ -252,6 +263,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
   }
   if (!strcmp(key, "use_hires")) {
     n->use_hires = value;
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "tconv_up")) {
+    n->tconv_up = value;
     return MAUA_OK;
   }
   if (!strcmp(key, "fuse_torgb")) {
@@ -341,6 +356,8 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
     MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
     int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, c->wsq, c->Co, c->Ci, 3, c->up,
                                  (c->up == 2) ? (n->nv_compat & 1) : 0, c->Co, c->Ci);
+    if (!rc && c->up == 2)
+      rc = launch_prep_tconv_weights(st, n->dtype, tmp, c->wt_t, c->Co, c->Ci, n->nv_compat & 1);
     hipStreamSynchronize(st);
     hipFree(tmp);
     return rc;
@@ -396,6 +413,20 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           rgb_fused = true;
         }
         if (int rc = launch_modconv_hires(st, a)) return rc;
+      } else if (c.up == 2 && n->tconv_up && ((hin >= 32 && hin <= 128) || n->tconv_up > 1)) {
+        // (measured: pays off for 32^2..128^2 inputs; below, the extra launch costs more than the MACs it saves,
+        //  above, the FIR pass costs what the MACs save; tconv_up = 2 forces it everywhere, for tests)
+        // minimal up-layer: t = conv_transpose2d(x*s, W, stride 2) on the matrix cores, then FIR + epilogue
+        ConvArgs a{};
+        a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;
+        a.y = n->tbuf; a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = 2;
+        if (int rc = launch_tconv2(st, n->dtype, a)) return rc;
+        prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
+        UpfirArgs u{};
+        u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
+        u.bias = c.bias; u.B = B; u.H = hin; u.W = hin; u.Co = c.Co;
+        u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
+        if (int rc = launch_upfir_epilogue(st, n->dtype, u)) return rc;
       } else {
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;

@@ -1,5 +1,6 @@
 """Per-launch HIP-event timings of one synthesis forward (GPU box).  python scripts/profile_layers.py [B] [res] [dtype]"""
 import ctypes as C
+import os
 import sys
 import time
 
@@ -23,7 +24,7 @@ print(f"setup+first forward {time.time()-t0:.1f}s")
 h = net._handle()
 lib = L.lib()
 import os
-for opt in ("use_hires", "fuse_torgb"):
+for opt in ("use_hires", "fuse_torgb", "tconv_up"):
     if os.environ.get("MAUA_" + opt.upper()) is not None:
         L.check(lib.maua_synth_set_option(h, opt.encode(), int(os.environ["MAUA_" + opt.upper()])))
 for it in range(3):
@@ -45,6 +46,9 @@ shapes = net.layer_shapes()
 li = 0
 for i, r in enumerate(net.block_resolutions):
     for k in range(1 if i == 0 else 2):
+        pfx, ci, co, rr, up = shapes[li]
+        if up == 2 and 32 <= rr // up <= 128 and os.environ.get("MAUA_TCONV_UP", "1") != "0" and dt == torch.bfloat16:
+            names.append("  (tconv part of next row)")
         names.append(shapes[li]); li += 1
     names.append(("torgb", shapes[li - 1][2], r))
 names.append("pack_rgb8")

@@ -117,3 +117,25 @@ def test_hires_kernels_match_generic_and_oracle():
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
     img_nf = net(ws, noise=noise).cpu()
     assert float((img_nf - img_h).abs().max()) <= 1e-4 * rng
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_tconv_up_matches_phase_kernels(dt):
+    """Up-layers as minimal transposed conv + FIR pass (default) vs the four 3x3 phase kernels: same layer outputs."""
+    from maua_amd import _lib as L
+    net, p = build(64, 2048, 128, dt)
+    g = torch.Generator().manual_seed(12)
+    B = 2
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    net.keep_features(True)
+    L.check(L.lib().maua_synth_set_option(net._handle(), b"tconv_up", 2))  # every up-layer, also the tiny ones
+    img_t = net(ws, noise=noise).cpu()
+    feats_t = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    L.check(L.lib().maua_synth_set_option(net._handle(), b"tconv_up", 0))
+    img_p = net(ws, noise=noise).cpu()
+    feats_p = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    for l, (a, b) in enumerate(zip(feats_t, feats_p)):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), f"layer {l}"
+    assert float((img_t - img_p).abs().max()) <= tol * float(img_p.abs().max())
