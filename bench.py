@@ -51,8 +51,11 @@ def kernel_of(ci, co, res, up):
         return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     cov = co * up * up
     if cov % 128 == 0:
-        return "modconv3x3_kernel<bf16,4,4,2,1,3>" if hin * hin >= 4096 else "modconv3x3_kernel<bf16,2,4,2,1,3>"
-    return "modconv3x3_kernel<bf16,4,1,2,2,9>" if cov % 64 == 0 else "modconv3x3_kernel<bf16,4,1,2,1,9>"
+        k128 = ci % 64 == 0
+        if hin * hin >= 4096:
+            return "modconv3x3_kernel<bf16,4,4,2,1,3,%d>" % (128 if k128 else 64)
+        return "modconv3x3_kernel<bf16,2,4,2,1,3,%d>" % (128 if (k128 and hin * hin < 256) else 64)
+    return "modconv3x3_kernel<bf16,4,1,2,2,9,64>" if cov % 64 == 0 else "modconv3x3_kernel<bf16,4,1,2,1,9,64>"
 
 
 def layer_table(net):

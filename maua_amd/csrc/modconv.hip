@@ -27,8 +27,7 @@
 
 namespace maua {
 
-constexpr int KCB = 64;       // bytes of K (input channels) per LDS row chunk
-constexpr int RS = KCB + 16;  // LDS row stride in bytes
+// KCB = bytes of K (input channels) per LDS row chunk (template parameter: 64 or 128); the LDS row stride is KCB + 16
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -78,14 +77,15 @@ struct ConvGeom {
 // Accumulators are kept TRANSPOSED (MFMA called as W x X^T): a lane owns one pixel and 4-channel runs, so the
 // epilogue needs one noise value per lane, float4 demod/bias loads, packs 4 channels per LDS store, and the tile
 // leaves the workgroup as full 16-byte coalesced NHWC rows.
-template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int TG>
+template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int TG, int KCB>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvArgs a, ConvGeom g) {
+  constexpr int RS = KCB + 16;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   constexpr int KC = KCB / (int)sizeof(T);   // channels per K chunk
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte piece
-  constexpr int WREGS = (TG * BN * 4 + NT - 1) / NT;         // weight pieces per thread per stage
-  constexpr int HREGS = ((BM == 128 ? 204 : 396) * 4 + NT - 1) / NT;  // halo pieces per thread per chunk (max over tile shapes)
+  constexpr int WREGS = (TG * BN * (KCB / 16) + NT - 1) / NT;         // weight pieces per thread per stage
+  constexpr int HREGS = ((BM == 128 ? 204 : 396) * (KCB / 16) + NT - 1) / NT;  // halo pieces per thread per chunk (max over tile shapes)
   constexpr int ES = BN * (int)sizeof(T) + 16;               // epilogue tile row stride (bytes)
   constexpr int PPP = BN * (int)sizeof(T) / 16;              // 16-byte pieces per output pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,14 +127,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  const int q = tid & 3;   // which 16-byte piece of a 64-byte row this thread stages (NT % 4 == 0)
-  const int rq = tid >> 2;  // first row / halo pixel this thread stages
+  constexpr int PR = KCB / 16;  // 16-byte pieces per LDS row
+  const int q = tid % PR;       // which piece of a row this thread stages (NT % PR == 0)
+  const int rq = tid / PR;      // first row / halo pixel this thread stages
 
   // halo pixel -> global offset (elements), -1 outside the image; fixed for the whole K loop
   long hoff[HREGS];
 #pragma unroll
   for (int i = 0; i < HREGS; i++) {
-    int p = rq + i * (NT / 4);
+    int p = rq + i * (NT / PR);
     hoff[i] = -1;
     if (p < g.halo_px) {
       int py = (int)(((unsigned)p * g.inv_hw2) >> 20);
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   int wlds[WREGS];
 #pragma unroll
   for (int i = 0; i < WREGS; i++) {
-    int row = rq + i * (NT / 4);
+    int row = rq + i * (NT / PR);
     if (row >= TG * BN) row = TG * BN - 1;  // only when TG*BN*4 % NT != 0: duplicate a valid row, never stored
     int t = row / BN, n = row - t * BN;
     wrow[i] = wp + ((long)t * CoV + n0 + n) * a.Ci + q * EPC;
@@ -173,12 +174,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   }
 #define MAUA_STORE_W()                                                                                    \
   _Pragma("unroll") for (int i = 0; i < WREGS; i++) {                                                    \
-    if ((TG * BN * 4) % NT == 0 || rq + i * (NT / 4) < TG * BN)                                           \
+    if ((TG * BN * PR) % NT == 0 || rq + i * (NT / PR) < TG * BN)                                           \
       *reinterpret_cast<u32x4*>(wt + wlds[i]) = wreg[i];                                                  \
   }
 #define MAUA_STORE_H()                                                                                    \
   _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                    \
-    int p = rq + i * (NT / 4);                                                                            \
+    int p = rq + i * (NT / PR);                                                                            \
     if (p < g.halo_px) *reinterpret_cast<u32x4*>(halo + p * RS + q * 16) = Mma<T>::scale(hreg[i], sv);    \
   }
 
@@ -286,9 +287,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   }
 }
 
-template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int TG>
+template <typename T, int WAVES_M, int WAVES_N, int WM, int WN, int TG, int KCB>
 static int launch_variant(hipStream_t stream, const ConvArgs& a) {
-  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64, RS = KCB + 16;
+  MAUA_REQUIRE(a.Ci % (KCB / (int)sizeof(T)) == 0, "modconv3x3: Ci must be a multiple of the K chunk (pad channels)");
   ConvGeom g;
   int tw = a.W > 16 ? 32 : a.W > 8 ? 16 : a.W > 4 ? 8 : 4;
   g.tw_log2 = tw == 32 ? 5 : tw == 16 ? 4 : tw == 8 ? 3 : 2;
@@ -301,14 +303,14 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
   g.phases = a.up * a.up;
   static const int dbg_env = getenv("MAUA_DBG") ? atoi(getenv("MAUA_DBG")) : 0;
   g.dbg = dbg_env;
-  MAUA_REQUIRE(g.halo_px <= (((BM == 128 ? 204 : 396) * 4 + NT - 1) / NT) * (NT / 4),
+  MAUA_REQUIRE(g.halo_px <= (((BM == 128 ? 204 : 396) * (KCB / 16) + NT - 1) / NT) * (NT / (KCB / 16)),
                "modconv3x3: halo does not fit the prefetch registers");
   size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
   size_t smem_epi = (size_t)BM * (BN * sizeof(T) + 16);
   size_t smem = std::max(smem_main, smem_epi);
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv3x3: LDS budget exceeded");
   MAUA_REQUIRE(a.B <= 65535 && (a.Co * g.phases / BN) <= 65535, "modconv3x3: grid too large");
-  auto kern = modconv3x3_kernel<T, WAVES_M, WAVES_N, WM, WN, TG>;
+  auto kern = modconv3x3_kernel<T, WAVES_M, WAVES_N, WM, WN, TG, KCB>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   // x = spatial tiles, y = sample, z = tile of virtual output channels (phase * Co + co): consecutive workgroups
@@ -321,18 +323,21 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
 
 template <typename T>
 static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
-  constexpr int KC = KCB / (int)sizeof(T);
-  MAUA_REQUIRE(a.Ci % KC == 0, "modconv3x3: Ci must be a multiple of the K chunk (pad channels)");
+  MAUA_REQUIRE(a.Ci % 32 == 0, "modconv3x3: Ci must be a multiple of 32 (pad channels)");
   MAUA_REQUIRE(a.Co % 32 == 0, "modconv3x3: Co must be a multiple of 32 (pad channels)");
   MAUA_REQUIRE(a.up == 1 || a.up == 2, "modconv3x3: up must be 1 or 2");
   if (a.B == 0) return MAUA_OK;
   const int cov = a.Co * a.up * a.up;  // virtual output channels: up-layers carry their 4 parities in N
   // 8 / 16 waves per workgroup: measured 1.15x over 4 waves at the same tile (more waves hide the two barriers
   // per stage); the 256-pixel tile pays off once a sample has >= 16 of them
-  if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3>(stream, a);
-  if (cov % 128 == 0) return launch_variant<T, 2, 4, 2, 1, 3>(stream, a);
-  if (cov % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9>(stream, a);
-  return launch_variant<T, 4, 1, 2, 1, 9>(stream, a);
+  // K chunk: 128 bytes (fewer, longer stages) measured 1.1-1.2x over 64 except on the 32^2 layers
+  const bool k128 = a.Ci % (128 / (int)sizeof(T)) == 0;
+  if (cov % 128 == 0 && a.H * a.W >= 4096 && k128) return launch_variant<T, 4, 4, 2, 1, 3, 128>(stream, a);
+  if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
+  if (cov % 128 == 0 && a.H * a.W < 256 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);
+  if (cov % 128 == 0) return launch_variant<T, 2, 4, 2, 1, 3, 64>(stream, a);
+  if (cov % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9, 64>(stream, a);
+  return launch_variant<T, 4, 1, 2, 1, 9, 64>(stream, a);
 }
 
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {

@@ -15,7 +15,7 @@
 
 namespace maua {
 
-constexpr int TKCB = 64, TRS = TKCB + 16;
+constexpr int TKCB = 128, TRS = TKCB + 16, TPR = TKCB / 16;  // K chunk bytes, LDS row stride, pieces per row
 
 template <typename T> struct TMma;
 template <> struct TMma<bf16_t> {
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
   constexpr int NT = 512, BM = 256;
   constexpr int KC = TKCB / (int)sizeof(T);
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int WREGS = (9 * 32 * 4 + NT - 1) / NT;  // 3
-  constexpr int HREGS = (297 * 4 + NT - 1) / NT;     // halo <= (8+1)*(32+1) = 297 px (max over tile shapes: 17*17, 33*9, 65*5)
+  constexpr int WREGS = (9 * 32 * TPR + NT - 1) / NT;
+  constexpr int HREGS = (325 * TPR + NT - 1) / NT;   // halo <= 65*5 = 325 px (tile shapes: 9*33, 17*17, 33*9, 65*5)
   constexpr int ES = 128 * (int)sizeof(T) + 16;
   constexpr int PPP = 128 * (int)sizeof(T) / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,11 +100,11 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
 #pragma unroll
     for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
 
-  const int q = tid & 3, rq = tid >> 2;
+  const int q = tid % TPR, rq = tid / TPR;
   long hoff[HREGS];
 #pragma unroll
   for (int i = 0; i < HREGS; i++) {
-    const int p = rq + i * (NT / 4);
+    const int p = rq + i * (NT / TPR);
     hoff[i] = -1;
     if (p < g.halo_px) {
       const int py = (int)(((unsigned)p * g.inv_hw1) >> 20);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
   int wlds[WREGS];
 #pragma unroll
   for (int i = 0; i < WREGS; i++) {
-    int row = rq + i * (NT / 4);
+    int row = rq + i * (NT / TPR);
     if (row >= 9 * 32) row = 9 * 32 - 1;
     const int k = row >> 5, n = row & 31;
     wrow[i] = wp + ((((long)kTconvSlot[k] * CB + cb) * 4 + kTconvCls[k]) * 32 + n) * a.Ci + q * EPC;
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < HREGS; i++) {
-      const int p = rq + i * (NT / 4);
+      const int p = rq + i * (NT / TPR);
       if (p < g.halo_px) *reinterpret_cast<u32x4*>(halo + p * TRS + q * 16) = TMma<T>::scale(hreg[i], sv);
     }
 #pragma unroll
     for (int i = 0; i < WREGS; i++)
-      if (rq + i * (NT / 4) < 9 * 32) *reinterpret_cast<u32x4*>(wt + wlds[i]) = wreg[i];
+      if (rq + i * (NT / TPR) < 9 * 32) *reinterpret_cast<u32x4*>(wt + wlds[i]) = wreg[i];
     __syncthreads();
     if (c + 1 < n_chunks) TC_LOAD((c + 1) * KC)
 #pragma unroll
@@ -228,7 +228,7 @@ static int launch_tconv_t(hipStream_t stream, const ConvArgs& a) {
   nt += make_region(regs.r[1], 0, a.W, a.H + 1, 1, nt);
   nt += make_region(regs.r[2], a.H, 0, 1, a.W, nt);
   regs.halo_max = std::max(regs.r[0].halo_px, std::max(regs.r[1].halo_px, regs.r[2].halo_px));
-  MAUA_REQUIRE(regs.halo_max <= ((297 * 4 + 511) / 512) * 128, "tconv2: halo does not fit the prefetch registers");
+  MAUA_REQUIRE(regs.halo_max <= 325, "tconv2: halo does not fit the prefetch registers");
   size_t smem = std::max((size_t)regs.halo_max * TRS + (size_t)9 * 32 * TRS, (size_t)256 * (128 * sizeof(T) + 16));
   auto kern = tconv2_kernel<T>;
   if (smem > 64 * 1024)

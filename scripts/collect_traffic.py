@@ -35,9 +35,13 @@ def run(counter):
 
 
 def bench_name(k):
-    m = re.search(r"modconv3x3_kernel<unsigned short, (\d), (\d), (\d), (\d), (\d)>", k)
+    m = re.search(r"modconv3x3_kernel<unsigned short, (\d), (\d), (\d), (\d), (\d), (\d+)>", k)
     if m:
-        return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s>" % m.groups()
+        return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s,%s>" % m.groups()
+    if "tconv2_kernel<unsigned short>" in k:
+        return "tconv2_kernel<bf16>"
+    if "upfir_epilogue_kernel<unsigned short" in k:
+        return "upfir_epilogue_kernel<bf16>"
     m = re.search(r"modconv_hires_kernel<(\d+), (\d+), (\d)>", k)
     if m:
         return "modconv_hires_kernel<%s,%s,%s>" % m.groups()
