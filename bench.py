@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (reference sample.py default batch_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
     return ap.parse_args()
@@ -47,7 +47,7 @@ def kernel_of(ci, co, res, up):
     hin = res // up
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
-    if up == 2 and 32 <= hin <= 128:
+    if up == 2 and 32 <= hin <= 256:
         return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     cov = co * up * up
     if cov % 128 == 0:

@@ -70,14 +70,19 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
         wf[tap * KS + cs] = o;
       }
   }
-  // per-lane epilogue constants: 4 quads of 4 consecutive channels
-  float4 dv[4], bv[4];
+  // per-lane epilogue constants: 4 quads of 4 consecutive channels.  lrelu is positively homogeneous, so the gain
+  // is folded in: act(acc*d + nz + b) * g == act(acc*(d*g) + (nz*g + b*g)) for g > 0.
+  float dv[16], bv[16];
 #pragma unroll
   for (int qd = 0; qd < 4; qd++) {
     const int co = nsub * 32 + 8 * qd + 4 * h;
-    dv[qd] = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
-    bv[qd] = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 d4 = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    dv[qd * 4] = d4.x * a.gain; dv[qd * 4 + 1] = d4.y * a.gain; dv[qd * 4 + 2] = d4.z * a.gain; dv[qd * 4 + 3] = d4.w * a.gain;
+    bv[qd * 4] = b4.x * a.gain; bv[qd * 4 + 1] = b4.y * a.gain; bv[qd * 4 + 2] = b4.z * a.gain; bv[qd * 4 + 3] = b4.w * a.gain;
   }
+  const float nz_scale = a.noise_strength * a.gain;
+  const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
   // fused toRGB as one more MFMA: B rows 0..2 = bf16(hi) part of the pre-modulated RGB weights, rows 8..10 = the
   // bf16 remainder (w = hi + lo to ~2^-17), everything else zero; rgb[c] = acc[row c] + acc[row 8+c], both of
   // which land in the h == 0 lane of the pixel.
@@ -166,19 +171,16 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
         const int gy = ty0 + ms + half, gx = tx0 + r;
         const int pa = phase / UP, pb = phase - pa * UP;
         float nz = 0.f;
-        if (nb) nz = nb[(long)(gy * UP + pa) * Wo + gx * UP + pb] * a.noise_strength;
+        if (nb) nz = nb[(long)(gy * UP + pa) * Wo + gx * UP + pb] * nz_scale;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           float v[4];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const float ac = half == 0 ? acc0[qd * 4 + k] : acc1[qd * 4 + k];
-            const float dd = k == 0 ? dv[qd].x : k == 1 ? dv[qd].y : k == 2 ? dv[qd].z : dv[qd].w;
-            const float bb = k == 0 ? bv[qd].x : k == 1 ? bv[qd].y : k == 2 ? bv[qd].z : bv[qd].w;
-            float t = ac * dd + nz + bb;
-            t = (t > 0.f ? t : t * a.alpha) * a.gain;   // lrelu (alpha = 1 gives linear)
-            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-            v[k] = t;
+            float t = fmaf(ac, dv[qd * 4 + k], nz + bv[qd * 4 + k]);
+            t = fmaxf(t, t * a.alpha);                 // lrelu for 0 <= alpha <= 1 (alpha = 1 gives linear)
+            v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);  // clamp
           }
           const int nv = phase * CO + nsub * 32 + 8 * qd + 4 * h;
           *reinterpret_cast<uint2*>(epi + m * ES + nv * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));

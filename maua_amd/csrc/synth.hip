@@ -401,7 +401,9 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       const float nz_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
       void* y = n->keep_features ? c.feat : n->act[cur];
       const int hin = c.res / c.up;
-      if (n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, hin, hin)) {
+      const int tconv_max = n->tconv_up == 1 ? 256 : n->tconv_up;  // option value > 1 = largest input size routed
+      const bool via_tconv = c.up == 2 && n->tconv_up && hin >= (n->tconv_up == 1 ? 32 : 1) && hin <= tconv_max;
+      if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, hin, hin)) {
         HiresArgs a{};
         a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
         a.noise_strength = nz_strength; a.bias = c.bias; a.y = y;
@@ -413,9 +415,9 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           rgb_fused = true;
         }
         if (int rc = launch_modconv_hires(st, a)) return rc;
-      } else if (c.up == 2 && n->tconv_up && ((hin >= 32 && hin <= 128) || n->tconv_up > 1)) {
-        // (measured: pays off for 32^2..128^2 inputs; below, the extra launch costs more than the MACs it saves,
-        //  above, the FIR pass costs what the MACs save; tconv_up = 2 forces it everywhere, for tests)
+      } else if (via_tconv) {
+        // (measured: pays off for 32^2..256^2 inputs; below, the extra launch costs more than the MACs it saves,
+        //  above, the FIR pass costs more than the MACs save; a tconv_up value > 1 sets the largest routed input size)
         // minimal up-layer: t = conv_transpose2d(x*s, W, stride 2) on the matrix cores, then FIR + epilogue
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;

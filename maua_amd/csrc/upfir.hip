@@ -85,9 +85,12 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
     // epilogue
     float dv[EPC], bv[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; e++) {
-      dv[e] = a.d ? a.d[(long)b * a.Co + pc * EPC + e] : 1.f;
-      bv[e] = a.bias ? a.bias[pc * EPC + e] : 0.f;
+    for (int e4 = 0; e4 < EPC; e4 += 4) {  // 16-byte loads: the kernel is bound by vector-memory instruction issue
+      const float4 d4 = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + pc * EPC + e4)
+                            : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + pc * EPC + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[e4] = d4.x; dv[e4 + 1] = d4.y; dv[e4 + 2] = d4.z; dv[e4 + 3] = d4.w;
+      bv[e4] = b4.x; bv[e4 + 1] = b4.y; bv[e4 + 2] = b4.z; bv[e4 + 3] = b4.w;
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -119,6 +122,8 @@ int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a) {
   if (a.B == 0) return MAUA_OK;
   const int epc = dtype == MAUA_BF16 ? 8 : 4;
   MAUA_REQUIRE(a.Co % epc == 0, "upfir_epilogue: Co must be a multiple of the 16-byte piece");
+  MAUA_REQUIRE((!a.d || ((uintptr_t)a.d % 16) == 0) && (!a.bias || ((uintptr_t)a.bias % 16) == 0),
+               "upfir_epilogue: d and bias must be 16-byte aligned");
   const long total = (long)a.H * a.W * (a.Co / epc);
   const dim3 grid((unsigned)std::min<long>((total + 255) / 256, 4096), a.B);
   const bool lr = a.act == MAUA_ACT_LRELU;

@@ -47,7 +47,7 @@ li = 0
 for i, r in enumerate(net.block_resolutions):
     for k in range(1 if i == 0 else 2):
         pfx, ci, co, rr, up = shapes[li]
-        if up == 2 and 32 <= rr // up <= 128 and os.environ.get("MAUA_TCONV_UP", "1") != "0" and dt == torch.bfloat16:
+        if up == 2 and 32 <= rr // up <= 256 and os.environ.get("MAUA_TCONV_UP", "1") != "0":
             names.append("  (tconv part of next row)")
         names.append(shapes[li]); li += 1
     names.append(("torgb", shapes[li - 1][2], r))

@@ -129,7 +129,7 @@ def test_tconv_up_matches_phase_kernels(dt):
     ws = torch.randn(B, net.num_ws, 64, generator=g)
     noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
     net.keep_features(True)
-    L.check(L.lib().maua_synth_set_option(net._handle(), b"tconv_up", 2))  # every up-layer, also the tiny ones
+    L.check(L.lib().maua_synth_set_option(net._handle(), b"tconv_up", 1 << 20))  # every up-layer, also the tiny and the largest ones
     img_t = net(ws, noise=noise).cpu()
     feats_t = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
     L.check(L.lib().maua_synth_set_option(net._handle(), b"tconv_up", 0))
