@@ -233,6 +233,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
   __syncthreads();  // main-loop LDS is dead from here on
   char* epi = smem;
+  // lrelu / linear (every synthesis layer): positively homogeneous, so the gain is folded into the coefficients,
+  // act(acc*d + nz + b)*g == act(acc*(d*g) + (nz + b)*g); other activations keep the reference order of operations
+  const float alpha = a.act == MAUA_ACT_LINEAR ? 1.f : a.alpha;
+  const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f;
+  const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
 #pragma unroll
   for (int i = 0; i < WM; i++) {
     const int m = (wm * WM + i) * 32 + r;
@@ -241,25 +246,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     const bool inside = gy < a.H && gx < a.W;
 #pragma unroll
     for (int j = 0; j < WN; j++) {
+      // a 32-channel group never straddles an output parity (Co % 32 == 0): phase and channel base are wave-uniform
+      const int nvb = n0 + (wn * WN + j) * 32;
+      const int ph = g.phases == 1 ? 0 : (nvb >= a.Co) + (nvb >= 2 * a.Co) + (nvb >= 3 * a.Co);
+      const int cob = nvb - ph * a.Co;
+      const int pa = ph >> (a.up - 1), pb = ph & (a.up - 1);
+      float nz = 0.f;
+      if (nb && inside) nz = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb] * a.noise_strength;
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {
         const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive virtual channels (tile-local)
-        const int nv = n0 + nl;
-        const int ph = g.phases == 1 ? 0 : nv / a.Co;
-        const int co = nv - ph * a.Co;
-        const int pa = ph / a.up, pb = ph - pa * a.up;
-        float nz = 0.f;
-        if (nb && inside) nz = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb] * a.noise_strength;
+        const int co = cob + 8 * qd + 4 * h;
         float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
         if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);
-        float v[4] = {acc[i][j][qd * 4 + 0] * dv.x + nz + bv.x, acc[i][j][qd * 4 + 1] * dv.y + nz + bv.y,
-                      acc[i][j][qd * 4 + 2] * dv.z + nz + bv.z, acc[i][j][qd * 4 + 3] * dv.w + nz + bv.w};
+        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float v[4];
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          float t = activate(v[k], a.act, a.alpha) * a.gain;
-          if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-          v[k] = t;
+          for (int k = 0; k < 4; k++) {
+            float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
+            t = fmaxf(t, t * alpha);
+            v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
+            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+            v[k] = t;
+          }
         }
         char* dst = epi + m * ES + nl * (int)sizeof(T);
         if constexpr (sizeof(T) == 2)
@@ -277,9 +293,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     const int gy = ty0 + ty, gx = tx0 + tx;
     if (gy < a.H && gx < a.W) {
       const int nv = n0 + pc * EPC;
-      const int ph = g.phases == 1 ? 0 : nv / a.Co;
+      const int ph = g.phases == 1 ? 0 : (nv >= a.Co) + (nv >= 2 * a.Co) + (nv >= 3 * a.Co);
       const int co = nv - ph * a.Co;
-      const int pa = ph / a.up, pb = ph - pa * a.up;
+      const int pa = ph >> (a.up - 1), pb = ph & (a.up - 1);
       const long pix = (long)(gy * a.up + pa) * Wo + gx * a.up + pb;
       *reinterpret_cast<uint4*>(yb + (pix * a.Co + co) * (long)sizeof(T)) =
           *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);

@@ -291,6 +291,7 @@ int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
   MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "modconv_hires: lrelu / linear only");
   HiresArgs b = a;
   if (a.act == MAUA_ACT_LINEAR) b.alpha = 1.f;
+  MAUA_REQUIRE(b.alpha >= 0.f && b.alpha <= 1.f && b.gain > 0.f, "modconv_hires: needs 0 <= alpha <= 1 and gain > 0");
   if (a.Ci == 32) return launch_hires_variant<32, 32, 1>(stream, b);
   if (a.up == 1) return launch_hires_variant<64, 64, 1>(stream, b);
   MAUA_REQUIRE(!a.rgb_out, "modconv_hires: toRGB fusion is for conv1 layers");

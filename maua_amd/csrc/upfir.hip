@@ -92,21 +92,29 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
       dv[e4] = d4.x; dv[e4 + 1] = d4.y; dv[e4 + 2] = d4.z; dv[e4 + 3] = d4.w;
       bv[e4] = b4.x; bv[e4 + 1] = b4.y; bv[e4 + 2] = b4.z; bv[e4 + 3] = b4.w;
     }
+    if constexpr (LRELU) {  // lrelu is positively homogeneous: fold the gain into the coefficients
+#pragma unroll
+      for (int e = 0; e < EPC; e++) { dv[e] *= a.gain; bv[e] *= a.gain; }
+    }
+    const float nzs = LRELU ? a.noise_strength * a.gain : a.noise_strength;
+    const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         const long pix = (long)(Y0 + i) * Wo + X0 + j;
-        const float nz = nb ? nb[pix] * a.noise_strength : 0.f;
+        const float nz = nb ? nb[pix] * nzs : 0.f;
         float o[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; e++) {
-          float t = acc[i][j][e] * dv[e] + nz + bv[e];
-          if constexpr (LRELU) t = t > 0.f ? t : t * a.alpha;
-          else t = activate(t, a.act, a.alpha);
-          t *= a.gain;
-          if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-          o[e] = t;
+          if constexpr (LRELU) {
+            float t = fmaf(acc[i][j][e], dv[e], nz + bv[e]);
+            t = fmaxf(t, t * a.alpha);  // 0 <= alpha <= 1
+            o[e] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+          } else {
+            float t = activate(acc[i][j][e] * dv[e] + nz + bv[e], a.act, a.alpha) * a.gain;
+            o[e] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+          }
         }
         T* dst = yb + pix * a.Co + pc * EPC;
         if constexpr (sizeof(T) == 2)
@@ -126,7 +134,7 @@ int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a) {
                "upfir_epilogue: d and bias must be 16-byte aligned");
   const long total = (long)a.H * a.W * (a.Co / epc);
   const dim3 grid((unsigned)std::min<long>((total + 255) / 256, 4096), a.B);
-  const bool lr = a.act == MAUA_ACT_LRELU;
+  const bool lr = a.act == MAUA_ACT_LRELU && a.alpha >= 0.f && a.alpha <= 1.f && a.gain > 0.f;  // folded-gain fast path
   if (dtype == MAUA_BF16) {
     if (lr) hipLaunchKernelGGL((upfir_epilogue_kernel<bf16_t, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((upfir_epilogue_kernel<bf16_t, false>), grid, dim3(256), 0, stream, a);
