@@ -87,7 +87,7 @@ int maua_synth_num_ws(const maua_synth* net);
 int maua_synth_num_layers(const maua_synth* net);
 /* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug);
  * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward;
- * "tconv_up" (default 1) runs up-layers with 32^2..256^2 inputs as the minimal stride-2 transposed convolution + a
+ * "tconv_up" (default 1) runs up-layers with 32^2..512^2 inputs as the minimal stride-2 transposed convolution + a
  * FIR/epilogue pass (0 = four 3x3 phase kernels everywhere, 4x the MACs; v > 1 = every up-layer with input size <= v);
  * "use_hires" (default 1) / "fuse_torgb" (default 1) select the register-stationary high-resolution kernels and
  * the toRGB fusion (0 = generic kernels everywhere, for A/B comparisons and parity tests). */

@@ -348,6 +348,12 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   // per stage); the 256-pixel tile pays off once a sample has >= 16 of them
   // K chunk: 128 bytes (fewer, longer stages) measured 1.1-1.2x over 64 except on the 32^2 layers
   const bool k128 = a.Ci % (128 / (int)sizeof(T)) == 0;
+  static const int force = getenv("MAUA_VARIANT") ? atoi(getenv("MAUA_VARIANT")) : 0;  // experiments only
+  if (force && cov % 128 == 0) {
+    if (force == 1) return launch_variant<T, 2, 4, 2, 1, 3, 64>(stream, a);
+    if (force == 2 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);
+    if (force == 3) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
+  }
   if (cov % 128 == 0 && a.H * a.W >= 4096 && k128) return launch_variant<T, 4, 4, 2, 1, 3, 128>(stream, a);
   if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
   if (cov % 128 == 0 && a.H * a.W < 256 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);

@@ -15,7 +15,7 @@
 
 namespace maua {
 
-constexpr int TKCB = 128, TRS = TKCB + 16, TPR = TKCB / 16;  // K chunk bytes, LDS row stride, pieces per row
+constexpr int TKCB = 64, TRS = TKCB + 16, TPR = TKCB / 16;  // K chunk bytes, LDS row stride, pieces per row
 
 template <typename T> struct TMma;
 template <> struct TMma<bf16_t> {
@@ -62,7 +62,7 @@ __device__ __constant__ const int kTconvSlot[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};
 __device__ __constant__ const int kTconvCls[9] = {0, 0, 1, 0, 2, 0, 1, 2, 3};
 
 template <typename T>
-__global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions regs) {
+__global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions regs) {
   // one launch covers the three regions; a workgroup's geometry is uniform
   const TconvGeom g = (int)blockIdx.x >= regs.r[2].tile0 ? regs.r[2] : (int)blockIdx.x >= regs.r[1].tile0 ? regs.r[1] : regs.r[0];
   constexpr int NT = 512, BM = 256;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
     for (int e = 0; e < 16; e++) acc[c][e] = 0.f;
 
   const int q = tid % TPR, rq = tid / TPR;
-  long hoff[HREGS];
+  int hoff[HREGS];  // element offsets inside the sample (a sample stays below 2^31 elements: launcher check)
 #pragma unroll
   for (int i = 0; i < HREGS; i++) {
     const int p = rq + i * (NT / TPR);
@@ -110,29 +110,29 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
       const int py = (int)(((unsigned)p * g.inv_hw1) >> 20);
       const int px = p - py * g.hw1;
       const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = ((long)gy * a.W + gx) * a.Ci + q * EPC;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = (gy * a.W + gx) * a.Ci + q * EPC;
     }
   }
   u32x4 wreg[WREGS], hreg[HREGS];
   float sv[EPC];
-  const T* wrow[WREGS];
+  int wrow[WREGS];
   int wlds[WREGS];
 #pragma unroll
   for (int i = 0; i < WREGS; i++) {
     int row = rq + i * (NT / TPR);
     if (row >= 9 * 32) row = 9 * 32 - 1;
     const int k = row >> 5, n = row & 31;
-    wrow[i] = wp + ((((long)kTconvSlot[k] * CB + cb) * 4 + kTconvCls[k]) * 32 + n) * a.Ci + q * EPC;
+    wrow[i] = (((kTconvSlot[k] * CB + cb) * 4 + kTconvCls[k]) * 32 + n) * a.Ci + q * EPC;
     wlds[i] = row * TRS + q * 16;
   }
 
 #define TC_LOAD(C0)                                                                                     \
   {                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < WREGS; i++) wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + (C0)); \
+    _Pragma("unroll") for (int i = 0; i < WREGS; i++) wreg[i] = *reinterpret_cast<const u32x4*>(wp + (wrow[i] + (C0))); \
     _Pragma("unroll") for (int e = 0; e < EPC; e++) sv[e] = sb[(C0) + q * EPC + e];                     \
     _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                \
       hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                                  \
-      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + (C0));                 \
+      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + (hoff[i] + (C0)));                 \
     }                                                                                                   \
   }
 
@@ -152,23 +152,33 @@ __global__ __launch_bounds__(512) void tconv2_kernel(ConvArgs a, TconvRegions re
     if (c + 1 < n_chunks) TC_LOAD((c + 1) * KC)
 #pragma unroll
     for (int ks = 0; ks < TKCB / 32; ks++) {
-      // A fragments for the four shifts (dy,dx) = (-1,-1), (-1,0), (0,-1), (0,0)
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(halo + offa + (-g.hw1 - 1) * TRS + ks * 32);
-      const u32x4 a1 = *reinterpret_cast<const u32x4*>(halo + offa + (-g.hw1) * TRS + ks * 32);
-      const u32x4 a2 = *reinterpret_cast<const u32x4*>(halo + offa + (-1) * TRS + ks * 32);
-      const u32x4 a3 = *reinterpret_cast<const u32x4*>(halo + offa + ks * 32);
-      u32x4 bk[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) bk[k] = *reinterpret_cast<const u32x4*>(wt + k * 32 * TRS + offb + ks * 32);
-      TMma<T>::step(acc[0], bk[0], a0);
-      TMma<T>::step(acc[1], bk[2], a1);
-      TMma<T>::step(acc[2], bk[4], a2);
-      TMma<T>::step(acc[3], bk[8], a3);
-      TMma<T>::step(acc[0], bk[1], a1);
-      TMma<T>::step(acc[1], bk[6], a3);
-      TMma<T>::step(acc[2], bk[7], a3);
-      TMma<T>::step(acc[0], bk[3], a2);
-      TMma<T>::step(acc[0], bk[5], a3);
+      // A fragments for the four shifts (dy,dx) = (-1,-1), (-1,0), (0,-1), (0,0), each followed by the weight blocks
+      // that use it (few fragments live at a time: the kernel runs at 128 VGPRs for 2 workgroups per CU)
+#define TC_A(SH) (*reinterpret_cast<const u32x4*>(halo + offa + (SH) * TRS + ks * 32))
+#define TC_B(K) (*reinterpret_cast<const u32x4*>(wt + (K) * 32 * TRS + offb + ks * 32))
+      {
+        const u32x4 a0 = TC_A(-g.hw1 - 1);
+        TMma<T>::step(acc[0], TC_B(0), a0);
+      }
+      {
+        const u32x4 a1 = TC_A(-g.hw1);
+        TMma<T>::step(acc[1], TC_B(2), a1);
+        TMma<T>::step(acc[0], TC_B(1), a1);
+      }
+      {
+        const u32x4 a2 = TC_A(-1);
+        TMma<T>::step(acc[2], TC_B(4), a2);
+        TMma<T>::step(acc[0], TC_B(3), a2);
+      }
+      {
+        const u32x4 a3 = TC_A(0);
+        TMma<T>::step(acc[3], TC_B(8), a3);
+        TMma<T>::step(acc[1], TC_B(6), a3);
+        TMma<T>::step(acc[2], TC_B(7), a3);
+        TMma<T>::step(acc[0], TC_B(5), a3);
+      }
+#undef TC_A
+#undef TC_B
     }
   }
 #undef TC_LOAD
@@ -221,6 +231,7 @@ template <typename T>
 static int launch_tconv_t(hipStream_t stream, const ConvArgs& a) {
   constexpr int KC = TKCB / (int)sizeof(T);
   MAUA_REQUIRE(a.Ci % KC == 0 && a.Co % 32 == 0, "tconv2: channel counts must be multiples of 32");
+  MAUA_REQUIRE((long)a.H * a.W * a.Ci < (1L << 31) && 16L * a.Co * a.Ci < (1L << 31), "tconv2: 32-bit offsets");
   if (a.B == 0) return MAUA_OK;
   // main H x W block, then the last column (n = W) and the last row (m = H) of the (H+1) x (W+1) position grid
   TconvRegions regs;

@@ -401,7 +401,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       const float nz_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
       void* y = n->keep_features ? c.feat : n->act[cur];
       const int hin = c.res / c.up;
-      const int tconv_max = n->tconv_up == 1 ? 256 : n->tconv_up;  // option value > 1 = largest input size routed
+      const int tconv_max = n->tconv_up == 1 ? 512 : n->tconv_up;  // option value > 1 = largest input size routed
       const bool via_tconv = c.up == 2 && n->tconv_up && hin >= (n->tconv_up == 1 ? 32 : 1) && hin <= tconv_max;
       if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, hin, hin)) {
         HiresArgs a{};
@@ -416,8 +416,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         }
         if (int rc = launch_modconv_hires(st, a)) return rc;
       } else if (via_tconv) {
-        // (measured: pays off for 32^2..256^2 inputs; below, the extra launch costs more than the MACs it saves,
-        //  above, the FIR pass costs more than the MACs save; a tconv_up value > 1 sets the largest routed input size)
+        // (measured: pays off from 32^2 inputs up; below, the extra launch costs more than the MACs it saves,
+        //  a tconv_up value > 1 sets the largest routed input size)
         // minimal up-layer: t = conv_transpose2d(x*s, W, stride 2) on the matrix cores, then FIR + epilogue
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;

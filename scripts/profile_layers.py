@@ -41,13 +41,15 @@ net(ws, out=out, rgb8_out=u8)
 n = C.c_int()
 ms = (C.c_float * 64)()
 L.check(lib.maua_synth_get_profile(h, ms, 64, C.byref(n)))
+tc = int(os.environ.get("MAUA_TCONV_UP", "1"))  # mirrors synth.hip: 0 off, 1 = 32..512, v > 1 = every input <= v
+tc_lo, tc_hi = (32, 512) if tc == 1 else (1, tc) if tc > 1 else (1, 0)
 names = ["styles"]
 shapes = net.layer_shapes()
 li = 0
 for i, r in enumerate(net.block_resolutions):
     for k in range(1 if i == 0 else 2):
         pfx, ci, co, rr, up = shapes[li]
-        if up == 2 and 32 <= rr // up <= 256 and os.environ.get("MAUA_TCONV_UP", "1") != "0":
+        if up == 2 and tc_lo <= rr // up <= tc_hi:
             names.append("  (tconv part of next row)")
         names.append(shapes[li]); li += 1
     names.append(("torgb", shapes[li - 1][2], r))
