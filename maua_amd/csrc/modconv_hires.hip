@@ -18,7 +18,7 @@
 namespace maua {
 
 template <int CI, int CO, int UP>
-__global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(HiresArgs a) {
+__global__ __launch_bounds__(256, 2) void modconv_hires_kernel(HiresArgs a) {
   constexpr int P = UP * UP;                      // output parities
   constexpr int NV = CO * P;                      // virtual output channels
   constexpr int KS = CI / 16;                     // MFMA k-steps per tap
@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* epi = smem + HALO_PX * RSH;
+  // CI == 64: 36 weight fragments leave no room for the epilogue constants at 2 waves per SIMD -> they live in LDS
+  constexpr bool LEAN = CI == 64;
+  float* bias_s = reinterpret_cast<float*>(epi + BM * ES);            // [CO] bias * gain
+  u32x4* rf_s = reinterpret_cast<u32x4*>(epi + BM * ES + CO * 4);      // [CO/16][64 lanes] toRGB B fragments
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -51,11 +55,15 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
   // ---- B fragments: W[tap][phase][co][ci] * s[b][ci] -> bf16, resident for the whole kernel
   u32x4 wf[NKS];
   {
+    // CI == 64: the lane's output channel (MFMA A row r) also gets its demodulation coefficient and the layer gain
+    // here, act(d*acc + nz + b)*g == act(acc' + (nz + b)*g) with w' = w*s*d*g (lrelu is positively homogeneous);
+    // CI == 32 keeps d*g in registers (measured faster there)
+    const float dco = LEAN ? (a.d ? a.d[(long)b * CO + nsub * 32 + r] : 1.f) * a.gain : 1.f;
     float sv[KS][8];
 #pragma unroll
     for (int cs = 0; cs < KS; cs++)
 #pragma unroll
-      for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e];
+      for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e] * dco;
     const bf16_t* wbase = reinterpret_cast<const bf16_t*>(a.w);
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
@@ -70,23 +78,26 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
         wf[tap * KS + cs] = o;
       }
   }
-  // per-lane epilogue constants: 4 quads of 4 consecutive channels.  lrelu is positively homogeneous, so the gain
-  // is folded in: act(acc*d + nz + b) * g == act(acc*(d*g) + (nz*g + b*g)) for g > 0.
-  float dv[16], bv[16];
+  // per-lane epilogue constants: bias * gain for 4 quads of 4 consecutive channels
+  float bv[LEAN ? 1 : 16], dv[LEAN ? 1 : 16];
+  if constexpr (LEAN) {
+    if (tid < CO) bias_s[tid] = (a.bias ? a.bias[tid] : 0.f) * a.gain;
+  } else {
 #pragma unroll
   for (int qd = 0; qd < 4; qd++) {
     const int co = nsub * 32 + 8 * qd + 4 * h;
-    const float4 d4 = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    dv[qd * 4] = d4.x * a.gain; dv[qd * 4 + 1] = d4.y * a.gain; dv[qd * 4 + 2] = d4.z * a.gain; dv[qd * 4 + 3] = d4.w * a.gain;
     bv[qd * 4] = b4.x * a.gain; bv[qd * 4 + 1] = b4.y * a.gain; bv[qd * 4 + 2] = b4.z * a.gain; bv[qd * 4 + 3] = b4.w * a.gain;
+    const float4 d4 = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * CO + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+    dv[qd * 4] = d4.x * a.gain; dv[qd * 4 + 1] = d4.y * a.gain; dv[qd * 4 + 2] = d4.z * a.gain; dv[qd * 4 + 3] = d4.w * a.gain;
+  }
   }
   const float nz_scale = a.noise_strength * a.gain;
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
   // fused toRGB as one more MFMA: B rows 0..2 = bf16(hi) part of the pre-modulated RGB weights, rows 8..10 = the
   // bf16 remainder (w = hi + lo to ~2^-17), everything else zero; rgb[c] = acc[row c] + acc[row 8+c], both of
   // which land in the h == 0 lane of the pixel.
-  u32x4 rf[CO / 16];
+  u32x4 rf[LEAN ? 1 : CO / 16];
   if (a.rgb_out) {
     const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
 #pragma unroll
@@ -102,7 +113,8 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
           o[k] = pack2bf(w0, w1);
         }
       }
-      rf[ks] = o;
+      if constexpr (LEAN) { if (wave == 0) rf_s[ks * 64 + lane] = o; }
+      else rf[ks] = o;
     }
   }
 
@@ -143,12 +155,16 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
     __syncthreads();
     if (tile + (int)gridDim.x < n_tiles) MAUA_HIRES_LOAD_HALO(tile + (int)gridDim.x)  // flies during the MFMAs
 
-    // ---- multiply: two image rows (M sub-tiles) at a time share every B fragment
+    // ---- multiply: PAIR image rows (M sub-tiles) at a time share every B fragment (CI == 64: one row at a time,
+    // the second accumulator would not fit next to 36 weight fragments at 2 waves per SIMD)
+    constexpr int PAIR = LEAN ? 1 : 2;
 #pragma unroll
-    for (int mp = 0; mp < MSW; mp += 2) {
-      f32x16 acc0, acc1;
+    for (int mp = 0; mp < MSW; mp += PAIR) {
+      f32x16 acc[PAIR];
 #pragma unroll
-      for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
+      for (int i = 0; i < PAIR; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
       const int ms = ms0 + mp;
       const char* abase = halo + ((ms + 1) * HW2 + (r + 1)) * RSH + h * 16;
 #pragma unroll
@@ -157,16 +173,17 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
 #pragma unroll
         for (int cs = 0; cs < KS; cs++) {
           const char* ap = abase + (dy * HW2 + dx) * RSH + cs * 32;
-          const u32x4 a0 = *reinterpret_cast<const u32x4*>(ap);
-          const u32x4 a1 = *reinterpret_cast<const u32x4*>(ap + HW2 * RSH);
           const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[tap * KS + cs]);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, a0), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, a1), acc1, 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < PAIR; i++) {
+            const u32x4 av = *reinterpret_cast<const u32x4*>(ap + i * HW2 * RSH);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, av), acc[i], 0, 0, 0);
+          }
         }
       }
-      // ---- epilogue into the LDS tile: lane = pixel (ms or ms+1, r), 16 channels in 4 quads
+      // ---- epilogue into the LDS tile: lane = pixel (ms + i, r), 16 channels in 4 quads
 #pragma unroll
-      for (int half = 0; half < 2; half++) {
+      for (int half = 0; half < PAIR; half++) {
         const int m = (ms + half) * 32 + r;
         const int gy = ty0 + ms + half, gx = tx0 + r;
         const int pa = phase / UP, pb = phase - pa * UP;
@@ -174,11 +191,19 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
         if (nb) nz = nb[(long)(gy * UP + pa) * Wo + gx * UP + pb] * nz_scale;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-          float v[4];
+          float v[4], bq[4];
+          if constexpr (LEAN) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nsub * 32 + 8 * qd + 4 * h);
+            bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) bq[k] = bv[qd * 4 + k];
+          }
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const float ac = half == 0 ? acc0[qd * 4 + k] : acc1[qd * 4 + k];
-            float t = fmaf(ac, dv[qd * 4 + k], nz + bv[qd * 4 + k]);
+            float t;
+            if constexpr (LEAN) t = acc[half][qd * 4 + k] + (nz + bq[k]);  // d * gain is inside the weights
+            else t = fmaf(acc[half][qd * 4 + k], dv[qd * 4 + k], nz + bq[k]);
             t = fmaxf(t, t * a.alpha);                 // lrelu for 0 <= alpha <= 1 (alpha = 1 gives linear)
             v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);  // clamp
           }
@@ -212,7 +237,9 @@ __global__ __launch_bounds__(256, CI == 32 ? 2 : 1) void modconv_hires_kernel(Hi
 #pragma unroll
           for (int ks = 0; ks < CO / 16; ks++) {
             const u32x4 av = *reinterpret_cast<const u32x4*>(epi + (row * 32 + r) * ES + (ks * 16 + 8 * h) * 2);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]),
+            u32x4 rfk;
+            if constexpr (LEAN) rfk = rf_s[ks * 64 + lane]; else rfk = rf[ks];
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfk),
                                                            __builtin_bit_cast(bf16x8, av), racc, 0, 0, 0);
           }
           if (h == 0) {
@@ -263,7 +290,7 @@ template <int CI, int CO, int UP>
 static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
   constexpr int HALO_PX = (TH + 2) * (TW + 2);
-  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16);
+  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + CO * 4 + (CO / 16) * 64 * 16;
   auto kern = modconv_hires_kernel<CI, CO, UP>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
