@@ -18,7 +18,7 @@
 namespace maua {
 
 template <int CI, int CO, int UP>
-__global__ __launch_bounds__(256, 2) void modconv_hires_kernel(HiresArgs a) {
+__global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(HiresArgs a) {
   constexpr int P = UP * UP;                      // output parities
   constexpr int NV = CO * P;                      // virtual output channels
   constexpr int KS = CI / 16;                     // MFMA k-steps per tap
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void modconv_hires_kernel(HiresArgs a) {
   char* halo = smem;
   char* epi = smem + HALO_PX * RSH;
   // CI == 64: 36 weight fragments leave no room for the epilogue constants at 2 waves per SIMD -> they live in LDS
-  constexpr bool LEAN = CI == 64;
+  constexpr bool LEAN = true;
   float* bias_s = reinterpret_cast<float*>(epi + BM * ES);            // [CO] bias * gain
   u32x4* rf_s = reinterpret_cast<u32x4*>(epi + BM * ES + CO * 4);      // [CO/16][64 lanes] toRGB B fragments
 
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void modconv_hires_kernel(HiresArgs a) {
 
     // ---- multiply: PAIR image rows (M sub-tiles) at a time share every B fragment (CI == 64: one row at a time,
     // the second accumulator would not fit next to 36 weight fragments at 2 waves per SIMD)
-    constexpr int PAIR = LEAN ? 1 : 2;
+    constexpr int PAIR = 1;
 #pragma unroll
     for (int mp = 0; mp < MSW; mp += PAIR) {
       f32x16 acc[PAIR];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void modconv_hires_kernel(HiresArgs a) {
     if constexpr (UP == 1) {
       if (a.rgb_out) {
         constexpr int ROWS_W = TH / 4;  // image rows per wave
-#pragma unroll
+#pragma unroll 1
         for (int rw = 0; rw < ROWS_W; rw++) {
           const int row = wave * ROWS_W + rw;
           f32x16 racc;
@@ -297,7 +297,8 @@ static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   const int n_tiles = (a.W / TW) * (a.H / TH);
   // persistent workgroups: ~2 per CU over all samples, each walks the tiles of ONE sample (its styles are baked
   // into the register-resident weights)
-  int per_sample = std::max(1, std::min(n_tiles, (512 + a.B - 1) / a.B));
+  constexpr int WG_PER_CU = CI == 64 ? 2 : 3;
+  int per_sample = std::max(1, std::min(n_tiles, (256 * WG_PER_CU + a.B - 1) / a.B));
   hipLaunchKernelGGL(kern, dim3(per_sample, a.B), dim3(256), smem, stream, a);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
