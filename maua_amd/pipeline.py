@@ -44,15 +44,19 @@ def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4
     return lat.contiguous(), {"seeds": seeds, "schedule": f"spline_loops(n_loops={n_loops}) x2 blended by onsets, gaussian sigma=2"}
 
 
-def measured_traffic(kernel_name):
-    """HBM bytes per launch (at the bench's default batch of 16 frames per step) measured with rocprofv3 --pmc:
-    profiles/traffic.json, written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with
-    the corrections of MI355X_MICROARCH.md §HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  None if absent."""
+def measured_traffic(kernel_name, batch=None):
+    """HBM bytes per launch measured with rocprofv3 --pmc: profiles/traffic.json, written by
+    scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes over bench.py with the corrections of
+    MI355X_MICROARCH.md §HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  The file records the frames per step it was
+    collected at; activations scale with the batch, so another `batch` is scaled linearly.  None if absent."""
     p = Path(__file__).resolve().parent.parent / "profiles" / "traffic.json"
     if not p.exists():
         return None
     try:
         v = json.loads(p.read_text()).get(kernel_name)
-        return None if v is None else float(v["bytes_per_launch"])
+        if v is None:
+            return None
+        scale = (batch / v["batch"]) if (batch and v.get("batch")) else 1.0
+        return float(v["bytes_per_launch"]) * scale
     except Exception:
         return None

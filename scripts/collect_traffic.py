@@ -18,13 +18,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
+BATCH = int(os.environ.get("BATCH", "32"))  # frames per step (bench.py's default)
 
 
 def run(counter):
     os.makedirs(OUT, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", OUT, "-o", counter, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+           "--batch", str(BATCH)]
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     f = glob.glob(os.path.join(OUT, f"{counter}_counter_collection.csv"))[0]
     per = collections.defaultdict(list)
@@ -46,7 +48,7 @@ def bench_name(k):
     if m:
         return "modconv_hires_kernel<%s,%s,%s>" % m.groups()
     for n in ("torgb_kernel", "pack_rgb8_kernel", "styles_affine_kernel", "styles_demod_kernel",
-              "noise_loop_sumsq_kernel", "noise_loop_write_kernel"):
+              "noise_loop_batch_sumsq_kernel", "noise_loop_batch_write_kernel"):
         if n in k:
             return n
     return None
@@ -62,6 +64,7 @@ def main():
         f = 2.0 * 1024 * sum(fetch[k]) / len(fetch[k])
         w = 1024 * sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
         out[n] = {"bytes_per_launch": f + w, "fetch_bytes": f, "write_bytes": w, "launches_sampled": len(fetch[k]),
+                  "batch": BATCH,
                   "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane coalesced), KiB -> B; WRITE_SIZE as reported"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "traffic.json"), "w"), indent=1)
