@@ -287,17 +287,10 @@ class MauaSynthesizer(torch.nn.Module):
         self._hook_handles = []
 
 
-def _state_dict_from_file(model_file, prefix):
-    """A torch-saved state dict (``.pt``) whose keys follow the reference's inference layout
-    ("synthesis.bs.0.conv1.weight", "mapping.fcs.0.weight" ...).  NVIDIA pickles / rosinality checkpoints
-    (maua/GAN/load.py) need the un-vendored nv package and are a SURVEY 8(f) N1 item."""
-    sd = torch.load(model_file, map_location="cpu")
-    if isinstance(sd, dict) and "state_dict" in sd:
-        sd = sd["state_dict"]
-    out = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
-    if not out:
-        raise ValueError(f"{model_file}: no '{prefix}*' keys; expected a state dict in the reference's inference layout")
-    return out
+def _load_generator(model_file, inference, dtype=torch.bfloat16):
+    """maua/GAN/load.py:191-207 via maua_amd.load (rosinality / NVIDIA state-dict / flat state-dict checkpoints)."""
+    from .load import load_network_cached
+    return load_network_cached(model_file, inference, dtype)
 
 
 class StyleGAN2Mapper(MauaMapper):
@@ -305,11 +298,10 @@ class StyleGAN2Mapper(MauaMapper):
 
     def __init__(self, model_file=None, inference=False, generator=None):
         super().__init__()
-        self.G_map = MappingNetwork(z_dim=512, c_dim=0, w_dim=512, num_ws=18, generator=generator)
-        if model_file is not None and model_file != "None":
-            sd = _state_dict_from_file(model_file, "mapping.")
-            self.G_map = MappingNetwork(512, 0, 512, _num_ws_from_sd(_state_dict_from_file(model_file, "synthesis.")))
-            self.G_map.load_state_dict(sd)
+        if model_file is None or model_file == "None":
+            self.G_map = MappingNetwork(z_dim=512, c_dim=0, w_dim=512, num_ws=18, generator=generator)
+        else:
+            self.G_map = _load_generator(model_file, inference).mapping
         self.z_dim, self.c_dim = self.G_map.z_dim, self.G_map.c_dim
         self.modulation_targets = {"latent_z": (self.z_dim,), "truncation": (1,)}
 
@@ -341,10 +333,7 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
             self.G_synth = SynthesisNetwork(w_dim=512, img_resolution=img_resolution, img_channels=3, dtype=dtype,
                                             generator=generator)
         else:
-            sd = _state_dict_from_file(model_file, "synthesis.")
-            res = 4 * 2 ** (_num_ws_from_sd(sd) // 2 - 1)
-            self.G_synth = SynthesisNetwork(w_dim=512, img_resolution=res, img_channels=3, dtype=dtype)
-            self.G_synth.load_state_dict(sd, strict=False)
+            self.G_synth = _load_generator(model_file, inference, dtype).synthesis
         R = self.G_synth.img_resolution
         if output_size is None:
             output_size = (R, R)

@@ -128,6 +128,8 @@ def synthesis_layer(p, prefix, x, w, up=1, noise=None, noise_strength=1.0, gain=
     styles = fully_connected(w, p[prefix + ".affine.weight"], p[prefix + ".affine.bias"])
     if noise is None:
         noise = p[prefix + ".noise_const"]
+    if nv_compat and (prefix + ".noise_strength") in p:  # upstream: learned per-layer strength
+        noise_strength = float(p[prefix + ".noise_strength"].reshape(-1)[0])
     noise = noise * noise_strength
     x = ops.modulated_conv2d(x, p[prefix + ".weight"], styles, noise=noise, up=up, padding=1,
                              resample_filter=p[prefix + ".resample_filter"], flip_weight=nv_compat)

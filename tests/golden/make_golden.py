@@ -37,6 +37,8 @@ ABSENT = {"librosa", "madmom", "torchaudio", "openunmix", "torchcubicspline", "t
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, name, path, target=None):
+        if name.startswith("maua.GAN.nv"):  # un-vendored git submodule (empty directory in the reference tree)
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
         if name.split(".")[0] in ABSENT:
             try:  # prefer the real module when the image has it
                 for f in sys.meta_path:
@@ -381,6 +383,73 @@ def golden_io():
     img.view(-1)[: len(vals)] = vals
     b = np.frombuffer(RIO.tensor2bytes(img), dtype=np.uint8).reshape(4, 8, 3)
     save("g14_tensor2bytes", img=img, bytes=b)
+
+
+def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
+    """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
+    maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""
+    from maua_amd.load import synthetic_rosinality_checkpoint as build
+    return build(res, n_map, seed, const_input)
+
+
+def golden_load():
+    """maua/GAN/load.py:18-127 key mapping for both target layouts.  The Generator classes are replaced by a recorder
+    (the nv train network is un-vendored; the in-tree inference network is additionally loaded for real to check
+    that the produced keys are exactly its state dict).  Stored: per produced key its shape, sum and abs-sum."""
+    import json
+    import tempfile
+    import maua.GAN.load as RL
+    from maua.GAN.wrappers.inference import stylegan2 as inf
+
+    class Recorder:
+        last = None
+
+        def __init__(self, *a, **k):
+            self.args, self.kwargs = a, k
+
+        def load_state_dict(self, sd):
+            Recorder.last = (dict(sd), self.args, self.kwargs)
+
+    out = {}
+    for const_input in (True,):
+        for for_inference in (False, True):
+            ck = synthetic_rosinality_checkpoint(const_input=const_input)
+            raises = None
+            if for_inference:
+                # reference quirk (load.py:79-88): with for_inference=True a 'convs.N.noise.weight' key falls into the
+                # "not recognized" branch, i.e. the converter raises on every real rosinality checkpoint.  Record that,
+                # then pin the inference-layout mapping on the checkpoint without those keys.
+                with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+                    torch.save(ck, f.name)
+                    try:
+                        RL.load_rosinality2ada(f.name, for_inference=True)
+                        raises = False
+                    except Exception as e:
+                        raises = "not recognized" in str(e)
+                ck["g_ema"] = {k: v for k, v in ck["g_ema"].items() if not (k.startswith("convs.") and k.endswith("noise.weight"))}
+            with tempfile.NamedTemporaryFile(suffix=".pt") as f:
+                torch.save(ck, f.name)
+                real_inf = inf.Generator
+                RL.stylegan2_train = MagicMock()
+                RL.stylegan2_train.Generator = Recorder
+                inf.Generator = Recorder
+                try:
+                    RL.load_rosinality2ada(f.name, for_inference=for_inference)
+                finally:
+                    inf.Generator = real_inf
+                sd, args, kwargs = Recorder.last
+                entry = {k: {"shape": list(v.shape), "sum": float(v.double().sum()), "abs": float(v.double().abs().sum())}
+                         for k, v in sd.items()}
+                strict_ok = None
+                if for_inference:  # the in-tree inference Generator must accept exactly these keys
+                    G = real_inf(*args, **kwargs)
+                    G.load_state_dict(sd)
+                    strict_ok = True
+                out[f"rosinality_const{int(const_input)}_inference{int(for_inference)}"] = {
+                    "generator_args": [int(a) for a in args], "mapping_layers": int(kwargs["mapping_kwargs"]["num_layers"]),
+                    "strict_load_ok": strict_ok, "reference_raises_on_conv_noise_weight": raises, "keys": entry}
+    (HERE / "g15_load_keymap.json").write_text(json.dumps(out, indent=0, sort_keys=True))
+    print("g15_load_keymap.json", {k: len(v["keys"]) for k, v in out.items()})
 
 
 if __name__ == "__main__":
