@@ -444,90 +444,107 @@ int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt,
 
 // ------------------------------------------------------------------------------------------------ styles / demod
 // Two launches per batch for ALL layers (17 conv + 9 toRGB at 1024^2): (1) s = affine(w) (stylegan2.py:48-58,:230,
-// :269), (2) demod coefficients (ops.py:168-171) / pre-modulated toRGB weights.  Tiny GEMVs: the only thing that
-// matters is parallelism, so the grid is (layer, sample, 64-output slice) and every wave keeps 4 independent
-// dot products in flight.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-__global__ __launch_bounds__(256) void styles_affine_kernel(const StyleLayer* __restrict__ layers,
-                                                            const float* __restrict__ ws, int num_ws, int w_dim) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* wv = reinterpret_cast<float*>(smem);  // w_dim
-  const StyleLayer L = layers[blockIdx.x];
-  const int b = blockIdx.y, c0 = blockIdx.z * 64;
-  if (c0 >= L.Cs) return;
+// :269), (2) demod coefficients (ops.py:168-171) / pre-modulated toRGB weights.  Both are small GEMMs
+// out[row][sample] = sum_k M[row][k] * vec[sample][k] (rows = channels, <= 32 samples per pass), done with the exact
+// f32 MFMA (v_mfma_f32_32x32x2_f32): a workgroup owns 32 matrix rows of one layer for all samples, its 4 waves split
+// K and reduce through LDS.  A sample is a column of the MFMA, so its arithmetic does not depend on where it sits in
+// the batch (frames stay bit-identical under any batching / sharding).
+//   lane (r = l & 31, h = l >> 5) feeds M[row0 + r][k8 + 4h + v] and vec[n = r][k8 + 4h + v] to MFMA number v of
+//   the 8-column block k8: one float4 load per operand per lane per block.
+template <typename VecLoad, typename Store>
+__device__ __forceinline__ void rows_times_samples(const float* __restrict__ M, int K, int row0, int rows_valid, int B,
+                                                   VecLoad vec_load, Store store, float* red /* LDS [4][16][64] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* wsrc = ws + ((long)b * num_ws + L.w_index) * w_dim;
-  for (int i = threadIdx.x; i < w_dim; i += blockDim.x) wv[i] = wsrc[i];
-  __syncthreads();
-  const float wgain = rsqrtf((float)w_dim);
-  for (int g = 0; g < 4; g++) {
-    const int ci0 = c0 + wave * 16 + g * 4;  // 4 outputs at a time
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane; k < w_dim; k += 64) {
-      const float w = wv[k];
+  const int r = lane & 31, h = lane >> 5;
+  const int kq = (K / 4 + 7) / 8 * 8;  // K columns per wave, a multiple of the 8-column block
+  const int k_lo = wave * kq, k_hi = min(K, k_lo + kq);
+  const bool row_ok = r < rows_valid;
+  const float* mrow = M + (long)(row0 + (row_ok ? r : 0)) * K;
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    f32x16 acc;
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (ci0 + j < L.Cin) acc[j] += L.affine_w[(long)(ci0 + j) * w_dim + k] * w;
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    const bool smp_ok = b0 + r < B;
+#pragma unroll 4
+    for (int k8 = k_lo; k8 < k_hi; k8 += 8) {
+      const int k = k8 + 4 * h;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row_ok && k < K) a = *reinterpret_cast<const float4*>(mrow + k);
+      if (smp_ok && k < K) v = vec_load(b0 + r, k);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, v.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, v.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, v.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, v.w, acc, 0, 0, 0);
     }
+    // K-split reduction, fixed order wave 0 + 1 + 2 + 3
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float t = wave_sum(acc[j]);
-      const int ci = ci0 + j;
-      if (lane == 0 && ci < L.Cs) L.s[(long)b * L.Cs + ci] = ci < L.Cin ? (t * wgain + L.affine_b[ci]) * L.scale : 0.f;
+    for (int e = 0; e < 16; e++) red[(wave * 16 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const float t = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;  // D layout: lane = column (sample), 16 rows per lane
+        if (row < rows_valid && smp_ok) store(b0 + r, row0 + row, t);
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void styles_demod_kernel(const StyleLayer* __restrict__ layers) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s2 = reinterpret_cast<float*>(smem);  // Cin: s (toRGB) or s^2 (conv)
+__global__ __launch_bounds__(256) void styles_affine_kernel(const StyleLayer* __restrict__ layers,
+                                                            const float* __restrict__ ws, int num_ws, int w_dim, int B) {
+  __shared__ float red[4 * 16 * 64];
   const StyleLayer L = layers[blockIdx.x];
-  const int b = blockIdx.y, z = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * 32;
+  if (c0 >= L.Cs) return;
+  const float wgain = rsqrtf((float)w_dim);
+  const float* wbase = ws + (long)L.w_index * w_dim;
+  const long wstride = (long)num_ws * w_dim;
+  rows_times_samples(
+      L.affine_w, w_dim, c0, min(32, L.Cin - c0), B,
+      [&](int b, int k) { return *reinterpret_cast<const float4*>(wbase + b * wstride + k); },
+      [&](int b, int ci, float t) { L.s[(long)b * L.Cs + ci] = (t * wgain + L.affine_b[ci]) * L.scale; }, red);
+  // channel padding of the styles buffer
+  for (int i = threadIdx.x; i < B * 32; i += blockDim.x) {
+    const int b = i >> 5, ci = c0 + (i & 31);
+    if (ci >= L.Cin && ci < L.Cs) L.s[(long)b * L.Cs + ci] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void styles_demod_kernel(const StyleLayer* __restrict__ layers, int B) {
+  __shared__ float red[4 * 16 * 64];
+  const StyleLayer L = layers[blockIdx.x];
   if (L.d) {
-    const int c0 = z * 64;
+    const int c0 = blockIdx.y * 32;
     if (c0 >= L.Cd) return;
-    for (int i = threadIdx.x; i < L.Cin; i += blockDim.x) {
-      const float v = L.s[(long)b * L.Cs + i];
-      s2[i] = v * v;
-    }
-    __syncthreads();
-    for (int g = 0; g < 4; g++) {
-      const int co0 = c0 + wave * 16 + g * 4;
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int k = lane; k < L.Cin; k += 64) {
-        const float v = s2[k];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (co0 + j < L.Co) acc[j] += v * L.wsq[(long)(co0 + j) * L.Cin + k];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float t = wave_sum(acc[j]);
-        const int co = co0 + j;
-        if (lane == 0 && co < L.Cd) L.d[(long)b * L.Cd + co] = co < L.Co ? rsqrtf(t + 1e-8f) : 0.f;
-      }
+    rows_times_samples(
+        L.wsq, L.Cin, c0, min(32, L.Co - c0), B,
+        [&](int b, int k) {
+          const float4 v = *reinterpret_cast<const float4*>(L.s + (long)b * L.Cs + k);
+          return make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+        },
+        [&](int b, int co, float t) { L.d[(long)b * L.Cd + co] = rsqrtf(t + 1e-8f); }, red);
+    for (int i = threadIdx.x; i < B * 32; i += blockDim.x) {
+      const int b = i >> 5, co = c0 + (i & 31);
+      if (co >= L.Co && co < L.Cd) L.d[(long)b * L.Cd + co] = 0.f;
     }
   } else if (L.wmod) {
-    const int i = z * 256 + threadIdx.x;
-    if (i < 3 * L.Cin) L.wmod[(long)b * 3 * L.Cin + i] = L.wrgb[i] * L.s[(long)b * L.Cs + (i % L.Cin)];
+    const int n = B * 3 * L.Cin;
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+      const int b = i / (3 * L.Cin), r = i - b * 3 * L.Cin;
+      L.wmod[i] = L.wrgb[r] * L.s[(long)b * L.Cs + (r % L.Cin)];
+    }
   }
 }
 
 int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
                   int w_dim, int B, int max_channels) {
   if (B == 0 || n_layers == 0) return MAUA_OK;
-  const int nz = cdiv(std::max(max_channels, 64), 64);
-  hipLaunchKernelGGL(styles_affine_kernel, dim3(n_layers, B, nz), dim3(256), (size_t)w_dim * sizeof(float), stream,
-                     layers_dev, ws, num_ws, w_dim);
-  const int nz2 = std::max(nz, cdiv(3 * max_channels, 256));
-  hipLaunchKernelGGL(styles_demod_kernel, dim3(n_layers, B, nz2), dim3(256), (size_t)max_channels * sizeof(float), stream,
-                     layers_dev);
+  MAUA_REQUIRE(w_dim % 4 == 0 && max_channels % 4 == 0, "styles: w_dim and channel counts must be multiples of 4");
+  const int ny = cdiv(std::max(max_channels, 32), 32);
+  hipLaunchKernelGGL(styles_affine_kernel, dim3(n_layers, ny), dim3(256), 0, stream, layers_dev, ws, num_ws, w_dim, B);
+  hipLaunchKernelGGL(styles_demod_kernel, dim3(n_layers, ny), dim3(256), 0, stream, layers_dev, B);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
