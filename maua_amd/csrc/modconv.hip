@@ -553,6 +553,45 @@ int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers
 // stylegan2.py:268-272 (1x1 modulated conv without demodulation, bias, clamp) fused with SynthesisBlock's
 // img = upsample2d(img) + y (stylegan2.py:372-378; ops.py:117-133).  HBM-bound: x is read once in 16-byte
 // pieces, LP lanes cooperate on one pixel and reduce with wave shuffles.
+// bias + clamp of one pixel's RGB, the FIR-upsampled skip of the previous image, planar f32 store
+__device__ __forceinline__ void torgb_finish(const RgbArgs& a, int b, long p, float r0, float r1, float r2) {
+  const long HW = (long)a.H * a.W;
+  const int Hp = a.H >> 1, Wp = a.W >> 1;
+  int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
+  float o3[3] = {r0 + a.bias[0], r1 + a.bias[1], r2 + a.bias[2]};
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    if (a.clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.clamp), a.clamp);
+  if (a.prev) {
+    // upsample2d: zero-insert x2, pad (2,1,2,1), correlate with 4f
+    const float* pv = a.prev + (long)b * 3 * Hp * Wp;
+    // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
+    // parity hits a real sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index
+    // u = 2*iy - y + 2 (same products, same u-major order as the 16-tap correlation)
+    const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
+    float u3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+      const int iy = iy0 + dy, u = 2 * iy - y + 2;
+      const bool oky = iy >= 0 && iy < Hp;
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++) {
+        const int ix = ix0 + dx, v = 2 * ix - x + 2;
+        const bool ok = oky && ix >= 0 && ix < Wp;
+        const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
+        const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+        const long o = ok ? (long)iy * Wp + ix : 0;
+        u3[0] += pv[o] * f;
+        u3[1] += pv[(long)Hp * Wp + o] * f;
+        u3[2] += pv[2L * Hp * Wp + o] * f;
+      }
+    }
+    o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
+  }
+  float* ob = a.out + (long)b * 3 * HW + p;
+  ob[0] = o3[0]; ob[HW] = o3[1]; ob[2 * HW] = o3[2];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void torgb_kernel(RgbArgs a, int lp_log2) {
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -595,41 +634,59 @@ __global__ __launch_bounds__(256) void torgb_kernel(RgbArgs a, int lp_log2) {
       r1 += __shfl_xor(r1, o);
       r2 += __shfl_xor(r2, o);
     }
-    if (sub == 0) {
-      int y = (int)(p / a.W), x = (int)(p - (long)y * a.W);
-      float o3[3] = {r0 + a.bias[0], r1 + a.bias[1], r2 + a.bias[2]};
+    if (sub == 0) torgb_finish(a, b, p, r0, r1, r2);
+  }
+}
+
+// bf16 inputs: the 1x1 convolution itself on the matrix cores.  out[3][px] = Wmod[3][C] x X^T[C][px] per 32 pixels:
+// A = pre-modulated weights split into bf16 hi (rows 0..2) + lo remainder (rows 8..10; w = hi + lo to ~2^-17, the
+// same trick as the fused toRGB of modconv_hires.hip), resident in registers; B = the pixels' channel pieces, loaded
+// straight from HBM in the MFMA operand layout (lane = pixel, 16 bytes = 8 channels) — no LDS, no cross-lane
+// reduction, ~1 VALU op per 16 bytes instead of 24 FMAs + shuffles.
+template <int NF>
+__global__ __launch_bounds__(256) void torgb_mfma_kernel(RgbArgs a) {
+  constexpr int C = NF * 16;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  u32x4 wf[NF];
+  {
+    const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
 #pragma unroll
-      for (int c = 0; c < 3; c++)
-        if (a.clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.clamp), a.clamp);
-      if (a.prev) {
-        // upsample2d: zero-insert x2, pad (2,1,2,1), correlate with 4f
-        const float* pv = a.prev + (long)b * 3 * Hp * Wp;
-        // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
-        // parity hits a real sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index
-        // u = 2*iy - y + 2 (same products, same u-major order as the 16-tap correlation)
-        const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
-        float u3[3] = {0.f, 0.f, 0.f};
+    for (int ks = 0; ks < NF; ks++) {
+      u32x4 o = u32x4{0u, 0u, 0u, 0u};
+      if (c_rgb >= 0) {
+        const float* src = a.wmod + ((long)b * 3 + c_rgb) * C + ks * 16 + 8 * h;
+        const float4 s0 = *reinterpret_cast<const float4*>(src), s1 = *reinterpret_cast<const float4*>(src + 4);
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-        for (int dy = 0; dy < 2; dy++) {
-          const int iy = iy0 + dy, u = 2 * iy - y + 2;
-          const bool oky = iy >= 0 && iy < Hp;
-#pragma unroll
-          for (int dx = 0; dx < 2; dx++) {
-            const int ix = ix0 + dx, v = 2 * ix - x + 2;
-            const bool ok = oky && ix >= 0 && ix < Wp;
-            const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
-                  const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
-            const long o = ok ? (long)iy * Wp + ix : 0;
-            u3[0] += pv[o] * f;
-            u3[1] += pv[(long)Hp * Wp + o] * f;
-            u3[2] += pv[2L * Hp * Wp + o] * f;
-          }
+        for (int k = 0; k < 4; k++) {
+          float w0 = sv[2 * k], w1 = sv[2 * k + 1];
+          const float h0 = bf2f(f2bf(w0)), h1 = bf2f(f2bf(w1));
+          if (r >= 8) { w0 -= h0; w1 -= h1; }
+          o[k] = pack2bf(w0, w1);
         }
-        o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
       }
-      float* ob = a.out + (long)b * 3 * HW + p;
-      ob[0] = o3[0]; ob[HW] = o3[1]; ob[2 * HW] = o3[2];
+      wf[ks] = o;
     }
+  }
+  const long HW = (long)a.H * a.W;
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * HW * C;
+  const long n_groups = (HW + 31) / 32;
+  for (long gi = (long)blockIdx.x * 4 + (threadIdx.x >> 6); gi < n_groups; gi += (long)gridDim.x * 4) {
+    const long p = gi * 32 + r;
+    const bf16_t* px = xb + (p < HW ? p : HW - 1) * C + 8 * h;
+    u32x4 xv[NF];
+#pragma unroll
+    for (int ks = 0; ks < NF; ks++) xv[ks] = *reinterpret_cast<const u32x4*>(px + ks * 16);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NF; ks++)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, xv[ks]),
+                                                    acc, 0, 0, 0);
+    // D rows 0..2 (hi) and 8..10 (lo) of pixel r live in the h == 0 lane: acc[0..2] and acc[4..6]
+    if (h == 0 && p < HW) torgb_finish(a, b, p, acc[0] + acc[4], acc[1] + acc[5], acc[2] + acc[6]);
   }
 }
 
@@ -637,6 +694,19 @@ int launch_torgb(hipStream_t stream, int dtype, const RgbArgs& a) {
   if (a.B == 0) return MAUA_OK;
   const int epc = dtype == MAUA_BF16 ? 8 : 4;
   MAUA_REQUIRE(a.C % epc == 0, "torgb: C must be a multiple of the 16-byte piece");
+  // (C = 512 layers are <= 64^2: the fragment set-up of 32 k-steps costs more than it saves there)
+  if (dtype == MAUA_BF16 && (a.C == 32 || a.C == 64 || a.C == 128 || a.C == 256) && ((uintptr_t)a.wmod % 16) == 0) {
+    const long groups = ((long)a.H * a.W + 31) / 32;
+    const dim3 grid((unsigned)std::min<long>((groups + 3) / 4, 1024), a.B);
+    switch (a.C / 16) {
+      case 2: hipLaunchKernelGGL(torgb_mfma_kernel<2>, grid, dim3(256), 0, stream, a); break;
+      case 4: hipLaunchKernelGGL(torgb_mfma_kernel<4>, grid, dim3(256), 0, stream, a); break;
+      case 8: hipLaunchKernelGGL(torgb_mfma_kernel<8>, grid, dim3(256), 0, stream, a); break;
+      default: hipLaunchKernelGGL(torgb_mfma_kernel<16>, grid, dim3(256), 0, stream, a); break;
+    }
+    MAUA_HIP_CHECK(hipGetLastError());
+    return MAUA_OK;
+  }
   int pieces = a.C / epc;
   int lp_log2 = 0;
   while ((1 << (lp_log2 + 1)) <= pieces && lp_log2 < 4) lp_log2++;
