@@ -152,6 +152,26 @@ int maua_gaussian_filter1d(maua_ctx* ctx, const float* x, const float* taps, int
  * out3 (device) = {result, x_(lo), x_(hi)}; ranks2 (device, may be NULL) = {lo, hi} 0-based, -1 when empty. */
 int maua_order_stat(maua_ctx* ctx, const float* x, const uint8_t* mask, long n, int mode, float q, long k,
                     float* out3, long long* ranks2);
+/* ---- further audio features (selfsupervised/features/audio.py) ----
+ * c [M][N] = a [M][K] x b [N][K]^T (f32).  Replaces rosa/spectral.py:35-56 dct (as a cosine-basis product, used by
+ * audio.py:65-70 mfcc) and the phi @ chroma product of audio.py:50-62 tonnetz. */
+int maua_matmul_nt(maua_ctx* ctx, const float* a, const float* b, float* c, int M, int N, int K);
+/* replaces audio.py:118-126 spectral_flatness on the frame-major complex STFT spec [n_frames][n_bins]:
+ * out[f] = exp(mean(log(max(amin, |z|^power)))) / mean(max(amin, |z|^power)). */
+int maua_spectral_flatness(maua_ctx* ctx, const float* spec, int n_frames, int n_bins, float amin, float power,
+                           float* out);
+/* the per-band part of audio.py:76-115 spectral_contrast: for every frame sort |spec[f][lo..hi)| ascending
+ * (torch.sort :107) and return the mean of the first k (valley, :109) and of the last k (peak, :110); hi - lo <= 1024.
+ * The band edges / k follow the reference's float32 linspace comparisons and are computed by the caller. */
+int maua_band_sorted_means(maua_ctx* ctx, const float* spec, int n_frames, int n_bins, int lo, int hi, int k,
+                           float* valley, float* peak);
+/* out2 (device) = {min(x), max(x)} over n elements (processing.py:134-136). */
+int maua_minmax(maua_ctx* ctx, const float* x, long n, float* out2);
+/* replaces processing.py:133-139 emphasize on xn = (x - min) / max(x - min) (maua_normalize with eps 0):
+ * y = xn * (1 + tanh(strength * (xn - q))) * (max - min) + min; minmax_dev = {min, max} of x, q_dev = the quantile
+ * of xn (maua_order_stat mode 2), both device scalars. */
+int maua_emphasize(maua_ctx* ctx, const float* xn, long n, const float* minmax_dev, const float* q_dev, float strength,
+                   float* y);
 /* signal.py:69-76: mask[i] = x[i] > x[i+1] && x[i] > x[i-1] with neighbours clamped to the ends. */
 int maua_peak_mask(maua_ctx* ctx, const float* x, int n, uint8_t* mask);
 /* y = min(max(x, lo), hi + hi_add); lo = lo_dev[0] if lo_dev else lo_const; hi = hi_dev[0] (device scalars,

@@ -262,6 +262,8 @@ def gaussian_filter(x, sigma, mode="circular", causal=None, _classic=False):
     y = torch.empty_like(x)
     L.check(L.lib().maua_gaussian_filter1d(L.ctx(x.device), L.ptr(x), L.ptr(_f32(taps)), radius, T, C.c_long(Cn),
                                            L.PAD_MODES[mode], L.ptr(y)))
+    if x.dim() < 3:  # the reference lifts to 3-D and then squeezes EVERY singleton axis (processing.py:46-48):
+        y = y.reshape(shape + (1,) * (3 - x.dim())).squeeze()  # [T, 1] comes back as [T]
     return y
 
 
@@ -302,3 +304,128 @@ def salience_weighted(envelope, short_sigma=5, long_sigma=80):
     long = gaussian_filter(e, long_sigma, mode="reflect")
     w = (short / long) ** 2 * e
     return w.unsqueeze(1) if w.dim() < 2 else w
+
+
+# ------------------------------------------------------------------------------------------------ SURVEY 8(f) N3
+# further features of selfsupervised/features/audio.py (first batch: the ones that do not need the constant-Q stack)
+def emphasize(envs, strength, percentile):
+    """processing.py:133-139 on a [T] / [T, 1] envelope (the reference reduces over dim 0; one column here)."""
+    x = _f32(envs)
+    shape = x.shape
+    if x.numel() != x.shape[0]:
+        raise NotImplementedError("emphasize: one envelope column at a time")
+    x = x.reshape(-1)
+    lib, ctx = L.lib(), L.ctx(x.device)
+    mm = torch.empty((2,), dtype=torch.float32, device=x.device)
+    L.check(lib.maua_minmax(ctx, L.ptr(x), C.c_long(x.numel()), L.ptr(mm)))
+    xn = torch.empty_like(x)
+    L.check(lib.maua_normalize(ctx, L.ptr(x), C.c_long(x.numel()), C.c_float(0.0), L.ptr(xn)))
+    q, _ = order_stat(xn, 2, q=percentile / 100)
+    y = torch.empty_like(x)
+    L.check(lib.maua_emphasize(ctx, L.ptr(xn), C.c_long(x.numel()), L.ptr(mm), L.ptr(q), C.c_float(float(strength)), L.ptr(y)))
+    return y.reshape(shape)
+
+
+def drop_strength(audio, sr):
+    """features/audio.py:40-41 -> [T, 1, 1] (the reference unsqueezes the [T, 1] envelope once more)."""
+    return emphasize(gaussian_filter(rms(audio, sr), 10), strength=10, percentile=50).unsqueeze(1)
+
+
+def _matmul_nt(a, b):
+    a, b = _f32(a), _f32(b)
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    L.check(L.lib().maua_matmul_nt(L.ctx(a.device), L.ptr(a), L.ptr(b), L.ptr(c), M, N, K))
+    return c
+
+
+def dct(x, norm=None, n_keep=None):
+    """rosa/spectral.py:35-56: DCT-II along the last axis (the reference goes through an FFT; here the cosine basis
+    [n_keep, N], built in float64 on the host, multiplies the rows on the device)."""
+    x = _f32(x)
+    N = x.shape[-1]
+    n_keep = N if n_keep is None else n_keep
+    k = np.arange(n_keep, dtype=np.float64)[:, None]
+    n = np.arange(N, dtype=np.float64)[None, :]
+    basis = 2.0 * np.cos(np.pi * (2 * n + 1) * k / (2 * N))
+    if norm == "ortho":
+        basis[0] /= np.sqrt(N) * 2
+        basis[1:] /= np.sqrt(N / 2) * 2
+    out = _matmul_nt(x.reshape(-1, N), torch.from_numpy(basis.astype(np.float32)).to(x.device))
+    return out.reshape(*x.shape[:-1], n_keep)
+
+
+def mfcc(y, sr, n_mfcc=20, norm=False, **kwargs):
+    """features/audio.py:65-70 -> [T, n_mfcc]."""
+    S = power_to_db(melspectrogram(y, sr, **kwargs))           # [n_mels, T]
+    M = dct(S.permute(1, 0).contiguous(), norm="ortho", n_keep=n_mfcc)  # [T, n_mfcc]
+    if norm is True:
+        M = M / M.norm(p=2)
+    return M
+
+
+def tonnetz(y=None, sr=None, chroma=None):
+    """features/audio.py:50-62 given a chromagram [12 (or n_chroma), T] (chroma_cens / CQT are not implemented:
+    pass ``chroma``) -> [T, 6]."""
+    if chroma is None:
+        raise NotImplementedError("tonnetz needs a chromagram: chroma_cens (constant-Q stack) is not implemented")
+    ch = _f32(chroma)
+    n = ch.shape[0]
+    dim_map = torch.linspace(0, 12, n)
+    scale = torch.tensor([7.0 / 6, 7.0 / 6, 3.0 / 2, 3.0 / 2, 2.0 / 3, 2.0 / 3])
+    V = scale.reshape(-1, 1) * dim_map
+    V[::2] -= 0.5
+    R = torch.tensor([1, 1, 1, 1, 0.5, 0.5])
+    phi = R[:, None] * torch.cos(torch.pi * V)                  # [6, n] (host constants)
+    chn = ch / ch.norm(p=1, dim=0)
+    return _matmul_nt(chn.T.contiguous(), phi.to(ch.device))     # [T, 6]
+
+
+def spectral_flatness(y, sr=None, n_fft=2048, hop_length=1024, amin=1e-10, power=2.0, **_):
+    """features/audio.py:118-126 -> [T, 1]."""
+    buf = _frame_major(stft(y, n_fft, hop_length))
+    T = buf.shape[0] - 1                                         # spectrogram drops the last column
+    out = torch.empty((T,), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_spectral_flatness(L.ctx(buf.device), L.ptr(buf), T, buf.shape[1], C.c_float(amin),
+                                           C.c_float(power), L.ptr(out)))
+    return out.unsqueeze(-1)
+
+
+def contrast_bands(sr, n_fft=2048, fmin=200.0, n_bands=6, quantile=0.02):
+    """The band bookkeeping of features/audio.py:89-105 in the reference's own float32 arithmetic:
+    [(lo, hi, k)] bin ranges [lo, hi) of every band's sub_band and the number of sorted bins averaged."""
+    freq = torch.linspace(0, float(sr) / 2, int(1 + n_fft // 2))
+    octa = torch.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** torch.arange(0, n_bands + 1))
+    out = []
+    for k, (f_low, f_high) in enumerate(zip(octa[:-1], octa[1:])):
+        band = torch.logical_and(freq >= f_low, freq <= f_high)
+        idx = band.flatten().nonzero()
+        if k > 0:
+            band[idx[0] - 1] = True
+        if k == n_bands:
+            band[idx[-1] + 1:] = True
+        sel = band.nonzero().flatten()
+        lo, hi = int(sel[0]), int(sel[-1]) + 1
+        assert int(band.sum()) == hi - lo                        # contiguous by construction
+        kk = int(max(torch.round(quantile * torch.sum(band)), torch.ones(())))
+        if k < n_bands:
+            hi -= 1                                              # sub_band[:-1]
+        out.append((lo, hi, kk))
+    return out
+
+
+def spectral_contrast(y, sr, n_fft=2048, hop_length=1024, fmin=200.0, n_bands=6, quantile=0.02, linear=False, **_):
+    """features/audio.py:76-115 -> [T, n_bands + 1]."""
+    buf = _frame_major(stft(y, n_fft, hop_length))
+    T = buf.shape[0] - 1
+    bands = contrast_bands(sr, n_fft, fmin, n_bands, quantile)
+    valley = torch.empty((len(bands), T), dtype=torch.float32, device=buf.device)
+    peak = torch.empty_like(valley)
+    for k, (lo, hi, kk) in enumerate(bands):
+        L.check(L.lib().maua_band_sorted_means(L.ctx(buf.device), L.ptr(buf), T, buf.shape[1], lo, hi, kk,
+                                               L.ptr(valley[k]), L.ptr(peak[k])))
+    if linear:
+        return (peak - valley).T
+    return (power_to_db(peak) - power_to_db(valley)).T

@@ -1,0 +1,190 @@
+// Remaining audio features (first batch) — once-per-clip kernels, HBM/latency-bound by nature.
+//
+// Replaces (reference, selfsupervised/features/audio.py): mfcc :65-70 (dct = rosa/spectral.py:35-56, as a cosine
+// GEMM), tonnetz :50-62 (phi @ chroma), spectral_flatness :118-126, spectral_contrast :76-115 (sorted sub-band
+// means), drop_strength :40-41 / processing.py:133-139 emphasize.
+// Spectra arrive in this library's frame-major layout spec[frame][n_bins] (complex64), like audio.hip.
+#include "common.h"
+
+namespace maua {
+
+// ---------------------------------------------------------------------------------------------- C = A x B^T
+// A [M][K], B [N][K], C [M][N] (f32, row-major): 16 x 16 output tile per workgroup, K staged in 32-column chunks.
+__global__ __launch_bounds__(256) void matmul_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        float* __restrict__ Cm, int M, int N, int K) {
+  __shared__ float as[16][33], bs[16][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.y * 16 + ty, n = blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    for (int i = threadIdx.x; i < 16 * 32; i += 256) {
+      const int r = i >> 5, c = i & 31;
+      const int am = blockIdx.y * 16 + r, bn = blockIdx.x * 16 + r;
+      as[r][c] = (am < M && k0 + c < K) ? A[(long)am * K + k0 + c] : 0.f;
+      bs[r][c] = (bn < N && k0 + c < K) ? B[(long)bn * K + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 32; c++) acc = fmaf(as[ty][c], bs[tx][c], acc);
+    __syncthreads();
+  }
+  if (m < M && n < N) Cm[(long)m * N + n] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------- flatness
+// out[f] = exp(mean_bins(log(max(amin, |z|^power)))) / mean_bins(max(amin, |z|^power)); one workgroup per frame.
+__global__ __launch_bounds__(256) void flatness_kernel(const float2* __restrict__ spec, int n_bins, float amin,
+                                                       float power, float* __restrict__ out) {
+  __shared__ float red[2][256];
+  const float2* row = spec + (long)blockIdx.x * n_bins;
+  float sl = 0.f, sa = 0.f;
+  for (int i = threadIdx.x; i < n_bins; i += 256) {
+    const float2 z = row[i];
+    const float mag = sqrtf(z.x * z.x + z.y * z.y);
+    const float v = fmaxf(amin, power == 2.0f ? mag * mag : powf(mag, power));
+    sl += logf(v);
+    sa += v;
+  }
+  red[0][threadIdx.x] = sl;
+  red[1][threadIdx.x] = sa;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {  // fixed tree: deterministic
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = expf(red[0][0] / (float)n_bins) / (red[1][0] / (float)n_bins);
+}
+
+// ---------------------------------------------------------------------------------------------- sorted band means
+// For frame f: sort |spec[f][lo..hi)| ascending (bitonic in LDS, <= 1024 bins), valley = mean of the first k,
+// peak = mean of the last k (summed in ascending order like torch.mean over the sorted slice).
+__global__ __launch_bounds__(512) void band_sorted_means_kernel(const float2* __restrict__ spec, int n_bins, int lo,
+                                                                int hi, int k, float* __restrict__ valley,
+                                                                float* __restrict__ peak) {
+  __shared__ float v[1024];
+  const float2* row = spec + (long)blockIdx.x * n_bins;
+  const int n = hi - lo;
+  for (int i = threadIdx.x; i < 1024; i += 512) {
+    float x = __builtin_huge_valf();
+    if (i < n) {
+      const float2 z = row[lo + i];
+      x = sqrtf(z.x * z.x + z.y * z.y);
+    }
+    v[i] = x;
+  }
+  __syncthreads();
+  for (int size = 2; size <= 1024; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < 512; t += 512) {
+        const int i = 2 * t - (t & (stride - 1));
+        const int j = i + stride;
+        const bool up = (i & size) == 0;
+        const float a = v[i], b = v[j];
+        if ((a > b) == up) { v[i] = b; v[j] = a; }
+      }
+      __syncthreads();
+    }
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < k; i++) s += v[i];
+    valley[blockIdx.x] = s / (float)k;
+    s = 0.f;
+    for (int i = n - k; i < n; i++) s += v[i];
+    peak[blockIdx.x] = s / (float)k;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- min / max, emphasize
+__global__ __launch_bounds__(1024) void minmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out2) {
+  __shared__ float mn[1024], mx[1024];
+  float a = __builtin_huge_valf(), b = -__builtin_huge_valf();
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float v = x[i];
+    a = fminf(a, v);
+    b = fmaxf(b, v);
+  }
+  mn[threadIdx.x] = a;
+  mx[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      mn[threadIdx.x] = fminf(mn[threadIdx.x], mn[threadIdx.x + o]);
+      mx[threadIdx.x] = fmaxf(mx[threadIdx.x], mx[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = mn[0]; out2[1] = mx[0]; }
+}
+
+// processing.py:133-139 with xn = (x - min) / max(x - min) already formed: y = xn * (1 + tanh(s * (xn - q))) * range + min
+__global__ __launch_bounds__(256) void emphasize_kernel(const float* __restrict__ xn, long n, const float* __restrict__ mm,
+                                                        const float* __restrict__ q, float strength, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float lo = mm[0], range = mm[1] - mm[0];
+  const float v = xn[i];
+  const float e = v * (1.0f + tanhf(strength * (v - q[0])));
+  y[i] = e * range + lo;
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+int maua_matmul_nt(maua_ctx* ctx, const float* a, const float* b, float* c, int M, int N, int K) {
+  MAUA_REQUIRE(ctx, "maua_matmul_nt: ctx is NULL");
+  if (M == 0 || N == 0) return MAUA_OK;
+  MAUA_REQUIRE(a && b && c && K > 0, "maua_matmul_nt: NULL argument");
+  hipLaunchKernelGGL(matmul_nt_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, ctx->stream, a, b, c, M, N, K);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_spectral_flatness(maua_ctx* ctx, const float* spec, int n_frames, int n_bins, float amin, float power,
+                           float* out) {
+  MAUA_REQUIRE(ctx, "maua_spectral_flatness: ctx is NULL");
+  if (n_frames == 0) return MAUA_OK;
+  MAUA_REQUIRE(spec && out && n_bins > 0, "maua_spectral_flatness: NULL argument");
+  hipLaunchKernelGGL(flatness_kernel, dim3(n_frames), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const float2*>(spec), n_bins, amin, power, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_band_sorted_means(maua_ctx* ctx, const float* spec, int n_frames, int n_bins, int lo, int hi, int k,
+                           float* valley, float* peak) {
+  MAUA_REQUIRE(ctx, "maua_band_sorted_means: ctx is NULL");
+  if (n_frames == 0) return MAUA_OK;
+  MAUA_REQUIRE(spec && valley && peak, "maua_band_sorted_means: NULL argument");
+  MAUA_REQUIRE(0 <= lo && lo < hi && hi <= n_bins && hi - lo <= 1024, "maua_band_sorted_means: band must hold 1..1024 bins");
+  MAUA_REQUIRE(k >= 1 && k <= hi - lo, "maua_band_sorted_means: k out of range");
+  hipLaunchKernelGGL(band_sorted_means_kernel, dim3(n_frames), dim3(512), 0, ctx->stream,
+                     reinterpret_cast<const float2*>(spec), n_bins, lo, hi, k, valley, peak);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_minmax(maua_ctx* ctx, const float* x, long n, float* out2) {
+  MAUA_REQUIRE(ctx && x && out2 && n > 0, "maua_minmax: NULL or empty argument");
+  hipLaunchKernelGGL(minmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, x, n, out2);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_emphasize(maua_ctx* ctx, const float* xn, long n, const float* minmax_dev, const float* q_dev, float strength,
+                   float* y) {
+  MAUA_REQUIRE(ctx, "maua_emphasize: ctx is NULL");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(xn && minmax_dev && q_dev && y, "maua_emphasize: NULL argument");
+  hipLaunchKernelGGL(emphasize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xn, n, minmax_dev,
+                     q_dev, strength, y);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // extern "C"

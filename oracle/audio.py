@@ -244,3 +244,86 @@ def salience_weighted(env, short_sigma=5, long_sigma=80):
     long = gaussian_filter(env, long_sigma, mode="reflect")
     w = (short / long) ** 2 * env
     return w.unsqueeze(1) if w.dim() < 2 else w
+
+
+# ----------------------------------------------------------------------------- SURVEY 8(f) N3 (first batch)
+def emphasize(envs, strength, percentile):
+    """processing.py:133-139"""
+    mn = envs.min(dim=0).values
+    x = envs - mn
+    mx = x.max(dim=0).values
+    x = x / mx
+    x = x * (1 + torch.tanh(strength * (x - torch.quantile(x, q=percentile / 100, dim=0))))
+    return (x * mx) + mn
+
+
+def drop_strength(audio):
+    """features/audio.py:40-41"""
+    return emphasize(gaussian_filter(rms(audio), 10), strength=10, percentile=50).unsqueeze(1)
+
+
+def dct(x, norm=None):
+    """rosa/spectral.py:35-56 (Makhoul's FFT form of the DCT-II, as the reference computes it)."""
+    shape = x.shape
+    N = shape[-1]
+    x = x.contiguous().view(-1, N)
+    v = torch.cat([x[:, ::2], x[:, 1::2].flip([1])], dim=1)
+    Vc = torch.view_as_real(torch.fft.fft(v, dim=1))
+    k = -torch.arange(N, dtype=x.dtype)[None, :] * np.pi / (2 * N)
+    V = Vc[:, :, 0] * torch.cos(k) - Vc[:, :, 1] * torch.sin(k)
+    if norm == "ortho":
+        V[:, 0] /= np.sqrt(N) * 2
+        V[:, 1:] /= np.sqrt(N / 2) * 2
+    return 2 * V.view(*shape)
+
+
+def mfcc(y, sr, n_mfcc=20):
+    """features/audio.py:65-70"""
+    S = power_to_db(melspectrogram(y, sr))
+    return dct(S.permute(1, 0), norm="ortho").permute(1, 0)[:n_mfcc].T
+
+
+def tonnetz_from_chroma(chroma):
+    """features/audio.py:50-62 after the chromagram"""
+    dim_map = torch.linspace(0, 12, chroma.shape[0])
+    scale = torch.tensor([7.0 / 6, 7.0 / 6, 3.0 / 2, 3.0 / 2, 2.0 / 3, 2.0 / 3])
+    V = scale.reshape(-1, 1) * dim_map
+    V[::2] -= 0.5
+    R = torch.tensor([1, 1, 1, 1, 0.5, 0.5])
+    phi = R[:, None] * torch.cos(torch.pi * V)
+    return (phi @ (chroma / chroma.norm(p=1, dim=0))).T
+
+
+def spectral_flatness(y, amin=1e-10, power=2.0):
+    """features/audio.py:118-126"""
+    S = spectrogram(y, power=1.0)
+    S_thresh = torch.maximum(torch.tensor(amin), S ** power)
+    gmean = torch.exp(torch.mean(torch.log(S_thresh), axis=0))
+    return (gmean / torch.mean(S_thresh, axis=0)).unsqueeze(-1)
+
+
+def spectral_contrast(y, sr, fmin=200.0, n_bands=6, quantile=0.02, linear=False):
+    """features/audio.py:76-115"""
+    S = spectrogram(y, power=1)
+    freq = torch.linspace(0, float(sr) / 2, int(1 + N_FFT // 2))
+    octa = torch.zeros(n_bands + 2)
+    octa[1:] = fmin * (2.0 ** torch.arange(0, n_bands + 1))
+    valley = torch.zeros((n_bands + 1, S.shape[1]))
+    peak = torch.zeros_like(valley)
+    for k, (f_low, f_high) in enumerate(zip(octa[:-1], octa[1:])):
+        band = torch.logical_and(freq >= f_low, freq <= f_high)
+        idx = band.flatten().nonzero()
+        if k > 0:
+            band[idx[0] - 1] = True
+        if k == n_bands:
+            band[idx[-1] + 1:] = True
+        sub = S[band]
+        if k < n_bands:
+            sub = sub[:-1]
+        n = int(max(torch.round(quantile * torch.sum(band)), torch.ones(())))
+        srt = torch.sort(sub, dim=0).values
+        valley[k] = torch.mean(srt[:n], dim=0)
+        peak[k] = torch.mean(srt[-n:], dim=0)
+    if linear:
+        return (peak - valley).T
+    return (power_to_db(peak) - power_to_db(valley)).T

@@ -385,6 +385,28 @@ def golden_io():
     save("g14_tensor2bytes", img=img, bytes=b)
 
 
+def golden_features():
+    """SURVEY 8(f) N3 first batch: features/audio.py mfcc, spectral_flatness, spectral_contrast, drop_strength,
+    tonnetz (on a synthetic chromagram: chroma_cens needs the constant-Q stack), rosa dct, processing.emphasize."""
+    from maua.audiovisual.audioreactive.selfsupervised.features import audio as FA
+    from maua.audiovisual.audioreactive.selfsupervised.features import processing as FP
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import spectral
+
+    sr = 30720
+    a = synth_audio(4 * sr, sr, 1234)  # the g09 clip: 120 frames
+    a12 = synth_audio(12 * sr, sr, 77)  # 360 frames: the sigma = 10 filter of drop_strength needs > 40 frames
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 128, generator=g)
+    env = torch.rand(300, 1, generator=g)
+    chroma = torch.rand(12, 50, generator=g) + 0.05
+    save("g16_features", sr=np.int64(sr), n12=np.int64(12 * sr), seed12=np.int64(77),
+         mfcc=FA.mfcc(a, sr), flatness=FA.spectral_flatness(a, sr), contrast=FA.spectral_contrast(a, sr),
+         contrast_linear=FA.spectral_contrast(a, sr, linear=True), drop_strength=FA.drop_strength(a12, sr),
+         dct_in=x, dct_none=spectral.dct(x), dct_ortho=spectral.dct(x, norm="ortho"),
+         emph_in=env, emph_10_50=FP.emphasize(env, 10, 50), emph_3_80=FP.emphasize(env, 3, 80),
+         chroma=chroma, tonnetz=FA.tonnetz(a, sr, chroma_fn=lambda a_, sr_: chroma))
+
+
 def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
     """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
     maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""

@@ -221,3 +221,32 @@ def test_noise(golden):
     assert abs(float(y[0].square().mean().sqrt()) - 1.0) <= 1e-5
     ref = ON.loop(big.noise, big.idx, 1234, 1, 5)
     assert rel(y[:1], ref) <= 2e-5
+
+
+def test_features_n3(clip, golden):
+    """SURVEY 8(f) N3 first batch on the HIP path vs the reference's outputs (g16) and the oracle."""
+    import maua_amd.audio as A
+    from maua_amd.pipeline import synthetic_audio
+    g = golden("g16_features")
+    sr = int(g["sr"])
+    assert rel(A.dct(g["dct_in"].cuda()), g["dct_none"]) < 2e-6
+    assert rel(A.dct(g["dct_in"].cuda(), norm="ortho"), g["dct_ortho"]) < 2e-6
+    assert rel(A.dct(g["dct_in"].cuda(), norm="ortho", n_keep=20), g["dct_ortho"][:, :20]) < 2e-6
+    assert rel(A.emphasize(g["emph_in"].cuda(), 10, 50), g["emph_10_50"]) < 2e-6
+    assert rel(A.emphasize(g["emph_in"].cuda(), 3, 80), g["emph_3_80"]) < 2e-6
+    assert rel(A.mfcc(clip.cuda(), sr), g["mfcc"]) < 5e-5
+    assert rel(A.spectral_flatness(clip.cuda(), sr), g["flatness"]) < 5e-5
+    assert rel(A.spectral_contrast(clip.cuda(), sr), g["contrast"]) < 3e-4  # dB of near-zero valley bins
+    assert rel(A.spectral_contrast(clip.cuda(), sr, linear=True), g["contrast_linear"]) < 5e-5
+    assert rel(A.tonnetz(chroma=g["chroma"].cuda()), g["tonnetz"]) < 2e-6
+    a12 = synthetic_audio(int(g["n12"]), sr, int(g["seed12"]))
+    assert rel(A.drop_strength(a12.cuda(), sr), g["drop_strength"]) < 5e-5
+    # band bookkeeping is integer-exact against the oracle's boolean masks
+    bands = A.contrast_bands(sr)
+    assert bands == [(0, 13, 1), (13, 26, 1), (26, 53, 1), (53, 106, 1), (106, 213, 2), (213, 426, 4), (426, 1025, 12)]
+    # full-size property: sorted-band means bracket the band mean, flatness in (0, 1]
+    big = synthetic_audio(30720 * 20, sr, 5).cuda()
+    fl = A.spectral_flatness(big, sr)
+    assert float(fl.min()) > 0 and float(fl.max()) <= 1.0 + 1e-6
+    lin = A.spectral_contrast(big, sr, linear=True)
+    assert float(lin.min()) >= 0

@@ -281,3 +281,22 @@ def test_noise(golden):
 def test_tensor2bytes(golden):
     g = golden("g14_tensor2bytes")
     assert np.array_equal(OIO.tensor2bytes(g["img"]), g["bytes"].numpy())
+
+
+def test_features_n3(golden):
+    """SURVEY 8(f) N3 first batch: oracle restatements vs the reference's own outputs (g16)."""
+    from maua_amd.pipeline import synthetic_audio
+    g = golden("g16_features")
+    a = golden("g09_audio_clip")["audio"]
+    sr = int(g["sr"])
+    close(A.dct(g["dct_in"]), g["dct_none"], 1e-6)
+    close(A.dct(g["dct_in"], norm="ortho"), g["dct_ortho"], 1e-6)
+    close(A.emphasize(g["emph_in"], 10, 50), g["emph_10_50"], 1e-6)
+    close(A.emphasize(g["emph_in"], 3, 80), g["emph_3_80"], 1e-6)
+    close(A.mfcc(a, sr), g["mfcc"], 2e-5)
+    close(A.spectral_flatness(a), g["flatness"], 2e-5)
+    close(A.spectral_contrast(a, sr), g["contrast"], 2e-4)  # dB of near-zero valley bins amplifies 1e-6 STFT differences
+    close(A.spectral_contrast(a, sr, linear=True), g["contrast_linear"], 2e-5)
+    close(A.tonnetz_from_chroma(g["chroma"]), g["tonnetz"], 1e-6)
+    a12 = synthetic_audio(int(g["n12"]), sr, int(g["seed12"]))
+    close(A.drop_strength(a12), g["drop_strength"], 2e-5)
