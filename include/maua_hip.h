@@ -35,7 +35,7 @@ enum maua_act {
   MAUA_ACT_ELU = 5, MAUA_ACT_SELU = 6, MAUA_ACT_SOFTPLUS = 7, MAUA_ACT_SWISH = 8
 };
 /* gaussian_filter padding modes: reference signal.py:108-157 (F.pad modes) */
-enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLICATE = 2 };
+enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLICATE = 2, MAUA_PAD_CONSTANT = 3 };
 
 typedef struct maua_ctx maua_ctx;
 typedef struct maua_synth maua_synth;
@@ -91,6 +91,26 @@ int maua_synth_num_layers(const maua_synth* net);
  * FIR/epilogue pass (0 = four 3x3 phase kernels everywhere, 4x the MACs; v > 1 = every up-layer with input size <= v);
  * "use_hires" (default 1) / "fuse_torgb" (default 1) select the register-stationary high-resolution kernels and
  * the toRGB fusion (0 = generic kernels everywhere, for A/B comparisons and parity tests). */
+/* ---- arbitrary output sizes (maua/GAN/wrappers/stylegan2.py:104-151 change_output_resolution and
+ * :216-340 get_hook).  The feature map is resized at ONE layer and every later layer runs at the scaled size.
+ *  layer:  the reference's index into layer_names (0 = pre-hook on bs.0.conv1's input, L >= 1 = forward hook on
+ *          the L-th entry, i.e. synthesis layer L-1 in execution order); -1 removes the resize.
+ *  mode 0 "stretch": bicubic (align_corners False) to (target_h, target_w); the block's toRGB output is resized back
+ *          and the block's image forward again, as the reference's rgb / img hooks do.
+ *  mode 1 "pad-<how>-<where>": F.pad by (pad_left, pad_right, pad_top, pad_bottom) with pad_how (maua_pad_mode) /
+ *          pad_value; inverse = crop.  Negative padding is rejected (a TODO in the reference as well).
+ *  fill_noise_host: optional [C][target_h][target_w] f32 added to the resized FEATURES (the reference draws it once
+ *          per hook from the per-channel mean/std of the first resized batch, :233-248; the caller owns the RNG).
+ * Later layers need noise of their new size: maua_synth_layer_size reports it, maua_synth_load accepts a noise_const of
+ * exactly that size. */
+int maua_synth_set_resize(maua_synth* net, int layer, int mode, int target_h, int target_w, int pad_left, int pad_right,
+                          int pad_top, int pad_bottom, int pad_how, float pad_value, const float* fill_noise_host);
+/* output size (h, w) of synthesis layer `layer` (execution order), or of the final image for layer == -1 */
+int maua_synth_layer_size(const maua_synth* net, int layer, int* h, int* w);
+/* the torch ops the hooks are made of, on NCHW tensors (dtype f32 / bf16): mode 0 = F.interpolate(x, (out_h, out_w),
+ * mode="bicubic", align_corners=False); mode 1 = F.pad with left/top offsets (negative = crop), out size given. */
+int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, int W, int out_h, int out_w, int mode,
+                  int pad_left, int pad_top, int pad_how, float pad_value, int dtype);
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.

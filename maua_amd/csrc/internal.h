@@ -81,6 +81,22 @@ struct UpfirArgs {
 int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a);
 size_t prepped_weight_elems(int k, int up, int Cop, int Cip);
 
+// resize.hip: bicubic / pad / crop of NHWC features (network dtype) or planar images; optional per-channel noise
+struct ResizeArgs {
+  const void* x;
+  long x_bstride;   // elements between samples (0 = broadcast one sample)
+  void* y;
+  int B, H, W, C, oh, ow;
+  int mode;         // 0 bicubic, 1 pad / crop
+  int pl, pt;       // left / top offset of the input inside the output (negative = crop)
+  int how;          // maua_pad_mode
+  float value;
+  const float* noise;  // [C][oh][ow] or NULL
+};
+int launch_resize2d(hipStream_t stream, int dtype, bool nhwc, const ResizeArgs& a);
+int launch_skip_add(hipStream_t stream, const float* y, const float* prev, float* out, int B, int H, int W,
+                    const float* fir16);
+
 // styles / demod / toRGB pre-modulation for a list of layers in one launch
 struct StyleLayer {
   const float* affine_w;  // [Cin][w_dim]

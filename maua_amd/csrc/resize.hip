@@ -1,0 +1,182 @@
+// Feature-space / image resizing for arbitrary output sizes.
+//
+// Replaces (reference, maua/GAN/wrappers/stylegan2.py:216-340 get_hook): the "stretch" strategy's
+// torch.nn.functional.interpolate(x, size, mode="bicubic", align_corners=False) (:231, :253) and the "pad-*" strategies'
+// torch.nn.functional.pad(x, padding, mode, value) (:294) with their inverses (bicubic back / crop, :253, :313-323),
+// plus the per-channel fill noise added to resized features (:233-248, :296-311).
+// Bicubic follows ATen's upsample_bicubic2d: source index (o + 0.5) * in/out - 0.5, Keys kernel A = -0.75, the four
+// taps clamped to the image, x pass then y pass, float32 arithmetic.  HBM-bound gathers; NHWC for features
+// (16-byte channel pieces are overkill here: these run once per forward on one layer), planar f32 for RGB images.
+#include "common.h"
+#include "internal.h"
+
+namespace maua {
+
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+// source coordinate of padded position p for F.pad's modes; returns -1 when the value is the constant
+__device__ __forceinline__ int pad_src(int p, int n, int how) {
+  if (p >= 0 && p < n) return p;
+  switch (how) {
+    case MAUA_PAD_REFLECT: {
+      if (n == 1) return 0;
+      const int period = 2 * (n - 1);
+      int q = p % period;
+      if (q < 0) q += period;
+      return q < n ? q : period - q;
+    }
+    case MAUA_PAD_REPLICATE: return p < 0 ? 0 : n - 1;
+    case MAUA_PAD_CIRCULAR: {
+      int q = p % n;
+      return q < 0 ? q + n : q;
+    }
+    default: return -1;
+  }
+}
+
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(256) void resize2d_kernel(ResizeArgs a) {
+  // one thread per output element; NHWC: channel fastest, planar: x fastest
+  const long total = (long)a.B * a.C * a.oh * a.ow;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int b, c, oy, ox;
+  if (NHWC) {
+    c = (int)(idx % a.C);
+    long r = idx / a.C;
+    ox = (int)(r % a.ow); r /= a.ow;
+    oy = (int)(r % a.oh);
+    b = (int)(r / a.oh);
+  } else {
+    ox = (int)(idx % a.ow);
+    long r = idx / a.ow;
+    oy = (int)(r % a.oh); r /= a.oh;
+    c = (int)(r % a.C);
+    b = (int)(r / a.C);
+  }
+  const T* xb = reinterpret_cast<const T*>(a.x) + (long)b * a.x_bstride;
+  auto at = [&](int y, int x) -> float {
+    const long o = NHWC ? ((long)y * a.W + x) * a.C + c : ((long)c * a.H + y) * a.W + x;
+    return Elem<T>::load(xb + o);
+  };
+  float v;
+  if (a.mode == 0) {  // bicubic
+    const float sy = (oy + 0.5f) * ((float)a.H / (float)a.oh) - 0.5f;
+    const float sx = (ox + 0.5f) * ((float)a.W / (float)a.ow) - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float cy[4], cx[4];
+    cubic_coeffs(sy - fy, cy);
+    cubic_coeffs(sx - fx, cx);
+    const int iy = (int)fy, ix = (int)fx;
+    float rows[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int y = min(max(iy - 1 + i, 0), a.H - 1);
+      float r = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int x = min(max(ix - 1 + j, 0), a.W - 1);
+        r += at(y, x) * cx[j];
+      }
+      rows[i] = r;
+    }
+    v = rows[0] * cy[0] + rows[1] * cy[1] + rows[2] * cy[2] + rows[3] * cy[3];
+  } else {  // pad (positive offsets) / crop (negative offsets): output (oy, ox) <- input (oy - pt, ox - pl)
+    const int y = pad_src(oy - a.pt, a.H, a.how), x = pad_src(ox - a.pl, a.W, a.how);
+    v = (y < 0 || x < 0) ? a.value : at(y, x);
+  }
+  if (a.noise) v += a.noise[((long)c * a.oh + oy) * a.ow + ox];
+  T* yb = reinterpret_cast<T*>(a.y) + (long)b * a.C * a.oh * a.ow;
+  const long o = NHWC ? ((long)oy * a.ow + ox) * a.C + c : ((long)c * a.oh + oy) * a.ow + ox;
+  Elem<T>::store(yb + o, v);
+}
+
+int launch_resize2d(hipStream_t stream, int dtype, bool nhwc, const ResizeArgs& a) {
+  const long total = (long)a.B * a.C * a.oh * a.ow;
+  if (total == 0) return MAUA_OK;
+  MAUA_REQUIRE(a.H > 0 && a.W > 0, "resize2d: empty input");
+  MAUA_REQUIRE(a.mode == 0 || (a.how >= 0 && a.how <= 3), "resize2d: unknown padding mode");
+  if (a.mode == 1 && a.how == MAUA_PAD_REFLECT)
+    MAUA_REQUIRE(a.pl < a.W && a.ow - a.W - a.pl < a.W && a.pt < a.H && a.oh - a.H - a.pt < a.H,
+                 "resize2d: reflect padding must be smaller than the input (as torch)");
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MAUA_F32) {
+    if (nhwc) hipLaunchKernelGGL((resize2d_kernel<float, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((resize2d_kernel<float, false>), grid, dim3(256), 0, stream, a);
+  } else if (dtype == MAUA_BF16) {
+    if (nhwc) hipLaunchKernelGGL((resize2d_kernel<bf16_t, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((resize2d_kernel<bf16_t, false>), grid, dim3(256), 0, stream, a);
+  } else {
+    return fail("resize2d: unsupported dtype");
+  }
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// img = upsample2d(prev) + y (stylegan2.py:372-378 with ops.py:117-133), planar f32 [B][3][H][W], prev [B][3][H/2][W/2]
+__global__ __launch_bounds__(256) void skip_add_kernel(const float* __restrict__ y, const float* __restrict__ prev,
+                                                       float* __restrict__ out, int H, int W, float f0, float f1, float f4,
+                                                       float f5, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  long r = idx / W;
+  const int yy = (int)(r % H);
+  const long plane = r / H;  // b * 3 + c
+  const int Hp = H >> 1, Wp = W >> 1;
+  const float* pv = prev + plane * Hp * Wp;
+  const int iy0 = (yy - 1) >> 1, ix0 = (x - 1) >> 1;
+  float u = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const int iy = iy0 + dy, uu = 2 * iy - yy + 2;
+    const bool oky = iy >= 0 && iy < Hp;
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++) {
+      const int ix = ix0 + dx, vv = 2 * ix - x + 2;
+      const bool ok = oky && ix >= 0 && ix < Wp;
+      const bool uh = uu == 1 || uu == 2, vh = vv == 1 || vv == 2;
+      const float f = !ok ? 0.f : uh ? (vh ? f5 : f4) : (vh ? f1 : f0);
+      u += pv[ok ? (long)iy * Wp + ix : 0] * f;
+    }
+  }
+  out[idx] = u + y[idx];
+}
+
+int launch_skip_add(hipStream_t stream, const float* y, const float* prev, float* out, int B, int H, int W,
+                    const float* fir16) {
+  const long total = (long)B * 3 * H * W;
+  if (total == 0) return MAUA_OK;
+  MAUA_REQUIRE(H % 2 == 0 && W % 2 == 0, "skip_add: the image must be twice the previous one");
+  hipLaunchKernelGGL(skip_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, prev, out, H, W,
+                     fir16[0], fir16[1], fir16[4], fir16[5], total);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // namespace maua
+
+using namespace maua;
+
+extern "C" {
+
+int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, int W, int out_h, int out_w, int mode,
+                  int pad_left, int pad_top, int pad_how, float pad_value, int dtype) {
+  MAUA_REQUIRE(ctx, "maua_resize2d: ctx is NULL");
+  if ((long)N * C * out_h * out_w == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y, "maua_resize2d: NULL argument");
+  MAUA_REQUIRE(mode == 0 || mode == 1, "maua_resize2d: mode must be 0 (bicubic) or 1 (pad / crop)");
+  ResizeArgs a{};
+  a.x = x; a.x_bstride = (long)C * H * W; a.y = y; a.B = N; a.H = H; a.W = W; a.C = C; a.oh = out_h; a.ow = out_w;
+  a.mode = mode; a.pl = pad_left; a.pt = pad_top; a.how = pad_how; a.value = pad_value; a.noise = nullptr;
+  return launch_resize2d(ctx->stream, dtype, false, a);
+}
+
+}  // extern "C"

@@ -19,6 +19,9 @@ namespace {
 struct ConvLayer {
   int block, which;  // which: 0 = conv0 (up 2), 1 = conv1
   int Ci, Co, res, up, w_index;
+  int ih = 0, iw = 0;   // input grid of this launch
+  int oh = 0, ow = 0;   // conv output grid (= where the noise is added)
+  int fh = 0, fw = 0;   // grid handed to the next layer (differs from oh x ow only on the resized layer)
   float* affine_w = nullptr;  // [Ci][w_dim]
   float* affine_b = nullptr;  // [Ci]
   float* bias = nullptr;      // [Co]
@@ -33,6 +36,7 @@ struct ConvLayer {
 };
 struct RgbLayer {
   int block, C, res, w_index;
+  int h = 0, w = 0;     // grid toRGB runs on (the block's feature grid)
   float* affine_w = nullptr;
   float* affine_b = nullptr;
   float* wrgb = nullptr;  // [3][C]
@@ -62,6 +66,13 @@ struct maua_synth {
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
+  // one feature-space resize (wrappers/stylegan2.py:104-151): rs_layer = -1 none, 0 = before layer 0, L = after layer L-1
+  int rs_layer = -1, rs_mode = 0, rs_th = 0, rs_tw = 0, rs_pl = 0, rs_pr = 0, rs_pt = 0, rs_pb = 0, rs_how = 3;
+  float rs_value = 0.f;
+  float* rs_noise = nullptr;   // [C][th][tw] fill noise or NULL
+  void* const_rs = nullptr;    // resized const input (rs_layer == 0)
+  float* rgb_tmp[2] = {nullptr, nullptr};
+  int out_h = 0, out_w = 0;    // final image
   // profile mode: HIP events recorded on the ctx stream around every launch of a forward
   int profile = 0;
   std::vector<hipEvent_t> ev;
@@ -89,6 +100,26 @@ static void prof_mark(maua_synth* n, const char* name) {
 
 static int channels_for(int res, int base, int maxc) { return std::min(base / res, maxc); }
 
+// per-layer grids: native power-of-two sizes, scaled from the resized layer on
+static void compute_dims(maua_synth* n) {
+  int h = 4, w = 4;
+  if (n->rs_layer == 0) { h = n->rs_th; w = n->rs_tw; }
+  size_t li = 0;
+  for (int blk = 0; blk < n->nblocks; blk++) {
+    const int nconv = blk == 0 ? 1 : 2;
+    for (int k = 0; k < nconv; k++, li++) {
+      ConvLayer& c = n->convs[li];
+      c.ih = h; c.iw = w;
+      c.oh = h * c.up; c.ow = w * c.up;
+      h = c.oh; w = c.ow;
+      if (n->rs_layer == (int)li + 1) { h = n->rs_th; w = n->rs_tw; }
+      c.fh = h; c.fw = w;
+    }
+    n->rgbs[blk].h = h; n->rgbs[blk].w = w;
+  }
+  n->out_h = h; n->out_w = w;
+}
+
 static int free_workspace(maua_synth* n) {
   for (auto& c : n->convs) {
     if (c.s) hipFree(c.s);
@@ -112,6 +143,12 @@ static int free_workspace(maua_synth* n) {
   n->style_table_dev = nullptr;
   if (n->tbuf) hipFree(n->tbuf);
   n->tbuf = nullptr;
+  if (n->const_rs) hipFree(n->const_rs);
+  n->const_rs = nullptr;
+  for (int i = 0; i < 2; i++) {
+    if (n->rgb_tmp[i]) hipFree(n->rgb_tmp[i]);
+    n->rgb_tmp[i] = nullptr;
+  }
   n->bcap = 0;
   return MAUA_OK;
 }
@@ -124,22 +161,29 @@ static int ensure_workspace(maua_synth* n, int B) {
   for (auto& c : n->convs) {
     MAUA_HIP_CHECK(hipMalloc((void**)&c.s, (size_t)B * c.Ci * sizeof(float)));
     MAUA_HIP_CHECK(hipMalloc((void**)&c.d, (size_t)B * c.Co * sizeof(float)));
-    size_t e = (size_t)c.res * c.res * c.Co;
-    max_act = std::max(max_act, e);
+    size_t e = (size_t)c.fh * c.fw * c.Co;
+    max_act = std::max(max_act, std::max(e, (size_t)c.oh * c.ow * c.Co));
     if (n->keep_features) MAUA_HIP_CHECK(hipMalloc(&c.feat, (size_t)B * e * n->esize));
   }
   for (auto& r : n->rgbs) {
     MAUA_HIP_CHECK(hipMalloc((void**)&r.s, (size_t)B * r.C * sizeof(float)));
     MAUA_HIP_CHECK(hipMalloc((void**)&r.wmod, (size_t)B * 3 * r.C * sizeof(float)));
   }
-  if (!n->keep_features)
+  if (!n->keep_features || n->rs_layer >= 1)  // (the resized layer always goes through a scratch buffer)
     for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->act[i], (size_t)B * max_act * n->esize));
+  if (n->rs_layer == 0)
+    MAUA_HIP_CHECK(hipMalloc(&n->const_rs, (size_t)n->rs_th * n->rs_tw * n->convs[0].Ci * n->esize));
+  if (n->rs_layer >= 1) {
+    const ConvLayer& hc = n->convs[n->rs_layer - 1];
+    const size_t px = std::max((size_t)hc.oh * hc.ow, (size_t)n->rs_th * n->rs_tw);
+    for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc((void**)&n->rgb_tmp[i], (size_t)B * 3 * px * sizeof(float)));
+  }
   size_t max_t = 0;
   for (auto& c : n->convs)
-    if (c.up == 2) max_t = std::max(max_t, (size_t)(c.res + 1) * (c.res + 1) * c.Co);
+    if (c.up == 2) max_t = std::max(max_t, (size_t)(c.oh + 1) * (c.ow + 1) * c.Co);
   if (max_t) MAUA_HIP_CHECK(hipMalloc(&n->tbuf, (size_t)B * max_t * n->esize));
   for (int i = 0; i < 2; i++)
-    MAUA_HIP_CHECK(hipMalloc((void**)&n->img[i], (size_t)B * 3 * n->res * n->res * sizeof(float)));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->img[i], (size_t)B * 3 * std::max(n->out_h * n->out_w, n->res * n->res) * sizeof(float)));
   // style table
   std::vector<StyleLayer> tab;
   for (auto& c : n->convs) {
@@ -201,6 +245,7 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
     g.block = i; g.C = co; g.res = r; g.w_index = widx;  // toRGB shares the next block's first w (stylegan2.py:431-433)
     n->rgbs.push_back(g);
   }
+  compute_dims(n);
   hipError_t e = hipSuccess;
   auto A = [&](void** p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes);
@@ -246,11 +291,68 @@ void maua_synth_destroy(maua_synth* n) {
     hipFree(g.affine_w); hipFree(g.affine_b); hipFree(g.wrgb); hipFree(g.bias);
   }
   hipFree(n->const_x);
+  if (n->rs_noise) hipFree(n->rs_noise);
   delete n;
 }
 
 int maua_synth_num_ws(const maua_synth* n) { return n ? n->num_ws : 0; }
 int maua_synth_num_layers(const maua_synth* n) { return n ? (int)n->convs.size() : 0; }
+
+int maua_synth_set_resize(maua_synth* n, int layer, int mode, int target_h, int target_w, int pad_left, int pad_right,
+                          int pad_top, int pad_bottom, int pad_how, float pad_value, const float* fill_noise_host) {
+  MAUA_REQUIRE(n, "maua_synth_set_resize: net is NULL");
+  MAUA_REQUIRE(layer >= -1 && layer <= (int)n->convs.size(), "maua_synth_set_resize: no such layer");
+  MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
+  const std::vector<ConvLayer> before = n->convs;
+  if (layer >= 0) {
+    MAUA_REQUIRE(mode == 0 || mode == 1, "maua_synth_set_resize: mode must be 0 (stretch) or 1 (pad)");
+    MAUA_REQUIRE(target_h >= 1 && target_w >= 1, "maua_synth_set_resize: empty target size");
+    // native grid of the hooked tensor
+    const int nat = layer == 0 ? 4 : n->convs[layer - 1].res;
+    if (mode == 1) {
+      MAUA_REQUIRE(pad_left >= 0 && pad_right >= 0 && pad_top >= 0 && pad_bottom >= 0,
+                   "maua_synth_set_resize: negative padding is not supported");
+      MAUA_REQUIRE(pad_how >= 0 && pad_how <= 3, "maua_synth_set_resize: unknown padding mode");
+      MAUA_REQUIRE(target_h == nat + pad_top + pad_bottom && target_w == nat + pad_left + pad_right,
+                   "maua_synth_set_resize: target size must equal the layer size plus the padding");
+    }
+    // the up-layers double the grid: every layer after the hook must stay even where toRGB upsamples the skip image
+    n->rs_layer = layer; n->rs_mode = mode; n->rs_th = target_h; n->rs_tw = target_w;
+    n->rs_pl = pad_left; n->rs_pr = pad_right; n->rs_pt = pad_top; n->rs_pb = pad_bottom;
+    n->rs_how = pad_how; n->rs_value = pad_value;
+  } else {
+    n->rs_layer = -1;
+  }
+  if (n->rs_noise) hipFree(n->rs_noise);
+  n->rs_noise = nullptr;
+  if (layer >= 0 && fill_noise_host) {
+    const int C = layer == 0 ? n->convs[0].Ci : n->convs[layer - 1].Co;
+    const size_t cnt = (size_t)C * target_h * target_w;
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->rs_noise, cnt * sizeof(float)));
+    MAUA_HIP_CHECK(hipMemcpy(n->rs_noise, fill_noise_host, cnt * sizeof(float), hipMemcpyHostToDevice));
+  }
+  compute_dims(n);
+  free_workspace(n);
+  // layers whose grid changed get a zeroed noise_const of the new size (the caller uploads fresh noise, :141-150)
+  for (size_t i = 0; i < n->convs.size(); i++) {
+    ConvLayer& c = n->convs[i];
+    if (c.oh != before[i].oh || c.ow != before[i].ow) {
+      hipFree(c.noise_const);
+      c.noise_const = nullptr;
+      MAUA_HIP_CHECK(hipMalloc((void**)&c.noise_const, (size_t)c.oh * c.ow * sizeof(float)));
+      MAUA_HIP_CHECK(hipMemset(c.noise_const, 0, (size_t)c.oh * c.ow * sizeof(float)));
+    }
+  }
+  return MAUA_OK;
+}
+
+int maua_synth_layer_size(const maua_synth* n, int layer, int* h, int* w) {
+  MAUA_REQUIRE(n && h && w, "maua_synth_layer_size: NULL argument");
+  MAUA_REQUIRE(layer >= -1 && layer < (int)n->convs.size(), "maua_synth_layer_size: no such layer");
+  if (layer < 0) { *h = n->out_h; *w = n->out_w; }
+  else { *h = n->convs[layer].oh; *w = n->convs[layer].ow; }
+  return MAUA_OK;
+}
 
 int maua_synth_set_option(maua_synth* n, const char* key, int value) {
   MAUA_REQUIRE(n && key, "maua_synth_set_option: NULL argument");
@@ -342,7 +444,7 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
   if (par == "bias") return upload(c->bias, host, count, c->Co, name);
   if (par == "affine.weight") return upload(c->affine_w, host, count, (size_t)c->Ci * n->w_dim, name);
   if (par == "affine.bias") return upload(c->affine_b, host, count, c->Ci, name);
-  if (par == "noise_const") return upload(c->noise_const, host, count, (size_t)c->res * c->res, name);
+  if (par == "noise_const") return upload(c->noise_const, host, count, (size_t)c->oh * c->ow, name);
   if (par == "noise_strength") {
     if (count != 1) return fail("maua_synth_load: noise_strength is a scalar");
     c->noise_strength = host[0];
@@ -385,6 +487,17 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   const void* x = n->const_x;
   long x_bstride = 0;
   int cur = 0;
+  // the one feature-space resize (get_hook's resize(x, feat=True)): bicubic / pad + fill noise, NHWC
+  auto resize_feat = [&](const void* src, long src_bstride, int nb, int H, int W, int C, void* dst) -> int {
+    ResizeArgs r{};
+    r.x = src; r.x_bstride = src_bstride; r.y = dst; r.B = nb; r.H = H; r.W = W; r.C = C; r.oh = n->rs_th; r.ow = n->rs_tw;
+    r.mode = n->rs_mode; r.pl = n->rs_pl; r.pt = n->rs_pt; r.how = n->rs_how; r.value = n->rs_value; r.noise = n->rs_noise;
+    return launch_resize2d(st, n->dtype, true, r);
+  };
+  if (n->rs_layer == 0) {  // pre-hook on the first layer: its input (the learned const) is resized
+    if (int rc = resize_feat(n->const_x, 0, 1, 4, 4, n->convs[0].Ci, n->const_rs)) return rc;
+    x = n->const_rs;
+  }
   const float* prev_img = nullptr;
   int img_cur = 0;
   size_t li = 0;
@@ -397,19 +510,21 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
     for (int k = 0; k < nconv; k++, li++) {
       ConvLayer& c = n->convs[li];
       const float* nz = (noise && noise[li]) ? noise[li] : c.noise_const;
-      const long nz_stride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.res * c.res) : 0;
+      const long nz_stride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.oh * c.ow) : 0;
       const float nz_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
-      void* y = n->keep_features ? c.feat : n->act[cur];
-      const int hin = c.res / c.up;
+      const bool hooked = n->rs_layer == (int)li + 1;  // this layer's output is resized before anything reads it
+      void* y = hooked ? n->act[cur] : n->keep_features ? c.feat : n->act[cur];
+      const int hin = std::min(c.ih, c.iw), hin_max = std::max(c.ih, c.iw);
       const int tconv_max = n->tconv_up == 1 ? 512 : n->tconv_up;  // option value > 1 = largest input size routed
-      const bool via_tconv = c.up == 2 && n->tconv_up && hin >= (n->tconv_up == 1 ? 32 : 1) && hin <= tconv_max;
-      if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, hin, hin)) {
+      const bool via_tconv = c.up == 2 && n->tconv_up && hin >= (n->tconv_up == 1 ? 32 : 1) && hin_max <= tconv_max;
+      const bool rs_block = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;  // toRGB needs the hook path
+      if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};
         a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
         a.noise_strength = nz_strength; a.bias = c.bias; a.y = y;
-        a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
+        a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
-        if (c.which == 1 && n->fuse_torgb) {  // conv1: the block's toRGB + skip rides on the epilogue tile
+        if (c.which == 1 && n->fuse_torgb && !rs_block) {  // conv1: the block's toRGB + skip rides on the epilogue tile
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;
@@ -421,12 +536,12 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         // minimal up-layer: t = conv_transpose2d(x*s, W, stride 2) on the matrix cores, then FIR + epilogue
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;
-        a.y = n->tbuf; a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = 2;
+        a.y = n->tbuf; a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 2;
         if (int rc = launch_tconv2(st, n->dtype, a)) return rc;
         prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
         UpfirArgs u{};
         u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
-        u.bias = c.bias; u.B = B; u.H = hin; u.W = hin; u.Co = c.Co;
+        u.bias = c.bias; u.B = B; u.H = c.ih; u.W = c.iw; u.Co = c.Co;
         u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
         if (int rc = launch_upfir_epilogue(st, n->dtype, u)) return rc;
       } else {
@@ -434,19 +549,53 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;
         a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength;
         a.bias = c.bias; a.y = y;
-        a.B = B; a.H = hin; a.W = hin; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
+        a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
         if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
       }
       prof_mark(n, c.which == 0 ? "conv0" : "conv1");
       x = y;
-      x_bstride = (long)c.res * c.res * c.Co;
+      x_bstride = (long)c.oh * c.ow * c.Co;
       cur ^= 1;
+      if (hooked) {  // forward hook: resize(output, feat=True)
+        void* dst = n->keep_features ? c.feat : n->act[cur];
+        if (int rc = resize_feat(x, x_bstride, B, c.oh, c.ow, c.Co, dst)) return rc;
+        x = dst;
+        x_bstride = (long)c.fh * c.fw * c.Co;
+        cur ^= 1;
+      }
     }
-    if (!rgb_fused) {
+    const bool rs_here = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;
+    if (rs_here) {
+      // the reference's rgb_hook / img_hook around the resized block (get_hook :325-338): toRGB runs on the resized
+      // features, its output goes back to the layer's native grid (bicubic back / crop), joins the skip image there,
+      // and the block's image is resized forward again (no fill noise on images)
+      const ConvLayer& hc = n->convs[n->rs_layer - 1];
+      const int nh = hc.oh, nw = hc.ow;  // native grid of the block
+      RgbArgs r{};
+      r.x = x; r.wmod = g.wmod; r.bias = g.bias; r.prev = nullptr;
+      r.out = n->rgb_tmp[0]; r.B = B; r.H = g.h; r.W = g.w; r.C = g.C; r.clamp = 256.f;
+      memcpy(r.fir, n->fir, sizeof(r.fir));
+      if (int rc = launch_torgb(st, n->dtype, r)) return rc;
+      ResizeArgs inv{};
+      inv.x = n->rgb_tmp[0]; inv.x_bstride = 3L * g.h * g.w; inv.y = n->rgb_tmp[1]; inv.B = B; inv.H = g.h; inv.W = g.w;
+      inv.C = 3; inv.oh = nh; inv.ow = nw; inv.mode = n->rs_mode; inv.pl = -n->rs_pl; inv.pt = -n->rs_pt;
+      inv.how = MAUA_PAD_CONSTANT; inv.value = 0.f; inv.noise = nullptr;
+      if (int rc = launch_resize2d(st, MAUA_F32, false, inv)) return rc;
+      const float* native = n->rgb_tmp[1];
+      if (prev_img) {
+        if (int rc = launch_skip_add(st, n->rgb_tmp[1], prev_img, n->rgb_tmp[0], B, nh, nw, n->fir)) return rc;
+        native = n->rgb_tmp[0];
+      }
+      ResizeArgs fwd{};
+      fwd.x = native; fwd.x_bstride = 3L * nh * nw; fwd.y = rgb_out; fwd.B = B; fwd.H = nh; fwd.W = nw; fwd.C = 3;
+      fwd.oh = g.h; fwd.ow = g.w; fwd.mode = n->rs_mode; fwd.pl = n->rs_pl; fwd.pt = n->rs_pt; fwd.how = n->rs_how;
+      fwd.value = n->rs_value; fwd.noise = nullptr;
+      if (int rc = launch_resize2d(st, MAUA_F32, false, fwd)) return rc;
+    } else if (!rgb_fused) {
       RgbArgs r{};
       r.x = x; r.wmod = g.wmod; r.bias = g.bias; r.prev = prev_img;
-      r.out = rgb_out; r.B = B; r.H = g.res; r.W = g.res; r.C = g.C; r.clamp = 256.f;
+      r.out = rgb_out; r.B = B; r.H = g.h; r.W = g.w; r.C = g.C; r.clamp = 256.f;
       memcpy(r.fir, n->fir, sizeof(r.fir));
       if (int rc = launch_torgb(st, n->dtype, r)) return rc;
     }
@@ -455,7 +604,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
     img_cur ^= 1;
   }
   if (rgb8_out) {
-    if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->res, n->res)) return rc;
+    if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->out_h, n->out_w)) return rc;
     prof_mark(n, "pack_rgb8");
   }
   return MAUA_OK;
@@ -493,8 +642,8 @@ int maua_synth_get_feature(maua_synth* n, int layer, int B, float* out_nchw) {
   MAUA_REQUIRE(B <= n->bcap, "maua_synth_get_feature: batch larger than the last forward");
   ConvLayer& c = n->convs[layer];
   hipStream_t st = n->ctx->stream;
-  if (n->dtype == MAUA_BF16) return launch_nhwc_to_nchw<bf16_t, float>(st, c.feat, out_nchw, B, c.Co, c.res * c.res, c.Co);
-  return launch_nhwc_to_nchw<float, float>(st, c.feat, out_nchw, B, c.Co, c.res * c.res, c.Co);
+  if (n->dtype == MAUA_BF16) return launch_nhwc_to_nchw<bf16_t, float>(st, c.feat, out_nchw, B, c.Co, c.fh * c.fw, c.Co);
+  return launch_nhwc_to_nchw<float, float>(st, c.feat, out_nchw, B, c.Co, c.fh * c.fw, c.Co);
 }
 
 }  // extern "C"

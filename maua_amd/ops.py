@@ -169,3 +169,31 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     styles = torch.ones((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
     return modulated_conv2d(x, w, styles, up=up, down=down, padding=padding, resample_filter=f, demodulate=False,
                             flip_weight=flip_weight)
+
+
+_PAD_HOW = {"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}
+
+
+def interpolate_bicubic(x, size):
+    """torch.nn.functional.interpolate(x, size, mode="bicubic", align_corners=False) on NCHW f32 / bf16 — the
+    "stretch" resize of wrappers/stylegan2.py:231,253."""
+    x = L.dev_tensor(x)
+    n, c, h, w = x.shape
+    oh, ow = int(size[0]), int(size[1])
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+    L.check(L.lib().maua_resize2d(L.ctx(x.device), L.ptr(x), L.ptr(y), n, c, h, w, oh, ow, 0, 0, 0, 3, C.c_float(0.0),
+                                  L.dtype_id(x)))
+    return y
+
+
+def pad2d(x, padding, mode="constant", value=0.0):
+    """torch.nn.functional.pad(x, (left, right, top, bottom), mode, value) on NCHW (wrappers/stylegan2.py:294);
+    negative entries crop (the pad strategies' inverse, :313-323)."""
+    x = L.dev_tensor(x)
+    n, c, h, w = x.shape
+    pl, pr, pt, pb = (int(p) for p in padding)
+    oh, ow = h + pt + pb, w + pl + pr
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+    L.check(L.lib().maua_resize2d(L.ctx(x.device), L.ptr(x), L.ptr(y), n, c, h, w, oh, ow, 1, pl, pt, _PAD_HOW[mode],
+                                  C.c_float(float(value)), L.dtype_id(x)))
+    return y

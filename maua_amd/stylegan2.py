@@ -14,6 +14,8 @@ import ctypes as C
 from math import sqrt
 from typing import Dict, Optional
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -104,6 +106,7 @@ class SynthesisNetwork(torch.nn.Module):
         self._net = None  # device handle, created on first use
         self._net_device = None
         self._keep_features = False
+        self._resize = None  # feature-space resize spec (set_resize), re-applied when the device object is rebuilt
 
     # -- parameters ------------------------------------------------------------------------------------
     def state_dict(self, *a, **k):
@@ -160,9 +163,62 @@ class SynthesisNetwork(torch.nn.Module):
                 L.check(lib.maua_synth_load(net, k.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
             L.check(lib.maua_synth_set_option(net, b"keep_features", int(self._keep_features)))
             self._net, self._net_device = net, dev
+            if self._resize is not None:
+                self._apply_resize()
         else:
             L.ctx(dev)  # re-bind torch's current stream
         return self._net
+
+    # -- arbitrary output size ---------------------------------------------------------
+    def set_resize(self, layer, mode="stretch", target=None, padding=(0, 0, 0, 0), pad_how="constant", pad_value=0.0,
+                   fill_noise=None, noise_generator=None):
+        """Resize the feature map at ``layer`` (index into the reference's layer_names: 0 = input of bs.0.conv1,
+        L >= 1 = output of synthesis layer L-1) to ``target`` = (h, w); every later layer runs at the scaled size.
+        ``mode``: "stretch" (bicubic) or "pad" with ``padding`` = (left, right, top, bottom), ``pad_how`` in
+        {"constant", "reflect", "replicate", "circular"}.  ``fill_noise``: optional [C, h, w] tensor added to the
+        resized features.  Layers after the resize get fresh N(0,1) noise_const of their new size from
+        ``noise_generator`` (wrappers/stylegan2.py:139-150).  ``layer=None`` removes the resize."""
+        if layer is None:
+            self._resize = None
+            if self._net is not None:
+                L.check(L.lib().maua_synth_set_resize(self._net, -1, 0, 0, 0, 0, 0, 0, 0, 3, C.c_float(0.0), None))
+            return
+        fn = None if fill_noise is None else np.ascontiguousarray(fill_noise.detach().float().cpu().numpy())
+        self._resize = dict(layer=int(layer), mode={"stretch": 0, "pad": 1}[mode], th=int(target[0]), tw=int(target[1]),
+                            padding=tuple(int(p) for p in padding),
+                            how={"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}[pad_how],
+                            value=float(pad_value), fill=fn)
+        if self._net is not None or torch.cuda.is_available():
+            self._handle() if self._net is None else self._apply_resize()
+            # fresh noise buffers for the layers whose size changed
+            for l, (pfx, _, _, _, _) in enumerate(self.layer_shapes()):
+                h, w = self.layer_size(l)
+                if tuple(self._params[pfx + ".noise_const"].shape) != (h, w):
+                    nz = torch.randn((h, w), generator=noise_generator)
+                    self._params[pfx + ".noise_const"] = nz
+                    a = np.ascontiguousarray(nz.numpy(), dtype=np.float32)
+                    L.check(L.lib().maua_synth_load(self._net, (pfx + ".noise_const").encode(),
+                                                    a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+
+    def _apply_resize(self):
+        r = self._resize
+        fill = None if r["fill"] is None else r["fill"].ctypes.data_as(C.c_void_p)
+        pl, pr, pt, pb = r["padding"]
+        L.check(L.lib().maua_synth_set_resize(self._net, r["layer"], r["mode"], r["th"], r["tw"], pl, pr, pt, pb,
+                                              r["how"], C.c_float(r["value"]), fill))
+
+    def layer_size(self, layer):
+        """(h, w) of synthesis layer ``layer``'s output (= its noise size); layer -1: the final image."""
+        if self._net is None and self._resize is None:
+            r = self.img_resolution if layer < 0 else self.layer_shapes()[layer][3]
+            return r, r
+        h, w = C.c_int(), C.c_int()
+        L.check(L.lib().maua_synth_layer_size(self._handle(), layer, C.byref(h), C.byref(w)))
+        return h.value, w.value
+
+    @property
+    def output_hw(self):
+        return self.layer_size(-1)
 
     def keep_features(self, flag=True):
         self._keep_features = bool(flag)
@@ -183,16 +239,16 @@ class SynthesisNetwork(torch.nn.Module):
             if t is None:
                 ptrs[l], strides[l] = None, 0
                 continue
-            res = shapes[l][3]
+            rh, rw = self.layer_size(l)
             t = L.dev_tensor(t, torch.float32)
-            if t.shape[-2:] != (res, res):  # wrappers/stylegan2.py:92-98: resize mismatching noise
-                t = torch.nn.functional.interpolate(t.reshape(-1, 1, *t.shape[-2:]), (res, res), mode="bicubic",
+            if tuple(t.shape[-2:]) != (rh, rw):  # wrappers/stylegan2.py:92-98: resize mismatching noise
+                t = torch.nn.functional.interpolate(t.reshape(-1, 1, *t.shape[-2:]), (rh, rw), mode="bicubic",
                                                     align_corners=False).contiguous()
-            nb = t.numel() // (res * res)
+            nb = t.numel() // (rh * rw)
             if nb not in (1, B):
                 raise ValueError(f"noise{l}: batch {nb} does not match latents batch {B}")
             keep.append(t)
-            ptrs[l], strides[l] = t.data_ptr(), (0 if nb == 1 else res * res)
+            ptrs[l], strides[l] = t.data_ptr(), (0 if nb == 1 else rh * rw)
         return ptrs, strides, keep
 
     def forward(self, ws, noise_mode="const", noise=None, out=None, rgb8_out=None):
@@ -207,9 +263,9 @@ class SynthesisNetwork(torch.nn.Module):
         B = ws.shape[0]
         if tuple(ws.shape[1:]) != (self.num_ws, self.w_dim):
             raise ValueError(f"ws must be [B, {self.num_ws}, {self.w_dim}], got {tuple(ws.shape)}")
-        R = self.img_resolution
         if out is None and rgb8_out is None:
-            out = torch.empty((B, 3, R, R), dtype=torch.float32, device=ws.device)
+            oh, ow = self.output_hw
+            out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=ws.device)
         ptrs, strides, keep = self._noise_args(noise, B)
         L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
         del keep
@@ -217,7 +273,10 @@ class SynthesisNetwork(torch.nn.Module):
 
     def get_feature(self, layer, B):
         shp = self.layer_shapes()[layer]
-        out = torch.empty((B, shp[2], shp[3], shp[3]), dtype=torch.float32, device="cuda")
+        h, w = self.layer_size(layer)
+        if self._resize is not None and self._resize["layer"] == layer + 1:  # the hook's output replaces the layer's
+            h, w = self._resize["th"], self._resize["tw"]
+        out = torch.empty((B, shp[2], h, w), dtype=torch.float32, device="cuda")
         L.check(L.lib().maua_synth_get_feature(self._handle(), layer, B, L.ptr(out)))
         return out
 
@@ -309,6 +368,38 @@ class StyleGAN2Mapper(MauaMapper):
         return self.G_map.forward(latent_z, class_conditioning, truncation_psi=truncation)
 
 
+def resize_strategy(layer_size, target_hw, strategy):
+    """The strategy strings of get_hook (wrappers/stylegan2.py:216-290) -> SynthesisNetwork.set_resize kwargs."""
+    th, tw = target_hw
+    if strategy == "stretch":
+        return dict(mode="stretch")
+    if strategy.startswith("pad"):
+        parts = strategy.split("-")
+        if len(parts) != 3:  # (the reference's CLI default "pad-zero" unpacks into 3 names and fails, SURVEY Q7)
+            raise ValueError(f"Resize strategy must be 'pad-<how>-<where>': {strategy}")
+        _, how, where = parts
+        pad_h, pad_w = th - layer_size, tw - layer_size
+        if pad_h < 0 or pad_w < 0:
+            raise NotImplementedError("negative padding (output smaller than the layer) is a TODO in the reference too")
+        half = lambda p: (p // 2, round(1e-16 + p / 2))
+        if where == "out":
+            padding = (*half(pad_w), *half(pad_h))
+        elif where == "left":
+            padding = (pad_w, 0, *half(pad_h))
+        elif where == "right":
+            padding = (0, pad_w, *half(pad_h))
+        elif where == "top":
+            padding = (*half(pad_w), pad_h, 0)
+        elif where == "bottom":
+            padding = (*half(pad_w), 0, pad_h)
+        else:
+            raise ValueError(f"Resize strategy not found: {strategy}")
+        if how in ("reflect", "replicate", "circular"):
+            return dict(mode="pad", padding=padding, pad_how=how, pad_value=0.0)
+        return dict(mode="pad", padding=padding, pad_how="constant", pad_value=float(how))
+    raise Exception(f"Resize strategy not found: {strategy}")
+
+
 def _num_ws_from_sd(sd):
     n = 0
     while f"bs.{n}.conv1.weight" in sd:
@@ -317,16 +408,18 @@ def _num_ws_from_sd(sd):
 
 
 class StyleGAN2Synthesizer(MauaSynthesizer):
-    """maua/GAN/wrappers/stylegan2.py:22-102: same constructor, attributes (w_dim, num_ws, layer_names,
-    modulation_targets, output_size, G_synth) and forward kwargs.  Only the native output size is implemented
-    (the reference's resize hooks do not run on CPU and are a SURVEY 8(f) N2 item); geometric transforms likewise."""
+    """maua/GAN/wrappers/stylegan2.py:22-151: same constructor, attributes (w_dim, num_ws, layer_names,
+    modulation_targets, output_size, G_synth) and forward kwargs, incl. arbitrary output sizes through the
+    feature-space resize of change_output_resolution ("stretch" / "pad-<how>-<where>" at ``layer``).  The geometric
+    transform hooks (kornia translate / rotate / zoom, :153-194) are not implemented."""
 
     def __init__(self, model_file=None, inference=False, output_size=None, strategy="stretch", layer=0,
                  img_resolution=1024, dtype=torch.bfloat16, generator=None):
         super().__init__()
         if model_file is None or model_file == "None":
-            # The reference always builds the 1024 net and reaches other sizes through feature-space resize hooks
-            # (not implemented, N2).  A square power-of-two output_size selects a native random-init net instead.
+            # The reference always builds the 1024 net and reaches other sizes through feature-space resize hooks.
+            # For a random-init net a square power-of-two output_size selects the NATIVE net of that size instead
+            # (SURVEY config C0); every other size goes through change_output_resolution like the reference.
             if output_size is not None and output_size[0] == output_size[1] and output_size[0] >= 8 \
                     and (output_size[0] & (output_size[0] - 1)) == 0:
                 img_resolution = int(output_size[0])
@@ -337,19 +430,53 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
         R = self.G_synth.img_resolution
         if output_size is None:
             output_size = (R, R)
-        if tuple(output_size) != (R, R):
-            raise NotImplementedError(f"output_size {tuple(output_size)} != native {(R, R)}: feature-space resizing "
-                                      "(wrappers/stylegan2.py:104-151) is not implemented yet")
         self.w_dim, self.num_ws = self.G_synth.w_dim, self.G_synth.num_ws
         self.layer_names = [f"bs.{c // 2}.conv{1 if bs == 4 else c % 2}"
                             for c, bs in enumerate(sorted(self.G_synth.block_resolutions * 2))]
         self.modulation_targets = {"latent_w": (self.w_dim,), "latent_w_plus": (self.num_ws, self.w_dim),
                                    "translation": (2,), "rotation": (1,)}
-        self.output_size = tuple(output_size)
+        self.output_size = (R, R)
+        self._generator = generator
+        self.change_output_resolution(tuple(output_size), strategy, layer)
 
-    def change_output_resolution(self, output_size, strategy, layer):
-        if tuple(output_size) != self.output_size:
-            raise NotImplementedError("feature-space resizing is not implemented yet")
+    def change_output_resolution(self, output_size, strategy, layer, add_noise=True):
+        """wrappers/stylegan2.py:104-151 + get_hook :216-340.  ``output_size`` is (width, height) like the reference
+        (:217 flips it); it is rounded to a multiple of img_resolution // layer_size.  The per-channel fill noise of
+        the resized features (drawn by the reference from the statistics of one random forward, :233-248) and the new
+        noise buffers of the later layers (:141-146) come from this object's generator."""
+        G = self.G_synth
+        R = G.img_resolution
+        G.set_resize(None)
+        if tuple(output_size) != (R, R):
+            _, block, _conv = self.layer_names[layer].split(".")
+            layer_size = 4 * 2 ** int(block)
+            lay_mult = R // layer_size
+            unrounded = np.array(output_size) / lay_mult
+            target = np.round(unrounded).astype(int)                 # (W, H)
+            if sum(abs(unrounded - target)) > 1e-10:
+                warnings.warn(f"Layer {layer} resizes to multiples of {lay_mult}. --output-size rounded to "
+                              f"{lay_mult * target}")
+            tw, th = int(target[0]), int(target[1])
+            kw = resize_strategy(layer_size, (th, tw), strategy)
+            gen = self._generator
+            G.set_resize(layer, target=(th, tw), noise_generator=gen, **kw)
+            if add_noise:
+                # statistics of the resized features of one random forward (the reference's warm-up call, :149)
+                if layer == 0:
+                    const = G.state_dict()["bs.0.const"][None]
+                    x = ops.interpolate_bicubic(const, (th, tw)) if kw["mode"] == "stretch" else \
+                        ops.pad2d(const, kw["padding"], kw["pad_how"], kw["pad_value"])
+                else:
+                    keep = G._keep_features
+                    G.keep_features(True)
+                    G.forward(torch.randn((1, self.num_ws, self.w_dim), generator=gen))
+                    x = G.get_feature(layer - 1, 1)
+                    G.keep_features(keep)
+                x = x.float().cpu()
+                mean, std = x.mean((0, 2, 3)), x.transpose(0, 1).reshape(x.shape[1], -1).std(1)
+                fill = torch.randn(x.shape[1:], generator=gen) * std[:, None, None] + mean[:, None, None]
+                G.set_resize(layer, target=(th, tw), fill_noise=fill, noise_generator=gen, **kw)
+        self.output_size = tuple(output_size)
 
     def forward(self, latents, translation=None, translation_layer=7, zoom=None, zoom_layer=7, zoom_center=None,
                 rotation=None, rotation_layer=7, rotation_center=None, rgb8_out=None, **noise):
@@ -368,7 +495,7 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
         for l, layer in enumerate(self.layer_names[1:]):
             if l > layer_limit:
                 continue
-            h = w = shapes[l][3]
+            h, w = self.G_synth.layer_size(l)
             n = torch.nn.functional.interpolate(noise, (h, w), mode="bicubic", align_corners=False)
             noises[f"noise{l}"] = n / n.std((1, 2, 3), keepdim=True)
         return noises

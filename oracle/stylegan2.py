@@ -145,11 +145,34 @@ def torgb_layer(p, prefix, x, w, conv_clamp=256.0):
     return ops.bias_act(x, p[prefix + ".bias"], clamp=conv_clamp)
 
 
-def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False):
+def _hook_resize(x, rs, feat):
+    """get_hook's resize (wrappers/stylegan2.py:223-250 "stretch", :284-313 "pad-*"): the torch ops the hooks call."""
+    if rs["mode"] == "stretch":
+        x = F.interpolate(x, tuple(rs["target"]), mode="bicubic", align_corners=False)
+    else:
+        x = F.pad(x, tuple(rs["padding"]), mode=rs.get("pad_how", "constant"), value=rs.get("pad_value", 0.0))
+    if feat and rs.get("fill") is not None:
+        x = x + rs["fill"][None].to(x)
+    return x
+
+
+def _hook_inverse(x, rs, layer_size):
+    """get_hook's inverse (:252-253 bicubic back to the layer size, :315-327 crop the padding)."""
+    if rs["mode"] == "stretch":
+        return F.interpolate(x, (layer_size, layer_size), mode="bicubic", align_corners=False)
+    pl, pr, pt, pb = rs["padding"]
+    return x[..., pt:x.shape[-2] - pb, pl:x.shape[-1] - pr]
+
+
+def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False, resize=None):
     """stylegan2.py:429-436 + SynthesisBlock.forward :340-382 ('skip' architecture).
 
     ``noise``: optional list, one [B|1,1,h,w] tensor per synthesis layer in
     execution order (what StyleGAN2Synthesizer.forward installs, wrappers/stylegan2.py:85-100).
+    ``resize``: optional dict(layer, mode "stretch"|"pad", target (h, w), padding (l, r, t, b), pad_how, pad_value,
+    fill [C, h, w]) — the forward (pre-)hooks of change_output_resolution (wrappers/stylegan2.py:104-151):
+    layer 0 resizes the input of the first layer, layer L >= 1 the output of synthesis layer L-1, whose block also
+    gets the rgb (inverse) and img (resize) hooks.
     """
     nblocks = 0
     while f"bs.{nblocks}.conv1.weight" in p:
@@ -158,26 +181,38 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
     w_idx = 0
     li = 0
     feats = []
+    rs_layer = -1 if resize is None else resize["layer"]
     for i in range(nblocks):
         def nz():
             return None if noise is None or li >= len(noise) else noise[li]
+        hooked_here = False
         if i == 0:
             x = p["bs.0.const"].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+            if rs_layer == 0:
+                x = _hook_resize(x, resize, True)
         else:
             x = synthesis_layer(p, f"bs.{i}.conv0", x, ws[:, w_idx], up=2, noise=nz(),
                                 noise_strength=noise_strength, nv_compat=nv_compat)
+            if rs_layer == li + 1:
+                x, hooked_here = _hook_resize(x, resize, True), True
             feats.append(x)
             w_idx += 1
             li += 1
         x = synthesis_layer(p, f"bs.{i}.conv1", x, ws[:, w_idx], up=1, noise=nz(),
                             noise_strength=noise_strength, nv_compat=nv_compat)
+        if rs_layer == li + 1:
+            x, hooked_here = _hook_resize(x, resize, True), True
         feats.append(x)
         w_idx += 1
         li += 1
         if img is not None:
             img = ops.upsample2d(img, p[f"bs.{i}.resample_filter"])
         y = torgb_layer(p, f"bs.{i}.torgb", x, ws[:, w_idx])
+        if hooked_here:
+            y = _hook_inverse(y, resize, 4 * 2 ** i)
         img = y if img is None else img + y
+        if hooked_here:
+            img = _hook_resize(img, resize, False)
     if return_features:
         return img, feats
     return img

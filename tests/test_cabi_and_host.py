@@ -109,8 +109,17 @@ def test_wrappers_structure():
     assert G.get_z_latents("0-4").shape == (4, 512)
     G1024 = StyleGAN2(model_file=None)
     assert G1024.res == 1024 and G1024.num_ws == 18 and len(G1024.synthesizer.layer_names) == 18
-    with pytest.raises(NotImplementedError):
+    # other sizes go through the feature-space resize, which needs the HIP device (no CPU fallback)
+    from maua_amd._lib import MauaHipError
+    from maua_amd.stylegan2 import resize_strategy
+    with pytest.raises(MauaHipError):
         StyleGAN2(model_file=None, output_size=(1920, 1080))
+    assert resize_strategy(4, (4, 8), "stretch") == dict(mode="stretch")
+    assert resize_strategy(16, (17, 30), "pad-0.5-left") == dict(mode="pad", padding=(14, 0, 0, 1), pad_how="constant",
+                                                                 pad_value=0.5)
+    assert resize_strategy(4, (5, 7), "pad-reflect-out")["padding"] == (1, 2, 0, 1)
+    with pytest.raises(ValueError):
+        resize_strategy(4, (4, 8), "pad-zero")  # the reference's CLI default does not parse there either (Q7)
     sd = G.synthesizer.G_synth.state_dict()
     assert sd["bs.0.const"].shape == (512, 4, 4) and sd["bs.4.conv1.weight"].shape == (512, 512, 3, 3)
 

@@ -1,0 +1,127 @@
+"""SURVEY 8(f) N2 — arbitrary output sizes: the resize ops against the torch functions the reference's hooks call
+(wrappers/stylegan2.py:216-340) and the synthesis network with one feature-space resize against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) / max(1e-20, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("shape,size", [((2, 5, 4, 4), (3, 7)), ((1, 3, 16, 16), (9, 30)), ((2, 8, 7, 13), (14, 26)),
+                                         ((1, 4, 32, 32), (32, 32)), ((1, 2, 9, 9), (4, 4))])
+def test_bicubic_matches_torch(shape, size):
+    from maua_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(shape, generator=g)
+    want = F.interpolate(x, size, mode="bicubic", align_corners=False)
+    assert rel(ops.interpolate_bicubic(x.cuda(), size), want) < 2e-6
+    got16 = ops.interpolate_bicubic(x.cuda().bfloat16(), size)
+    assert got16.dtype == torch.bfloat16 and rel(got16, F.interpolate(x.bfloat16().float(), size, mode="bicubic",
+                                                                      align_corners=False)) < 1e-2
+
+
+@pytest.mark.parametrize("mode", ["constant", "reflect", "replicate", "circular"])
+def test_pad_matches_torch(mode):
+    from maua_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn((2, 3, 6, 9), generator=g)
+    for padding in [(1, 2, 0, 1), (0, 0, 3, 3), (5, 4, 2, 1)]:
+        want = F.pad(x, padding, mode=mode, value=0.25) if mode == "constant" else F.pad(x, padding, mode=mode)
+        got = ops.pad2d(x.cuda(), padding, mode, 0.25)
+        assert torch.equal(got.cpu(), want), (mode, padding)
+    # crop = negative padding (the pad strategies' inverse)
+    assert torch.equal(ops.pad2d(x.cuda(), (-1, -2, 0, -1)).cpu(), x[..., 0:5, 1:7])
+    if mode == "reflect":
+        from maua_amd._lib import MauaHipError
+        with pytest.raises(MauaHipError):
+            ops.pad2d(x.cuda(), (9, 0, 0, 0), mode)  # torch rejects pad >= size too
+
+
+def _net(res, dt, seed=3):
+    from maua_amd.stylegan2 import SynthesisNetwork
+    g = torch.Generator().manual_seed(seed)
+    net = SynthesisNetwork(64, res, 3, channel_base=2048, channel_max=64, dtype=dt, generator=g)
+    p = net.state_dict()
+    g2 = torch.Generator().manual_seed(seed + 1)
+    for k in p:
+        if k.endswith(".bias") and "affine" not in k:
+            p[k] = torch.randn(p[k].shape, generator=g2) * 0.1
+    net.load_state_dict(p)
+    return net
+
+
+CASES = [
+    dict(layer=0, mode="stretch", target=(3, 5)),                                   # pre-hook on the const input
+    dict(layer=0, mode="pad", target=(4, 7), padding=(1, 2, 0, 0), pad_how="reflect"),
+    dict(layer=2, mode="stretch", target=(6, 11)),                                  # after bs.1.conv0 (8x8 -> 6x11)
+    dict(layer=3, mode="stretch", target=(12, 7)),                                  # after bs.1.conv1
+    dict(layer=4, mode="pad", target=(19, 22), padding=(2, 4, 1, 2), pad_how="constant", pad_value=0.3),
+    dict(layer=5, mode="pad", target=(16, 24), padding=(8, 0, 0, 0), pad_how="circular"),
+    dict(layer=7, mode="stretch", target=(40, 24)),                                 # last layer of a 32-net
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"L{c['layer']}-{c['mode']}")
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_synthesis_with_resize_matches_oracle(case, dt):
+    from oracle import stylegan2 as OS
+    net = _net(32, dt)
+    g = torch.Generator().manual_seed(17)
+    B = 2
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    C = 64
+    th, tw = case["target"]
+    fill = torch.randn((C, th, tw), generator=g) * 0.5
+    kw = {k: v for k, v in case.items() if k not in ("layer", "target")}
+    net.keep_features(True)
+    net.set_resize(case["layer"], target=case["target"], fill_noise=fill, noise_generator=torch.Generator().manual_seed(5), **kw)
+    img = net(ws).cpu()
+    p = net.state_dict()  # includes the re-drawn noise buffers
+    rs = dict(case, fill=fill, padding=case.get("padding", (0, 0, 0, 0)))
+    ref, feats = OS.synthesis_network(p, ws, return_features=True, resize=rs)
+    assert img.shape == ref.shape
+    # sizes: every layer after the resize scales from the target
+    for l in range(net.num_layers):
+        assert tuple(feats[l].shape[-2:]) == tuple(net.get_feature(l, B).shape[-2:]), l
+    assert net.output_hw == tuple(ref.shape[-2:])
+    tol = 2e-5 if dt == torch.float32 else 3e-2
+    for l in range(net.num_layers):
+        assert rel(net.get_feature(l, B), feats[l]) <= tol, f"layer {l}"
+    assert rel(img, ref) <= tol
+    # u8 frames at the new size
+    u8 = torch.empty((B, ref.shape[-2], ref.shape[-1], 3), dtype=torch.uint8, device="cuda")
+    net(ws, rgb8_out=u8)
+    want = ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)
+    assert int((u8.cpu().int() - want.int()).abs().max()) <= (0 if dt == torch.float32 else 1)
+    # removing the resize restores the native network
+    net.set_resize(None)
+    assert net.output_hw == (32, 32)
+
+
+def test_wrapper_output_size_and_noise_kwargs():
+    """StyleGAN2(output_size=(W, H), strategy, layer) like the reference; noise kwargs follow the new layer sizes."""
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer
+    gen = torch.Generator().manual_seed(0)
+    syn = StyleGAN2Synthesizer(None, False, (96, 40), "stretch", 2, img_resolution=64, dtype=torch.float32, generator=gen)
+    G = syn.G_synth
+    assert syn.output_size == (96, 40) and G.output_hw == (40, 96)       # lay_mult = 64 // 8 = 8 -> 5 x 12 at layer 2
+    assert G.layer_size(1) == (8, 8) and G.layer_size(2) == (5, 12) and G.layer_size(3) == (10, 24)
+    ws = torch.randn(2, syn.num_ws, 512, generator=gen)
+    img = syn.forward(ws)
+    assert tuple(img.shape) == (2, 3, 40, 96) and bool(torch.isfinite(img).all())
+    pyr = syn.make_noise_pyramid(torch.randn(2, 1, 16, 16, generator=gen))
+    assert tuple(pyr["noise3"].shape[-2:]) == G.layer_size(3)
+    img2 = syn.forward(ws, **pyr)
+    assert tuple(img2.shape) == (2, 3, 40, 96) and not torch.equal(img, img2)
+    with pytest.warns(UserWarning):                                          # 100 is not a multiple of 8
+        syn.change_output_resolution((100, 72), "pad-reflect-out", 2)
+    assert G.output_hw == (72, 96) and tuple(syn.forward(ws).shape) == (2, 3, 72, 96)
+    syn.change_output_resolution((64, 64), "stretch", 2)
+    assert G.output_hw == (64, 64)
