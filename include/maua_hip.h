@@ -108,9 +108,14 @@ int maua_synth_set_resize(maua_synth* net, int layer, int mode, int target_h, in
 /* output size (h, w) of synthesis layer `layer` (execution order), or of the final image for layer == -1 */
 int maua_synth_layer_size(const maua_synth* net, int layer, int* h, int* w);
 /* the torch ops the hooks are made of, on NCHW tensors (dtype f32 / bf16): mode 0 = F.interpolate(x, (out_h, out_w),
- * mode="bicubic", align_corners=False); mode 1 = F.pad with left/top offsets (negative = crop), out size given. */
+ * mode="bicubic", align_corners=False); mode 1 = F.pad with left/top offsets (negative = crop), out size given;
+ * mode 2 = bicubic with align_corners=True (maua/ops/image.py:240, the post-render resample). */
 int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, int W, int out_h, int out_w, int mode,
                   int pad_left, int pad_top, int pad_how, float pad_value, int dtype);
+/* depthwise 1-D correlation of planar f32 [planes][H][W] along rows (axis 0) or columns (axis 1) with reflect padding
+ * `radius` (taps [2*radius+1], device): the lanczos pre-filter of maua/ops/image.py:226-236 resample. */
+int maua_conv1d_reflect(maua_ctx* ctx, const float* x, float* y, const float* taps, int radius, int axis, long planes,
+                        int H, int W);
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.

@@ -23,8 +23,9 @@ class MauaPatch:
 
     def force_output_size(self, video):
         t, c, h, w = video.shape
-        if (w, h) != tuple(self.synthesizer.output_size):
-            raise NotImplementedError("post-render resampling (maua/ops/image.py:214-240) is not implemented yet")
+        if (w, h) != tuple(self.synthesizer.output_size):  # lanczos + bicubic (maua/ops/image.py:214-240)
+            from ....ops import resample
+            video = resample(video, tuple(reversed(self.synthesizer.output_size)))
         return video
 
 

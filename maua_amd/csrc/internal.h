@@ -88,6 +88,7 @@ struct ResizeArgs {
   void* y;
   int B, H, W, C, oh, ow;
   int mode;         // 0 bicubic, 1 pad / crop
+  int align;        // bicubic: align_corners (source = o * (in-1)/(out-1)) instead of half-pixel centres
   int pl, pt;       // left / top offset of the input inside the output (negative = crop)
   int how;          // maua_pad_mode
   float value;

@@ -68,8 +68,11 @@ __global__ __launch_bounds__(256) void resize2d_kernel(ResizeArgs a) {
   };
   float v;
   if (a.mode == 0) {  // bicubic
-    const float sy = (oy + 0.5f) * ((float)a.H / (float)a.oh) - 0.5f;
-    const float sx = (ox + 0.5f) * ((float)a.W / (float)a.ow) - 0.5f;
+    // ATen area_pixel_compute_source_index: align_corners -> o * (in - 1) / (out - 1), else half-pixel centres
+    const float sy = a.align ? (a.oh > 1 ? oy * ((float)(a.H - 1) / (float)(a.oh - 1)) : 0.f)
+                             : (oy + 0.5f) * ((float)a.H / (float)a.oh) - 0.5f;
+    const float sx = a.align ? (a.ow > 1 ? ox * ((float)(a.W - 1) / (float)(a.ow - 1)) : 0.f)
+                             : (ox + 0.5f) * ((float)a.W / (float)a.ow) - 0.5f;
     const float fy = floorf(sy), fx = floorf(sx);
     float cy[4], cx[4];
     cubic_coeffs(sy - fy, cy);
@@ -120,6 +123,26 @@ int launch_resize2d(hipStream_t stream, int dtype, bool nhwc, const ResizeArgs& 
   return MAUA_OK;
 }
 
+// depthwise 1-D correlation along H (axis 0) or W (axis 1) of planar f32 [planes][H][W] with reflect padding: the
+// lanczos pre-filter of maua/ops/image.py:226-236 (F.pad reflect + F.conv2d with a [k,1] / [1,k] kernel)
+__global__ __launch_bounds__(256) void conv1d_planar_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ taps, int radius, int axis, int H,
+                                                            int W, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int xx = (int)(idx % W);
+  const long r = idx / W;
+  const int yy = (int)(r % H);
+  const float* pl = x + (r / H) * H * W;
+  float acc = 0.f;
+  for (int k = -radius; k <= radius; k++) {
+    const int sy = axis == 0 ? pad_src(yy + k, H, MAUA_PAD_REFLECT) : yy;
+    const int sx = axis == 1 ? pad_src(xx + k, W, MAUA_PAD_REFLECT) : xx;
+    acc += pl[(long)sy * W + sx] * taps[k + radius];
+  }
+  y[idx] = acc;
+}
+
 // img = upsample2d(prev) + y (stylegan2.py:372-378 with ops.py:117-133), planar f32 [B][3][H][W], prev [B][3][H/2][W/2]
 __global__ __launch_bounds__(256) void skip_add_kernel(const float* __restrict__ y, const float* __restrict__ prev,
                                                        float* __restrict__ out, int H, int W, float f0, float f1, float f4,
@@ -167,13 +190,29 @@ using namespace maua;
 
 extern "C" {
 
+int maua_conv1d_reflect(maua_ctx* ctx, const float* x, float* y, const float* taps, int radius, int axis, long planes,
+                        int H, int W) {
+  MAUA_REQUIRE(ctx, "maua_conv1d_reflect: ctx is NULL");
+  const long total = planes * H * W;
+  if (total == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y && taps && x != y, "maua_conv1d_reflect: NULL or aliased argument");
+  MAUA_REQUIRE(axis == 0 || axis == 1, "maua_conv1d_reflect: axis must be 0 (rows) or 1 (columns)");
+  MAUA_REQUIRE(radius >= 0 && radius < (axis == 0 ? H : W), "maua_conv1d_reflect: reflect padding must be smaller than the image");
+  hipLaunchKernelGGL(conv1d_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, y, taps,
+                     radius, axis, H, W, total);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, int W, int out_h, int out_w, int mode,
                   int pad_left, int pad_top, int pad_how, float pad_value, int dtype) {
   MAUA_REQUIRE(ctx, "maua_resize2d: ctx is NULL");
   if ((long)N * C * out_h * out_w == 0) return MAUA_OK;
   MAUA_REQUIRE(x && y, "maua_resize2d: NULL argument");
-  MAUA_REQUIRE(mode == 0 || mode == 1, "maua_resize2d: mode must be 0 (bicubic) or 1 (pad / crop)");
+  MAUA_REQUIRE(mode >= 0 && mode <= 2, "maua_resize2d: mode must be 0 (bicubic), 1 (pad / crop) or 2 (bicubic, align_corners)");
   ResizeArgs a{};
+  a.align = mode == 2;
+  if (mode == 2) mode = 0;
   a.x = x; a.x_bstride = (long)C * H * W; a.y = y; a.B = N; a.H = H; a.W = W; a.C = C; a.oh = out_h; a.ow = out_w;
   a.mode = mode; a.pl = pad_left; a.pt = pad_top; a.how = pad_how; a.value = pad_value; a.noise = nullptr;
   return launch_resize2d(ctx->stream, dtype, false, a);

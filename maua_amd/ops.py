@@ -197,3 +197,44 @@ def pad2d(x, padding, mode="constant", value=0.0):
     L.check(L.lib().maua_resize2d(L.ctx(x.device), L.ptr(x), L.ptr(y), n, c, h, w, oh, ow, 1, pl, pt, _PAD_HOW[mode],
                                   C.c_float(float(value)), L.dtype_id(x)))
     return y
+
+
+def _lanczos_taps(ratio, a=2):
+    """maua/ops/image.py:198-211 lanczos(ramp(ratio, a), a), in the reference's float32 arithmetic."""
+    import math
+    n = math.ceil(a / ratio + 1)
+    out = torch.empty([n])
+    cur = 0
+    for i in range(n):
+        out[i] = cur
+        cur += ratio
+    x = torch.cat([-out[1:].flip([0]), out])[1:-1]
+    sinc = lambda v: torch.where(v != 0, torch.sin(math.pi * v) / (math.pi * v), v.new_ones([]))
+    k = torch.where(torch.logical_and(-a < x, x < a), sinc(x) * sinc(x / a), x.new_zeros([]))
+    return k / k.sum()
+
+
+def resample(input, size, align_corners=True):
+    """maua/ops/image.py:214-240: lanczos pre-filter along every axis that shrinks (reflect-padded 1-D correlation),
+    then bicubic to ``size`` = (h, w) (or the new length of the short side).  The post-render step of
+    MauaPatch.force_output_size (patches/base/__init__.py:21-25)."""
+    x = L.dev_tensor(input, torch.float32)
+    n, c, h, w = x.shape
+    if isinstance(size, (int, float)):
+        short, long = (w, h) if w <= h else (h, w)
+        new_short, new_long = round(size), round(size * long / short)
+        dw, dh = (new_short, new_long) if w <= h else (new_long, new_short)
+    else:
+        dh, dw = (int(s) for s in size)
+    lib, ctx = L.lib(), L.ctx(x.device)
+    for axis, (d, s) in enumerate(((dh, h), (dw, w))):
+        if d < s:
+            taps = L.dev_tensor(_lanczos_taps(d / s, 2), torch.float32)
+            y = torch.empty_like(x)
+            L.check(lib.maua_conv1d_reflect(ctx, L.ptr(x), L.ptr(y), L.ptr(taps), (taps.numel() - 1) // 2, axis,
+                                            C.c_long(n * c), h, w))
+            x = y
+    out = torch.empty((n, c, dh, dw), dtype=torch.float32, device=x.device)
+    L.check(lib.maua_resize2d(ctx, L.ptr(x), L.ptr(out), n, c, h, w, dh, dw, 2 if align_corners else 0, 0, 0, 3,
+                              C.c_float(0.0), L.dtype_id(x)))
+    return out

@@ -166,3 +166,44 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, resample_fi
     if noise is not None:
         y = y + noise
     return y
+
+
+def resample(input, size, align_corners=True):
+    """maua/ops/image.py:198-240 (sinc / lanczos / ramp / resample): lanczos-2 pre-filter on shrinking axes, then bicubic."""
+    import math
+
+    def sinc(v):
+        return torch.where(v != 0, torch.sin(math.pi * v) / (math.pi * v), v.new_ones([]))
+
+    def lanczos(v, a):
+        cond = torch.logical_and(-a < v, v < a)
+        out = torch.where(cond, sinc(v) * sinc(v / a), v.new_zeros([]))
+        return out / out.sum()
+
+    def ramp(ratio, width):
+        n = math.ceil(width / ratio + 1)
+        out = torch.empty([n])
+        cur = 0
+        for i in range(n):
+            out[i] = cur
+            cur += ratio
+        return torch.cat([-out[1:].flip([0]), out])[1:-1]
+
+    n, c, h, w = input.shape
+    if isinstance(size, (int, float)):
+        short, long = (w, h) if w <= h else (h, w)
+        new_short, new_long = round(size), round(size * long / short)
+        dw, dh = (new_short, new_long) if w <= h else (new_long, new_short)
+    else:
+        dh, dw = size
+    x = input.reshape(n * c, 1, h, w)
+    if dh < h:
+        k = lanczos(ramp(dh / h, 2), 2).to(x)
+        p = (k.shape[0] - 1) // 2
+        x = F.conv2d(F.pad(x, (0, 0, p, p), "reflect"), k[None, None, :, None])
+    if dw < w:
+        k = lanczos(ramp(dw / w, 2), 2).to(x)
+        p = (k.shape[0] - 1) // 2
+        x = F.conv2d(F.pad(x, (p, p, 0, 0), "reflect"), k[None, None, None, :])
+    x = x.reshape(n, c, h, w)
+    return F.interpolate(x, (dh, dw), mode="bicubic", align_corners=align_corners)

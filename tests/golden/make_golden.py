@@ -407,6 +407,16 @@ def golden_features():
          chroma=chroma, tonnetz=FA.tonnetz(a, sr, chroma_fn=lambda a_, sr_: chroma))
 
 
+def golden_resample():
+    """maua/ops/image.py:214-240 resample (lanczos pre-filter + bicubic align_corners=True): the post-process of
+    MauaPatch.force_output_size (patches/base/__init__.py:21-25)."""
+    from maua.ops import image as OI
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 20, 30, generator=g)
+    save("g17_resample", x=x, down=OI.resample(x, (16, 24)), down_h=OI.resample(x, (9, 30)), up=OI.resample(x, (25, 40)),
+         mixed=OI.resample(x, (28, 17)), short12=OI.resample(x, 12), lanczos_taps=OI.lanczos(OI.ramp(16 / 20, 2), 2))
+
+
 def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
     """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
     maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""

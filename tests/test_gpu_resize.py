@@ -125,3 +125,27 @@ def test_wrapper_output_size_and_noise_kwargs():
     assert G.output_hw == (72, 96) and tuple(syn.forward(ws).shape) == (2, 3, 72, 96)
     syn.change_output_resolution((64, 64), "stretch", 2)
     assert G.output_hw == (64, 64)
+
+
+def test_resample_matches_reference(golden):
+    """lanczos pre-filter + bicubic(align_corners=True) (maua/ops/image.py:214-240) vs the reference's outputs (g17)."""
+    from maua_amd import ops
+    g = golden("g17_resample")
+    x = g["x"].cuda()
+    assert rel(ops._lanczos_taps(16 / 20), g["lanczos_taps"]) < 1e-6
+    for size, key in [((16, 24), "down"), ((9, 30), "down_h"), ((25, 40), "up"), ((28, 17), "mixed"), (12, "short12")]:
+        assert rel(ops.resample(x, size), g[key]) < 3e-6, key
+
+
+def test_force_output_size_resamples():
+    """MauaPatch.force_output_size (patches/base/__init__.py:21-25) brings a rounded render to the requested size."""
+    from maua_amd.audiovisual.patches.base import MauaPatch
+
+    class P(MauaPatch):
+        def __init__(self):
+            self.synthesizer = type("S", (), {"output_size": (100, 72)})()
+
+    v = torch.rand(2, 3, 72, 96).cuda()
+    out = P().force_output_size(v)
+    assert tuple(out.shape) == (2, 3, 72, 100)
+    assert P().force_output_size(torch.rand(1, 3, 72, 100).cuda()).shape[-1] == 100

@@ -300,3 +300,14 @@ def test_features_n3(golden):
     close(A.tonnetz_from_chroma(g["chroma"]), g["tonnetz"], 1e-6)
     a12 = synthetic_audio(int(g["n12"]), sr, int(g["seed12"]))
     close(A.drop_strength(a12), g["drop_strength"], 2e-5)
+
+
+def test_resample(golden):
+    """maua/ops/image.py resample (SURVEY 8(f) N2 post-process): oracle vs the reference's outputs."""
+    g = golden("g17_resample")
+    x = g["x"]
+    close(O.resample(x, (16, 24)), g["down"], 1e-6)
+    close(O.resample(x, (9, 30)), g["down_h"], 1e-6)
+    close(O.resample(x, (25, 40)), g["up"], 1e-6)
+    close(O.resample(x, (28, 17)), g["mixed"], 1e-6)
+    close(O.resample(x, 12), g["short12"], 1e-6)
