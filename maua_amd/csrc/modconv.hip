@@ -68,7 +68,6 @@ struct ConvGeom {
   unsigned inv_hw2;     // ceil(2^20 / hw2) for the halo pixel -> (row, col) split
   int halo_px;          // (th+2)*(tw+2)
   int phases;           // up*up
-  int dbg;              // profiling experiments only (MAUA_DBG env): bit0 weights / bit1 halo always from chunk 0
 };
 
 // Pipeline: the K loop is a sequence of stages (input-channel chunk c, tap group g).  While stage s is multiplied
@@ -163,13 +162,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 
 #define MAUA_LOAD_W(C0, TG0)                                                                              \
   _Pragma("unroll") for (int i = 0; i < WREGS; i++)                                                      \
-      wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + ((g.dbg & 1) ? 0 : (long)(TG0) * tap_stride + (C0)));
+      wreg[i] = *reinterpret_cast<const u32x4*>(wrow[i] + ((long)(TG0) * tap_stride + (C0)));
 #define MAUA_LOAD_H(C0)                                                                                   \
   {                                                                                                       \
     _Pragma("unroll") for (int e = 0; e < EPC; e++) sv[e] = sb[(C0) + q * EPC + e];                       \
     _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                  \
       hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                                   \
-      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + ((g.dbg & 2) ? 0 : (C0))); \
+      if (hoff[i] >= 0) hreg[i] = *reinterpret_cast<const u32x4*>(xb + hoff[i] + (C0)); \
     }                                                                                                     \
   }
 #define MAUA_STORE_W()                                                                                    \
@@ -317,8 +316,6 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
   g.inv_hw2 = ((1u << 20) + g.hw2 - 1) / g.hw2;
   g.halo_px = (g.th + 2) * g.hw2;
   g.phases = a.up * a.up;
-  static const int dbg_env = getenv("MAUA_DBG") ? atoi(getenv("MAUA_DBG")) : 0;
-  g.dbg = dbg_env;
   MAUA_REQUIRE(g.halo_px <= (((BM == 128 ? 204 : 396) * (KCB / 16) + NT - 1) / NT) * (NT / (KCB / 16)),
                "modconv3x3: halo does not fit the prefetch registers");
   size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
@@ -348,12 +345,6 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   // per stage); the 256-pixel tile pays off once a sample has >= 16 of them
   // K chunk: 128 bytes (fewer, longer stages) measured 1.1-1.2x over 64 except on the 32^2 layers
   const bool k128 = a.Ci % (128 / (int)sizeof(T)) == 0;
-  static const int force = getenv("MAUA_VARIANT") ? atoi(getenv("MAUA_VARIANT")) : 0;  // experiments only
-  if (force && cov % 128 == 0) {
-    if (force == 1) return launch_variant<T, 2, 4, 2, 1, 3, 64>(stream, a);
-    if (force == 2 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);
-    if (force == 3) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
-  }
   if (cov % 128 == 0 && a.H * a.W >= 4096 && k128) return launch_variant<T, 4, 4, 2, 1, 3, 128>(stream, a);
   if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
   if (cov % 128 == 0 && a.H * a.W < 256 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);
