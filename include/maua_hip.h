@@ -105,6 +105,13 @@ int maua_synth_num_layers(const maua_synth* net);
  * exactly that size. */
 int maua_synth_set_resize(maua_synth* net, int layer, int mode, int target_h, int target_w, int pad_left, int pad_right,
                           int pad_top, int pad_bottom, int pad_how, float pad_value, const float* fill_noise_host);
+/* geometric transform hooks (wrappers/stylegan2.py:153-194 apply_translation / apply_zoom / apply_rotation = kornia
+ * translate / scale / rotate with padding_mode="reflection"): after layer `layer` (1-based index into layer_names) the
+ * features are warped per sample, bilinear, reflection-padded, align_corners=True.  inv_matrices_dev [B][6] maps an
+ * OUTPUT pixel (x, y) to its SOURCE pixel (row-major 2x3, device, owned by the caller and read by the next forwards);
+ * NULL clears the slot.  Slots 0..2 on the same layer run in slot order (the reference registers translate, zoom,
+ * rotate in that order). */
+int maua_synth_set_warp(maua_synth* net, int slot, int layer, const float* inv_matrices_dev);
 /* output size (h, w) of synthesis layer `layer` (execution order), or of the final image for layer == -1 */
 int maua_synth_layer_size(const maua_synth* net, int layer, int* h, int* w);
 /* the torch ops the hooks are made of, on NCHW tensors (dtype f32 / bf16): mode 0 = F.interpolate(x, (out_h, out_w),

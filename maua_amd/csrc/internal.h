@@ -97,6 +97,9 @@ struct ResizeArgs {
 int launch_resize2d(hipStream_t stream, int dtype, bool nhwc, const ResizeArgs& a);
 int launch_skip_add(hipStream_t stream, const float* y, const float* prev, float* out, int B, int H, int W,
                     const float* fir16);
+// bilinear, reflection-padded affine warp of NHWC features; minv [B][6] maps output pixels to source pixels
+int launch_warp_affine_nhwc(hipStream_t stream, int dtype, const void* x, void* y, const float* minv, int B, int H, int W,
+                            int C);
 
 // styles / demod / toRGB pre-modulation for a list of layers in one launch
 struct StyleLayer {

@@ -143,6 +143,63 @@ __global__ __launch_bounds__(256) void conv1d_planar_kernel(const float* __restr
   y[idx] = acc;
 }
 
+// Per-sample affine warp of NHWC features with bilinear sampling and reflection padding — what kornia's translate /
+// rotate / scale (wrappers/stylegan2.py:153-194; kornia = warp_affine -> F.affine_grid + F.grid_sample(bilinear,
+// padding_mode="reflection", align_corners=True)) do to a layer's output.  minv [B][6] maps OUTPUT pixel (x, y) to the
+// SOURCE pixel: sx = m0 x + m1 y + m2, sy = m3 x + m4 y + m5.
+__device__ __forceinline__ float reflect_coord(float x, int size) {
+  // grid_sample reflection, align_corners=True: reflect about 0 and size-1, then clip
+  if (size <= 1) return 0.f;
+  const float span = (float)(size - 1);
+  x = fabsf(x);
+  const float flips = floorf(x / span);
+  const float extra = x - flips * span;
+  x = (((int)flips) & 1) ? span - extra : extra;
+  return fminf(fmaxf(x, 0.f), span);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void warp_affine_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               const float* __restrict__ minv, int H, int W, int C,
+                                                               long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long r = idx / C;
+  const int ox = (int)(r % W); r /= W;
+  const int oy = (int)(r % H);
+  const int b = (int)(r / H);
+  const float* m = minv + (long)b * 6;
+  const float sx = reflect_coord(m[0] * ox + m[1] * oy + m[2], W);
+  const float sy = reflect_coord(m[3] * ox + m[4] * oy + m[5], H);
+  const float fx = floorf(sx), fy = floorf(sy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float tx = sx - fx, ty = sy - fy;
+  const T* xb = x + (long)b * H * W * C;
+  auto at = [&](int yy, int xx) -> float {
+    return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? Elem<T>::load(xb + ((long)yy * W + xx) * C + c) : 0.f;
+  };
+  // grid_sample's order: nw, ne, sw, se
+  const float v = at(y0, x0) * ((1.f - tx) * (1.f - ty)) + at(y0, x0 + 1) * (tx * (1.f - ty)) +
+                  at(y0 + 1, x0) * ((1.f - tx) * ty) + at(y0 + 1, x0 + 1) * (tx * ty);
+  Elem<T>::store(y + idx, v);
+}
+
+int launch_warp_affine_nhwc(hipStream_t stream, int dtype, const void* x, void* y, const float* minv, int B, int H, int W,
+                            int C) {
+  const long total = (long)B * H * W * C;
+  if (total == 0) return MAUA_OK;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == MAUA_F32)
+    hipLaunchKernelGGL(warp_affine_nhwc_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, minv, H, W, C, total);
+  else if (dtype == MAUA_BF16)
+    hipLaunchKernelGGL(warp_affine_nhwc_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, minv, H, W, C, total);
+  else
+    return fail("warp_affine: unsupported dtype");
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 // img = upsample2d(prev) + y (stylegan2.py:372-378 with ops.py:117-133), planar f32 [B][3][H][W], prev [B][3][H/2][W/2]
 __global__ __launch_bounds__(256) void skip_add_kernel(const float* __restrict__ y, const float* __restrict__ prev,
                                                        float* __restrict__ out, int H, int W, float f0, float f1, float f4,

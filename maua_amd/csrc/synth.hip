@@ -73,6 +73,9 @@ struct maua_synth {
   void* const_rs = nullptr;    // resized const input (rs_layer == 0)
   float* rgb_tmp[2] = {nullptr, nullptr};
   int out_h = 0, out_w = 0;    // final image
+  // geometric transform hooks (wrappers/stylegan2.py:153-194): up to 3 warps, applied in slot order after their layer
+  int warp_layer[3] = {-1, -1, -1};
+  const float* warp_minv[3] = {nullptr, nullptr, nullptr};  // device [B][6], owned by the caller
   // profile mode: HIP events recorded on the ctx stream around every launch of a forward
   int profile = 0;
   std::vector<hipEvent_t> ev;
@@ -169,8 +172,8 @@ static int ensure_workspace(maua_synth* n, int B) {
     MAUA_HIP_CHECK(hipMalloc((void**)&r.s, (size_t)B * r.C * sizeof(float)));
     MAUA_HIP_CHECK(hipMalloc((void**)&r.wmod, (size_t)B * 3 * r.C * sizeof(float)));
   }
-  if (!n->keep_features || n->rs_layer >= 1)  // (the resized layer always goes through a scratch buffer)
-    for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->act[i], (size_t)B * max_act * n->esize));
+  // (a resized / warped layer goes through scratch buffers, also when every layer keeps its own)
+  for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->act[i], (size_t)B * max_act * n->esize));
   if (n->rs_layer == 0)
     MAUA_HIP_CHECK(hipMalloc(&n->const_rs, (size_t)n->rs_th * n->rs_tw * n->convs[0].Ci * n->esize));
   if (n->rs_layer >= 1) {
@@ -343,6 +346,15 @@ int maua_synth_set_resize(maua_synth* n, int layer, int mode, int target_h, int 
       MAUA_HIP_CHECK(hipMemset(c.noise_const, 0, (size_t)c.oh * c.ow * sizeof(float)));
     }
   }
+  return MAUA_OK;
+}
+
+int maua_synth_set_warp(maua_synth* n, int slot, int layer, const float* inv_matrices_dev) {
+  MAUA_REQUIRE(n, "maua_synth_set_warp: net is NULL");
+  MAUA_REQUIRE(slot >= 0 && slot < 3, "maua_synth_set_warp: slot must be 0..2");
+  MAUA_REQUIRE(layer >= 1 && layer <= (int)n->convs.size(), "maua_synth_set_warp: layer must name a synthesis layer (1-based index into layer_names)");
+  n->warp_layer[slot] = inv_matrices_dev ? layer : -1;
+  n->warp_minv[slot] = inv_matrices_dev;
   return MAUA_OK;
 }
 
@@ -563,6 +575,18 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         x = dst;
         x_bstride = (long)c.fh * c.fw * c.Co;
         cur ^= 1;
+      }
+      for (int wsl = 0; wsl < 3; wsl++) {  // translate / zoom / rotate hooks on this layer (registered after the
+        if (n->warp_layer[wsl] != (int)li + 1 || !n->warp_minv[wsl]) continue;  // resize hook, so they run after it)
+        void* dst = n->act[cur];
+        if (dst == x) dst = n->act[cur ^ 1];
+        if (int rc = launch_warp_affine_nhwc(st, n->dtype, x, dst, n->warp_minv[wsl], B, c.fh, c.fw, c.Co)) return rc;
+        if (n->keep_features) {  // the hook's output replaces the layer's
+          MAUA_HIP_CHECK(hipMemcpyAsync(c.feat, dst, (size_t)B * c.fh * c.fw * c.Co * n->esize, hipMemcpyDeviceToDevice, st));
+        } else {
+          x = dst;
+          cur = (dst == n->act[0]) ? 1 : 0;
+        }
       }
     }
     const bool rs_here = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;

@@ -478,10 +478,68 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
                 G.set_resize(layer, target=(th, tw), fill_noise=fill, noise_generator=gen, **kw)
         self.output_size = tuple(output_size)
 
+    # -- geometric transform hooks (wrappers/stylegan2.py:153-194) ----------------------------------------
+    def _set_warp(self, slot, layer, matrix):
+        """matrix [B, 2, 3]: kornia's forward (source -> destination, pixel coordinates) affine of translate / scale /
+        rotate; the kernel samples the source at inverse(matrix) @ destination.  Like the reference's hooks, a warp
+        stays installed until a later call replaces it."""
+        M = torch.as_tensor(matrix, dtype=torch.float32).reshape(-1, 2, 3).cpu()
+        A, t = M[:, :, :2], M[:, :, 2:]
+        Ainv = torch.linalg.inv(A)
+        minv = L.dev_tensor(torch.cat([Ainv, -Ainv @ t], dim=2).reshape(-1, 6).contiguous(), torch.float32)
+        if not hasattr(self, "_warps"):
+            self._warps = {}
+        self._warps[slot] = minv  # keeps the device buffer alive
+        L.check(L.lib().maua_synth_set_warp(self.G_synth._handle(), slot, int(layer), L.ptr(minv)))
+
+    def _layer_hw(self, layer):
+        h, w = self.G_synth.layer_size(layer - 1)
+        r = self.G_synth._resize
+        if r is not None and r["layer"] == layer:  # the resize hook runs first: warps see the resized grid
+            h, w = r["th"], r["tw"]
+        return h, w
+
+    def apply_translation(self, layer, translation):
+        """:153-166 kT.translate(output, translation * [[h, w]], padding_mode="reflection")"""
+        h, w = self._layer_hw(layer)
+        t = torch.as_tensor(translation, dtype=torch.float32).reshape(-1, 2).cpu() * torch.tensor([[h, w]], dtype=torch.float32)
+        M = torch.eye(2, 3).repeat(len(t), 1, 1)
+        M[:, 0, 2], M[:, 1, 2] = t[:, 0], t[:, 1]
+        self._set_warp(0, layer, M)
+
+    @staticmethod
+    def _rotation_scale_matrix(angle_deg, scale, center, h, w, n):
+        """kornia get_rotation_matrix2d(center, angle, scale): [[a, b, (1-a) cx - b cy], [-b, a, b cx + (1-a) cy]] with
+        a = s cos, b = s sin; the default centre is the image centre ((w-1)/2, (h-1)/2)."""
+        if center is None:
+            center = torch.tensor([[(w - 1) / 2, (h - 1) / 2]], dtype=torch.float32).repeat(n, 1)
+        center = torch.as_tensor(center, dtype=torch.float32).reshape(-1, 2).cpu().expand(n, 2)
+        rad = torch.deg2rad(angle_deg)
+        a, b = scale * torch.cos(rad), scale * torch.sin(rad)
+        cx, cy = center[:, 0], center[:, 1]
+        return torch.stack([torch.stack([a, b, (1 - a) * cx - b * cy], 1),
+                            torch.stack([-b, a, b * cx + (1 - a) * cy], 1)], 1)
+
+    def apply_rotation(self, layer, angle, center):
+        """:168-180 kT.rotate(output, angle.squeeze(), center, padding_mode="reflection") (degrees, anti-clockwise)"""
+        h, w = self._layer_hw(layer)
+        ang = torch.as_tensor(angle, dtype=torch.float32).reshape(-1).cpu()
+        self._set_warp(2, layer, self._rotation_scale_matrix(ang, torch.ones_like(ang), center, h, w, len(ang)))
+
+    def apply_zoom(self, layer, zoom, center):
+        """:182-194 kT.scale(output, zoom.squeeze(), center, padding_mode="reflection")"""
+        h, w = self._layer_hw(layer)
+        z = torch.as_tensor(zoom, dtype=torch.float32).reshape(-1).cpu()
+        self._set_warp(1, layer, self._rotation_scale_matrix(torch.zeros_like(z), z, center, h, w, len(z)))
+
     def forward(self, latents, translation=None, translation_layer=7, zoom=None, zoom_layer=7, zoom_center=None,
                 rotation=None, rotation_layer=7, rotation_center=None, rgb8_out=None, **noise):
-        if translation is not None or zoom is not None or rotation is not None:
-            raise NotImplementedError("translation / zoom / rotation hooks (kornia) are not implemented yet")
+        if translation is not None:
+            self.apply_translation(translation_layer, translation)
+        if zoom is not None:
+            self.apply_zoom(zoom_layer, zoom, zoom_center)
+        if rotation is not None:
+            self.apply_rotation(rotation_layer, rotation, rotation_center)
         # noise kwargs are consumed in dict order as layer 0..16 (wrappers/stylegan2.py:86-100)
         nz = list(noise.values()) if noise else None
         return self.G_synth.forward(latents, noise_mode="const", noise=nz, rgb8_out=rgb8_out)

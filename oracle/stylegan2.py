@@ -164,7 +164,21 @@ def _hook_inverse(x, rs, layer_size):
     return x[..., pt:x.shape[-2] - pb, pl:x.shape[-1] - pr]
 
 
-def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False, resize=None):
+def warp_affine(x, M):
+    """kornia.geometry.transform.warp_affine(x, M, (h, w), mode="bilinear", padding_mode="reflection",
+    align_corners=True) as kornia composes it (un-vendored; wrappers/stylegan2.py:153-194 reach it through
+    kT.translate / rotate / scale): normalise the pixel-space affine, invert, F.affine_grid + F.grid_sample."""
+    B, _, h, w = x.shape
+    M3 = torch.eye(3).repeat(B, 1, 1)
+    M3[:, :2] = M
+    N = torch.tensor([[2.0 / max(w - 1, 1e-14), 0, -1], [0, 2.0 / max(h - 1, 1e-14), -1], [0, 0, 1]])
+    theta = torch.linalg.inv(N @ M3 @ torch.linalg.inv(N))[:, :2]
+    grid = F.affine_grid(theta, [B, x.shape[1], h, w], align_corners=True)
+    return F.grid_sample(x, grid, mode="bilinear", padding_mode="reflection", align_corners=True)
+
+
+def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False, resize=None,
+                      warps=()):
     """stylegan2.py:429-436 + SynthesisBlock.forward :340-382 ('skip' architecture).
 
     ``noise``: optional list, one [B|1,1,h,w] tensor per synthesis layer in
@@ -172,8 +186,14 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
     ``resize``: optional dict(layer, mode "stretch"|"pad", target (h, w), padding (l, r, t, b), pad_how, pad_value,
     fill [C, h, w]) — the forward (pre-)hooks of change_output_resolution (wrappers/stylegan2.py:104-151):
     layer 0 resizes the input of the first layer, layer L >= 1 the output of synthesis layer L-1, whose block also
-    gets the rgb (inverse) and img (resize) hooks.
+    gets the rgb (inverse) and img (resize) hooks.  ``warps``: sequence of (layer, M [B,2,3]) forward hooks applied in
+    order after the resize hook of their layer (the translate / zoom / rotate hooks, :153-194).
     """
+    def hooks(x_, l1):
+        for wl, M in warps:
+            if wl == l1:
+                x_ = warp_affine(x_, M)
+        return x_
     nblocks = 0
     while f"bs.{nblocks}.conv1.weight" in p:
         nblocks += 1
@@ -195,6 +215,7 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
                                 noise_strength=noise_strength, nv_compat=nv_compat)
             if rs_layer == li + 1:
                 x, hooked_here = _hook_resize(x, resize, True), True
+            x = hooks(x, li + 1)
             feats.append(x)
             w_idx += 1
             li += 1
@@ -202,6 +223,7 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
                             noise_strength=noise_strength, nv_compat=nv_compat)
         if rs_layer == li + 1:
             x, hooked_here = _hook_resize(x, resize, True), True
+        x = hooks(x, li + 1)
         feats.append(x)
         w_idx += 1
         li += 1

@@ -149,3 +149,54 @@ def test_force_output_size_resamples():
     out = P().force_output_size(v)
     assert tuple(out.shape) == (2, 3, 72, 100)
     assert P().force_output_size(torch.rand(1, 3, 72, 100).cuda()).shape[-1] == 100
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_transform_hooks_match_oracle(dt):
+    """translation / zoom / rotation forward kwargs (wrappers/stylegan2.py:65-84,153-194): bilinear, reflection-padded
+    per-sample warps after a layer, against the oracle's kornia-style affine_grid + grid_sample composition."""
+    from oracle import stylegan2 as OS
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer
+    gen = torch.Generator().manual_seed(4)
+    syn = StyleGAN2Synthesizer(None, False, (64, 64), "stretch", 0, img_resolution=64, dtype=dt, generator=gen)
+    G = syn.G_synth
+    B = 2
+    ws = torch.randn(B, syn.num_ws, 512, generator=gen)
+    translation = torch.tensor([[0.1, -0.05], [-0.3, 0.2]])
+    zoom = torch.tensor([0.8, 1.25])
+    rotation = torch.tensor([12.0, -33.0])
+    img = syn.forward(ws, translation=translation, translation_layer=5, zoom=zoom, zoom_layer=7, rotation=rotation,
+                      rotation_layer=7).cpu()
+    # the same matrices, as kornia builds them
+    h5, w5 = G.layer_size(4)
+    h7, w7 = G.layer_size(6)
+    Mt = torch.eye(2, 3).repeat(B, 1, 1)
+    Mt[:, 0, 2], Mt[:, 1, 2] = translation[:, 0] * h5, translation[:, 1] * w5
+    Mz = StyleGAN2Synthesizer._rotation_scale_matrix(torch.zeros(B), zoom, None, h7, w7, B)
+    Mr = StyleGAN2Synthesizer._rotation_scale_matrix(rotation, torch.ones(B), None, h7, w7, B)
+    ref = OS.synthesis_network(G.state_dict(), ws, warps=[(5, Mt), (7, Mz), (7, Mr)])
+    tol = 2e-4 if dt == torch.float32 else 4e-2
+    assert rel(img, ref) <= tol
+    plain = OS.synthesis_network(G.state_dict(), ws)
+    assert rel(plain, ref) > 0.05  # the hooks do something
+    # hooks persist until replaced (like the reference's registered hooks); identity warps restore the plain image
+    syn.forward(ws, translation=torch.zeros(B, 2), translation_layer=5, zoom=torch.ones(B), rotation=torch.zeros(B))
+    assert rel(syn.forward(ws).cpu(), plain) <= tol
+
+
+def test_transform_after_resize_hook():
+    """A warp registered on the resized layer sees the resized grid (the resize hook is registered first)."""
+    from oracle import stylegan2 as OS
+    net = _net(32, torch.float32)
+    g = torch.Generator().manual_seed(8)
+    ws = torch.randn(1, net.num_ws, 64, generator=g)
+    net.set_resize(3, target=(12, 7), noise_generator=torch.Generator().manual_seed(5))
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer
+    syn = StyleGAN2Synthesizer.__new__(StyleGAN2Synthesizer)
+    torch.nn.Module.__init__(syn)
+    syn.G_synth = net
+    syn.apply_rotation(3, torch.tensor([20.0]), None)
+    img = net(ws).cpu()
+    Mr = StyleGAN2Synthesizer._rotation_scale_matrix(torch.tensor([20.0]), torch.ones(1), None, 12, 7, 1)
+    ref = OS.synthesis_network(net.state_dict(), ws, resize=dict(layer=3, mode="stretch", target=(12, 7)), warps=[(3, Mr)])
+    assert rel(img, ref) <= 2e-4
