@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
         const int py = p / HW2, px = p - py * HW2;                                                \
         const int gy = tyi_ * TH - 1 + py, gx = txi_ * TW - 1 + px;                               \
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)                                           \
-          hreg[i] = *reinterpret_cast<const u32x4*>(xb + ((long)gy * a.W + gx) * CI + q * 8);     \
+          hreg[i] = *reinterpret_cast<const u32x4*>(xb + (unsigned)((gy * a.W + gx) * CI + q * 8));     \
       }                                                                                           \
     }                                                                                             \
   }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
         const int gy = ty0 + ms + half, gx = tx0 + r;
         const int pa = phase / UP, pb = phase - pa * UP;
         float nz = 0.f;
-        if (nb) nz = nb[(long)(gy * UP + pa) * Wo + gx * UP + pb] * nz_scale;
+        if (nb) nz = nb[(unsigned)((gy * UP + pa) * Wo + gx * UP + pb)] * nz_scale;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           float v[4], bq[4];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       const int nv = pc * 8;
       const int ph = nv / CO, co = nv - ph * CO;
       const int pa = ph / UP, pb = ph - pa * UP;
-      const long pix = (long)(gy * UP + pa) * Wo + gx * UP + pb;
+      const unsigned pix = (unsigned)((gy * UP + pa) * Wo + gx * UP + pb);
       *reinterpret_cast<uint4*>(yb + (pix * CO + co) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
     }
     // ---- fused toRGB + upsampled skip (conv1 layers only): [32 px x CO] x [CO x 3(+3)] on the matrix cores, the
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
 #pragma unroll
             for (int c = 0; c < 3; c++)
               if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
-            const long HWl = (long)a.H * a.W;
+            const unsigned HWl = (unsigned)(a.H * a.W);
             if (a.rgb_prev) {
               const int Hp = a.H >> 1, Wp = a.W >> 1;
               const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
@@ -268,15 +268,15 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
                   const bool ok = oky && ix >= 0 && ix < Wp;
                   const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
                   const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
-                  const long o = ok ? (long)iy * Wp + ix : 0;
+                  const unsigned o = ok ? (unsigned)(iy * Wp + ix) : 0u;
                   u3[0] += pv[o] * f;
-                  u3[1] += pv[(long)Hp * Wp + o] * f;
-                  u3[2] += pv[2L * Hp * Wp + o] * f;
+                  u3[1] += pv[(unsigned)(Hp * Wp) + o] * f;
+                  u3[2] += pv[2u * (unsigned)(Hp * Wp) + o] * f;
                 }
               }
               o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
             }
-            float* ob = a.rgb_out + (long)b * 3 * HWl + (long)y * a.W + x;
+            float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
             ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
           }
         }
@@ -316,6 +316,8 @@ bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W) {
 int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
   if (a.B == 0) return MAUA_OK;
   MAUA_REQUIRE(hires_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_hires: unsupported shape");
+  MAUA_REQUIRE((long)a.H * a.up * a.W * a.up * std::max(a.Ci, a.Co) * 2 < (1L << 31),
+               "modconv_hires: a sample must stay below 2 GiB (32-bit in-sample offsets)");
   MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "modconv_hires: lrelu / linear only");
   HiresArgs b = a;
   if (a.act == MAUA_ACT_LINEAR) b.alpha = 1.f;
