@@ -166,7 +166,19 @@ int maua_mel_power(maua_ctx* ctx, const float* spec, int n_frames_used, const fl
 /* replaces rosa/convert.py:7-12 power_to_db (in place on mel) + rosa/beat.py:13-21: env[f] = mean_m relu(dB lag-1
  * difference), left-padded by pad_width zeros, cropped to T. */
 int maua_onset_from_mel(maua_ctx* ctx, float* mel_inout, int n_mels, int T, float amin, float top_db, int pad_width,
-                        float* env);
+                        int aggregate /* 0 = torch.mean (beat.py:10), 1 = torch.median(...).values (:44) */, float* env);
+/* the same transforms with any power-of-two n_fft <= 2048, any hop and the caller's window (device, [n_fft]):
+ * rosa/beat.py:33-39 fourier_tempogram = stft(onset_envelope, n_fft=win_length, hop_length=1) and the istft of
+ * :67.  spec [1 + n_samples / hop][n_fft / 2 + 1] complex64, frame-major. */
+int maua_stft_general(maua_ctx* ctx, const float* y, int n_samples, int n_fft, int hop, const float* window_dev,
+                      float* out_frames_bins_complex);
+int maua_istft_general(maua_ctx* ctx, const float* spec_frames_bins_complex, int n_frames, int n_fft, int hop,
+                       const float* window_dev, int length, float* y);
+/* rosa/beat.py:50-64 (plp steps 3-4) in place on a frame-major tempogram: zero the bins whose tempo (tempo_freq_dev
+ * [n_bins], BPM) lies outside [tempo_min, tempo_max], keep only the bins at each frame's peak of log1p(1e6 |z|), divide
+ * by finfo.tiny ** 0.5 + the frame's largest magnitude. */
+int maua_plp_select(maua_ctx* ctx, float* tempogram_frames_bins_complex, int n_frames, int n_bins,
+                    const float* tempo_freq_dev, float tempo_min, float tempo_max);
 /* replaces processing.py:53-56 normalize (eps = 1e-8) and signal.py:27-38 normalize (eps = 0):
  * y = (x - min) / ((max - min) + eps) over all n elements. */
 int maua_normalize(maua_ctx* ctx, const float* x, long n, float eps, float* y);

@@ -156,13 +156,19 @@ def power_to_db(magnitude, ref_value=1.0, amin=1e-10, top_db=80.0):
 
 
 def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None):
-    """beat.py:10-23 -> [T] on device."""
+    """beat.py:10-23 -> [T] on device.  ``aggregate``: None / torch.mean, or "median" (what plp passes, beat.py:44)."""
     S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=11025.0)
     n_mels, T = S.shape
     env = torch.empty((T,), dtype=torch.float32, device=S.device)
     pad_width = 1 + n_fft // (2 * hop_length)
+    if aggregate is None or aggregate is torch.mean or aggregate == "mean":
+        agg = 0
+    elif aggregate == "median":
+        agg = 1
+    else:
+        raise NotImplementedError("onset_strength: aggregate must be torch.mean or 'median'")
     L.check(L.lib().maua_onset_from_mel(L.ctx(S.device), L.ptr(S), n_mels, T, C.c_float(1e-10), C.c_float(80.0),
-                                        pad_width, L.ptr(env)))
+                                        pad_width, agg, L.ptr(env)))
     return env
 
 
@@ -429,3 +435,71 @@ def spectral_contrast(y, sr, n_fft=2048, hop_length=1024, fmin=200.0, n_bands=6,
     if linear:
         return (peak - valley).T
     return (power_to_db(peak) - power_to_db(valley)).T
+
+
+# ---- predominant local pulse (rosa/beat.py:24-75) ----------------------------------------------------------------
+def _pow2(n):
+    return n >= 2 and (n & (n - 1)) == 0
+
+
+def stft_general(y, n_fft, hop_length, window=None):
+    """rosa/spectral.py:10-21 for any power-of-two n_fft <= 2048 and any hop (centre / reflect) -> complex64
+    [n_fft // 2 + 1, 1 + len(y) // hop] as a transposed view of the frame-major buffer."""
+    if not _pow2(n_fft) or n_fft > 2048:
+        raise NotImplementedError("the HIP FFT handles power-of-two lengths up to 2048")
+    y = _f32(y).reshape(-1)
+    win = _f32(torch.hann_window(n_fft) if window is None else window)
+    frames = 1 + y.numel() // hop_length
+    out = torch.empty((frames, n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
+    L.check(L.lib().maua_stft_general(L.ctx(y.device), L.ptr(y), y.numel(), n_fft, hop_length, L.ptr(win), L.ptr(out)))
+    return torch.view_as_complex(out).T
+
+
+def istft_general(spec, n_fft, hop_length, length, window=None):
+    buf = _frame_major(spec if spec.is_cuda else L.dev_tensor(spec, torch.complex64))
+    win = _f32(torch.hann_window(n_fft) if window is None else window).to(buf.device)
+    y = torch.empty((int(length),), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_istft_general(L.ctx(buf.device), L.ptr(buf), buf.shape[0], n_fft, hop_length, L.ptr(win),
+                                       int(length), L.ptr(y)))
+    return y
+
+
+def fourier_tempo_frequencies(sr, win_length=1024, hop_length=1024, device="cpu"):
+    """beat.py:24-28 (BPM of every tempogram bin; float32 linspace like the reference)."""
+    rate = sr * 60 / float(hop_length)
+    return torch.linspace(0, float(rate) / 2, int(1 + win_length // 2), device=device)
+
+
+def fourier_tempogram(y=None, sr=22050, onset_envelope=None, hop_length=1024, win_length=1024):
+    """beat.py:31-39: STFT of the onset envelope with hop 1."""
+    if onset_envelope is None:
+        onset_envelope = onset_strength(y, sr, hop_length=hop_length)
+    return stft_general(onset_envelope, win_length, 1)
+
+
+def plp(y, sr, hop_length=1024, win_length=1024, tempo_min=60, tempo_max=180):
+    """beat.py:42-75 predominant local pulse -> [T] in [0, 1]."""
+    env = onset_strength(y, sr, hop_length=hop_length, aggregate="median")
+    T = env.numel()
+    W = min(T, win_length)
+    if not _pow2(W):
+        raise NotImplementedError(f"plp: clips shorter than win_length ({win_length} frames) need a {W}-point FFT; "
+                                  "the HIP FFT handles powers of two")
+    ft = fourier_tempogram(onset_envelope=env, sr=sr, hop_length=hop_length, win_length=W)
+    buf = _frame_major(ft)                                      # [T + 1, W/2 + 1, 2], owns its memory
+    freqs = _f32(fourier_tempo_frequencies(sr, W, hop_length))
+    L.check(L.lib().maua_plp_select(L.ctx(buf.device), L.ptr(buf), buf.shape[0], buf.shape[1], L.ptr(freqs),
+                                    C.c_float(-1e30 if tempo_min is None else tempo_min),
+                                    C.c_float(1e30 if tempo_max is None else tempo_max)))
+    pulse = istft_general(torch.view_as_complex(buf).T, W, 1, T)
+    mm = torch.empty((2,), dtype=torch.float32, device=pulse.device)
+    L.check(L.lib().maua_minmax(L.ctx(pulse.device), L.ptr(pulse), C.c_long(T), L.ptr(mm)))
+    clamped = torch.empty_like(pulse)
+    L.check(L.lib().maua_clamp(L.ctx(pulse.device), L.ptr(pulse), None, L.ptr(mm[1:]), C.c_float(0.0), C.c_float(0.0),
+                               C.c_long(T), L.ptr(clamped)))
+    return normalize(clamped)
+
+
+def pulse(audio, sr):
+    """features/audio.py:72-73 -> [T, 1]."""
+    return plp(percussive(audio), sr).unsqueeze(-1)

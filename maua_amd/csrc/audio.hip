@@ -32,16 +32,19 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 // dst[q + 2s*p] = a + b, dst[q + 2s*p + s] = (a - b) * exp(-2 pi i p / n).
 // tw[k] = exp(-2 pi i k / 2048), k < 1024 (computed on the host in double).  dir = +1 forward, -1 inverse
 // (conjugated twiddles, no 1/N scaling).  Returns the buffer holding the result.
-__device__ float2* fft2048(float2* a, float2* b, const float2* __restrict__ tw, int dir) {
+// The same network runs any power-of-two length N <= 2048 (the tempogram of beat.py:33-39 uses 1024): the twiddle
+// table is read with stride 2048 / N.
+__device__ float2* fft_pow2(float2* a, float2* b, const float2* __restrict__ tw, int dir, int N, int logN) {
   float2* src = a;
   float2* dst = b;
-  for (int t = 0; t < 11; t++) {
+  const int tws = NFFT / N;
+  for (int t = 0; t < logN; t++) {
     const int s = 1 << t;
-    for (int i = threadIdx.x; i < NFFT / 2; i += blockDim.x) {
+    for (int i = threadIdx.x; i < N / 2; i += blockDim.x) {
       const int p = i >> t, q = i & (s - 1);
       const float2 u = src[i];
-      const float2 v = src[i + NFFT / 2];
-      float2 w = tw[p * s];
+      const float2 v = src[i + N / 2];
+      float2 w = tw[p * s * tws];
       if (dir < 0) w.y = -w.y;
       const float2 d = make_float2(u.x - v.x, u.y - v.y);
       dst[q + 2 * s * p] = make_float2(u.x + v.x, u.y + v.y);
@@ -53,6 +56,9 @@ __device__ float2* fft2048(float2* a, float2* b, const float2* __restrict__ tw, 
     dst = tmp;
   }
   return src;
+}
+__device__ __forceinline__ float2* fft2048(float2* a, float2* b, const float2* __restrict__ tw, int dir) {
+  return fft_pow2(a, b, tw, dir, NFFT, 11);
 }
 
 // ---- STFT: one workgroup per frame -------------------------------------------------------------------------------
@@ -108,6 +114,102 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
     env += win[o] * win[o];
   }
   y[i] = (f1 < n_frames || (f0 >= 0 && f0 < n_frames)) ? acc / env : 0.f;
+}
+
+// ---- general framing (n_fft a power of two <= 2048, any hop, caller's window): beat.py:33-39 fourier_tempogram ----
+__global__ __launch_bounds__(256) void stft_general_kernel(const float* __restrict__ y, int n, const float* __restrict__ win,
+                                                           const float2* __restrict__ tw, float2* __restrict__ out,
+                                                           int n_fft, int logn, int hop) {
+  __shared__ float2 A[NFFT], B[NFFT];
+  const int f = blockIdx.x;
+  for (int i = threadIdx.x; i < n_fft; i += blockDim.x)
+    A[i] = make_float2(y[reflect_index(f * hop - n_fft / 2 + i, n)] * win[i], 0.f);
+  __syncthreads();
+  float2* r = fft_pow2(A, B, tw, +1, n_fft, logn);
+  const int nb = n_fft / 2 + 1;
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) out[(long)f * nb + k] = r[k];
+}
+
+__global__ __launch_bounds__(256) void istft_general_frames_kernel(const float2* __restrict__ spec,
+                                                                   const float* __restrict__ win,
+                                                                   const float2* __restrict__ tw, float* __restrict__ frames,
+                                                                   int n_fft, int logn) {
+  __shared__ float2 A[NFFT], B[NFFT];
+  const int f = blockIdx.x, nb = n_fft / 2 + 1;
+  for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
+    float2 v;
+    if (k < nb) {
+      v = spec[(long)f * nb + k];
+      if (k == 0 || k == n_fft / 2) v.y = 0.f;
+    } else {
+      v = spec[(long)f * nb + (n_fft - k)];
+      v.y = -v.y;
+    }
+    A[k] = v;
+  }
+  __syncthreads();
+  float2* r = fft_pow2(A, B, tw, -1, n_fft, logn);
+  for (int i = threadIdx.x; i < n_fft; i += blockDim.x) frames[(long)f * n_fft + i] = (r[i].x * (1.0f / n_fft)) * win[i];
+}
+
+__global__ __launch_bounds__(256) void istft_general_ola_kernel(const float* __restrict__ frames, const float* __restrict__ win,
+                                                                int n_frames, int n_fft, int hop, int length,
+                                                                float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= length) return;
+  const int p = i + n_fft / 2;  // position in the padded signal; frame f covers [f*hop, f*hop + n_fft)
+  int f_lo = (p - n_fft + hop) / hop;  // ceil((p - n_fft + 1) / hop) for p - n_fft + 1 > 0
+  if (p - n_fft + 1 <= 0) f_lo = 0;
+  const int f_hi = min(p / hop, n_frames - 1);
+  float acc = 0.f, env = 0.f;
+  for (int f = f_lo; f <= f_hi; f++) {  // ascending frame order: deterministic
+    const int o = p - f * hop;
+    acc += frames[(long)f * n_fft + o];
+    env += win[o] * win[o];
+  }
+  y[i] = env > 0.f ? acc / env : 0.f;
+}
+
+// ---- predominant local pulse, steps 3-4 of beat.py:42-75 on one tempogram frame per workgroup -----------------------
+// keep the tempo band, keep only the bins at the frame's peak of log1p(1e6 |z|), normalise by the largest magnitude
+__global__ __launch_bounds__(256) void plp_select_kernel(float2* __restrict__ ft, const float* __restrict__ tempo_freq,
+                                                         int nb, float tempo_min, float tempo_max) {
+  __shared__ float red[256];
+  float2* row = ft + (long)blockIdx.x * nb;
+  float peak = 0.f;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    const float fq = tempo_freq[k];
+    float2 z = row[k];
+    if (fq < tempo_min || fq > tempo_max) z = make_float2(0.f, 0.f);
+    row[k] = z;
+    peak = fmaxf(peak, log1pf(1e6f * hypotf(z.x, z.y)));
+  }
+  red[threadIdx.x] = peak;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  peak = red[0];
+  __syncthreads();
+  float amax = 0.f;
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    float2 z = row[k];
+    if (log1pf(1e6f * hypotf(z.x, z.y)) < peak) z = make_float2(0.f, 0.f);
+    row[k] = z;
+    amax = fmaxf(amax, hypotf(z.x, z.y));
+  }
+  red[threadIdx.x] = amax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float denom = 1.0842021724855044e-19f + red[0];  // finfo(float32).tiny ** 0.5 + max |z|
+  for (int k = threadIdx.x; k < nb; k += 256) {
+    const float2 z = row[k];
+    row[k] = make_float2(z.x / denom, z.y / denom);
+  }
 }
 
 // ---- magnitude ---------------------------------------------------------------------------------------------------
@@ -277,7 +379,7 @@ __global__ __launch_bounds__(256) void power_to_db_kernel(float* __restrict__ s,
 // onset envelope: apply the top_db floor, lag-1 difference, relu, mean over mels, left pad, crop (beat.py:13-21)
 __global__ __launch_bounds__(256) void onset_env_kernel(const float* __restrict__ db, const float* __restrict__ part,
                                                         int nparts, int n_mels, int T, float top_db, int pad_width,
-                                                        float* __restrict__ env) {
+                                                        int aggregate, float* __restrict__ env) {
   int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= T) return;
   float mn, mx;
@@ -286,11 +388,25 @@ __global__ __launch_bounds__(256) void onset_env_kernel(const float* __restrict_
   int c = f - pad_width;  // index into the diff sequence (length T-1): d[c] = db[c+1] - db[c]
   float acc = 0.f;
   if (c >= 0 && c + 1 < T) {
-    for (int m = 0; m < n_mels; m++) {
+    auto val = [&](int m) {
       float a = fmaxf(db[(long)m * T + c + 1], floor_db), b = fmaxf(db[(long)m * T + c], floor_db);
-      acc += fmaxf(a - b, 0.f);
+      return fmaxf(a - b, 0.f);
+    };
+    if (aggregate == 0) {  // torch.mean
+      for (int m = 0; m < n_mels; m++) acc += val(m);
+      acc /= (float)n_mels;
+    } else {  // torch.median(...).values: the lower middle element = rank (n - 1) / 2 in the stable order (beat.py:44)
+      const int want = (n_mels - 1) / 2;
+      for (int m = 0; m < n_mels; m++) {
+        const float v = val(m);
+        int rank = 0;
+        for (int j = 0; j < n_mels; j++) {
+          const float u = val(j);
+          rank += (u < v) || (u == v && j < m);
+        }
+        if (rank == want) acc = v;
+      }
     }
-    acc /= (float)n_mels;
   }
   env[f] = acc;
 }
@@ -555,6 +671,57 @@ int maua_stft(maua_ctx* ctx, const float* y, int n_samples, float* out_frames_bi
   return MAUA_OK;
 }
 
+static int log2_exact(int n) {
+  int l = 0;
+  while ((1 << l) < n) l++;
+  return (1 << l) == n ? l : -1;
+}
+
+int maua_stft_general(maua_ctx* ctx, const float* y, int n_samples, int n_fft, int hop, const float* window_dev,
+                      float* out_frames_bins_complex) {
+  MAUA_REQUIRE(ctx && y && window_dev && out_frames_bins_complex, "maua_stft_general: NULL argument");
+  const int logn = log2_exact(n_fft);
+  MAUA_REQUIRE(logn >= 1 && n_fft <= NFFT, "maua_stft_general: n_fft must be a power of two in [2, 2048]");
+  MAUA_REQUIRE(hop >= 1, "maua_stft_general: hop must be positive");
+  MAUA_REQUIRE(n_samples > n_fft / 2, "maua_stft_general: signal shorter than the reflect padding (n_fft/2)");
+  AudioTables t;
+  if (int rc = get_tables(ctx, t)) return rc;
+  const int frames = 1 + n_samples / hop;
+  hipLaunchKernelGGL(stft_general_kernel, dim3(frames), dim3(256), 0, ctx->stream, y, n_samples, window_dev, t.tw,
+                     (float2*)out_frames_bins_complex, n_fft, logn, hop);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_istft_general(maua_ctx* ctx, const float* spec_frames_bins_complex, int n_frames, int n_fft, int hop,
+                       const float* window_dev, int length, float* y) {
+  MAUA_REQUIRE(ctx && spec_frames_bins_complex && window_dev && y, "maua_istft_general: NULL argument");
+  const int logn = log2_exact(n_fft);
+  MAUA_REQUIRE(logn >= 1 && n_fft <= NFFT, "maua_istft_general: n_fft must be a power of two in [2, 2048]");
+  MAUA_REQUIRE(hop >= 1 && n_frames > 0 && length > 0, "maua_istft_general: empty input");
+  AudioTables t;
+  if (int rc = get_tables(ctx, t)) return rc;
+  if (int rc = scratch_reserve(ctx, (size_t)n_frames * n_fft * sizeof(float))) return rc;
+  float* frames = (float*)ctx->scratch;
+  hipLaunchKernelGGL(istft_general_frames_kernel, dim3(n_frames), dim3(256), 0, ctx->stream,
+                     (const float2*)spec_frames_bins_complex, window_dev, t.tw, frames, n_fft, logn);
+  hipLaunchKernelGGL(istft_general_ola_kernel, dim3(cdiv(length, 256)), dim3(256), 0, ctx->stream, frames, window_dev,
+                     n_frames, n_fft, hop, length, y);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_plp_select(maua_ctx* ctx, float* tempogram_frames_bins_complex, int n_frames, int n_bins,
+                    const float* tempo_freq_dev, float tempo_min, float tempo_max) {
+  MAUA_REQUIRE(ctx, "maua_plp_select: ctx is NULL");
+  if (n_frames == 0) return MAUA_OK;
+  MAUA_REQUIRE(tempogram_frames_bins_complex && tempo_freq_dev && n_bins > 0, "maua_plp_select: NULL argument");
+  hipLaunchKernelGGL(plp_select_kernel, dim3(n_frames), dim3(256), 0, ctx->stream, (float2*)tempogram_frames_bins_complex,
+                     tempo_freq_dev, n_bins, tempo_min, tempo_max);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 int maua_istft(maua_ctx* ctx, const float* spec_frames_bins_complex, int n_frames, int length, float* y) {
   MAUA_REQUIRE(ctx && spec_frames_bins_complex && y, "maua_istft: NULL argument");
   MAUA_REQUIRE(n_frames > 0 && length > 0, "maua_istft: empty input");
@@ -623,8 +790,9 @@ int maua_mel_power(maua_ctx* ctx, const float* spec_complex, int n_frames_used, 
 }
 
 int maua_onset_from_mel(maua_ctx* ctx, float* mel_inout, int n_mels, int T, float amin, float top_db, int pad_width,
-                        float* env) {
+                        int aggregate, float* env) {
   MAUA_REQUIRE(ctx && mel_inout && env, "maua_onset_from_mel: NULL argument");
+  MAUA_REQUIRE(aggregate == 0 || aggregate == 1, "maua_onset_from_mel: aggregate must be 0 (mean) or 1 (median)");
   if (T == 0) return MAUA_OK;
   const long n = (long)n_mels * T;
   if (int rc = scratch_reserve(ctx, MM_PARTS * 2 * sizeof(float))) return rc;
@@ -634,7 +802,7 @@ int maua_onset_from_mel(maua_ctx* ctx, float* mel_inout, int n_mels, int T, floa
   const int parts = grid_for(n, MM_PARTS);
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, mel_inout, n, part);
   hipLaunchKernelGGL(onset_env_kernel, dim3(cdiv(T, 256)), dim3(256), 0, ctx->stream, mel_inout, part, parts, n_mels, T,
-                     top_db, pad_width, env);
+                     top_db, pad_width, aggregate, env);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

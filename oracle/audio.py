@@ -131,11 +131,12 @@ def power_to_db(S, amin=1e-10, top_db=80.0):
     return torch.maximum(log_spec, log_spec.max() - top_db)
 
 
-def onset_strength(y, sr, n_fft=N_FFT, hop=HOP):
-    """beat.py:10-23 — mean over mels of the rectified lag-1 dB difference, left-padded by
-    1 + n_fft // (2*hop) zeros and cropped to the spectrogram length."""
+def onset_strength(y, sr, n_fft=N_FFT, hop=HOP, aggregate="mean"):
+    """beat.py:10-23 — mean (or, for plp :44, torch.median = lower middle) over mels of the rectified lag-1 dB
+    difference, left-padded by 1 + n_fft // (2*hop) zeros and cropped to the spectrogram length."""
     S = power_to_db(melspectrogram(y, sr, fmax=11025.0).abs())
-    d = torch.clamp(S[:, 1:] - S[:, :-1], min=0).mean(0)
+    d = torch.clamp(S[:, 1:] - S[:, :-1], min=0)
+    d = d.mean(0) if aggregate == "mean" else torch.median(d, dim=0).values
     pad_width = 1 + n_fft // (2 * hop)
     return F.pad(d, (pad_width, 0))[: S.shape[1]]
 
@@ -327,3 +328,27 @@ def spectral_contrast(y, sr, fmin=200.0, n_bands=6, quantile=0.02, linear=False)
     if linear:
         return (peak - valley).T
     return (power_to_db(peak) - power_to_db(valley)).T
+
+
+def plp(y, sr, hop=HOP, win_length=1024, tempo_min=60, tempo_max=180):
+    """rosa/beat.py:42-75 predominant local pulse."""
+    env = onset_strength(y, sr, aggregate="median")
+    W = min(len(env), win_length)
+    ft = stft(env, n_fft=W, hop=1)
+    rate = sr * 60 / float(hop)
+    freqs = torch.linspace(0, float(rate) / 2, int(1 + W // 2))
+    if tempo_min is not None:
+        ft[freqs < tempo_min] = 0
+    if tempo_max is not None:
+        ft[freqs > tempo_max] = 0
+    mag = torch.log1p(1e6 * torch.abs(ft))
+    ft[mag < mag.max(axis=0, keepdims=True).values] = 0
+    ft = ft / (torch.finfo(ft.dtype).tiny ** 0.5 + torch.abs(ft.abs().max(axis=0, keepdim=True).values))
+    pulse = istft(ft, n_fft=W, hop=1, length=len(env))
+    pulse = torch.clamp(pulse, torch.zeros(()), pulse.max())
+    return normalize(pulse)
+
+
+def pulse(audio, sr):
+    """features/audio.py:72-73"""
+    return plp(percussive(audio), sr).unsqueeze(-1)

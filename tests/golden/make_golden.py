@@ -407,6 +407,18 @@ def golden_features():
          chroma=chroma, tonnetz=FA.tonnetz(a, sr, chroma_fn=lambda a_, sr_: chroma))
 
 
+def golden_pulse():
+    """features/audio.py:72-73 pulse = plp(percussive(audio)) (rosa/beat.py:42-75) on a 40 s synthetic clip (1200 frames:
+    the tempogram window is 1024 frames)."""
+    from maua.audiovisual.audioreactive.selfsupervised.features import audio as FA
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import beat
+    sr = 30720
+    a = synth_audio(40 * sr, sr, 21)
+    env_med = beat.onset_strength(FA.percussive(a), sr, aggregate=lambda *ar, **kw: torch.median(*ar, **kw).values)
+    save("g18_pulse", sr=np.int64(sr), n=np.int64(40 * sr), seed=np.int64(21), pulse=FA.pulse(a, sr), env_median=env_med,
+         tempo_freqs=beat.fourier_tempo_frequencies(sr))
+
+
 def golden_resample():
     """maua/ops/image.py:214-240 resample (lanczos pre-filter + bicubic align_corners=True): the post-process of
     MauaPatch.force_output_size (patches/base/__init__.py:21-25)."""

@@ -311,3 +311,13 @@ def test_resample(golden):
     close(O.resample(x, (25, 40)), g["up"], 1e-6)
     close(O.resample(x, (28, 17)), g["mixed"], 1e-6)
     close(O.resample(x, 12), g["short12"], 1e-6)
+
+
+def test_pulse(golden):
+    """rosa/beat.py plp / features pulse: oracle vs the reference (g18, 40 s clip rebuilt from its seed)."""
+    from maua_amd.pipeline import synthetic_audio
+    g = golden("g18_pulse")
+    sr = int(g["sr"])
+    a = synthetic_audio(int(g["n"]), sr, int(g["seed"]))
+    close(A.onset_strength(A.percussive(a), sr, aggregate="median"), g["env_median"], 2e-4)
+    close(A.pulse(a, sr), g["pulse"], 2e-3)
