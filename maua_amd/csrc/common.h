@@ -25,6 +25,13 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
+// [-1, 1] float -> u8 exactly as render/ffmpeg.py:72 + ops/io.py:47-70: (x + 1) / 2, clamp, * 255, round half to even
+__device__ __forceinline__ uint32_t to_u8(float x) {
+  float v = (x + 1.0f) / 2.0f;
+  v = fminf(fmaxf(v, 0.f), 1.f);
+  return (uint32_t)__float2int_rn(v * 255.0f);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kDtype = MAUA_F32;

@@ -51,6 +51,8 @@ struct HiresArgs {
   float* rgb_out;         // [B][3][H][W]
   float rgb_clamp;
   float fir[16];
+  uint8_t* rgb8_out;      // optional: the final frame packed to u8 HWC in the same epilogue (last block only)
+  int rgb_skip_f32;       // with rgb8_out: do not store the f32 image (nobody reads it)
 };
 bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W);
 int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);

@@ -276,8 +276,14 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
               }
               o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
             }
-            float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
-            ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+            if (!a.rgb_skip_f32) {
+              float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
+              ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+            }
+            if (a.rgb8_out) {  // final block: the u8 HWC frame leaves from here (no separate pack pass)
+              uint8_t* o8 = a.rgb8_out + ((long)b * HWl + (unsigned)(y * a.W + x)) * 3;
+              o8[0] = (uint8_t)to_u8(o3[0]); o8[1] = (uint8_t)to_u8(o3[1]); o8[2] = (uint8_t)to_u8(o3[2]);
+            }
           }
         }
       }

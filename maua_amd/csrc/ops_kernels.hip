@@ -139,11 +139,6 @@ static int launch_upfirdn2d(maua_ctx* ctx, const void* x, const float* f, int fh
 
 // ------------------------------------------------------------------------------------------------ pack_rgb8
 // render/ffmpeg.py:72 + ops/io.py:47-70.  4 pixels per thread: 3x float4 planar loads, 3x u32 interleaved store.
-__device__ __forceinline__ uint32_t to_u8(float x) {
-  float v = (x + 1.0f) / 2.0f;
-  v = fminf(fmaxf(v, 0.f), 1.f);
-  return (uint32_t)__float2int_rn(v * 255.0f);  // round-half-even like torch.round
-}
 
 __global__ __launch_bounds__(256) void pack_rgb8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out,
                                                         long npix4, long HW) {

@@ -108,6 +108,7 @@ static void compute_dims(maua_synth* n) {
   int h = 4, w = 4;
   if (n->rs_layer == 0) { h = n->rs_th; w = n->rs_tw; }
   size_t li = 0;
+  bool rgb8_done = false;
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     for (int k = 0; k < nconv; k++, li++) {
@@ -513,6 +514,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   const float* prev_img = nullptr;
   int img_cur = 0;
   size_t li = 0;
+  bool rgb8_done = false;
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     RgbLayer& g = n->rgbs[blk];
@@ -540,6 +542,11 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;
+          if (last && rgb8_out) {  // the u8 frame is packed in the same epilogue
+            a.rgb8_out = rgb8_out;
+            a.rgb_skip_f32 = img_out == nullptr;
+            rgb8_done = true;
+          }
         }
         if (int rc = launch_modconv_hires(st, a)) return rc;
       } else if (via_tconv) {
@@ -628,8 +635,9 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
     img_cur ^= 1;
   }
   if (rgb8_out) {
-    if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->out_h, n->out_w)) return rc;
-    prof_mark(n, "pack_rgb8");
+    if (!rgb8_done)
+      if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->out_h, n->out_w)) return rc;
+    prof_mark(n, "pack_rgb8");  // zero-length when the last block's epilogue packed the frame
   }
   return MAUA_OK;
 }

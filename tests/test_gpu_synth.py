@@ -101,6 +101,15 @@ def test_hires_kernels_match_generic_and_oracle():
     net.keep_features(True)
     img_h = net(ws, noise=noise).cpu()
     feats_h = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    # the last block's fused epilogue also packs the u8 frame: with and without the f32 image in the same call
+    img_d = torch.empty((B, 3, 256, 256), device="cuda")
+    u8a = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
+    u8b = torch.empty_like(u8a)
+    net(ws, noise=noise, out=img_d, rgb8_out=u8a)
+    net(ws, noise=noise, rgb8_out=u8b)
+    assert torch.equal(img_d.cpu(), img_h)
+    want = ((img_d + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)
+    assert torch.equal(u8a, want) and torch.equal(u8b, want)
     h = net._handle()
     L.check(L.lib().maua_synth_set_option(h, b"use_hires", 0))
     img_g = net(ws, noise=noise).cpu()
