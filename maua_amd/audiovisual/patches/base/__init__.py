@@ -25,7 +25,16 @@ class MauaPatch:
         t, c, h, w = video.shape
         if (w, h) != tuple(self.synthesizer.output_size):  # lanczos + bicubic (maua/ops/image.py:214-240)
             from ....ops import resample
-            video = resample(video, tuple(reversed(self.synthesizer.output_size)))
+            size = tuple(reversed(self.synthesizer.output_size))
+            if isinstance(video, torch.Tensor):
+                return resample(video, size)
+            # uint8 frame stacks (the memmap renderer hands its whole [T,3,H,W] array over): resample in chunks
+            import numpy as np
+            out = np.empty((t, c, size[0], size[1]), dtype=np.uint8)
+            for i in range(0, t, 64):
+                chunk = torch.from_numpy(np.ascontiguousarray(video[i:i + 64])).float()
+                out[i:i + 64] = resample(chunk, size).clamp(0, 255).round().byte().cpu().numpy()
+            return out
         return video
 
 

@@ -16,6 +16,8 @@ class MemMap(Renderer):
     def __call__(self, synthesizer, inputs, postprocess=lambda x: x):
         T = n_frames_of(inputs)
         W, H = synthesizer.output_size
+        if hasattr(synthesizer, "G_synth"):  # the size actually rendered (output_size rounded to the resize layer's
+            H, W = synthesizer.G_synth.output_hw  # multiple; force_output_size resamples afterwards)
         os.makedirs(os.path.dirname(self.cache_file) or ".", exist_ok=True)
         frames = np.lib.format.open_memmap(self.cache_file, mode="w+", dtype=np.uint8, shape=(T, 3, H, W))
         for i in range(0, T, self.batch_size):

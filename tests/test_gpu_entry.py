@@ -75,3 +75,22 @@ def test_sample_generate(wav, wav_long, tmp_path):
     _, fr2 = generate(wav, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path),
                       dtype=torch.float32, reference_tail=True)
     assert fr2.shape[0] == 344 and torch.equal(fr2, frames[:344])
+
+
+def test_generate_non_native_size(wav, tmp_path, monkeypatch):
+    """The CLI entry point at a size the network does not produce natively: the synthesizer resizes its features at
+    resize_layer, rounds to the layer's multiple and force_output_size resamples to the request."""
+    from maua_amd.audiovisual.generate import generate_audiovisal_from_patch
+    monkeypatch.chdir(tmp_path)
+    import os, warnings
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(repo)
+    os.symlink(os.path.join(repo, "maua_amd"), tmp_path / "maua_amd")
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # "resizes to multiples of ..." (200 is not a multiple of 1024 // 64)
+        video, _ = generate_audiovisal_from_patch(
+            audio_file=wav, model_file="None", patch_file="maua_amd/audiovisual/patches/examples/stylegan2.py",
+            patch_name=None, renderer="memmap", renderer_kwargs={}, fps=30, out_size=(200, 136), resize_strategy="stretch",
+            resize_layer=9)
+    assert video.shape == (32, 3, 136, 200) and video.std() > 1.0
