@@ -4,6 +4,7 @@ frames -> VideoWriter.  The (x+1)/2 -> clamp -> u8 HWC conversion the reference 
 import torch
 
 from ...pipeline import frame_range
+from ... import _lib as L
 from ...video import VideoWriter
 from . import Renderer, batch_inputs, n_frames_of
 
@@ -22,9 +23,20 @@ class FFMPEG(Renderer):
         W, H = synthesizer.output_size
         with VideoWriter(self.output_file if world == 1 else f"{self.output_file}.part{rank}", (W, H), self.fps,
                          self.audio_file, self.audio_offset, self.audio_duration, self.ffmpeg_preset) as video:
+            rh, rw = synthesizer.G_synth.output_hw if hasattr(synthesizer, "G_synth") else (H, W)
             for i in range(lo, hi, self.batch_size):
                 b = min(self.batch_size, hi - i)
                 u8 = torch.empty((b, H, W, 3), dtype=torch.uint8, device="cuda")
-                synthesizer(**batch_inputs(inputs, i, b), rgb8_out=u8)
+                if (rh, rw) == (H, W):  # the u8 frame is packed inside the synthesis call
+                    synthesizer(**batch_inputs(inputs, i, b), rgb8_out=u8)
+                else:
+                    # output_size was rounded to the resize layer's multiple: render/ffmpeg.py:72-73 — frames in
+                    # [0, 1] go through the patch's postprocess (force_output_size resamples), then the u8 pack
+                    frames = synthesizer(**batch_inputs(inputs, i, b)).add(1).div(2)
+                    frames = postprocess(frames) if postprocess is not None else frames
+                    frames = frames.mul(2).sub(1).contiguous()
+                    if tuple(frames.shape[-2:]) != (H, W):
+                        raise ValueError(f"postprocess returned {tuple(frames.shape[-2:])}, the writer expects {(H, W)}")
+                    L.check(L.lib().maua_pack_rgb8(L.ctx(frames.device), L.ptr(frames), L.ptr(u8), b, H, W))
                 video.write(u8)
         return self.output_file

@@ -94,3 +94,17 @@ def test_generate_non_native_size(wav, tmp_path, monkeypatch):
             patch_name=None, renderer="memmap", renderer_kwargs={}, fps=30, out_size=(200, 136), resize_strategy="stretch",
             resize_layer=9)
     assert video.shape == (32, 3, 136, 200) and video.std() > 1.0
+    # the ffmpeg renderer: frames are resampled by the patch's postprocess before the u8 pack
+    import json, shutil
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out, _ = generate_audiovisal_from_patch(
+            audio_file=wav, model_file="None", patch_file="maua_amd/audiovisual/patches/examples/stylegan2.py",
+            patch_name=None, renderer="ffmpeg", renderer_kwargs=dict(output_file=str(tmp_path / "n.mp4")), fps=30,
+            out_size=(200, 136), resize_strategy="stretch", resize_layer=9)
+    if not shutil.which("ffmpeg"):
+        meta = json.loads(open(out + ".json").read())
+        assert meta["frames"] == 32 and (meta["width"], meta["height"]) == (200, 136)
+        raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(32, 136, 200, 3)
+        assert raw.std() > 1.0
