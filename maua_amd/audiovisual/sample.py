@@ -100,13 +100,11 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
              batch_size: int = 32, device: str = "cuda", tempo: float = 120.0, out_dir: str = "output",
              reference_tail: bool = False, dtype=torch.bfloat16):
     """sample.py:36-101.  ``reference_tail=True`` reproduces the reference loop's dropped tail."""
-    if aspect_ratio != 1:
-        raise NotImplementedError("aspect_ratio != 1 needs the feature-space resize hooks (N2)")
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31, size=()).item())
     rank, world = world_info()
     res = round(1024 / downscale_factor)
-    out_size = (res, res)
+    out_size = (round(aspect_ratio * 1024 / downscale_factor), res)   # (width, height), sample.py:53
     out_file = f"{out_dir}/{Path(audio_file).stem}_RandomPatches++_seed{seed}_{out_size[0]}x{out_size[1]}.mp4"
     audio, sr = load_audio(audio_file, audio_offset, audio_duration, fps)
     features = retrieve_music_information(audio, sr)
@@ -124,7 +122,10 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     if reference_tail and len(latents) % batch_size == 0:
         T -= batch_size  # range(0, len - B, B) never reaches the last full batch either
     lo, hi = frame_range(T, rank, world)
-    local = torch.empty((hi - lo, res, res, 3), dtype=torch.uint8, device="cuda")
+    # the network renders output_size rounded to the resize layer's multiple (wrappers/stylegan2.py:115-120); the
+    # reference writes those frames into a writer opened at out_size — here they are resampled to out_size first
+    rh, rw = G.synthesizer.G_synth.output_hw
+    local = torch.empty((hi - lo, rh, rw, 3), dtype=torch.uint8, device="cuda")
     for i in range(lo, hi, batch_size):
         b = min(batch_size, hi - i)
         nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
@@ -134,7 +135,12 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
         wav = audio_file if str(audio_file).lower().endswith(".wav") else None
         with VideoWriter(out_file, out_size, fps, wav, audio_offset, audio_duration) as video:
             for i in range(0, T, 64):
-                video.write(frames[i:i + 64])
+                chunk = frames[i:i + 64]
+                if (rw, rh) != tuple(out_size):
+                    from ..ops import resample
+                    f = resample(chunk.permute(0, 3, 1, 2).float(), (out_size[1], out_size[0]))
+                    chunk = f.clamp(0, 255).round().byte().permute(0, 2, 3, 1).contiguous()
+                video.write(chunk)
         patch.save(out_file.replace(".mp4", ".json"))
     return out_file, frames
 

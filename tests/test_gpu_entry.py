@@ -77,6 +77,18 @@ def test_sample_generate(wav, wav_long, tmp_path):
     assert fr2.shape[0] == 344 and torch.equal(fr2, frames[:344])
 
 
+def test_sample_generate_aspect_ratio(wav_long, tmp_path):
+    """aspect_ratio != 1 (sample.py:53): the 1024 net resized at layer 0 ("stretch"), 768 x 512 at downscale 2."""
+    import shutil
+    from maua_amd.audiovisual.sample import generate
+    out_file, frames = generate(wav_long, None, seed=3, fps=30, downscale_factor=2, aspect_ratio=1.5, batch_size=16,
+                                out_dir=str(tmp_path))
+    assert tuple(frames.shape) == (352, 512, 768, 3) and "768x512" in out_file and float(frames.float().std()) > 1.0
+    if not shutil.which("ffmpeg"):
+        meta = json.loads(open(out_file + ".json").read())
+        assert (meta["width"], meta["height"], meta["frames"]) == (768, 512, 352)
+
+
 def test_generate_non_native_size(wav, tmp_path, monkeypatch):
     """The CLI entry point at a size the network does not produce natively: the synthesizer resizes its features at
     resize_layer, rounds to the layer's multiple and force_output_size resamples to the request."""
