@@ -50,6 +50,8 @@ def kernel_of(ci, co, res, up):
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
     cov = co * up * up
+    if up == 1 and hin * hin <= 256 and cov % 128 == 0:
+        return "modconv3x3_kernel<bf16,4,1,2,1,9,64>"
     if cov % 128 == 0:
         k128 = ci % 64 == 0
         if hin * hin >= 4096:

@@ -345,6 +345,10 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   // per stage); the 256-pixel tile pays off once a sample has >= 16 of them
   // K chunk: 128 bytes (fewer, longer stages) measured 1.1-1.2x over 64 except on the 32^2 layers
   const bool k128 = a.Ci % (128 / (int)sizeof(T)) == 0;
+  // tiny up=1 layers (4^2..16^2) are bound by the latency of streaming the weights through few workgroups: 32-channel
+  // N tiles give 4x the workgroups and 9-tap stages a third of the dependent stages (measured 0.058 -> 0.047 ms at 4^2,
+  // 0.065 -> 0.049 at 16^2; up=2 layers would re-stage the halo for 64 virtual-channel tiles and lose)
+  if (a.up == 1 && a.H * a.W <= 256 && cov % 128 == 0) return launch_variant<T, 4, 1, 2, 1, 9, 64>(stream, a);
   if (cov % 128 == 0 && a.H * a.W >= 4096 && k128) return launch_variant<T, 4, 4, 2, 1, 3, 128>(stream, a);
   if (cov % 128 == 0 && a.H * a.W >= 4096) return launch_variant<T, 4, 4, 2, 1, 3, 64>(stream, a);
   if (cov % 128 == 0 && a.H * a.W < 256 && k128) return launch_variant<T, 2, 4, 2, 1, 3, 128>(stream, a);
