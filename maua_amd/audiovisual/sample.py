@@ -86,6 +86,28 @@ class Patch(torch.nn.Module):
             noise = N.noise_patch(self.rng, noise, self.features, self.tempo, self.fps, **sub)
         return latents, noise
 
+    def __repr__(self):
+        """patch.py:157-178: the two sub-patch tables."""
+        reprs = []
+        for patches in [self.latent_patches, self.noise_patches]:
+            header = [""] + [k for k in patches[0]]
+            values = [[str(i + 1)] + [(f"{v:.4f}" if isinstance(v, float) else f"{v}").replace("spectral_", "")
+                                      for v in p.values()] for i, p in enumerate(patches)]
+            widths = [max(len(row[n]) for row in [header] + values) for n in range(len(header))]
+            rows = [header, ["-" * w for w in widths]] + values
+            reprs.append([" | ".join(row[c].ljust(widths[c]) for c in range(len(row))) for row in rows])
+        return ("Patch(\n  Latent(\n    " + "\n    ".join(reprs[0]) + "\n  ),\n  Noise(\n    " + "\n    ".join(reprs[1])
+                + "\n  )\n)")
+
+    @staticmethod
+    def load(path, features, tempo, fps, device="cuda"):
+        """patch.py:190-197: a fresh Patch whose attributes are overwritten by the saved JSON (seed, sub-patch lists,
+        base-noise parameters), so the same file reproduces the same latent / noise sequences."""
+        patch = Patch(features=features, tempo=tempo, fps=fps, device=device)
+        for key, val in json.loads(Path(path).read_text()).items():
+            setattr(patch, key, val)
+        return patch
+
     def save(self, path):
         Path(path).write_text(json.dumps(dict(seed=self.seed, latent_patches=self.latent_patches,
                                               noise_patches=self.noise_patches, n_base_latents=self.n_base_latents,
@@ -108,7 +130,10 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     out_file = f"{out_dir}/{Path(audio_file).stem}_RandomPatches++_seed{seed}_{out_size[0]}x{out_size[1]}.mp4"
     audio, sr = load_audio(audio_file, audio_offset, audio_duration, fps)
     features = retrieve_music_information(audio, sr)
-    patch = Patch(features=features, tempo=tempo, seed=seed, fps=fps)
+    if patch_file is None:
+        patch = Patch(features=features, tempo=tempo, seed=seed, fps=fps)
+    else:  # sample.py:62-66
+        patch = Patch.load(patch_file, features=features, tempo=tempo, fps=fps)
     G = StyleGAN2(model_file=stylegan2_checkpoint, output_size=out_size, dtype=dtype,
                   generator=torch.Generator().manual_seed(seed))
     if latent_seeds is None:

@@ -75,6 +75,10 @@ def test_sample_generate(wav, wav_long, tmp_path):
     _, fr2 = generate(wav, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path),
                       dtype=torch.float32, reference_tail=True)
     assert fr2.shape[0] == 344 and torch.equal(fr2, frames[:344])
+    # a saved patch file reproduces the render (sample.py:62-66 Patch.load)
+    _, fr3 = generate(wav, None, patch_file=out_file.replace(".mp4", ".json"), seed=5, fps=30, downscale_factor=4,
+                      batch_size=8, out_dir=str(tmp_path / "again"), dtype=torch.float32)
+    assert torch.equal(fr3, frames)
 
 
 def test_sample_generate_aspect_ratio(wav_long, tmp_path):
