@@ -216,6 +216,10 @@ int maua_minmax(maua_ctx* ctx, const float* x, long n, float* out2);
  * of xn (maua_order_stat mode 2), both device scalars. */
 int maua_emphasize(maua_ctx* ctx, const float* xn, long n, const float* minmax_dev, const float* q_dev, float strength,
                    float* y);
+/* signal.py:84-105 compress / expand before their normalise: y = x * ratio where x > threshold (invert: x < threshold) */
+int maua_threshold_scale(maua_ctx* ctx, const float* x, long n, float threshold, float ratio, int invert, float* y);
+/* latent.py:46-51 on same-shape operands: mode 0 eerp a^(1-t) * b^t, mode 1 copeerp a^t (1 - b^t) / (1 - a^t + b^t) */
+int maua_eerp(maua_ctx* ctx, const float* a, const float* b, const float* t, long n, int mode, float* y);
 /* signal.py:69-76: mask[i] = x[i] > x[i+1] && x[i] > x[i-1] with neighbours clamped to the ends. */
 int maua_peak_mask(maua_ctx* ctx, const float* x, int n, uint8_t* mask);
 /* y = min(max(x, lo), hi + hi_add); lo = lo_dev[0] if lo_dev else lo_const; hi = hi_dev[0] (device scalars,

@@ -5,9 +5,9 @@ import torch
 from ..audio import (gaussian_filter as _gf_selfsup, harmonic, hpss, istft, melspectrogram, onset_strength, percussive,  # noqa
                      rms as _rms, spectrogram, stft)
 from ..audio_io import load_audio as _load
-from ..latent import (multi_weighted, select_modulo, single_weighted, slerp, slerp_loops, spline_loops,  # noqa
-                      tempo_loops)
-from ..signal import gaussian_filter, normalize, percentile, percentile_clip, resample  # noqa
+from ..latent import (copeerp, eerp, multi_weighted, select_modulo, single_weighted, slerp, slerp_loops,  # noqa
+                      spline_loops, tempo_loops)
+from ..signal import compress, expand, gaussian_filter, normalize, percentile, percentile_clip, resample  # noqa
 
 
 def load_audio(audio_file, offset=0, duration=-1, cache=True):
@@ -29,3 +29,24 @@ def onsets(audio, sr, type="rosa", prepercussive=4):
 
 def rms(audio, sr):
     return _rms(torch.as_tensor(audio), sr).squeeze(-1)
+
+
+def _butter(audio, sr, cutoff, kind, db_per_octave):
+    """maua/audiovisual/audioreactive/audio.py:96-112: a Butterworth IIR (scipy sosfilt) over the decoded numpy
+    signal — a serial recurrence on the host, once per clip, exactly as the reference runs it (scipy is a listed
+    dependency of the reference and part of this image)."""
+    from scipy import signal as sps
+    a = audio.detach().cpu().numpy() if isinstance(audio, torch.Tensor) else audio
+    return sps.sosfilt(sps.butter(db_per_octave, cutoff, kind, fs=sr, output="sos"), a)
+
+
+def low_pass(audio, sr, fmax=200, db_per_octave=12):
+    return _butter(audio, sr, fmax, "low", db_per_octave)
+
+
+def high_pass(audio, sr, fmin=3000, db_per_octave=12):
+    return _butter(audio, sr, fmin, "high", db_per_octave)
+
+
+def band_pass(audio, sr, fmin=200, fmax=3000, db_per_octave=12):
+    return _butter(audio, sr, [fmin, fmax], "band", db_per_octave)

@@ -130,6 +130,30 @@ __global__ __launch_bounds__(256) void emphasize_kernel(const float* __restrict_
   y[i] = e * range + lo;
 }
 
+// signal.py:84-100 compress / expand (before the normalise): y = x * ratio where x > threshold (invert: x < threshold)
+__global__ __launch_bounds__(256) void threshold_scale_kernel(const float* __restrict__ x, long n, float threshold,
+                                                              float ratio, int invert, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  const bool hit = invert ? v < threshold : v > threshold;
+  y[i] = hit ? v * ratio : v;
+}
+
+// latent.py:46-51: mode 0 eerp a^(1-t) * b^t ; mode 1 copeerp a^t * (1 - b^t) / (1 - a^t + b^t); same-shape operands
+__global__ __launch_bounds__(256) void eerp_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ t, long n, int mode, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float av = a[i], bv = b[i], tv = t[i];
+  if (mode == 0) {
+    y[i] = powf(av, 1.f - tv) * powf(bv, tv);
+  } else {
+    const float at = powf(av, tv), bt = powf(bv, tv);
+    y[i] = at * (1.f - bt) / (1.f - at + bt);
+  }
+}
+
 }  // namespace maua
 
 using namespace maua;
@@ -183,6 +207,25 @@ int maua_emphasize(maua_ctx* ctx, const float* xn, long n, const float* minmax_d
   MAUA_REQUIRE(xn && minmax_dev && q_dev && y, "maua_emphasize: NULL argument");
   hipLaunchKernelGGL(emphasize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, xn, n, minmax_dev,
                      q_dev, strength, y);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_threshold_scale(maua_ctx* ctx, const float* x, long n, float threshold, float ratio, int invert, float* y) {
+  MAUA_REQUIRE(ctx, "maua_threshold_scale: ctx is NULL");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y, "maua_threshold_scale: NULL argument");
+  hipLaunchKernelGGL(threshold_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, threshold,
+                     ratio, invert, y);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_eerp(maua_ctx* ctx, const float* a, const float* b, const float* t, long n, int mode, float* y) {
+  MAUA_REQUIRE(ctx, "maua_eerp: ctx is NULL");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(a && b && t && y && (mode == 0 || mode == 1), "maua_eerp: NULL argument or unknown mode");
+  hipLaunchKernelGGL(eerp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, b, t, n, mode, y);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

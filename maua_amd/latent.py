@@ -163,3 +163,22 @@ def latent_patch(rng, latents, palette, segmentations, features, tempo, fps, pat
     sequence = A.gaussian_filter(sequence, 1)
     mod = (mod_feat_weight * features[mod_feat]).reshape(len(latents), -1)[:, 0] if merge_type == "modulate" else None
     return merge(latents, sequence, merge_type, merge_depth, mod)
+
+
+def _eerp(a, b, t, mode):
+    a, b, t = (A._f32(torch.as_tensor(v)) for v in (a, b, t))
+    a, b, t = torch.broadcast_tensors(a, b, t)
+    a, b, t = a.contiguous(), b.contiguous(), t.contiguous()
+    y = torch.empty_like(a)
+    L.check(L.lib().maua_eerp(L.ctx(a.device), L.ptr(a), L.ptr(b), L.ptr(t), C.c_long(a.numel()), mode, L.ptr(y)))
+    return y
+
+
+def eerp(a, b, t):
+    """latent.py:46-47 exponential interpolation a^(1-t) * b^t"""
+    return _eerp(a, b, t, 0)
+
+
+def copeerp(a, b, t):
+    """latent.py:50-51"""
+    return _eerp(a, b, t, 1)

@@ -52,3 +52,18 @@ def percentile_clip(signal, percent):
 
 def gaussian_filter(x, sigma, causal=None, mode="circular"):
     return A.gaussian_filter(x, sigma, mode=mode, causal=causal, _classic=True)
+
+
+def compress(signal, threshold, ratio, invert=False):
+    """signal.py:84-100: values above (invert: below) ``threshold`` are multiplied by ``ratio``, then normalize.
+    (The reference scales its argument in place; this returns a new tensor.)"""
+    x = A._f32(signal)
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_threshold_scale(L.ctx(x.device), L.ptr(x), C.c_long(x.numel()), C.c_float(float(threshold)),
+                                         C.c_float(float(ratio)), int(bool(invert)), L.ptr(y)))
+    return normalize(y)
+
+
+def expand(signal, threshold, ratio, invert=False):
+    """signal.py:103-105: alias of compress"""
+    return compress(signal, threshold, ratio, invert)

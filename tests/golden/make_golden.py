@@ -419,6 +419,24 @@ def golden_pulse():
          tempo_freqs=beat.fourier_tempo_frequencies(sr))
 
 
+def golden_classic():
+    """Small classic-API pieces: signal.compress / expand (:84-105), latent.eerp / copeerp (:46-51), audio.low_pass /
+    high_pass / band_pass (:96-112; scipy Butterworth on the host)."""
+    import sys as _sys
+    from maua.audiovisual.audioreactive import latent as RL
+    from maua.audiovisual.audioreactive import audio as RA
+    RS = _sys.modules["maua.audiovisual.audioreactive.signal"]
+    g = torch.Generator().manual_seed(12)
+    e = torch.rand(150, generator=g)
+    a, b, t = torch.rand(6, 8, generator=g) + 0.1, torch.rand(6, 8, generator=g) + 0.1, torch.rand(6, 1, generator=g)
+    x = synth_audio(2048, 30720, 3).numpy()
+    unwrap = lambda f: getattr(f, "__wrapped__", f)
+    save("g19_classic", e=e, comp_hi=RS.compress(e.clone(), 0.6, 0.5), comp_lo=RS.expand(e.clone(), 0.3, 2.0, invert=True),
+         a=a, b=b, t=t, eerp=RL.eerp(a, b, t), copeerp=RL.copeerp(a, b, t), x=x,
+         low=unwrap(RA.low_pass)(x, 30720, 200), high=unwrap(RA.high_pass)(x, 30720, 3000),
+         band=unwrap(RA.band_pass)(x, 30720, 200, 3000))
+
+
 def golden_resample():
     """maua/ops/image.py:214-240 resample (lanczos pre-filter + bicubic align_corners=True): the post-process of
     MauaPatch.force_output_size (patches/base/__init__.py:21-25)."""

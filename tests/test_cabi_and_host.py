@@ -177,3 +177,13 @@ def test_generate_cli_argument_surface():
         assert sig.parameters[name].default == default
     with pytest.raises(SystemExit):
         G.main([])  # --audio_file / --model_file are required
+
+
+def test_pass_filters_match_reference(golden):
+    """audio.py:96-112 low / high / band pass (host scipy Butterworth, like the reference) vs its outputs (g19)."""
+    from maua_amd.audiovisual import audioreactive as ar
+    g = golden("g19_classic")
+    x = g["x"].numpy()
+    for fn, key, args in [(ar.low_pass, "low", (200,)), (ar.high_pass, "high", (3000,)), (ar.band_pass, "band", (200, 3000))]:
+        y = fn(x, 30720, *args)
+        assert np.allclose(y, g[key].numpy(), rtol=1e-9, atol=1e-12), key

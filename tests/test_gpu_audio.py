@@ -277,3 +277,13 @@ def test_pulse_and_general_stft(golden):
     # may pick the other one, so compare robustly: nearly all frames agree closely
     err = (p.cpu() - g["pulse"]).abs().squeeze()
     assert float((err < 5e-3).float().mean()) > 0.98, float(err.max())
+
+
+def test_classic_compress_eerp(golden):
+    """signal.compress / expand and latent.eerp / copeerp vs the reference's outputs (g19)."""
+    from maua_amd.audiovisual import audioreactive as ar
+    g = golden("g19_classic")
+    assert rel(ar.compress(g["e"].cuda(), 0.6, 0.5), g["comp_hi"]) < 2e-6
+    assert rel(ar.expand(g["e"].cuda(), 0.3, 2.0, invert=True), g["comp_lo"]) < 2e-6
+    assert rel(ar.eerp(g["a"].cuda(), g["b"].cuda(), g["t"].cuda()), g["eerp"]) < 5e-6
+    assert rel(ar.copeerp(g["a"].cuda(), g["b"].cuda(), g["t"].cuda()), g["copeerp"]) < 5e-5
