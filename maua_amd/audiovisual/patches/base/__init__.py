@@ -10,16 +10,20 @@ from ... import audioreactive as ar
 
 
 class MauaPatch:
+    """Base of user patches.  Attributes the reference's patches rely on: ``audio`` (numpy, mono), ``sr``,
+    ``duration`` (s), ``fps``, ``n_frames``, ``audio_file``, ``device``; subclasses provide ``mapper`` /
+    ``synthesizer`` and the four ``process_*`` stages."""
+
     def __init__(self, audio_file, fps=24, offset=0, duration=-1) -> None:
-        self.fps = fps
-        self.audio_file = audio_file
-        self.audio, self.sr, self.duration = ar.load_audio(audio_file, offset, duration)
-        self.audio = self.audio.numpy()
-        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.n_frames = round(self.duration * self.fps)  # Python round: half to even (base/__init__.py:16)
+        waveform, self.sr, self.duration = ar.load_audio(audio_file, offset, duration)
+        self.audio = waveform.numpy()
+        self.audio_file, self.fps = audio_file, fps
+        # Python's round: half to even, like the reference (base/__init__.py:16)
+        self.n_frames = round(self.duration * self.fps)
+        self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
     def process_audio(self):
-        pass
+        """hook: derive envelopes / features from self.audio (default: nothing)"""
 
     def force_output_size(self, video):
         t, c, h, w = video.shape

@@ -1,20 +1,26 @@
-"""Render back-ends (drop-in for maua/audiovisual/render/__init__.py:1-18)."""
+"""Render back-ends.  Interface of maua/audiovisual/render/__init__.py:1-18 (``Renderer`` base with a ``device``
+attribute, ``get_output_class(name)``), plus the two helpers the back-ends share for slicing per-frame inputs."""
+import importlib
+
 import torch
+
+_BACKENDS = {"memmap": (".memmap", "MemMap"), "ffmpeg": (".ffmpeg", "FFMPEG")}
 
 
 class Renderer:
+    """Base of the back-ends; ``device`` is where they run the synthesizer."""
+
     def __init__(self):
-        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
 
 def get_output_class(renderer):
-    if renderer == "memmap":
-        from .memmap import MemMap
-        return MemMap
-    if renderer == "ffmpeg":
-        from .ffmpeg import FFMPEG
-        return FFMPEG
-    raise NotImplementedError
+    """Name -> back-end class (imported on demand); unknown names raise NotImplementedError like the reference."""
+    try:
+        module, cls = _BACKENDS[renderer]
+    except KeyError:
+        raise NotImplementedError(f"unknown renderer {renderer!r}; choose from {sorted(_BACKENDS)}") from None
+    return getattr(importlib.import_module(module, __name__), cls)
 
 
 def batch_inputs(inputs, i, b):
