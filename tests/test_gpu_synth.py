@@ -148,3 +148,17 @@ def test_tconv_up_matches_phase_kernels(dt):
     for l, (a, b) in enumerate(zip(feats_t, feats_p)):
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()), f"layer {l}"
     assert float((img_t - img_p).abs().max()) <= tol * float(img_p.abs().max())
+
+
+@pytest.mark.parametrize("B", [1, 33, 70])
+def test_odd_batch_sizes_are_batch_independent(B):
+    """Any batch size (the styles GEMMs tile samples by 32, workspaces grow on demand): every frame equals the same
+    frame rendered alone-ish (in a batch of 2), bit for bit."""
+    net, p = build(64, 2048, 64, torch.bfloat16)
+    g = torch.Generator().manual_seed(9)
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    img = net(ws).cpu()
+    assert bool(torch.isfinite(img).all())
+    for i in sorted({0, B // 2, B - 1}):
+        pair = torch.stack([ws[i], ws[(i + 1) % B]])
+        assert torch.equal(net(pair).cpu()[0], img[i]), i
