@@ -40,7 +40,8 @@ enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLI
 typedef struct maua_ctx maua_ctx;
 typedef struct maua_synth maua_synth;
 
-/* ---- context ------------------------------------------------------------------------------------ */
+/* ---- context (library plumbing: no reference counterpart — the reference relies on torch's current device and
+ * stream; a maua_ctx carries exactly that: device ordinal, HIP stream, a scratch arena) --------------------------- */
 const char* maua_version(void);
 const char* maua_last_error(void);
 /* stream: a hipStream_t (NULL = the device's default stream); pass torch's current stream handle. */
@@ -83,8 +84,8 @@ int maua_pack_rgb8(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int
 int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_base, int channel_max, int dtype,
                       int nv_compat, maua_synth** out);
 void maua_synth_destroy(maua_synth* net);
-int maua_synth_num_ws(const maua_synth* net);
-int maua_synth_num_layers(const maua_synth* net);
+int maua_synth_num_ws(const maua_synth* net);      /* SynthesisNetwork.num_ws, inference/stylegan2.py:409-427 */
+int maua_synth_num_layers(const maua_synth* net);  /* synthesis layers in execution order (17 at 1024^2) */
 /* options: "keep_features" (0/1) keeps every layer's activation for maua_synth_get_feature (parity/debug);
  * "profile" (0/1) records HIP events on the ctx stream around every launch of a forward;
  * "tconv_up" (default 1) runs up-layers with 32^2..512^2 inputs as the minimal stride-2 transposed convolution + a
@@ -124,7 +125,8 @@ int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, in
 int maua_conv1d_reflect(maua_ctx* ctx, const float* x, float* y, const float* taps, int radius, int axis, long planes,
                         int H, int W);
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
-/* name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
+/* the load_state_dict of the inference modules (inference/stylegan2.py:195-436 parameter / buffer names).
+ * name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.
  * Synchronous.  Unknown names return MAUA_ERR ("resample_filter" buffers are accepted and checked). */
 int maua_synth_load(maua_synth* net, const char* name, const float* host_data, size_t count);
@@ -141,12 +143,12 @@ int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const*
  * then pack_rgb8 if requested.  Synchronises on the last event;
  * a call with ms_out != NULL resets the recording (ms_out == NULL only returns the count). */
 int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* count);
-/* debug/parity: copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
+/* debug/parity (what a torch forward hook on SynthesisLayer would capture): copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
 int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
 
 /* ---- audio pre-pass (once per clip).  n_fft = 2048, hop = 1024, periodic Hann, centre/reflect padding ---- */
 /* Spectra are FRAME-major: spec[frame][bin] complex64 (re, im interleaved), 1025 bins. */
-int maua_stft_num_frames(int n_samples); /* 1 + n_samples / 1024 */
+int maua_stft_num_frames(int n_samples); /* 1 + n_samples / 1024: torch.stft centre framing, rosa/spectral.py:10-21 */
 /* replaces rosa/spectral.py:10-21 stft (torch.stft).  y [n_samples] f32 -> spec [frames][1025] complex. */
 int maua_stft(maua_ctx* ctx, const float* y, int n_samples, float* spec);
 /* replaces rosa/spectral.py:24-32 istft (torch.istft, center=True, length=...).  -> y [length] f32. */
