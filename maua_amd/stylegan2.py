@@ -319,8 +319,12 @@ class MappingNetwork(torch.nn.Module):
             y = x @ (w.T if self.nv_compat else w)
             x = ops.bias_act(y[:, :, None, None], b, act="lrelu")[:, :, 0, 0]
         x = x.unsqueeze(1).repeat(1, self.num_ws, 1)
-        if truncation_psi != 1:
-            x = self._params["w_avg"].to(x.device).lerp(x, truncation_psi)
+        if truncation_psi != 1:  # stylegan2.py:185-190: lerp towards w_avg, all ws or only the first `cutoff`
+            w_avg = self._params["w_avg"].to(x.device)
+            if truncation_cutoff is None:
+                x = w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
         return x
 
 

@@ -109,8 +109,9 @@ def fully_connected(x, weight, bias, activation="linear", lr_multiplier=1.0, nv_
     return ops.bias_act(y, b, act=activation)
 
 
-def mapping_network(p, z, truncation_psi=1.0, num_ws_=18, lr_multiplier=0.01, nv_compat=False):
-    """stylegan2.py:161-192 (c_dim == 0, truncation_cutoff None)."""
+def mapping_network(p, z, truncation_psi=1.0, num_ws_=18, lr_multiplier=0.01, nv_compat=False,
+                    truncation_cutoff=None):
+    """stylegan2.py:161-192 (c_dim == 0)."""
     x = ops.normalize_2nd_moment(z)
     i = 0
     while f"fcs.{i}.weight" in p:
@@ -118,7 +119,10 @@ def mapping_network(p, z, truncation_psi=1.0, num_ws_=18, lr_multiplier=0.01, nv
         i += 1
     x = x.unsqueeze(1).repeat(1, num_ws_, 1)
     if truncation_psi != 1:
-        x = p["w_avg"].lerp(x, truncation_psi)
+        if truncation_cutoff is None:
+            x = p["w_avg"].lerp(x, truncation_psi)
+        else:
+            x[:, :truncation_cutoff] = p["w_avg"].lerp(x[:, :truncation_cutoff], truncation_psi)
     return x
 
 

@@ -175,7 +175,7 @@ def golden_modules():
     z = torch.randn(5, 16, generator=g)
     sd = {k: v for k, v in m.state_dict().items()}
     save("g07_mapping", z=z, y_psi1=m(z, None), y_psi07=m(z, None, truncation_psi=0.7),
-         **{k.replace(".", "__"): v for k, v in sd.items()})
+         y_cut2=m(z, None, truncation_psi=0.5, truncation_cutoff=2), **{k.replace(".", "__"): v for k, v in sd.items()})
 
     # full-size mapping init parity: seed -> state dict checksum + a forward
     torch.manual_seed(11)

@@ -130,6 +130,10 @@ def test_loaded_network_matches_oracle(tmp_path, for_inference):
     mp = {k: v for k, v in G.mapping.state_dict().items()}
     ws_ref = OS.mapping_network(mp, z, truncation_psi=0.7, num_ws_=G.num_ws, nv_compat=not for_inference)
     assert float((ws - ws_ref).abs().max()) <= 1e-4 * float(ws_ref.abs().max())
+    ws_cut = G.mapping(z, truncation_psi=0.5, truncation_cutoff=4).cpu()
+    ws_cut_ref = OS.mapping_network(mp, z, truncation_psi=0.5, num_ws_=G.num_ws, nv_compat=not for_inference,
+                                    truncation_cutoff=4)
+    assert float((ws_cut - ws_cut_ref).abs().max()) <= 1e-4 * float(ws_ref.abs().max())
     img = G.synthesis(ws).cpu()
     ref = OS.synthesis_network(p, ws_ref, nv_compat=not for_inference)
     assert float((img - ref).abs().max()) <= 2e-4 * float(ref.abs().max())

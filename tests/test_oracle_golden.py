@@ -76,6 +76,7 @@ def test_norm2nd_fc_mapping(golden):
     p = {k.replace("__", "."): v for k, v in g.items() if k.startswith("fcs") or k == "w_avg"}
     close(S.mapping_network(p, g["z"], 1.0, num_ws_=6), g["y_psi1"], 2e-6)
     close(S.mapping_network(p, g["z"], 0.7, num_ws_=6), g["y_psi07"], 2e-6)
+    close(S.mapping_network(p, g["z"], 0.5, num_ws_=6, truncation_cutoff=2), g["y_cut2"], 2e-6)
 
 
 def test_mapping_init_order(golden):
