@@ -156,7 +156,10 @@ def main():
     net, latents, noise, info = build_inputs(device, rank, world)
     B = a.batch
     lo, hi = pipeline.frame_range(T_FRAMES, rank, world)
-    out_u8 = torch.empty((a.steps, B, RES, RES, 3), dtype=torch.uint8, device=device)
+    # every timed step packs its frames into its own slot; the slots form a ring so that a long run (--steps in the
+    # thousands) stays within HBM: 64 slots x 32 frames x 3 MiB = 6 GiB per rank, 8x that on rank 0 for the gather
+    keep = max(1, min(a.steps, 64))
+    out_u8 = torch.empty((keep, B, RES, RES, 3), dtype=torch.uint8, device=device)
     scratch_u8 = torch.empty((B, RES, RES, 3), dtype=torch.uint8, device=device)
 
     def step(k, u8):
@@ -178,7 +181,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        step(k, out_u8[k])
+        step(k, out_u8[k % keep])
     fence()
     elapsed = time.perf_counter() - t0
     # per-launch HIP-event durations recorded on the kernels' stream during the timed steps
