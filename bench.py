@@ -78,6 +78,8 @@ def layer_table(net):
             if kern.startswith("modconv_hires") and up == 1:  # + fused toRGB: img write + upsampled skip read
                 gflop += 2 * r * r * co * 3 / 1e9
                 byts += r * r * 12 + (r // 2) ** 2 * 12
+                if i == len(net.block_resolutions) - 1:  # last block: the features are not stored and the image
+                    byts += r * r * 3 - res * res * co * 2 - r * r * 12  # leaves as u8 (no f32 image, no pack pass)
             if kern.startswith("tconv2"):  # two launches: MACs on the first, the output write on the second
                 t_bytes = (res + 1) * (res + 1) * co * 2
                 rows.append((pfx + ".tconv", kern, gflop, hin * hin * ci * 2 + t_bytes))

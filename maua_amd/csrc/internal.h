@@ -41,7 +41,7 @@ struct HiresArgs {
   long noise_bstride;
   float noise_strength;
   const float* bias;    // [Co] or NULL
-  void* y;              // NHWC bf16 [B][H*up][W*up][Co]
+  void* y;              // NHWC bf16 [B][H*up][W*up][Co]; NULL with rgb_out: features are not stored
   int B, H, W, Ci, Co, up, act;
   float alpha, gain, clamp;
   // fused toRGB (conv1 only; rgb_out == NULL disables)

@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       }
     }
     __syncthreads();
-    // ---- read-out: full 16-byte NHWC pieces
-    for (int p = tid; p < BM * PPP; p += 256) {
+    // ---- read-out: full 16-byte NHWC pieces (y == NULL: the last block's conv1 output only feeds the fused toRGB)
+    if (a.y) for (int p = tid; p < BM * PPP; p += 256) {
       const int m = p / PPP, pc = p - m * PPP;
       const int gy = ty0 + (m >> 5), gx = tx0 + (m & 31);
       const int nv = pc * 8;
@@ -325,6 +325,7 @@ int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
   MAUA_REQUIRE((long)a.H * a.up * a.W * a.up * std::max(a.Ci, a.Co) * 2 < (1L << 31),
                "modconv_hires: a sample must stay below 2 GiB (32-bit in-sample offsets)");
   MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "modconv_hires: lrelu / linear only");
+  MAUA_REQUIRE(a.y || a.rgb_out, "modconv_hires: no output (y is optional only with the fused toRGB)");
   HiresArgs b = a;
   if (a.act == MAUA_ACT_LINEAR) b.alpha = 1.f;
   MAUA_REQUIRE(b.alpha >= 0.f && b.alpha <= 1.f && b.gain > 0.f, "modconv_hires: needs 0 <= alpha <= 1 and gain > 0");

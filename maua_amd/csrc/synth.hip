@@ -547,6 +547,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             a.rgb_skip_f32 = img_out == nullptr;
             rgb8_done = true;
           }
+          // the last block's features have no reader besides the toRGB fused here: skip their HBM store
+          if (last && !n->keep_features && !hooked) a.y = nullptr;
         }
         if (int rc = launch_modconv_hires(st, a)) return rc;
       } else if (via_tconv) {
