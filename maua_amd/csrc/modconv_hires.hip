@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
   constexpr bool LEAN = true;
   float* bias_s = reinterpret_cast<float*>(epi + BM * ES);            // [CO] bias * gain
   u32x4* rf_s = reinterpret_cast<u32x4*>(epi + BM * ES + CO * 4);      // [CO/16][64 lanes] toRGB B fragments
+  // the tile's window of the previous block's image (the toRGB skip): [3][PH][PW] f32, zero outside the image
+  constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, PREGS = (3 * PH * PW + 255) / 256;
+  float* prev_s = reinterpret_cast<float*>(epi + BM * ES + CO * 4 + (CO / 16) * 64 * 16);
+  float* noise_s = prev_s + PREGS * 256;  // [4 waves][64]: each wave's two image rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
   // which land in the h == 0 lane of the pixel.
   u32x4 rf[LEAN ? 1 : CO / 16];
   if (a.rgb_out) {
-    const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
+    // (rows 4..6 / 12..14 repeat them: the h == 1 lanes then hold the same sums and can finish a second image row)
+    const int c_rgb = (r < 16 && (r & 3) < 3) ? (r & 3) : -1;
 #pragma unroll
     for (int ks = 0; ks < CO / 16; ks++) {
       u32x4 o = u32x4{0u, 0u, 0u, 0u};
@@ -126,6 +131,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
   // halo staging: piece index -> (pixel, 16-byte piece)
   const int q = tid % PIECES, rq = tid / PIECES;
   u32x4 hreg[HREGS];
+  const bool with_prev = UP == 1 && a.rgb_out && a.rgb_prev;
+  const float* pvb = a.rgb_prev + (long)b * 3 * (a.H >> 1) * (a.W >> 1);
 #define MAUA_HIRES_LOAD_HALO(TILE)                                                               \
   {                                                                                               \
     const int tyi_ = (TILE) / tiles_x, txi_ = (TILE) - tyi_ * tiles_x;                            \
@@ -153,6 +160,32 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       if (p < HALO_PX) *reinterpret_cast<u32x4*>(halo + p * RSH + q * 16) = hreg[i];
     }
     __syncthreads();
+    if constexpr (UP == 1) {
+      // the tile's noise and its window of the previous image travel global -> LDS without passing through
+      // registers (LDS-direct loads: lane l of a wave fills dword l of the wave's 256-byte slot); they are waited
+      // for (vmcnt) in the epilogue, the whole multiply phase later
+      if (nb) {  // lane -> pixel (ms0 + (lane >> 5), lane & 31): exactly the pixels this wave's epilogue covers
+        const float* src = nb + (unsigned)((ty0 + ms0 + h) * a.W + tx0 + r);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(noise_s + wave * 64), 4, 0, 0);
+      }
+      if (with_prev) {
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+        for (int i = 0; i < PREGS; i++) {
+          int e = tid + i * 256;
+          asm volatile("" : "+v"(e));  // re-derive the window coordinates per tile instead of keeping them in registers
+          const int c = e / (PH * PW), py = (e - c * PH * PW) / PW;
+          const int px = e - c * PH * PW - py * PW;
+          // (coordinates clamped into the image: the FIR below zeroes the taps that fall outside)
+          const int gy = min(max(tyi * (TH / 2) - 1 + py, 0), Hp - 1), gx = min(max(txi * (TW / 2) - 1 + px, 0), Wp - 1);
+          if (e < 3 * PH * PW)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(pvb + (unsigned)((c * Hp + gy) * Wp + gx)),
+                (__attribute__((address_space(3))) void*)(prev_s + i * 256 + wave * 64), 4, 0, 0);
+        }
+      }
+    }
     if (tile + (int)gridDim.x < n_tiles) MAUA_HIRES_LOAD_HALO(tile + (int)gridDim.x)  // flies during the MFMAs
 
     // ---- multiply: PAIR image rows (M sub-tiles) at a time share every B fragment (CI == 64: one row at a time,
@@ -188,7 +221,12 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
         const int gy = ty0 + ms + half, gx = tx0 + r;
         const int pa = phase / UP, pb = phase - pa * UP;
         float nz = 0.f;
-        if (nb) nz = nb[(unsigned)((gy * UP + pa) * Wo + gx * UP + pb)] * nz_scale;
+        if constexpr (UP == 1) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads of this tile have landed
+          if (nb) nz = noise_s[wave * 64 + (ms + half - ms0) * 32 + r] * nz_scale;
+        } else {
+          if (nb) nz = nb[(unsigned)((gy * UP + pa) * Wo + gx * UP + pb)] * nz_scale;
+        }
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           float v[4], bq[4];
@@ -224,66 +262,71 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       *reinterpret_cast<uint4*>(yb + (pix * CO + co) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
     }
     // ---- fused toRGB + upsampled skip (conv1 layers only): [32 px x CO] x [CO x 3(+3)] on the matrix cores, the
-    // activated bf16 outputs are the A operand straight from the epilogue tile
+    // activated bf16 outputs are the A operand straight from the epilogue tile.  Every lane finishes ONE pixel:
+    // with two image rows per wave the h == 0 lanes take the first and the h == 1 lanes the second (the repeated
+    // weight rows put the sums into both halves); with one row per wave the h == 1 lanes idle.
     if constexpr (UP == 1) {
       if (a.rgb_out) {
         constexpr int ROWS_W = TH / 4;  // image rows per wave
+        float o3[3];
 #pragma unroll 1
         for (int rw = 0; rw < ROWS_W; rw++) {
-          const int row = wave * ROWS_W + rw;
+          const int row_m = wave * ROWS_W + rw;
           f32x16 racc;
 #pragma unroll
           for (int e = 0; e < 16; e++) racc[e] = 0.f;
 #pragma unroll
           for (int ks = 0; ks < CO / 16; ks++) {
-            const u32x4 av = *reinterpret_cast<const u32x4*>(epi + (row * 32 + r) * ES + (ks * 16 + 8 * h) * 2);
-            u32x4 rfk;
-            if constexpr (LEAN) rfk = rf_s[ks * 64 + lane]; else rfk = rf[ks];
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rfk),
+            const u32x4 av = *reinterpret_cast<const u32x4*>(epi + (row_m * 32 + r) * ES + (ks * 16 + 8 * h) * 2);
+            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf_s[ks * 64 + lane]),
                                                            __builtin_bit_cast(bf16x8, av), racc, 0, 0, 0);
           }
-          if (h == 0) {
-            const int y = ty0 + row, x = tx0 + r;
-            float o3[3] = {racc[0] + racc[4] + a.rgb_bias[0], racc[1] + racc[5] + a.rgb_bias[1],
-                           racc[2] + racc[6] + a.rgb_bias[2]};
+          if (rw == 0 || h == rw) { o3[0] = racc[0] + racc[4]; o3[1] = racc[1] + racc[5]; o3[2] = racc[2] + racc[6]; }
+        }
+        if (ROWS_W == 2 || h == 0) {
+          const int row = wave * ROWS_W + (ROWS_W == 2 ? h : 0);
+          const int y = ty0 + row, x = tx0 + r;
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-              if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
-            const unsigned HWl = (unsigned)(a.H * a.W);
-            if (a.rgb_prev) {
-              const int Hp = a.H >> 1, Wp = a.W >> 1;
-              const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
-              // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
-              // parity hits a real sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index
-              // u = 2*iy - y + 2 (same products, same u-major order as the 16-tap correlation)
-              const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
-              float u3[3] = {0.f, 0.f, 0.f};
+          for (int c = 0; c < 3; c++) {
+            o3[c] += a.rgb_bias[c];
+            if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
+          }
+          const unsigned HWl = (unsigned)(a.H * a.W);
+          if (a.rgb_prev) {
+            // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its branch-free 2x2 form: only the taps whose
+            // parity hits a real sample are non-zero -> window rows {iy0, iy0+1}, cols {ix0, ix0+1} with
+            // iy0 = (y-1)>>1, filter index u = 2*iy - y + 2 (same products, same u-major order as the 16-tap
+            // correlation; taps outside the image get a zero coefficient)
+            const int py0 = ((row - 1) >> 1) + 1, px0 = ((r - 1) >> 1) + 1;
+            const int iy0 = (ty0 >> 1) - 1 + py0, ix0 = (tx0 >> 1) - 1 + px0;
+            int par = (row & 1) * 2 + (r & 1);
+            asm volatile("" : "+v"(par));  // (keeps the four per-lane coefficients out of the loop-invariant registers)
+            const bool yo = par & 2, xo = par & 1;  // odd output coordinate: first tap is fir index 1, second 3
+            float u3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-              for (int dy = 0; dy < 2; dy++) {
-                const int iy = iy0 + dy, u = 2 * iy - y + 2;
-                const bool oky = iy >= 0 && iy < Hp;
+            for (int dy = 0; dy < 2; dy++) {
+              const bool uh = (dy == 0) == yo;  // fir[u][v] takes 3 distinct values: u, v in {1,2} or {0,3}
+              const bool oky = iy0 + dy >= 0 && iy0 + dy < (a.H >> 1);
 #pragma unroll
-                for (int dx = 0; dx < 2; dx++) {
-                  const int ix = ix0 + dx, v = 2 * ix - x + 2;
-                  const bool ok = oky && ix >= 0 && ix < Wp;
-                  const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
-                  const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
-                  const unsigned o = ok ? (unsigned)(iy * Wp + ix) : 0u;
-                  u3[0] += pv[o] * f;
-                  u3[1] += pv[(unsigned)(Hp * Wp) + o] * f;
-                  u3[2] += pv[2u * (unsigned)(Hp * Wp) + o] * f;
-                }
+              for (int dx = 0; dx < 2; dx++) {
+                const bool vh = (dx == 0) == xo;
+                const bool ok = oky && ix0 + dx >= 0 && ix0 + dx < (a.W >> 1);
+                const float f = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+                const float* ps = prev_s + (py0 + dy) * PW + px0 + dx;
+                u3[0] += ps[0] * f;
+                u3[1] += ps[PH * PW] * f;
+                u3[2] += ps[2 * PH * PW] * f;
               }
-              o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
             }
-            if (!a.rgb_skip_f32) {
-              float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
-              ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
-            }
-            if (a.rgb8_out) {  // final block: the u8 HWC frame leaves from here (no separate pack pass)
-              uint8_t* o8 = a.rgb8_out + ((long)b * HWl + (unsigned)(y * a.W + x)) * 3;
-              o8[0] = (uint8_t)to_u8(o3[0]); o8[1] = (uint8_t)to_u8(o3[1]); o8[2] = (uint8_t)to_u8(o3[2]);
-            }
+            o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
+          }
+          if (!a.rgb_skip_f32) {
+            float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
+            ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+          }
+          if (a.rgb8_out) {  // final block: the u8 HWC frame leaves from here (no separate pack pass)
+            uint8_t* o8 = a.rgb8_out + ((long)b * HWl + (unsigned)(y * a.W + x)) * 3;
+            o8[0] = (uint8_t)to_u8(o3[0]); o8[1] = (uint8_t)to_u8(o3[1]); o8[2] = (uint8_t)to_u8(o3[2]);
           }
         }
       }
@@ -296,7 +339,8 @@ template <int CI, int CO, int UP>
 static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
   constexpr int HALO_PX = (TH + 2) * (TW + 2);
-  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + CO * 4 + (CO / 16) * 64 * 16;
+  size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + CO * 4 + (CO / 16) * 64 * 16 +
+                ((3 * (TH / 2 + 2) * (TW / 2 + 2) + 255) / 256 + 1) * 1024;  // + previous-image window + noise
   auto kern = modconv_hires_kernel<CI, CO, UP>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
