@@ -45,10 +45,10 @@ def kernel_of(ci, co, res, up):
     """Which kernel instantiation synth.hip launches for a layer (mirrors launch_modconv_t / hires_supported);
     names match the rocprofv3 kernel-trace rows."""
     hin = res // up
-    if up == 2 and 32 <= hin <= 512:
-        return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
+    if up == 2 and 32 <= hin <= 512:
+        return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     cov = co * up * up
     if up == 1 and hin * hin <= 256 and cov % 128 == 0:
         return "modconv3x3_kernel<bf16,4,1,2,1,9,64>"

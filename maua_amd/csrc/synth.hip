@@ -530,7 +530,12 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       void* y = hooked ? n->act[cur] : n->keep_features ? c.feat : n->act[cur];
       const int hin = std::min(c.ih, c.iw), hin_max = std::max(c.ih, c.iw);
       const int tconv_max = n->tconv_up == 1 ? 512 : n->tconv_up;  // option value > 1 = largest input size routed
-      const bool via_tconv = c.up == 2 && n->tconv_up && hin >= (n->tconv_up == 1 ? 32 : 1) && hin_max <= tconv_max;
+      // (default routing: where the register-stationary kernel exists (bf16 64 -> 32 channels, the 1024^2 layer) its
+      //  FIR-folded phase form beats tconv + upfir, whose t round trip is HBM-bound there: 1.33 vs 1.56 ms at B = 32)
+      const bool hires_up = c.up == 2 && n->tconv_up == 1 && n->use_hires &&
+                            hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw);
+      const bool via_tconv = c.up == 2 && n->tconv_up && !hires_up && hin >= (n->tconv_up == 1 ? 32 : 1) &&
+                             hin_max <= tconv_max;
       const bool rs_block = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;  // toRGB needs the hook path
       if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};

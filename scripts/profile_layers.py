@@ -49,7 +49,8 @@ li = 0
 for i, r in enumerate(net.block_resolutions):
     for k in range(1 if i == 0 else 2):
         pfx, ci, co, rr, up = shapes[li]
-        if up == 2 and tc_lo <= rr // up <= tc_hi:
+        hires_up = tc == 1 and dt == torch.bfloat16 and (ci, co) == (64, 32) and os.environ.get('MAUA_USE_HIRES', '1') != '0'
+        if up == 2 and tc_lo <= rr // up <= tc_hi and not hires_up:
             names.append("  (tconv part of next row)")
         names.append(shapes[li]); li += 1
     names.append(("torgb", shapes[li - 1][2], r))
