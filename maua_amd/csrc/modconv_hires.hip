@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
   // the tile's window of the previous block's image (the toRGB skip): [3][PH][PW] f32, zero outside the image
   constexpr int PH = TH / 2 + 2, PW = TW / 2 + 2, PREGS = (3 * PH * PW + 255) / 256;
   float* prev_s = reinterpret_cast<float*>(epi + BM * ES + CO * 4 + (CO / 16) * 64 * 16);
-  float* noise_s = prev_s + PREGS * 256;  // [4 waves][64]: each wave's two image rows
+  float* noise_s = prev_s + PREGS * 256;  // [4 waves][MSW rows][32]: the noise of each wave's output pixels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -160,6 +160,19 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       if (p < HALO_PX) *reinterpret_cast<u32x4*>(halo + p * RSH + q * 16) = hreg[i];
     }
     __syncthreads();
+    if constexpr (UP == 2) {
+      // (same LDS-direct path as below; lane (h, r) fetches the noise of output pixel (2 gy + pa, 2 gx + pb) for
+      //  tile rows 2 j + h: two loads cover the wave's four rows)
+      if (nb) {
+        const int pa = phase >> 1, pb = phase & 1;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const float* src = nb + (unsigned)(((ty0 + 2 * j + h) * 2 + pa) * Wo + (tx0 + r) * 2 + pb);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(noise_s + wave * 128 + j * 64), 4, 0, 0);
+        }
+      }
+    }
     if constexpr (UP == 1) {
       // the tile's noise and its window of the previous image travel global -> LDS without passing through
       // registers (LDS-direct loads: lane l of a wave fills dword l of the wave's 256-byte slot); they are waited
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
       if (nb) {  // lane -> pixel (ms0 + (lane >> 5), lane & 31): exactly the pixels this wave's epilogue covers
         const float* src = nb + (unsigned)((ty0 + ms0 + h) * a.W + tx0 + r);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(noise_s + wave * 64), 4, 0, 0);
+            (__attribute__((address_space(3))) void*)(noise_s + wave * (MSW * 32)), 4, 0, 0);
       }
       if (with_prev) {
         const int Hp = a.H >> 1, Wp = a.W >> 1;
@@ -221,12 +234,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
         const int gy = ty0 + ms + half, gx = tx0 + r;
         const int pa = phase / UP, pb = phase - pa * UP;
         float nz = 0.f;
-        if constexpr (UP == 1) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads of this tile have landed
-          if (nb) nz = noise_s[wave * 64 + (ms + half - ms0) * 32 + r] * nz_scale;
-        } else {
-          if (nb) nz = nb[(unsigned)((gy * UP + pa) * Wo + gx * UP + pb)] * nz_scale;
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads of this tile have landed
+        if (nb) nz = noise_s[wave * (MSW * 32) + (ms + half - ms0) * 32 + r] * nz_scale;
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
           float v[4], bq[4];
@@ -340,7 +349,7 @@ static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
   constexpr int HALO_PX = (TH + 2) * (TW + 2);
   size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + CO * 4 + (CO / 16) * 64 * 16 +
-                ((3 * (TH / 2 + 2) * (TW / 2 + 2) + 255) / 256 + 1) * 1024;  // + previous-image window + noise
+                ((3 * (TH / 2 + 2) * (TW / 2 + 2) + 255) / 256 + UP) * 1024;  // + previous-image window + noise
   auto kern = modconv_hires_kernel<CI, CO, UP>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
