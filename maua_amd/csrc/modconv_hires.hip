@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
     }
   }
 
+  float rgb_b[3] = {0.f, 0.f, 0.f};  // read once (scalar): a load inside the tile loop would drain vmcnt every tile
+  if (a.rgb_out) { rgb_b[0] = a.rgb_bias[0]; rgb_b[1] = a.rgb_bias[1]; rgb_b[2] = a.rgb_bias[2]; }
   const int tiles_x = a.W / TW, n_tiles = tiles_x * (a.H / TH);
   const int Ho = a.H * UP, Wo = a.W * UP;
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
           const int y = ty0 + row, x = tx0 + r;
 #pragma unroll
           for (int c = 0; c < 3; c++) {
-            o3[c] += a.rgb_bias[c];
+            o3[c] += rgb_b[c];
             if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
           }
           const unsigned HWl = (unsigned)(a.H * a.W);

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 for lib in "" $(ls build_ab/libmaua_abl*.so); do
   if [ -n "$lib" ]; then export MAUA_HIP_LIB=$PWD/$lib; fi
-  python bench.py --steps 20 2>/dev/null | tail -1 > /tmp/b.json
+  python bench.py --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/b.json
   python - "$lib" <<'PY'
 import json, sys
 d = json.loads(open("/tmp/b.json").read())
