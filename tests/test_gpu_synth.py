@@ -126,6 +126,16 @@ def test_hires_kernels_match_generic_and_oracle():
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
     img_nf = net(ws, noise=noise).cpu()
     assert float((img_nf - img_h).abs().max()) <= 1e-4 * rng
+    # without keep_features the last block's conv1 does not store its features (only its fused toRGB reads them):
+    # same image, same u8 frame, bit for bit
+    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 1))
+    net.keep_features(False)
+    img_e = torch.empty_like(img_d)
+    u8c = torch.empty_like(u8a)
+    u8d = torch.empty_like(u8a)
+    net(ws, noise=noise, out=img_e, rgb8_out=u8c)
+    net(ws, noise=noise, rgb8_out=u8d)
+    assert torch.equal(img_e, img_d) and torch.equal(u8c, u8a) and torch.equal(u8d, u8a)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
