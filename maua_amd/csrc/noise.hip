@@ -41,9 +41,9 @@ __device__ __forceinline__ float fast_cos(float x) {
   return ((q + 1) & 2) ? -v : v;
 }
 
-__device__ __forceinline__ float loop_value(float idx, float n0, float n1, float n2, float sigma50) {
-  float freqs = fast_cos(idx + n0) / sigma50;   // noise.py:50
-  return fast_sin(freqs + n1) * n2;             // noise.py:51
+__device__ __forceinline__ float loop_value(float idx, float n0, float n1, float n2, float inv_sigma50) {
+  float freqs = fast_cos(idx + n0) * inv_sigma50;   // noise.py:50 (division by sigma/50 as a multiplication)
+  return fast_sin(freqs + n1) * n2;                 // noise.py:51
 }
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -58,36 +58,76 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;  // valid in thread 0
 }
 
-// pass 1: partial[b][blk] = sum over the block's slice of out^2
+// The two passes of one (layer, frame), shared by the single-module and the batched kernels so that both produce the
+// same bits: 16-byte loads/stores when the plane size allows (hw % 4 == 0: every size the generator uses), the
+// per-thread accumulation order is fixed by (block, nblk).
+static int noise_nparts(int hw) { return std::min(NZ_BLOCKS, cdiv(hw, (hw & 3) ? 256 : 1024)); }
+static int noise_wblk(int hw) { return std::min(256, cdiv(hw, (hw & 3) ? 256 : 1024)); }  // blocks of the write pass
+
+// pass 1: this thread's part of sum(value^2) over slice `blk` of `nblk`
+__device__ __forceinline__ float loop_sumsq_slice(const float* __restrict__ planes, int hw, float id, float inv_s, int blk,
+                                                  int nblk) {
+  float acc = 0.f;
+  if ((hw & 3) == 0) {
+    const float4* p0 = reinterpret_cast<const float4*>(planes);
+    const float4* p1 = reinterpret_cast<const float4*>(planes + hw);
+    const float4* p2 = reinterpret_cast<const float4*>(planes + 2 * (long)hw);
+    for (int v = blk * 256 + threadIdx.x; v < (hw >> 2); v += nblk * 256) {
+      const float4 a = p0[v], b = p1[v], c = p2[v];
+      const float x = loop_value(id, a.x, b.x, c.x, inv_s), y = loop_value(id, a.y, b.y, c.y, inv_s);
+      const float z = loop_value(id, a.z, b.z, c.z, inv_s), w = loop_value(id, a.w, b.w, c.w, inv_s);
+      acc += x * x; acc += y * y; acc += z * z; acc += w * w;
+    }
+  } else {
+    for (int p = blk * 256 + threadIdx.x; p < hw; p += nblk * 256) {
+      const float v = loop_value(id, planes[p], planes[hw + p], planes[2 * (long)hw + p], inv_s);
+      acc += v * v;
+    }
+  }
+  return acc;
+}
+
+// pass 2: out = value / (sqrt(mean) + eps)   (noise.py:52; the division as a multiplication by the reciprocal)
+__device__ __forceinline__ void loop_write_slice(const float* __restrict__ planes, int hw, float id, float inv_s,
+                                                 float inv_denom, int blk, int nblk, float* __restrict__ out) {
+  if ((hw & 3) == 0) {
+    const float4* p0 = reinterpret_cast<const float4*>(planes);
+    const float4* p1 = reinterpret_cast<const float4*>(planes + hw);
+    const float4* p2 = reinterpret_cast<const float4*>(planes + 2 * (long)hw);
+    float4* o = reinterpret_cast<float4*>(out);
+    for (int v = blk * 256 + threadIdx.x; v < (hw >> 2); v += nblk * 256) {
+      const float4 a = p0[v], b = p1[v], c = p2[v];
+      o[v] = make_float4(loop_value(id, a.x, b.x, c.x, inv_s) * inv_denom, loop_value(id, a.y, b.y, c.y, inv_s) * inv_denom,
+                         loop_value(id, a.z, b.z, c.z, inv_s) * inv_denom, loop_value(id, a.w, b.w, c.w, inv_s) * inv_denom);
+    }
+  } else {
+    for (int p = blk * 256 + threadIdx.x; p < hw; p += nblk * 256)
+      out[p] = loop_value(id, planes[p], planes[hw + p], planes[2 * (long)hw + p], inv_s) * inv_denom;
+  }
+}
+
+__device__ __forceinline__ float loop_inv_denom(const float* __restrict__ partial, int nparts, int hw) {
+  float tot = 0.f;
+  for (int i = 0; i < nparts; i++) tot += partial[i];  // fixed order, identical in every thread
+  return 1.f / (sqrtf(tot / (float)hw) + 1.1920928955078125e-07f);  // torch.finfo(float32).eps
+}
+
 __global__ __launch_bounds__(256) void noise_loop_sumsq_kernel(const float* __restrict__ planes,
                                                                const float* __restrict__ idx, int i0, int hw,
-                                                               float sigma50, float* __restrict__ partial) {
+                                                               float inv_s, float* __restrict__ partial) {
   __shared__ float sh[4];
   const int b = blockIdx.y;
-  const float id = idx[i0 + b];
-  float acc = 0.f;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
-    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
-    acc += v * v;
-  }
-  float t = block_sum(acc, sh);
+  const float t = block_sum(loop_sumsq_slice(planes, hw, idx[i0 + b], inv_s, blockIdx.x, gridDim.x), sh);
   if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = t;
 }
 
-// pass 2: out = value / (sqrt(mean) + eps)   (noise.py:52)
 __global__ __launch_bounds__(256) void noise_loop_write_kernel(const float* __restrict__ planes,
                                                                const float* __restrict__ idx, int i0, int hw,
-                                                               float sigma50, const float* __restrict__ partial,
+                                                               float inv_s, const float* __restrict__ partial,
                                                                int nparts, float* __restrict__ out) {
   const int b = blockIdx.y;
-  float tot = 0.f;
-  for (int i = 0; i < nparts; i++) tot += partial[b * nparts + i];  // fixed order, identical in every thread
-  const float denom = sqrtf(tot / (float)hw) + 1.1920928955078125e-07f;  // torch.finfo(float32).eps
-  const float id = idx[i0 + b];
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x) {
-    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
-    out[(long)b * hw + p] = v / denom;
-  }
+  const float inv_denom = loop_inv_denom(partial + b * nparts, nparts, hw);
+  loop_write_slice(planes, hw, idx[i0 + b], inv_s, inv_denom, blockIdx.x, gridDim.x, out + (long)b * hw);
 }
 
 // All layers of a batch in two launches: the per-layer descriptors travel in the kernel arguments.
@@ -97,8 +137,9 @@ struct NoiseBatch {
   const float* idx[NZ_MAX_LAYERS];
   float* out[NZ_MAX_LAYERS];
   int hw[NZ_MAX_LAYERS];
-  float sigma50[NZ_MAX_LAYERS];
+  float inv_s[NZ_MAX_LAYERS];
   int nparts[NZ_MAX_LAYERS];
+  int wblk[NZ_MAX_LAYERS];   // blocks of the write pass (the grid is sized for the largest layer)
   int i0, B;
 };
 
@@ -106,35 +147,20 @@ __global__ __launch_bounds__(256) void noise_loop_batch_sumsq_kernel(NoiseBatch 
   __shared__ float sh[4];
   const int l = blockIdx.z, b = blockIdx.y;
   if ((int)blockIdx.x >= nb.nparts[l]) return;
-  const int hw = nb.hw[l];
-  const float* planes = nb.planes[l];
-  const float id = nb.idx[l][nb.i0 + b];
-  const float sigma50 = nb.sigma50[l];
-  float acc = 0.f;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += nb.nparts[l] * blockDim.x) {
-    float v = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50);
-    acc += v * v;
-  }
-  float t = block_sum(acc, sh);
+  const float t = block_sum(
+      loop_sumsq_slice(nb.planes[l], nb.hw[l], nb.idx[l][nb.i0 + b], nb.inv_s[l], blockIdx.x, nb.nparts[l]), sh);
   if (threadIdx.x == 0) partial[((long)l * nb.B + b) * NZ_BLOCKS + blockIdx.x] = t;
 }
 
 __global__ __launch_bounds__(256) void noise_loop_batch_write_kernel(NoiseBatch nb, const float* __restrict__ partial) {
   const int l = blockIdx.z, b = blockIdx.y;
+  if ((int)blockIdx.x >= nb.wblk[l]) return;
   const int hw = nb.hw[l];
-  if ((long)blockIdx.x * blockDim.x >= hw) return;
-  float tot = 0.f;
-  for (int i = 0; i < nb.nparts[l]; i++) tot += partial[((long)l * nb.B + b) * NZ_BLOCKS + i];
-  const float denom = sqrtf(tot / (float)hw) + 1.1920928955078125e-07f;
-  const float* planes = nb.planes[l];
-  const float id = nb.idx[l][nb.i0 + b];
-  const float sigma50 = nb.sigma50[l];
-  float* out = nb.out[l] + (long)b * hw;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += gridDim.x * blockDim.x)
-    out[p] = loop_value(id, planes[p], planes[hw + p], planes[2 * hw + p], sigma50) / denom;
+  const float inv_denom = loop_inv_denom(partial + ((long)l * nb.B + b) * NZ_BLOCKS, nb.nparts[l], hw);
+  loop_write_slice(nb.planes[l], hw, nb.idx[l][nb.i0 + b], nb.inv_s[l], inv_denom, blockIdx.x, nb.wblk[l],
+                   nb.out[l] + (long)b * hw);
 }
 
-// Blend / Multiply: out[b,p] = sum_m noise[m,p] * mod[b,m]  (+ sum_m noise2[m,p] * (1 - mod[b,m]))
 __global__ __launch_bounds__(256) void noise_mix_kernel(const float* __restrict__ noise, const float* __restrict__ noise2,
                                                         const float* __restrict__ mod, int M, int hw,
                                                         float* __restrict__ out) {
@@ -181,15 +207,15 @@ int maua_noise_loop(maua_ctx* ctx, const float* planes, const float* idx, int i0
   MAUA_REQUIRE(planes && idx && out, "maua_noise_loop: NULL argument");
   MAUA_REQUIRE(sigma != 0.f, "maua_noise_loop: sigma must be non-zero");
   const int hw = h * w;
-  const int nblk = std::min(NZ_BLOCKS, cdiv(hw, 256));
+  const int nblk = noise_nparts(hw);
   if (int rc = scratch_reserve(ctx, (size_t)B * nblk * sizeof(float))) return rc;
   float* partial = (float*)ctx->scratch;
-  const float sigma50 = (float)((double)sigma / 50.0);
-  hipLaunchKernelGGL(noise_loop_sumsq_kernel, dim3(nblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, sigma50,
+  const float inv_s = (float)(50.0 / (double)sigma);
+  hipLaunchKernelGGL(noise_loop_sumsq_kernel, dim3(nblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, inv_s,
                      partial);
   MAUA_HIP_CHECK(hipGetLastError());
-  const int wblk = std::min(256, cdiv(hw, 256));
-  hipLaunchKernelGGL(noise_loop_write_kernel, dim3(wblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, sigma50,
+  const int wblk = noise_wblk(hw);
+  hipLaunchKernelGGL(noise_loop_write_kernel, dim3(wblk, B), dim3(256), 0, ctx->stream, planes, idx, i0, hw, inv_s,
                      partial, nblk, out);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
@@ -202,20 +228,21 @@ int maua_noise_loop_batch(maua_ctx* ctx, int n, const float* const* planes, cons
   MAUA_REQUIRE(planes && idx && h && w && sigma && out, "maua_noise_loop_batch: NULL argument");
   MAUA_REQUIRE(n <= NZ_MAX_LAYERS, "maua_noise_loop_batch: at most 24 layers per call");
   NoiseBatch nb{};
-  int max_hw = 0;
+  int max_wblk = 1;
   for (int l = 0; l < n; l++) {
     MAUA_REQUIRE(planes[l] && idx[l] && out[l] && sigma[l] != 0.f, "maua_noise_loop_batch: NULL layer argument");
     nb.planes[l] = planes[l]; nb.idx[l] = idx[l]; nb.out[l] = out[l];
     nb.hw[l] = h[l] * w[l];
-    nb.sigma50[l] = (float)((double)sigma[l] / 50.0);
-    nb.nparts[l] = std::min(NZ_BLOCKS, cdiv(nb.hw[l], 256));
-    max_hw = std::max(max_hw, nb.hw[l]);
+    nb.inv_s[l] = (float)(50.0 / (double)sigma[l]);
+    nb.nparts[l] = noise_nparts(nb.hw[l]);
+    nb.wblk[l] = noise_wblk(nb.hw[l]);
+    max_wblk = std::max(max_wblk, nb.wblk[l]);
   }
   nb.i0 = i0; nb.B = B;
   if (int rc = scratch_reserve(ctx, (size_t)n * B * NZ_BLOCKS * sizeof(float))) return rc;
   float* partial = (float*)ctx->scratch;
   hipLaunchKernelGGL(noise_loop_batch_sumsq_kernel, dim3(NZ_BLOCKS, B, n), dim3(256), 0, ctx->stream, nb, partial);
-  hipLaunchKernelGGL(noise_loop_batch_write_kernel, dim3(std::min(256, cdiv(max_hw, 1024)), B, n), dim3(256), 0,
+  hipLaunchKernelGGL(noise_loop_batch_write_kernel, dim3(max_wblk, B, n), dim3(256), 0,
                      ctx->stream, nb, partial);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
