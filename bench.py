@@ -75,7 +75,7 @@ def layer_table(net):
             gflop = 2 * hin * hin * 9 * ci * co / 1e9
             byts = (hin * hin * ci + res * res * co) * 2 + res * res * 4  # bf16 in/out + f32 noise
             kern = kernel_of(ci, co, res, up)
-            if kern.startswith("modconv_hires") and up == 1:  # + fused toRGB: img write + upsampled skip read
+            if up == 1 and (kern.startswith("modconv_hires") or (co == 128 and res * res >= 4096)):  # + fused toRGB: img write + upsampled skip read
                 gflop += 2 * r * r * co * 3 / 1e9
                 byts += r * r * 12 + (r // 2) ** 2 * 12
                 if i == len(net.block_resolutions) - 1:  # last block: the features are not stored and the image
@@ -87,7 +87,8 @@ def layer_table(net):
             else:
                 rows.append((pfx, kern, gflop, byts))
         c = shapes[li - 1][2]
-        fused = kernel_of(c, c, r, 1).startswith("modconv_hires")
+        # toRGB rides on the conv1 epilogue: register-stationary kernels, and the generic kernel when Co == its N tile
+        fused = kernel_of(c, c, r, 1).startswith("modconv_hires") or (c == 128 and r * r >= 4096)
         rows.append((f"bs.{i}.torgb", "torgb(fused)" if fused else "torgb_kernel",
                      0.0 if fused else 2 * r * r * c * 3 / 1e9,
                      0.0 if fused else r * r * c * 2 + r * r * 12 + (r // 2) ** 2 * 12))

@@ -27,8 +27,17 @@ struct ConvArgs {
   int B, H, W, Ci, Co, up;
   int act;
   float alpha, gain, clamp;
+  // optional fused toRGB + upsampled skip on a conv1 layer whose channels fit one N tile (bf16, up == 1, Co == 128:
+  // modconv_rgb_fusable); rgb_out == NULL disables.  Same meaning as in HiresArgs.
+  const float* rgb_wmod;  // [B][3][Co]
+  const float* rgb_bias;  // [3]
+  const float* rgb_prev;  // [B][3][H/2][W/2] or NULL
+  float* rgb_out;         // [B][3][H][W]
+  float rgb_clamp;
+  float fir[16];
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
+bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
 
 // high-resolution specialisation (modconv_hires.hip): weights stationary in registers, persistent tile walk,
 // optional fused toRGB + skip on conv1 layers

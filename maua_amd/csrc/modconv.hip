@@ -285,8 +285,100 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     }
   }
   __syncthreads();
+  // ---- fused toRGB + upsampled skip (conv1 layers whose Co == BN, bf16): [32 px x Co] x [Co x 3(+3)] on the matrix
+  // cores, the activated bf16 outputs are the operand straight from the epilogue tile (the block's features are not
+  // re-read by a toRGB pass).  Rows 0..2 of the weight operand = bf16(hi) part of the pre-modulated RGB weights, rows
+  // 8..10 = the bf16 remainder (w = hi + lo to ~2^-17); rgb[c] = acc[row c] + acc[row 8 + c], both of which land in
+  // the h == 0 lane of the pixel.  One wave per 32-pixel sub-tile.
+  if constexpr (sizeof(T) == 2) {
+    if (a.rgb_out && wave < BM / 32) {
+      const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
+      const int mrow = wave * 32 + r;
+      const int y = ty0 + (mrow >> g.tw_log2), x = tx0 + (mrow & (tw - 1));
+      const bool px_ok = h == 0 && y < a.H && x < a.W;
+      // This phase is the workgroup's tail (nothing else hides it): every global load it needs is requested up
+      // front - the 2x2 taps of the previous image and all weight pieces - so that one memory latency is exposed
+      // instead of one per k-step plus one for the skip.
+      // upsample2d (zero-insert x2, pad (2,1,2,1), 4x4 FIR) in its 2x2 form: only the taps whose parity hits a real
+      // sample are non-zero -> rows {iy0, iy0+1}, cols {ix0, ix0+1}, filter index u = 2*iy - y + 2 (same products,
+      // same u-major order as the 16-tap correlation)
+      float pvv[3][4], pf[4];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; t4++) { pf[t4] = 0.f; pvv[0][t4] = pvv[1][t4] = pvv[2][t4] = 0.f; }
+      if (a.rgb_prev && px_ok) {
+        const int Hp = a.H >> 1, Wp = a.W >> 1;
+        const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
+        const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+          const int iy = iy0 + dy, u = 2 * iy - y + 2;
+          const bool oky = iy >= 0 && iy < Hp;
+#pragma unroll
+          for (int dx = 0; dx < 2; dx++) {
+            const int ix = ix0 + dx, v = 2 * ix - x + 2;
+            const bool ok = oky && ix >= 0 && ix < Wp;
+            const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;  // fir[u][v] takes 3 distinct values
+            pf[dy * 2 + dx] = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+            const unsigned o = ok ? (unsigned)(iy * Wp + ix) : 0u;
+            pvv[0][dy * 2 + dx] = pv[o];
+            pvv[1][dy * 2 + dx] = pv[(unsigned)(Hp * Wp) + o];
+            pvv[2][dy * 2 + dx] = pv[2u * (unsigned)(Hp * Wp) + o];
+          }
+        }
+      }
+      float4 wsrc[BN / 16][2];
+      const float* wbase = a.rgb_wmod + ((long)b * 3 + (c_rgb >= 0 ? c_rgb : 0)) * a.Co + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < BN / 16; ks++) {
+        wsrc[ks][0] = *reinterpret_cast<const float4*>(wbase + ks * 16);
+        wsrc[ks][1] = *reinterpret_cast<const float4*>(wbase + ks * 16 + 4);
+      }
+      const float rb0 = a.rgb_bias[0], rb1 = a.rgb_bias[1], rb2 = a.rgb_bias[2];
+      const float row_mask = c_rgb >= 0 ? 1.f : 0.f, lo_mask = r >= 8 ? 1.f : 0.f;
+      f32x16 racc;
+#pragma unroll
+      for (int e = 0; e < 16; e++) racc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < BN / 16; ks++) {
+        // branch-free on purpose (per-lane masks as factors): with conditionals the compiler wraps every element in
+        // its own exec-mask branch and sinks the loads into them
+        const float4 w0 = wsrc[ks][0], w1 = wsrc[ks][1];
+        float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        u32x4 wf;
+#pragma unroll
+        for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * bf2f(f2bf(wv[k]))) * row_mask;  // hi rows: w, lo rows: w - bf16(w)
+#pragma unroll
+        for (int k = 0; k < 4; k++) wf[k] = pack2bf(wv[2 * k], wv[2 * k + 1]);
+        const u32x4 av = *reinterpret_cast<const u32x4*>(epi + mrow * ES + (ks * 16 + 8 * h) * 2);
+        racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, av),
+                                                       racc, 0, 0, 0);
+      }
+      if (px_ok) {
+        float o3[3] = {racc[0] + racc[4] + rb0, racc[1] + racc[5] + rb1, racc[2] + racc[6] + rb2};
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
+        const unsigned HWl = (unsigned)(a.H * a.W);
+        if (a.rgb_prev) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float u = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) u += pvv[c][t4] * pf[t4];
+            o3[c] = u + o3[c];
+          }
+        }
+        float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
+        ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+      }
+    }
+  }
   char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ho * Wo * a.Co * (long)sizeof(T);
-  for (int p = tid; p < BM * PPP; p += NT) {
+  // (with the fused toRGB the waves that did not take part in it write the whole tile meanwhile)
+  const bool rgb_split = sizeof(T) == 2 && a.rgb_out && NT > (BM / 32) * 64;
+  const int ro_tid = rgb_split ? tid - (BM / 32) * 64 : tid, ro_nt = rgb_split ? NT - (BM / 32) * 64 : NT;
+  if (ro_tid >= 0)
+  for (int p = ro_tid; p < BM * PPP; p += ro_nt) {
     const int m = p / PPP, pc = p - m * PPP;
     const int ty = m >> g.tw_log2, tx = m & (tw - 1);
     const int gy = ty0 + ty, gx = tx0 + tx;
@@ -318,6 +410,8 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
   g.phases = a.up * a.up;
   MAUA_REQUIRE(g.halo_px <= (((BM == 128 ? 204 : 396) * (KCB / 16) + NT - 1) / NT) * (NT / (KCB / 16)),
                "modconv3x3: halo does not fit the prefetch registers");
+  MAUA_REQUIRE(!a.rgb_out || (sizeof(T) == 2 && a.up == 1 && a.Co == BN && a.rgb_wmod && a.rgb_bias),
+               "modconv3x3: fused toRGB needs bf16, up == 1 and all output channels in one N tile");
   size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
   size_t smem_epi = (size_t)BM * (BN * sizeof(T) + 16);
   size_t smem = std::max(smem_main, smem_epi);
@@ -355,6 +449,11 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
   if (cov % 128 == 0) return launch_variant<T, 2, 4, 2, 1, 3, 64>(stream, a);
   if (cov % 64 == 0) return launch_variant<T, 4, 1, 2, 2, 9, 64>(stream, a);
   return launch_variant<T, 4, 1, 2, 1, 9, 64>(stream, a);
+}
+
+// conv1 layers whose toRGB can ride on the epilogue tile: the variants with a 128-channel N tile (launch_modconv_t)
+bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W) {
+  return dtype == MAUA_BF16 && up == 1 && Co == 128 && Ci % 32 == 0 && H * W >= 4096 && (H % 2) == 0 && (W % 2) == 0;
 }
 
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {

@@ -577,6 +577,12 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+        if (c.which == 1 && n->fuse_torgb && !rs_block &&
+            modconv_rgb_fusable(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // the block's toRGB + skip in the epilogue
+          a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
+          memcpy(a.fir, n->fir, sizeof(a.fir));
+          rgb_fused = true;
+        }
         if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
       }
       prof_mark(n, c.which == 0 ? "conv0" : "conv1");

@@ -208,6 +208,12 @@ def test_full_size_network_properties_and_oracle_frame():
     L.check(L.lib().maua_synth_set_option(h, b"use_hires", 1))
     L.check(L.lib().maua_synth_set_option(h, b"tconv_up", 1))
     assert psnr(img.cpu(), img_g.cpu()) >= 45.0
+    # toRGB fused into the conv1 epilogues (register-stationary kernels at 512^2 / 1024^2, the generic kernel at 256^2
+    # where Co == its N tile) vs the stand-alone toRGB kernels: same image up to f32 summation order
+    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
+    img_nf = net(ws, noise=noise_d)
+    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 1))
+    assert float((img_nf - img).abs().max()) <= 1e-4 * float(img.max() - img.min())
     # one full-size frame against the oracle (fp32, CPU): same bar as the small bf16 nets
     nthr = torch.get_num_threads()
     torch.set_num_threads(min(32, nthr))
