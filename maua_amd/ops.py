@@ -102,6 +102,19 @@ def upsample2d(x, f, up=2, padding=0, gain=1):
     return upfirdn2d(x, f, up=up, padding=p, gain=_num(gain) * up * up)
 
 
+def matmul_nt(a, b):
+    """c [M, N] = a [M, K] @ b [N, K]^T in f32 on the HIP path (maua_matmul_nt) - F.linear without the bias.  Used for
+    the small products of the path (mapping network, cosine bases) so that no BLAS library has to be initialised."""
+    a = L.dev_tensor(a, torch.float32).contiguous()
+    b = L.dev_tensor(b, torch.float32).contiguous()
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K, (a.shape, b.shape)
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    L.check(L.lib().maua_matmul_nt(L.ctx(a.device), L.ptr(a), L.ptr(b), L.ptr(c), M, N, K))
+    return c
+
+
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     """ops.py:142-143 — a [P,512] prologue of the mapper; plain torch on the caller's device."""
     return x / ((x * x).mean(dim=dim, keepdim=True) + eps).sqrt()

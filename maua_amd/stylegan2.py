@@ -282,8 +282,9 @@ class SynthesisNetwork(torch.nn.Module):
 
 
 class MappingNetwork(torch.nn.Module):
-    """inference/stylegan2.py:116-192 (c_dim == 0).  A [P,512] x 8 plain-GEMM chain executed once per clip with
-    torch's library GEMMs on the HIP device (rocBLAS); in-tree semantics incl. the x @ w quirk."""
+    """inference/stylegan2.py:116-192 (c_dim == 0).  A [P,512] x 8 small f32 GEMM chain executed once per clip through
+    the library's own `maua_matmul_nt` (initialising a BLAS library for it would cost the clip 0.5 s); in-tree semantics
+    incl. the x @ w quirk."""
 
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, lr_multiplier=0.01, nv_compat=False,
                  generator=None):
@@ -316,7 +317,8 @@ class MappingNetwork(torch.nn.Module):
         for i in range(self.num_layers):
             w = self._params[f"fcs.{i}.weight"].to(x.device) * (self.lr_multiplier / sqrt(self._params[f"fcs.{i}.weight"].shape[1]))
             b = self._params[f"fcs.{i}.bias"].to(x.device) * self.lr_multiplier
-            y = x @ (w.T if self.nv_compat else w)
+            # F.linear(x, w) upstream; the in-tree layer multiplies by the un-transposed matrix
+            y = ops.matmul_nt(x, w if self.nv_compat else w.T)
             x = ops.bias_act(y[:, :, None, None], b, act="lrelu")[:, :, 0, 0]
         x = x.unsqueeze(1).repeat(1, self.num_ws, 1)
         if truncation_psi != 1:  # stylegan2.py:185-190: lerp towards w_avg, all ws or only the first `cutoff`
