@@ -50,6 +50,8 @@ def kernel_of(ci, co, res, up):
     if up == 2 and 32 <= hin <= 512:
         return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
     cov = co * up * up
+    if hin * hin <= 64 and ci % 64 == 0 and cov % 128 == 0:
+        return "lowres_conv_kernel<bf16> (+premod, +epilogue)"  # one profile slot covers the three launches
     if up == 1 and hin * hin <= 256 and cov % 128 == 0:
         return "modconv3x3_kernel<bf16,4,1,2,1,9,64>"
     if cov % 128 == 0:

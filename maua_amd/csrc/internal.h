@@ -39,6 +39,12 @@ struct ConvArgs {
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
 
+// lowest-resolution layers (modconv_lowres.hip, <= 8x8 input pixels per sample): the GEMM over all samples at once,
+// split-K + deterministic reduce/epilogue.  xm / ws: workspaces of at least lowres_workspace() bytes.
+bool lowres_supported(int dtype, int Ci, int Co, int up, int H, int W);
+void lowres_workspace(int dtype, int B, int H, int W, int Ci, int Co, int up, size_t* xm_bytes, size_t* ws_bytes);
+int launch_modconv_lowres(hipStream_t stream, int dtype, const ConvArgs& a, void* xm, float* ws);
+
 // high-resolution specialisation (modconv_hires.hip): weights stationary in registers, persistent tile walk,
 // optional fused toRGB + skip on conv1 layers
 struct HiresArgs {

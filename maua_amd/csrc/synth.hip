@@ -62,10 +62,13 @@ struct maua_synth {
   std::vector<RgbLayer> rgbs;
   void* const_x = nullptr;  // NHWC [4][4][C0]
   int keep_features = 0;
+  int lowres = 1;      // <= 8x8 layers as one batch-wide split-K GEMM (option "lowres")
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
+  void* lowres_xm = nullptr;   // [Bcap] modconv_lowres workspaces (premodulated input, split-K partial sums)
+  float* lowres_ws = nullptr;
   // one feature-space resize (wrappers/stylegan2.py:104-151): rs_layer = -1 none, 0 = before layer 0, L = after layer L-1
   int rs_layer = -1, rs_mode = 0, rs_th = 0, rs_tw = 0, rs_pl = 0, rs_pr = 0, rs_pt = 0, rs_pb = 0, rs_how = 3;
   float rs_value = 0.f;
@@ -147,6 +150,10 @@ static int free_workspace(maua_synth* n) {
   n->style_table_dev = nullptr;
   if (n->tbuf) hipFree(n->tbuf);
   n->tbuf = nullptr;
+  if (n->lowres_xm) hipFree(n->lowres_xm);
+  if (n->lowres_ws) hipFree(n->lowres_ws);
+  n->lowres_xm = nullptr;
+  n->lowres_ws = nullptr;
   if (n->const_rs) hipFree(n->const_rs);
   n->const_rs = nullptr;
   for (int i = 0; i < 2; i++) {
@@ -186,6 +193,15 @@ static int ensure_workspace(maua_synth* n, int B) {
   for (auto& c : n->convs)
     if (c.up == 2) max_t = std::max(max_t, (size_t)(c.oh + 1) * (c.ow + 1) * c.Co);
   if (max_t) MAUA_HIP_CHECK(hipMalloc(&n->tbuf, (size_t)B * max_t * n->esize));
+  size_t lx = 0, lw = 0;
+  for (auto& c : n->convs)
+    if (lowres_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
+      size_t x1, w1;
+      lowres_workspace(n->dtype, B, c.ih, c.iw, c.Ci, c.Co, c.up, &x1, &w1);
+      lx = std::max(lx, x1); lw = std::max(lw, w1);
+    }
+  if (lx) MAUA_HIP_CHECK(hipMalloc(&n->lowres_xm, lx));
+  if (lw) MAUA_HIP_CHECK(hipMalloc((void**)&n->lowres_ws, lw));
   for (int i = 0; i < 2; i++)
     MAUA_HIP_CHECK(hipMalloc((void**)&n->img[i], (size_t)B * 3 * std::max(n->out_h * n->out_w, n->res * n->res) * sizeof(float)));
   // style table
@@ -374,6 +390,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->ev_used = 0;
     n->ev_names.clear();
     n->ev_fwd_start.clear();
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "lowres")) {
+    n->lowres = value;
     return MAUA_OK;
   }
   if (!strcmp(key, "use_hires")) {
@@ -577,6 +597,10 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+        if (n->lowres && lowres_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
+          // <= 8x8 input pixels: one GEMM over all samples, split-K (modconv_lowres.hip)
+          if (int rc = launch_modconv_lowres(st, n->dtype, a, n->lowres_xm, n->lowres_ws)) return rc;
+        } else {
         if (c.which == 1 && n->fuse_torgb && !rs_block &&
             modconv_rgb_fusable(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // the block's toRGB + skip in the epilogue
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
@@ -584,6 +608,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           rgb_fused = true;
         }
         if (int rc = launch_modconv3x3(st, n->dtype, a)) return rc;
+        }
       }
       prof_mark(n, c.which == 0 ? "conv0" : "conv1");
       x = y;
