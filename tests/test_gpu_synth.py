@@ -224,3 +224,27 @@ def test_full_size_network_properties_and_oracle_frame():
     rng = float(ref.max() - ref.min())
     assert psnr(img[:1].cpu(), ref) >= 40.0
     assert float((img[:1].cpu() - ref).abs().max()) <= 3e-2 * rng
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_lowres_gemm_matches_per_sample_kernels(dt):
+    """<= 8x8 layers as one batch-wide split-K GEMM (default) vs the per-sample tiles of the generic kernel: same layer
+    outputs; frames stay bit-identical across batch sizes (the K slices are fixed by the layer, not by the batch)."""
+    from maua_amd import _lib as L
+    net, p = build(64, 2048, 128, dt)
+    g = torch.Generator().manual_seed(31)
+    B = 5
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g).cuda() for s in net.layer_shapes()]
+    net.keep_features(True)
+    img_l = net(ws, noise=noise).cpu()
+    feats_l = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    one = net(ws[3:4], noise=[n[3:4] for n in noise]).cpu()
+    assert torch.equal(one[0], img_l[3])
+    L.check(L.lib().maua_synth_set_option(net._handle(), b"lowres", 0))
+    img_g = net(ws, noise=noise).cpu()
+    feats_g = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    for l, (a, b) in enumerate(zip(feats_l, feats_g)):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()), f"layer {l}"
+    assert float((img_l - img_g).abs().max()) <= tol * float(img_g.abs().max())
