@@ -63,6 +63,27 @@ __device__ __forceinline__ float activate(float x, int act, float alpha) {
   return x;
 }
 
+// LDS-direct load, 16 bytes per lane: lane l of the wave fetches 16 bytes from its own global address into bytes
+// [16 l, 16 l + 16) of the 1 KB LDS slot at `lds_wave_base` (wave-uniform) - no registers in flight, no ds_write.
+// Issued from inline assembly on purpose: with the builtin the compiler's waitcnt insertion treats later LDS reads as
+// aliasing and drains vmcnt(0) before the first of them, which also waits for every prefetch issued in between.  The
+// caller orders the data itself: the request is OLDER than register loads whose consumption (counted vmcnt retires in
+// order) precedes a barrier, and the LDS data are read only after that barrier.  M0 carries the LDS base; the kernels
+// that use this do not use M0 for anything else.
+__device__ __forceinline__ void lds_dma_b128(const void* g, void* lds_wave_base) {
+  const unsigned base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(base) : "memory");
+}
+
+// same with a wave-uniform base pointer (SGPR pair) + a 32-bit per-lane byte offset: one address VGPR instead of two
+__device__ __forceinline__ void lds_dma_b128(const void* sbase, unsigned voff_bytes, void* lds_wave_base) {
+  const unsigned base =
+      __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(base)
+               : "memory");
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(const std::string& msg);  // sets the thread-local error, returns MAUA_ERR

@@ -68,13 +68,15 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
   constexpr int NT = 512, BM = 256;
   constexpr int KC = TKCB / (int)sizeof(T);
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int WREGS = (9 * 32 * TPR + NT - 1) / NT;
+  constexpr int WROW = TKCB;                          // weight rows are unpadded in LDS (LDS-direct loads are linear)
+  constexpr int WBUF = 9 * 32 * WROW;                 // one K chunk of weights: 9 [32 x KC] blocks = 18 x 1 KB
+  constexpr int WDMA = (WBUF / 1024 + 7) / 8;         // LDS-direct load instructions per wave per chunk
   constexpr int HREGS = (325 * TPR + NT - 1) / NT;   // halo <= 65*5 = 325 px (tile shapes: 9*33, 17*17, 33*9, 65*5)
   constexpr int ES = 128 * (int)sizeof(T) + 16;
   constexpr int PPP = 128 * (int)sizeof(T) / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
-  char* wt = smem + regs.halo_max * TRS;
+  char* wt = smem + regs.halo_max * TRS;  // two buffers: chunk c + 1 arrives while chunk c is multiplied
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -92,7 +94,10 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
   const int m = wave * 32 + r;
   const int pty = m >> g.tw_log2, ptx = m & (tw - 1);
   const int offa = ((pty + 1) * g.hw1 + (ptx + 1)) * TRS + h * 16;
-  const int offb = r * TRS + h * 16;
+  // B fragments: the 16-byte piece p of weight row n sits at piece p ^ ((n >> 2) & 3) - with 64-byte rows this
+  // XOR makes a quarter-wave's ds_read_b128 hit 16 distinct bank groups (the padding trick needs a non-linear fill)
+  const int swz = (r >> 2) & 3;
+  const int offb0 = r * WROW + ((h ^ swz) << 4), offb1 = r * WROW + (((h ^ swz) ^ 2) << 4);
 
   f32x16 acc[4];
 #pragma unroll
@@ -113,22 +118,28 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
       if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = (gy * a.W + gx) * a.Ci + q * EPC;
     }
   }
-  u32x4 wreg[WREGS], hreg[HREGS];
+  u32x4 hreg[HREGS];
   float sv[EPC];
-  int wrow[WREGS];
-  int wlds[WREGS];
+  // weights travel global -> LDS directly: instruction ii (0..17) fills the 1 KB slot of rows 16 ii .. 16 ii + 15, lane
+  // l supplies row 16 ii + (l >> 2), LDS piece l & 3 = logical piece (l & 3) ^ ((row >> 2) & 3); wave w issues ii = w + 8 j
+  int woff[WDMA];
 #pragma unroll
-  for (int i = 0; i < WREGS; i++) {
-    int row = rq + i * (NT / TPR);
-    if (row >= 9 * 32) row = 9 * 32 - 1;
+  for (int j = 0; j < WDMA; j++) {
+    const int ii = wave + 8 * j;
+    const int row = std::min(16 * ii + (lane >> 2), 9 * 32 - 1);
     const int k = row >> 5, n = row & 31;
-    wrow[i] = (((kTconvSlot[k] * CB + cb) * 4 + kTconvCls[k]) * 32 + n) * a.Ci + q * EPC;
-    wlds[i] = row * TRS + q * 16;
+    const int piece = (lane & 3) ^ ((row >> 2) & 3);
+    woff[j] = (((kTconvSlot[k] * CB + cb) * 4 + kTconvCls[k]) * 32 + n) * a.Ci + piece * EPC;
+  }
+#define TC_DMA_W(C0, BUF)                                                                                \
+  {                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < WDMA; j++)                                                    \
+      if (wave + 8 * j < WBUF / 1024)                                                                    \
+        lds_dma_b128(wp + (C0), (unsigned)woff[j] * (unsigned)sizeof(T), wt + (BUF) * WBUF + (wave + 8 * j) * 1024); \
   }
 
 #define TC_LOAD(C0)                                                                                     \
   {                                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < WREGS; i++) wreg[i] = *reinterpret_cast<const u32x4*>(wp + (wrow[i] + (C0))); \
     _Pragma("unroll") for (int e = 0; e < EPC; e++) sv[e] = sb[(C0) + q * EPC + e];                     \
     _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                \
       hreg[i] = u32x4{0u, 0u, 0u, 0u};                                                                  \
@@ -136,26 +147,31 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
     }                                                                                                   \
   }
 
+  // Order matters: the weight request of a chunk is issued BEFORE that chunk's register loads (styles, halo).  vmcnt
+  // retires in order, so once a wave has consumed those registers (the LDS writes at the top of the chunk) its weight
+  // pieces have landed; the barrier after the LDS writes then makes all waves' pieces visible to all.
   const int n_chunks = a.Ci / KC;
+  TC_DMA_W(0, 0)
   TC_LOAD(0)
   for (int c = 0; c < n_chunks; c++) {
+    const char* wtb = wt + (c & 1) * WBUF;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < HREGS; i++) {
       const int p = rq + i * (NT / TPR);
       if (p < g.halo_px) *reinterpret_cast<u32x4*>(halo + p * TRS + q * 16) = TMma<T>::scale(hreg[i], sv);
     }
-#pragma unroll
-    for (int i = 0; i < WREGS; i++)
-      if (rq + i * (NT / TPR) < 9 * 32) *reinterpret_cast<u32x4*>(wt + wlds[i]) = wreg[i];
     __syncthreads();
-    if (c + 1 < n_chunks) TC_LOAD((c + 1) * KC)
+    if (c + 1 < n_chunks) {
+      TC_DMA_W((c + 1) * KC, (c + 1) & 1)
+      TC_LOAD((c + 1) * KC)
+    }
 #pragma unroll
     for (int ks = 0; ks < TKCB / 32; ks++) {
       // A fragments for the four shifts (dy,dx) = (-1,-1), (-1,0), (0,-1), (0,0), each followed by the weight blocks
       // that use it (few fragments live at a time: the kernel runs at 128 VGPRs for 2 workgroups per CU)
 #define TC_A(SH) (*reinterpret_cast<const u32x4*>(halo + offa + (SH) * TRS + ks * 32))
-#define TC_B(K) (*reinterpret_cast<const u32x4*>(wt + (K) * 32 * TRS + offb + ks * 32))
+#define TC_B(K) (*reinterpret_cast<const u32x4*>(wtb + (K) * 32 * WROW + (ks == 0 ? offb0 : offb1)))
       {
         const u32x4 a0 = TC_A(-g.hw1 - 1);
         TMma<T>::step(acc[0], TC_B(0), a0);
@@ -182,6 +198,7 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
     }
   }
 #undef TC_LOAD
+#undef TC_DMA_W
 
   // ---- raw t tile -> LDS [position][class*32 + ch] -> 16-byte NHWC pieces of t [2H+1][2W+1][Co]
   const int Ht = 2 * a.H + 1, Wt = 2 * a.W + 1;
@@ -240,7 +257,7 @@ static int launch_tconv_t(hipStream_t stream, const ConvArgs& a) {
   nt += make_region(regs.r[2], a.H, 0, 1, a.W, nt);
   regs.halo_max = std::max(regs.r[0].halo_px, std::max(regs.r[1].halo_px, regs.r[2].halo_px));
   MAUA_REQUIRE(regs.halo_max <= 325, "tconv2: halo does not fit the prefetch registers");
-  size_t smem = std::max((size_t)regs.halo_max * TRS + (size_t)9 * 32 * TRS, (size_t)256 * (128 * sizeof(T) + 16));
+  size_t smem = std::max((size_t)regs.halo_max * TRS + (size_t)2 * 9 * 32 * TKCB, (size_t)256 * (128 * sizeof(T) + 16));
   auto kern = tconv2_kernel<T>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
