@@ -85,6 +85,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte piece
   constexpr int WREGS = (TG * BN * (KCB / 16) + NT - 1) / NT;         // weight pieces per thread per stage
   constexpr int HREGS = ((BM == 128 ? 204 : 396) * (KCB / 16) + NT - 1) / NT;  // halo pieces per thread per chunk (max over tile shapes)
+  // The 16-wave / 128-byte-chunk variant (the 64^2..256^2 conv1 layers) brings its weights in by LDS-direct loads: two
+  // unpadded buffers (XOR-swizzled 16-byte pieces instead of the +16 row padding, which a linear fill cannot produce)
+  // still fit next to the halo (57 + 2 x 48 KB).  No prefetch registers, no ds_writes for the weights.
+  constexpr bool DMAW = KCB == 128 && NT == 1024 && TG == 3;
+  constexpr int WBUF = TG * BN * KCB;                        // bytes of one weight stage (DMAW)
+  constexpr int WDMA = DMAW ? WBUF / 1024 / (NT / 64) : 1;   // LDS-direct load instructions per wave per stage
+  static_assert(!DMAW || WBUF % (1024 * (NT / 64)) == 0, "weight stage must split evenly over the waves");
   constexpr int ES = BN * (int)sizeof(T) + 16;               // epilogue tile row stride (bytes)
   constexpr int PPP = BN * (int)sizeof(T) / 16;              // 16-byte pieces per output pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +123,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     offa[i] = ((ty + 1) * g.hw2 + (tx + 1)) * RS + h * 16;
   }
 #pragma unroll
-  for (int j = 0; j < WN; j++) offb[j] = ((wn * WN + j) * 32 + r) * RS + h * 16;
+  for (int j = 0; j < WN; j++) offb[j] = DMAW ? ((wn * WN + j) * 32 + r) * KCB : ((wn * WN + j) * 32 + r) * RS + h * 16;
+  const int swz = (r >> 1) & 7;  // DMAW: piece p of weight row n sits at piece p ^ ((n >> 1) & 7) (conflict-free b128 reads)
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -159,6 +167,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     wlds[i] = row * RS + q * 16;
   }
   const long tap_stride = (long)CoV * a.Ci;
+  // DMAW: instruction ii (0 .. WBUF/1024) fills the 1 KB slot of rows 8 ii .. 8 ii + 7; lane l supplies row 8 ii + (l >> 3),
+  // LDS piece l & 7 = logical piece (l & 7) ^ ((row >> 1) & 7); wave w issues ii = w + 16 j
+  unsigned woff[WDMA];
+  if constexpr (DMAW) {
+#pragma unroll
+    for (int j = 0; j < WDMA; j++) {
+      const int row = 8 * (wave + (NT / 64) * j) + (lane >> 3);
+      const int t = row / BN, n = row - t * BN;
+      const int piece = (lane & 7) ^ ((row >> 1) & 7);
+      woff[j] = (unsigned)((((long)t * CoV + n0 + n) * a.Ci + piece * EPC) * (long)sizeof(T));
+    }
+  }
+#define MAUA_DMA_W(C0, TG0, BUF)                                                                          \
+  {                                                                                                       \
+    const T* wsrc_ = wp + ((long)(TG0) * tap_stride + (C0));                                              \
+    _Pragma("unroll") for (int j = 0; j < WDMA; j++)                                                     \
+      lds_dma_b128(wsrc_, woff[j], wt + (BUF) * WBUF + (wave + (NT / 64) * j) * 1024);                    \
+  }
 
 #define MAUA_LOAD_W(C0, TG0)                                                                              \
   _Pragma("unroll") for (int i = 0; i < WREGS; i++)                                                      \
@@ -184,23 +210,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 
   constexpr int NG = 9 / TG;
   const int n_chunks = a.Ci / KC;
-  MAUA_LOAD_W(0, 0)
+  // DMAW ordering: a stage's weight request is issued BEFORE the register loads of the same stage boundary; vmcnt
+  // retires in order, so consuming those registers (halo stages) - or an explicit vmcnt(0) where the request is the
+  // wave's newest memory operation (the other stages) - means the wave's pieces have landed; the barrier that follows
+  // makes every wave's pieces visible.
+  if constexpr (DMAW) { MAUA_DMA_W(0, 0, 0) } else { MAUA_LOAD_W(0, 0) }
   MAUA_LOAD_H(0)
+  int wbuf = 0;
   for (int c = 0; c < n_chunks; c++) {
     const int c0 = c * KC;
 #pragma unroll
     for (int gi = 0; gi < NG; gi++) {
       __syncthreads();  // every wave is done reading the previous stage's LDS
       if (gi == 0) MAUA_STORE_H()
-      MAUA_STORE_W()
+      if constexpr (DMAW) {
+        if (gi != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        MAUA_STORE_W()
+      }
       __syncthreads();
       // next stage's global loads fly while this stage is multiplied
       if (gi + 1 < NG) {
-        MAUA_LOAD_W(c0, (gi + 1) * TG)
+        if constexpr (DMAW) { MAUA_DMA_W(c0, (gi + 1) * TG, wbuf ^ 1) } else { MAUA_LOAD_W(c0, (gi + 1) * TG) }
       } else if (c + 1 < n_chunks) {
-        MAUA_LOAD_W(c0 + KC, 0)
+        if constexpr (DMAW) { MAUA_DMA_W(c0 + KC, 0, wbuf ^ 1) } else { MAUA_LOAD_W(c0 + KC, 0) }
         MAUA_LOAD_H(c0 + KC)
       }
+      const char* wtb = DMAW ? wt + wbuf * WBUF : wt;
+      wbuf ^= 1;
 #pragma unroll
       for (int t = 0; t < TG; t++) {
         const int tap = gi * TG + t;                       // compile-time after unrolling
@@ -212,7 +249,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 #pragma unroll
           for (int i = 0; i < WM; i++) af[i] = *reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + ks * 32);
 #pragma unroll
-          for (int j = 0; j < WN; j++) bf[j] = *reinterpret_cast<const u32x4*>(wt + t * BN * RS + offb[j] + ks * 32);
+          for (int j = 0; j < WN; j++)
+            bf[j] = DMAW ? *reinterpret_cast<const u32x4*>(wtb + t * BN * KCB + offb[j] + (((h + 2 * ks) ^ swz) << 4))
+                         : *reinterpret_cast<const u32x4*>(wtb + t * BN * RS + offb[j] + ks * 32);
 #pragma unroll
           for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -222,6 +261,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
     }
   }
 #undef MAUA_LOAD_W
+#undef MAUA_DMA_W
 #undef MAUA_LOAD_H
 #undef MAUA_STORE_W
 #undef MAUA_STORE_H
@@ -412,7 +452,8 @@ static int launch_variant(hipStream_t stream, const ConvArgs& a) {
                "modconv3x3: halo does not fit the prefetch registers");
   MAUA_REQUIRE(!a.rgb_out || (sizeof(T) == 2 && a.up == 1 && a.Co == BN && a.rgb_wmod && a.rgb_bias),
                "modconv3x3: fused toRGB needs bf16, up == 1 and all output channels in one N tile");
-  size_t smem_main = (size_t)g.halo_px * RS + (size_t)TG * BN * RS;
+  constexpr bool DMAW = KCB == 128 && NT == 1024 && TG == 3;  // as in the kernel
+  size_t smem_main = (size_t)g.halo_px * RS + (DMAW ? (size_t)2 * TG * BN * KCB : (size_t)TG * BN * RS);
   size_t smem_epi = (size_t)BM * (BN * sizeof(T) + 16);
   size_t smem = std::max(smem_main, smem_epi);
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv3x3: LDS budget exceeded");
