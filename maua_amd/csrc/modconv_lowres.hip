@@ -260,9 +260,9 @@ void lowres_workspace(int dtype, int B, int H, int W, int Ci, int Co, int up, si
 
 int launch_modconv_lowres(hipStream_t stream, int dtype, const ConvArgs& a, void* xm, float* ws) {
   MAUA_REQUIRE(lowres_supported(dtype, a.Ci, a.Co, a.up, a.H, a.W), "modconv_lowres: unsupported shape");
+  if (a.B == 0) return MAUA_OK;
   MAUA_REQUIRE(xm && ws && a.s, "modconv_lowres: NULL workspace / styles");
   MAUA_REQUIRE((long)a.B * a.H * a.W * std::max(a.Ci, a.Co * a.up * a.up) < (1L << 31), "modconv_lowres: 32-bit pixel indices");
-  if (a.B == 0) return MAUA_OK;
   if (dtype == MAUA_BF16) return launch_lowres_t<bf16_t>(stream, a, xm, ws);
   return launch_lowres_t<float>(stream, a, xm, ws);
 }
