@@ -48,6 +48,10 @@ const char* maua_last_error(void);
 int maua_ctx_create(int device, void* stream, maua_ctx** out);
 int maua_ctx_set_stream(maua_ctx* ctx, void* stream);
 int maua_ctx_sync(maua_ctx* ctx);
+/* kernel-selection switches for A/B measurements and parity tests (no reference counterpart).
+ * "dma_conv" (default 1): maua_modconv2d runs eligible shapes (bf16, 3x3, up 1, Ci % 64 == 0, Co % 128 == 0,
+ * H % 8 == 0, W % 32 == 0) on the LDS-direct-load kernel of the synthesis hot path. */
+int maua_ctx_set_option(maua_ctx* ctx, const char* key, int value);
 void maua_ctx_destroy(maua_ctx* ctx);
 
 /* ---- B1: operator layer (NCHW contiguous, like the reference tensors) --------------------------- */

@@ -108,6 +108,7 @@ struct maua_ctx {
   // grow-only scratch arena for the operator-level entry points (layout conversion, prepared weights)
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  int dma_conv = 1;  // operator-level modconv: eligible shapes run the LDS-direct-load kernel (maua_ctx_set_option)
 };
 
 namespace maua {

@@ -45,6 +45,15 @@ int maua_ctx_set_stream(maua_ctx* ctx, void* stream) {
   return MAUA_OK;
 }
 
+int maua_ctx_set_option(maua_ctx* ctx, const char* key, int value) {
+  MAUA_REQUIRE(ctx && key, "maua_ctx_set_option: NULL argument");
+  if (std::string(key) == "dma_conv") {
+    ctx->dma_conv = value;
+    return MAUA_OK;
+  }
+  return maua::fail(std::string("maua_ctx_set_option: unknown option ") + key);
+}
+
 int maua_ctx_sync(maua_ctx* ctx) {
   MAUA_REQUIRE(ctx != nullptr, "maua_ctx_sync: ctx is NULL");
   MAUA_HIP_CHECK(hipStreamSynchronize(ctx->stream));

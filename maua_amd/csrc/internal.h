@@ -35,9 +35,16 @@ struct ConvArgs {
   float* rgb_out;         // [B][3][H][W]
   float rgb_clamp;
   float fir[16];
+  int variant;            // kernel-variant selector for same-process A/B measurements (0 = default)
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
+
+// modconv_dma.hip: up = 1, bf16, input already multiplied by the styles (x * s); both operands by LDS-direct loads
+bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W);
+bool dma_rgb_fusable(int Co);
+int launch_modconv_dma(hipStream_t stream, const ConvArgs& a);
+int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci);
 
 // lowest-resolution layers (modconv_lowres.hip, <= 8x8 input pixels per sample): the GEMM over all samples at once,
 // split-K + deterministic reduce/epilogue.  xm / ws: workspaces of at least lowres_workspace() bytes.
@@ -91,6 +98,7 @@ struct UpfirArgs {
   long noise_bstride;
   float noise_strength;
   const float* bias;   // [Co] or NULL
+  const float* out_scale;  // [B][Co] or NULL: the output is multiplied by the NEXT layer's styles (modconv_dma.hip)
   int B, H, W, Co;     // H, W = INPUT grid of the layer (output is 2H x 2W)
   int act;
   float alpha, gain, clamp;

@@ -1,0 +1,428 @@
+// Modulated 3x3 convolution (up = 1, bf16) for the MFMA-bound middle of the network, built around LDS-direct loads.
+//
+// Replaces (reference): ops.py:146-186 modulated_conv2d + :189-233 conv2d_resample (up = 1 branch) + :65-84 bias_act
+// (as called from stylegan2.py:238-250), for the layers whose input has ALREADY been multiplied by the layer's styles
+// (x' = x * s[b, ci]: the reference's own w = weight * styles, moved to the other operand; the producing layer's
+// epilogue applies it for free, see upfir.hip / synth.hip).  With the modulation out of the staging path neither
+// operand needs a register on its way from HBM/L2 to LDS, and the K loop becomes a plain software pipeline:
+//
+//   stage s = (64-channel chunk c, tap t):  A = a shifted window of the halo tile of chunk c (staged once per chunk,
+//                                           re-read for the 9 taps), B = the tap's [BN x 64] weight slice
+//   * both operands arrive by global_load_lds_dwordx4 (no VGPRs in flight, no ds_write): weights two stages ahead
+//     into a 2-slot ring, the next chunk's halo spread over the first stages of the current chunk into the other of
+//     two halo buffers;
+//   * ONE barrier per stage, placed before the stage's last k-step: by then every wave has issued (and waited for)
+//     its last fragment reads of the stage, so the slot can be refilled right behind the barrier, and the first
+//     fragments of stage s+1 are requested before the last MFMAs of stage s are issued - the matrix pipe does not
+//     drain at stage boundaries;
+//   * 8 waves, each owning a (WM*32 pixels) x (WN*32 channels) accumulator block (128 x 64 for the 256-channel N
+//     tile): 0.75 ds_read_b128 per MFMA instead of the 1.5 of the 16-wave / 64 x 32 blocks of modconv.hip.
+// LDS rows are 128 bytes, unpadded (an LDS-direct load fills 1 KB linearly); the 16-byte pieces of row p sit at piece
+// index q ^ ((p >> 1) & 7), applied on the SOURCE address of the load and on the fragment read, which makes every
+// ds_read_b128 of 32 consecutive rows bank-conflict-free.  Halo pixels outside the image are not loaded: their
+// rows are zeroed once before the loop.  Layout of the 149 KB (BN = 256): W[0] | W[1] | H[0] | H[1]; the epilogue tile reuses it.
+#include "common.h"
+#include "internal.h"
+
+namespace maua {
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HW2 = TW + 2, HALO_PX = (TH + 2) * HW2;  // 8 x 32 output pixels, 10 x 34 halo
+constexpr int KCB = 128;                                                // bytes of K per LDS row = 64 bf16 channels
+constexpr int KC = 64;
+constexpr int HB = HALO_PX * KCB;                                       // one halo buffer: 43 520 B
+
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// LDS-direct loads; lds_dst must be wave-uniform (SGPR).  M0 is written in the same statement that uses it.
+__device__ __forceinline__ void dma16_v(const void* gptr, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+__device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+}  // namespace
+
+// x' = bf16(x * s): only for callers whose producer could not apply the styles (operator-level entry point, hooks)
+__global__ __launch_bounds__(256) void premod_nhwc_kernel(const bf16_t* __restrict__ x, long x_bstride,
+                                                          const float* __restrict__ s, bf16_t* __restrict__ y, int B,
+                                                          long HW, int Ci) {
+  const int ppp = Ci / 8;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * HW * ppp) return;
+  const int pc = (int)(idx % ppp);
+  const long bp = idx / ppp;
+  const long p = bp % HW;
+  const int b = (int)(bp / HW);
+  const float4 s0 = *reinterpret_cast<const float4*>(s + (long)b * Ci + pc * 8);
+  const float4 s1 = *reinterpret_cast<const float4*>(s + (long)b * Ci + pc * 8 + 4);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(x + (long)b * x_bstride + p * Ci + pc * 8);
+  u32x4 o;
+  o[0] = pack2bf(bf2f((bf16_t)(v[0] & 0xffff)) * s0.x, bf2f((bf16_t)(v[0] >> 16)) * s0.y);
+  o[1] = pack2bf(bf2f((bf16_t)(v[1] & 0xffff)) * s0.z, bf2f((bf16_t)(v[1] >> 16)) * s0.w);
+  o[2] = pack2bf(bf2f((bf16_t)(v[2] & 0xffff)) * s1.x, bf2f((bf16_t)(v[2] >> 16)) * s1.y);
+  o[3] = pack2bf(bf2f((bf16_t)(v[3] & 0xffff)) * s1.z, bf2f((bf16_t)(v[3] >> 16)) * s1.w);
+  *reinterpret_cast<u32x4*>(y + bp * Ci + pc * 8) = o;
+}
+
+int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci) {
+  MAUA_REQUIRE(Ci % 8 == 0, "premod: Ci must be a multiple of 8");
+  if (B == 0) return MAUA_OK;
+  const long n = (long)B * HW * (Ci / 8);
+  hipLaunchKernelGGL(premod_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
+                     x_bstride, s, (bf16_t*)y, B, HW, Ci);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(ConvArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
+  static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
+  constexpr int BM = TH * TW, BN = WAVES_N * WN * 32;
+  constexpr int TB = BN * KCB;                          // bytes of one tap's weight slice (BN rows)
+  constexpr int WB = TPS * TB;                          // bytes of one weight stage (TPS taps)
+  constexpr int WJ = TB / 1024 / NW;                    // weight load instructions per wave per tap
+  constexpr int HJ = (HALO_PX * 8 + NT - 1) / NT;       // halo load instructions per wave per chunk
+  constexpr int Q = 4 * TPS;                            // 32-byte k-steps per stage
+  static_assert(TB % (1024 * NW) == 0 && HJ == 6 && (TPS == 1 || TPS == 2), "stage split");
+  constexpr int OFF_H = 2 * WB;
+  constexpr int ES = BN * 2 + 16, PPP = BN / 8;         // epilogue tile row stride, 16-byte pieces per pixel
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_x = a.W >> 5;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int b = blockIdx.y, n0 = blockIdx.z * BN;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.x_bstride * 2;
+  const char* wp = reinterpret_cast<const char*>(a.w);
+
+  // ---- sources of this lane's LDS-direct loads (fixed for the whole K loop apart from the chunk offset)
+  // halo: instruction ii = wave + NW j covers pieces [64 ii, 64 ii + 64) of the [340 px][8 pieces] buffer
+  // (out-of-image pixels are never loaded: their LDS rows are zeroed once, below, and keep that value)
+  unsigned hoff[HJ];
+#pragma unroll
+  for (int j = 0; j < HJ; j++) {
+    const int P = (wave + NW * j) * 64 + lane;
+    const int hp = P >> 3, q = (P & 7) ^ ((hp >> 1) & 7);
+    const int py = (hp * 1928) >> 16;  // hp / 34 for hp < 340
+    const int px = hp - py * HW2;
+    const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    hoff[j] = 0xffffffffu;
+    if (P < HALO_PX * 8) {
+      if (in) {
+        hoff[j] = (unsigned)(((gy * a.W + gx) * a.Ci + q * 8) * 2);
+      } else {
+        *reinterpret_cast<u32x4*>(smem + OFF_H + P * 16) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + OFF_H + HB + P * 16) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  // weights: instruction ii fills rows 8 ii .. 8 ii + 7 of a tap's [BN][8 pieces] slice
+  unsigned woff[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; j++) {
+    const int row = 8 * (wave + NW * j) + (lane >> 3);
+    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    woff[j] = (unsigned)((row * a.Ci + q * 8) * 2);
+  }
+  const long tap_stride = (long)a.Co * a.Ci * 2;  // bytes between taps ([tap][Co][Ci])
+  const char* wtile = wp + (long)n0 * a.Ci * 2;
+  const int n_chunks = a.Ci / KC;
+
+  // one tap (chunk C_, tap T_) into slice J_ of weight stage buffer BUF_
+#define MAUA_ISSUE_WTAP(C_, T_, BUF_, J_)                                                                \
+  {                                                                                                      \
+    const char* ws_ = wtile + (long)(T_) * tap_stride + (long)(C_) * (KC * 2);                           \
+    _Pragma("unroll") for (int jj = 0; jj < WJ; jj++)                                                   \
+        dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024);                \
+  }
+  // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
+#define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
+  {                                                                                                      \
+    _Pragma("unroll") for (int j_ = 0; j_ < TPS; j_++) {                                                \
+      const int lp_ = ((K_) % 9) * TPS + j_;                                                             \
+      const int c_ = (CC_) + ((K_) / 9) * TPS + lp_ / 9;                                                 \
+      if (c_ < n_chunks) MAUA_ISSUE_WTAP(c_, lp_ % 9, BUF_, j_)                                          \
+    }                                                                                                    \
+  }
+#define MAUA_ISSUE_H(J_, C_)                                                                             \
+  {                                                                                                      \
+    if ((C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
+      dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (wave + NW * (J_)) * 1024); \
+  }
+
+  // ---- fragment addresses: A (pixels) from the halo, B (channels) from the weight stage
+  const int hp00 = (wm * WM + 1) * HW2 + r + 1;                          // halo pixel of block row 0, centre tap
+  const unsigned b0 = (unsigned)(((wn * WN) * 32 + r) * KCB + ((((r >> 1) & 7) ^ h) << 4));
+  // k-step Q_ of the stage at position K_ of the period starting at chunk CC_ (weight stage buffer WBUF_)
+#define MAUA_LOAD_FRAGS(AF_, BF_, CC_, K_, Q_, WBUF_)                                                    \
+  {                                                                                                      \
+    const int lp_ = (K_) * TPS + (Q_) / 4, t_ = lp_ % 9, ks_ = (Q_) % 4;                                 \
+    const int hb_ = ((CC_) + lp_ / 9) & 1;                                                               \
+    _Pragma("unroll") for (int i = 0; i < WM; i++) {                                                    \
+      const int hp_ = hpv + (i + t_ / 3 - 1) * HW2 + (t_ % 3 - 1);                                       \
+      const unsigned o_ = OFF_H + hb_ * HB + hp_ * KCB + ((((hp_ >> 1) & 7) ^ h) << 4);                  \
+      AF_[i] = *reinterpret_cast<const u32x4*>(smem + (o_ ^ (ks_ << 5)));                                \
+    }                                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < WN; j++)                                                      \
+        BF_[j] = *reinterpret_cast<const u32x4*>(smem + (WBUF_) * WB + ((Q_) / 4) * TB + j * 32 * KCB + (b0 ^ (ks_ << 5))); \
+  }
+#define MAUA_MMA(AF_, BF_)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < WM; i++) _Pragma("unroll") for (int j = 0; j < WN; j++)         \
+      mma(acc[i][j], BF_[j], AF_[i]);  /* rows = channels, columns = pixels */
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  // ---- prologue: halo of chunk 0 (and, with two taps per stage, the first third of chunk 1's), weight stages 0 and 1
+#pragma unroll
+  for (int j = 0; j < HJ; j++) MAUA_ISSUE_H(j, 0)
+  if constexpr (TPS == 2) { MAUA_ISSUE_H(0, 1) MAUA_ISSUE_H(1, 1) }
+  MAUA_ISSUE_WSTAGE(0, 0, 0)
+  MAUA_ISSUE_WSTAGE(0, 1, 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  u32x4 af[WM], bf[WN], af1[WM], bf1[WN];
+  int hpv = hp00;
+  MAUA_LOAD_FRAGS(af, bf, 0, 0, 0, 0)
+
+  // A period = 9 stages = 9 TPS taps = TPS chunks; inside it every tap offset is a compile-time constant.
+  int pp = 0;  // parity of the period index (odd number of stages per period: the weight ring flips with it)
+  for (int cc = 0; cc < n_chunks; cc += TPS, pp ^= 1) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int wbuf = pp ^ (k & 1);
+      // (opaque copy per stage: keeps the tap x row fragment addresses from being hoisted out of the loop into
+      //  registers the accumulators need)
+      asm volatile("" : "+v"(hpv));
+      // k-steps 0 .. Q-2: fragments one step ahead of the MFMAs that consume them
+#define MAUA_STEP2(Q0_)                                                                                  \
+      MAUA_LOAD_FRAGS(af1, bf1, cc, k, Q0_ + 1, wbuf)                                                    \
+      MAUA_MMA(af, bf)                                                                                   \
+      if constexpr (Q0_ + 2 < Q) {                                                                       \
+        MAUA_LOAD_FRAGS(af, bf, cc, k, Q0_ + 2, wbuf)                                                    \
+        MAUA_MMA(af1, bf1)                                                                               \
+      }
+      MAUA_STEP2(0)
+      if constexpr (TPS == 2) { MAUA_STEP2(2) MAUA_STEP2(4) }
+      MAUA_STEP2(Q - 2)
+#undef MAUA_STEP2
+      // here: MFMAs of k-steps 0 .. Q-2 issued, fragments of k-step Q-1 in af1 / bf1.
+      // Every load this wave issued behind the previous barrier (the next stage's weights, pieces of a coming halo)
+      // has landed; the barrier publishes them and tells everybody that this stage's buffers have been read for the
+      // last time.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < 9) {
+        MAUA_LOAD_FRAGS(af, bf, cc, (k + 1) % 9, 0, wbuf ^ 1)
+      } else if (cc + TPS < n_chunks) {
+        MAUA_LOAD_FRAGS(af, bf, cc + TPS, 0, 0, wbuf ^ 1)
+      }
+      MAUA_ISSUE_WSTAGE(cc, k + 2, wbuf)  // stage s+2 into the slot stage s has just finished with
+      if constexpr (TPS == 1) {
+        if (k < HJ) MAUA_ISSUE_H(k, cc + 1)
+      } else {
+        // chunk cc+1 -> H[1]: free since the previous period's last stage, first read by the second tap of stage 4
+        if (k == 0) { MAUA_ISSUE_H(2, cc + 1) MAUA_ISSUE_H(3, cc + 1) }
+        if (k == 1) MAUA_ISSUE_H(4, cc + 1)
+        if (k == 2) MAUA_ISSUE_H(5, cc + 1)
+        // chunk cc+2 -> H[0]: free once stage 4 has read tap 8, first read by the next period's stage 0
+        if (k == 4) { MAUA_ISSUE_H(0, cc + 2) MAUA_ISSUE_H(1, cc + 2) }
+        if (k == 5) { MAUA_ISSUE_H(2, cc + 2) MAUA_ISSUE_H(3, cc + 2) }
+        if (k == 6) MAUA_ISSUE_H(4, cc + 2)
+        if (k == 7) MAUA_ISSUE_H(5, cc + 2)
+        if (k == 8) { MAUA_ISSUE_H(0, cc + 3) MAUA_ISSUE_H(1, cc + 3) }
+      }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      MAUA_MMA(af1, bf1)
+    }
+  }
+#undef MAUA_ISSUE_WTAP
+#undef MAUA_ISSUE_WSTAGE
+#undef MAUA_ISSUE_H
+#undef MAUA_LOAD_FRAGS
+#undef MAUA_MMA
+
+  // ---- epilogue: demod, noise, bias, activation, gain, clamp -> LDS tile [pixel][channel] -> coalesced NHWC rows
+  const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
+  __syncthreads();  // main-loop LDS is dead from here on
+  char* epi = smem;
+  const float alpha = a.act == MAUA_ACT_LINEAR ? 1.f : a.alpha;
+  const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f;
+  const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
+#pragma unroll
+  for (int i = 0; i < WM; i++) {
+    const int ty = wm * WM + i;
+    const int m = ty * 32 + r;
+    const int gy = ty0 + ty, gx = tx0 + r;
+    float nz = 0.f;
+    if (nb) nz = nb[(long)gy * a.W + gx] * a.noise_strength;
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive channels (tile-local)
+        const int co = n0 + nl;
+        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
+        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);
+        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float v[4];
+        if (fast) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
+            t = fmaxf(t, t * alpha);
+            v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
+            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+            v[k] = t;
+          }
+        }
+        *reinterpret_cast<uint2*>(epi + m * ES + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- fused toRGB + upsampled skip (conv1 layers whose channels all sit in this N tile): [32 px x Co] x [Co x 3(+3)]
+  // on the matrix cores straight from the epilogue tile, as in modconv.hip (weights split hi + lo to ~2^-17)
+  if (a.rgb_out) {
+    const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
+    const int mrow = wave * 32 + r;  // wave w owns image row w of the tile
+    const int y = ty0 + wave, x = tx0 + r;
+    const bool px_ok = h == 0;
+    float pvv[3][4], pf[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) { pf[t4] = 0.f; pvv[0][t4] = pvv[1][t4] = pvv[2][t4] = 0.f; }
+    if (a.rgb_prev && px_ok) {
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      const float* pv = a.rgb_prev + (long)b * 3 * Hp * Wp;
+      const int iy0 = (y - 1) >> 1, ix0 = (x - 1) >> 1;
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++) {
+        const int iy = iy0 + dy, u = 2 * iy - y + 2;
+        const bool oky = iy >= 0 && iy < Hp;
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+          const int ix = ix0 + dx, v = 2 * ix - x + 2;
+          const bool ok = oky && ix >= 0 && ix < Wp;
+          const bool uh = u == 1 || u == 2, vh = v == 1 || v == 2;
+          pf[dy * 2 + dx] = !ok ? 0.f : uh ? (vh ? a.fir[5] : a.fir[4]) : (vh ? a.fir[1] : a.fir[0]);
+          const unsigned o = ok ? (unsigned)(iy * Wp + ix) : 0u;
+          pvv[0][dy * 2 + dx] = pv[o];
+          pvv[1][dy * 2 + dx] = pv[(unsigned)(Hp * Wp) + o];
+          pvv[2][dy * 2 + dx] = pv[2u * (unsigned)(Hp * Wp) + o];
+        }
+      }
+    }
+    const float* wbase = a.rgb_wmod + ((long)b * 3 + (c_rgb >= 0 ? c_rgb : 0)) * a.Co + 8 * h;
+    const float rb0 = a.rgb_bias[0], rb1 = a.rgb_bias[1], rb2 = a.rgb_bias[2];
+    const float row_mask = c_rgb >= 0 ? 1.f : 0.f, lo_mask = r >= 8 ? 1.f : 0.f;
+    f32x16 racc;
+#pragma unroll
+    for (int e = 0; e < 16; e++) racc[e] = 0.f;
+#pragma unroll 8
+    for (int ks = 0; ks < BN / 16; ks++) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wbase + ks * 16);
+      const float4 w1 = *reinterpret_cast<const float4*>(wbase + ks * 16 + 4);
+      float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      u32x4 wf;
+#pragma unroll
+      for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * bf2f(f2bf(wv[k]))) * row_mask;  // hi rows: w, lo rows: w - bf16(w)
+#pragma unroll
+      for (int k = 0; k < 4; k++) wf[k] = pack2bf(wv[2 * k], wv[2 * k + 1]);
+      const u32x4 av = *reinterpret_cast<const u32x4*>(epi + mrow * ES + (ks * 16 + 8 * h) * 2);
+      racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, av), racc, 0,
+                                                     0, 0);
+    }
+    if (px_ok) {
+      float o3[3] = {racc[0] + racc[4] + rb0, racc[1] + racc[5] + rb1, racc[2] + racc[6] + rb2};
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (a.rgb_clamp >= 0.f) o3[c] = fminf(fmaxf(o3[c], -a.rgb_clamp), a.rgb_clamp);
+      const unsigned HWl = (unsigned)(a.H * a.W);
+      if (a.rgb_prev) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          float u = 0.f;
+#pragma unroll
+          for (int t4 = 0; t4 < 4; t4++) u += pvv[c][t4] * pf[t4];
+          o3[c] = u + o3[c];
+        }
+      }
+      float* ob = a.rgb_out + (long)b * 3 * HWl + (unsigned)(y * a.W + x);
+      ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+    }
+  }
+  char* yb = reinterpret_cast<char*>(a.y) + (long)b * a.H * a.W * a.Co * 2;
+  for (int p = tid; p < BM * PPP; p += NT) {
+    const int m = p / PPP, pc = p - m * PPP;
+    const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
+    *reinterpret_cast<uint4*>(yb + (pix * a.Co + n0 + pc * 8) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
+  }
+}
+
+bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
+  return dtype == MAUA_BF16 && up == 1 && Ci % KC == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN>
+static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
+  constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+  const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KCB + 2 * HB, (size_t)TH * TW * (BN * 2 + 16));
+  MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
+  MAUA_REQUIRE((a.Ci / KC) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
+  MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, PIN>;
+  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// a.x must already carry the styles (x * s[b, ci]); a.s is not read
+int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
+  MAUA_REQUIRE(dma_conv_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_dma: unsupported shape");
+  MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");
+  if (a.B == 0) return MAUA_OK;
+  MAUA_REQUIRE((long)a.H * a.W * a.Ci * 2 < (1L << 32), "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
+  const bool two = (a.Ci / KC) % 2 == 0;
+  if (a.variant == 2) {  // experiment arm
+    if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 1>(stream, a);
+    if (two) return launch_dma_variant<4, 2, 2, 2, 2, 1>(stream, a);
+    return launch_dma_variant<4, 2, 2, 2, 1, 1>(stream, a);
+  }
+  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 0>(stream, a);
+  if (two) return launch_dma_variant<4, 2, 2, 2, 2, 0>(stream, a);
+  return launch_dma_variant<4, 2, 2, 2, 1, 0>(stream, a);
+}
+
+bool dma_rgb_fusable(int Co) { return Co == 128 || Co == 256; }
+
+}  // namespace maua

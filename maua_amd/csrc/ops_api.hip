@@ -62,6 +62,8 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   size_t o_x = carve((size_t)N * H * W * Cip * es), o_y = carve((size_t)N * Ho * Wo * Cop * es);
   size_t o_w = carve(wt_elems * es), o_wsq = carve((size_t)Co * Ci * 4), o_s = carve((size_t)N * Cip * 4);
   size_t o_d = carve((size_t)N * Cop * 4), o_b = carve((size_t)Cop * 4);
+  const bool dma = ctx->dma_conv && k == 3 && dma_conv_supported(dtype, Cip, Cop, up, H, W);
+  size_t o_xm = dma ? carve((size_t)N * H * W * Cip * es) : 0;
   if (int rc = scratch_reserve(ctx, off)) return rc;
   char* base = (char*)ctx->scratch;
   hipStream_t st = ctx->stream;
@@ -96,7 +98,13 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   a.noise = noise; a.noise_bstride = noise_batch_stride; a.noise_strength = noise_strength;
   a.bias = bp; a.y = yn; a.B = N; a.H = H; a.W = W; a.Ci = Cip; a.Co = Cop; a.up = up;
   a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
-  if ((rc = launch_modconv3x3(st, dtype, a))) return rc;
+  if (dma) {  // the hot path's kernel for this shape: styles applied to the input first (there the producer does it)
+    if ((rc = launch_premod_nhwc(st, xn, a.x_bstride, sp, base + o_xm, N, (long)H * W, Cip))) return rc;
+    a.x = base + o_xm;
+    if ((rc = launch_modconv_dma(st, a))) return rc;
+  } else if ((rc = launch_modconv3x3(st, dtype, a))) {
+    return rc;
+  }
   return dtype == MAUA_BF16 ? launch_nhwc_to_nchw<bf16_t, bf16_t>(st, yn, y, N, Co, Ho * Wo, Cop)
                             : launch_nhwc_to_nchw<float, float>(st, yn, y, N, Co, Ho * Wo, Cop);
 }

@@ -66,6 +66,7 @@ struct maua_synth {
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
+  int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
   void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
   void* lowres_xm = nullptr;   // [Bcap] modconv_lowres workspaces (premodulated input, split-K partial sums)
   float* lowres_ws = nullptr;
@@ -112,6 +113,7 @@ static void compute_dims(maua_synth* n) {
   if (n->rs_layer == 0) { h = n->rs_th; w = n->rs_tw; }
   size_t li = 0;
   bool rgb8_done = false;
+  bool x_premod = false;  // the current x already carries the styles of the layer that reads it (modconv_dma.hip)
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     for (int k = 0; k < nconv; k++, li++) {
@@ -404,6 +406,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->tconv_up = value;
     return MAUA_OK;
   }
+  if (!strcmp(key, "dma_conv")) {
+    n->dma_conv = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "fuse_torgb")) {
     n->fuse_torgb = value;
     return MAUA_OK;
@@ -535,6 +541,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   int img_cur = 0;
   size_t li = 0;
   bool rgb8_done = false;
+  bool x_premod = false;  // the current x already carries the styles of the layer that reads it (modconv_dma.hip)
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     RgbLayer& g = n->rgbs[blk];
@@ -557,13 +564,40 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       const bool via_tconv = c.up == 2 && n->tconv_up && !hires_up && hin >= (n->tconv_up == 1 ? 32 : 1) &&
                              hin_max <= tconv_max;
       const bool rs_block = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;  // toRGB needs the hook path
-      if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
+      // a translate / zoom / rotate hook on this layer replaces its output before toRGB reads it: no fused toRGB then
+      bool warped = false;
+      for (int wsl = 0; wsl < 3; wsl++) warped = warped || (n->warp_layer[wsl] == (int)li + 1 && n->warp_minv[wsl]);
+      const bool fuse_rgb_ok = c.which == 1 && n->fuse_torgb && !rs_block && !warped;
+      // does the conv1 that follows this up-layer take pre-modulated input?  (then the epilogue below multiplies the
+      // output by that layer's styles; nothing else reads an up-layer's output)
+      const bool premod_in = x_premod;
+      x_premod = false;
+      bool premod_out = false;
+      if (via_tconv && n->dma_conv && !hooked && !warped && !n->keep_features && c.which == 0 && li + 1 < n->convs.size()) {
+        const ConvLayer& nx = n->convs[li + 1];
+        premod_out = nx.block == blk && dma_conv_supported(n->dtype, nx.Ci, nx.Co, nx.up, nx.ih, nx.iw);
+      }
+      if (premod_in) {
+        ConvArgs a{};
+        a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = nullptr; a.d = c.d;
+        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength;
+        a.bias = c.bias; a.y = y;
+        a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 1;
+        a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
+        if (fuse_rgb_ok && dma_rgb_fusable(c.Co) && (c.ih % 2) == 0 && (c.iw % 2) == 0) {
+          a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
+          memcpy(a.fir, n->fir, sizeof(a.fir));
+          rgb_fused = true;
+        }
+        a.variant = n->dma_conv;
+        if (int rc = launch_modconv_dma(st, a)) return rc;
+      } else if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};
         a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
         a.noise_strength = nz_strength; a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
-        if (c.which == 1 && n->fuse_torgb && !rs_block) {  // conv1: the block's toRGB + skip rides on the epilogue tile
+        if (fuse_rgb_ok) {  // conv1: the block's toRGB + skip rides on the epilogue tile
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;
@@ -588,6 +622,10 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         UpfirArgs u{};
         u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
         u.bias = c.bias; u.B = B; u.H = c.ih; u.W = c.iw; u.Co = c.Co;
+        if (premod_out) {
+          u.out_scale = n->convs[li + 1].s;
+          x_premod = true;
+        }
         u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
         if (int rc = launch_upfir_epilogue(st, n->dtype, u)) return rc;
       } else {
@@ -601,8 +639,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           // <= 8x8 input pixels: one GEMM over all samples, split-K (modconv_lowres.hip)
           if (int rc = launch_modconv_lowres(st, n->dtype, a, n->lowres_xm, n->lowres_ws)) return rc;
         } else {
-        if (c.which == 1 && n->fuse_torgb && !rs_block &&
-            modconv_rgb_fusable(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // the block's toRGB + skip in the epilogue
+        if (fuse_rgb_ok && modconv_rgb_fusable(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // the block's toRGB + skip in the epilogue
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;

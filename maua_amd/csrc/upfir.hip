@@ -53,7 +53,8 @@ __device__ __forceinline__ void upfir_hrow(const char* __restrict__ tb, uint32_t
 template <typename T, bool LRELU, int EP2>
 __device__ __forceinline__ void upfir_emit(const UpfirArgs& a, char* __restrict__ yb, const float* __restrict__ nb,
                                            bool rowok, uint32_t yoff, uint32_t pxb, uint32_t noff,
-                                           const f32x2_t (&dv)[EP2], const f32x2_t (&bv)[EP2], float nzs, float cl,
+                                           const f32x2_t (&dv)[EP2], const f32x2_t (&bv)[EP2],
+                                           const f32x2_t (&sv)[EP2], float nzs, float cl,
                                            const f32x2_t (&r0)[2][EP2], const f32x2_t (&r1)[2][EP2],
                                            const f32x2_t (&r2)[2][EP2], const f32x2_t (&r3)[2][EP2]) {
   if (!rowok) return;
@@ -76,7 +77,8 @@ __device__ __forceinline__ void upfir_emit(const UpfirArgs& a, char* __restrict_
       } else {
         t = f32x2_t{activate(t[0], a.act, a.alpha), activate(t[1], a.act, a.alpha)} * a.gain;
       }
-      o[e] = f32x2_t{__builtin_amdgcn_fmed3f(t[0], -cl, cl), __builtin_amdgcn_fmed3f(t[1], -cl, cl)};
+      // (sv: the NEXT layer's styles when its kernel wants pre-modulated input, else 1)
+      o[e] = f32x2_t{__builtin_amdgcn_fmed3f(t[0], -cl, cl), __builtin_amdgcn_fmed3f(t[1], -cl, cl)} * sv[e];
     }
     char* dst = yb + yoff + j * pxb;
     if constexpr (sizeof(T) == 2)
@@ -110,9 +112,12 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
   const uint32_t trb = (uint32_t)Wt * pxb, yrb = (uint32_t)Wo * pxb;
   const bool lok = X0 > 0, rok = X0 + 3 < Wt;
 
-  f32x2_t dv[EP2], bv[EP2];
+  f32x2_t dv[EP2], bv[EP2], sv[EP2];
 #pragma unroll
   for (int e4 = 0; e4 < EPC; e4 += 4) {
+    const float4 s4 = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + (long)b * a.Co + cho + e4)
+                                  : make_float4(1.f, 1.f, 1.f, 1.f);
+    sv[e4 / 2] = f32x2_t{s4.x, s4.y}; sv[e4 / 2 + 1] = f32x2_t{s4.z, s4.w};
     const float4 d4 = a.d ? *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + cho + e4)
                           : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + cho + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -139,13 +144,13 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
   const int yend = min(Y0 + UPFIR_ROWS, Ho);
   for (int yo = Y0; yo < yend; yo += 4) {
     upfir_hrow<T, EP2>(tb, toff, pxb, yo + 2 < Ht, lok, rok, h3);
-    upfir_emit<T, LRELU, EP2>(a, yb, nb, true, yoff, pxb, noff, dv, bv, nzs, cl, h0, h1, h2, h3);
+    upfir_emit<T, LRELU, EP2>(a, yb, nb, true, yoff, pxb, noff, dv, bv, sv, nzs, cl, h0, h1, h2, h3);
     upfir_hrow<T, EP2>(tb, toff + trb, pxb, yo + 3 < Ht, lok, rok, h0);
-    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 1 < Ho, yoff + yrb, pxb, noff + Wo, dv, bv, nzs, cl, h1, h2, h3, h0);
+    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 1 < Ho, yoff + yrb, pxb, noff + Wo, dv, bv, sv, nzs, cl, h1, h2, h3, h0);
     upfir_hrow<T, EP2>(tb, toff + 2 * trb, pxb, yo + 4 < Ht, lok, rok, h1);
-    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 2 < Ho, yoff + 2 * yrb, pxb, noff + 2 * Wo, dv, bv, nzs, cl, h2, h3, h0, h1);
+    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 2 < Ho, yoff + 2 * yrb, pxb, noff + 2 * Wo, dv, bv, sv, nzs, cl, h2, h3, h0, h1);
     upfir_hrow<T, EP2>(tb, toff + 3 * trb, pxb, yo + 5 < Ht, lok, rok, h2);
-    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 3 < Ho, yoff + 3 * yrb, pxb, noff + 3 * Wo, dv, bv, nzs, cl, h3, h0, h1, h2);
+    upfir_emit<T, LRELU, EP2>(a, yb, nb, yo + 3 < Ho, yoff + 3 * yrb, pxb, noff + 3 * Wo, dv, bv, sv, nzs, cl, h3, h0, h1, h2);
     toff += 4 * trb;
     yoff += 4 * yrb;
     noff += 4 * Wo;
@@ -156,6 +161,7 @@ int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a) {
   if (a.B == 0) return MAUA_OK;
   const int epc = dtype == MAUA_BF16 ? 8 : 4;
   MAUA_REQUIRE(a.Co % epc == 0, "upfir_epilogue: Co must be a multiple of the 16-byte piece");
+  MAUA_REQUIRE(!a.out_scale || ((uintptr_t)a.out_scale % 16) == 0, "upfir_epilogue: out_scale must be 16-byte aligned");
   MAUA_REQUIRE((!a.d || ((uintptr_t)a.d % 16) == 0) && (!a.bias || ((uintptr_t)a.bias % 16) == 0),
                "upfir_epilogue: d and bias must be 16-byte aligned");
   MAUA_REQUIRE(!a.noise || (((uintptr_t)a.noise % 8) == 0 && a.noise_bstride % 2 == 0),
