@@ -32,6 +32,13 @@ def generate_audiovisal_from_patch(audio_file: str, model_file: str, patch_file:
     def postprocess(video):
         return patch.force_output_size(patch.process_outputs(video))
 
+    # the renderers may pack u8 frames inside the synthesis call only when this closure changes nothing: the patch keeps
+    # the base classes' identity process_outputs (force_output_size is a no-op at the rendered size, which the
+    # renderer checks itself)
+    from .patches.base.stylegan2 import StyleGAN2Patch
+    po = getattr(type(patch), "process_outputs", None)
+    postprocess.identity_at_native_size = po is None or po is getattr(StyleGAN2Patch, "process_outputs")
+
     kwargs = dict(renderer_kwargs)
     if renderer == "ffmpeg":  # the writer muxes the clip's audio back in when it can read it (WAV)
         kwargs.update(fps=patch.fps,

@@ -27,7 +27,10 @@ class FFMPEG(Renderer):
             for i in range(lo, hi, self.batch_size):
                 b = min(self.batch_size, hi - i)
                 u8 = torch.empty((b, H, W, 3), dtype=torch.uint8, device="cuda")
-                if (rh, rw) == (H, W):  # the u8 frame is packed inside the synthesis call
+                # the u8 frame is packed inside the synthesis call only when the caller's postprocess is known to be
+                # the identity at this size; the reference always runs postprocess(frame_batch) first (:72-73)
+                identity = postprocess is None or getattr(postprocess, "identity_at_native_size", False)
+                if (rh, rw) == (H, W) and identity:
                     synthesizer(**batch_inputs(inputs, i, b), rgb8_out=u8)
                 else:
                     # output_size was rounded to the resize layer's multiple: render/ffmpeg.py:72-73 — frames in

@@ -83,7 +83,7 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
   return MAUA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN, int ABL = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
   }
   // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
 #define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
-  {                                                                                                      \
+  if (ABL != 1 || (K_) < 2) {                                                                            \
     _Pragma("unroll") for (int j_ = 0; j_ < TPS; j_++) {                                                \
       const int lp_ = ((K_) % 9) * TPS + j_;                                                             \
       const int c_ = (CC_) + ((K_) / 9) * TPS + lp_ / 9;                                                 \
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
   }
 #define MAUA_ISSUE_H(J_, C_)                                                                             \
   {                                                                                                      \
-    if ((C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
+    if ((ABL != 1 || (C_) == 0) && (C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
       dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (wave + NW * (J_)) * 1024); \
   }
 
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
   const unsigned b0 = (unsigned)(((wn * WN) * 32 + r) * KCB + ((((r >> 1) & 7) ^ h) << 4));
   // k-step Q_ of the stage at position K_ of the period starting at chunk CC_ (weight stage buffer WBUF_)
 #define MAUA_LOAD_FRAGS(AF_, BF_, CC_, K_, Q_, WBUF_)                                                    \
-  {                                                                                                      \
+  if (ABL != 3 || ((CC_) == 0 && (K_) == 0 && (Q_) < 2)) {                                               \
     const int lp_ = (K_) * TPS + (Q_) / 4, t_ = lp_ % 9, ks_ = (Q_) % 4;                                 \
     const int hb_ = ((CC_) + lp_ / 9) & 1;                                                               \
     _Pragma("unroll") for (int i = 0; i < WM; i++) {                                                    \
@@ -231,8 +231,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
       // Every load this wave issued behind the previous barrier (the next stage's weights, pieces of a coming halo)
       // has landed; the barrier publishes them and tells everybody that this stage's buffers have been read for the
       // last time.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if constexpr (ABL != 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       if (k + 1 < 9) {
         MAUA_LOAD_FRAGS(af, bf, cc, (k + 1) % 9, 0, wbuf ^ 1)
@@ -391,14 +393,14 @@ bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return dtype == MAUA_BF16 && up == 1 && Ci % KC == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN, int ABL = 0>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
   const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KCB + 2 * HB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
   MAUA_REQUIRE((a.Ci / KC) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, PIN>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, PIN, ABL>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -413,6 +415,11 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   if (a.B == 0) return MAUA_OK;
   MAUA_REQUIRE((long)a.H * a.W * a.Ci * 2 < (1L << 32), "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
   const bool two = (a.Ci / KC) % 2 == 0;
+  if (a.variant >= 3 && a.variant <= 5 && a.Co % 256 == 0) {  // ablation arms (wrong results, timing only)
+    if (a.variant == 3) return launch_dma_variant<2, 4, 4, 2, 1, 0, 1>(stream, a);
+    if (a.variant == 4) return launch_dma_variant<2, 4, 4, 2, 1, 0, 2>(stream, a);
+    return launch_dma_variant<2, 4, 4, 2, 1, 0, 3>(stream, a);
+  }
   if (a.variant == 2) {  // experiment arm
     if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 1>(stream, a);
     if (two) return launch_dma_variant<4, 2, 2, 2, 2, 1>(stream, a);

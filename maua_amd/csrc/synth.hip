@@ -518,7 +518,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   int max_c = 0;
   for (auto& c : n->convs) max_c = std::max(max_c, std::max(c.Ci, c.Co));
   // events accumulate across forwards until maua_synth_get_profile() reads and resets them
-  n->ev_fwd_start.push_back(n->ev_used);
+  if (n->profile) n->ev_fwd_start.push_back(n->ev_used);
   prof_mark(n, "begin");
   if (int rc = launch_styles(st, n->style_table_dev, ntab, ws, n->num_ws, n->w_dim, B, max_c)) return rc;
 

@@ -107,10 +107,17 @@ class SynthesisNetwork(torch.nn.Module):
         self._net_device = None
         self._keep_features = False
         self._resize = None  # feature-space resize spec (set_resize), re-applied when the device object is rebuilt
+        # noise buffers of the layers the resize re-sized: kept apart from _params, which always hold the network's
+        # own (native-size) noise_const, so that set_resize(None) / a second resize / a rebuilt device object all
+        # find the right tensors to upload
+        self._resized_noise = {}
 
     # -- parameters ------------------------------------------------------------------------------------
     def state_dict(self, *a, **k):
-        return dict(self._params)
+        """Parameters as the device object holds them: after a feature-space resize the later layers' noise_const
+        entries are the re-sized buffers, as in the reference (wrappers/stylegan2.py:141-146 replaces the modules'
+        buffers); the network's own buffers come back with set_resize(None)."""
+        return {**self._params, **self._resized_noise}
 
     def load_state_dict(self, sd, strict=True):
         missing = [k for k in self._params if k not in sd]
@@ -165,6 +172,7 @@ class SynthesisNetwork(torch.nn.Module):
             self._net, self._net_device = net, dev
             if self._resize is not None:
                 self._apply_resize()
+                self._upload_noise(None)
         else:
             L.ctx(dev)  # re-bind torch's current stream
         return self._net
@@ -180,8 +188,10 @@ class SynthesisNetwork(torch.nn.Module):
         ``noise_generator`` (wrappers/stylegan2.py:139-150).  ``layer=None`` removes the resize."""
         if layer is None:
             self._resize = None
+            self._resized_noise = {}
             if self._net is not None:
                 L.check(L.lib().maua_synth_set_resize(self._net, -1, 0, 0, 0, 0, 0, 0, 0, 3, C.c_float(0.0), None))
+                self._upload_noise(None)  # the device re-allocated (zeroed) the buffers whose size changed back
             return
         fn = None if fill_noise is None else np.ascontiguousarray(fill_noise.detach().float().cpu().numpy())
         self._resize = dict(layer=int(layer), mode={"stretch": 0, "pad": 1}[mode], th=int(target[0]), tw=int(target[1]),
@@ -189,16 +199,37 @@ class SynthesisNetwork(torch.nn.Module):
                             how={"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}[pad_how],
                             value=float(pad_value), fill=fn)
         if self._net is not None or torch.cuda.is_available():
-            self._handle() if self._net is None else self._apply_resize()
-            # fresh noise buffers for the layers whose size changed
-            for l, (pfx, _, _, _, _) in enumerate(self.layer_shapes()):
-                h, w = self.layer_size(l)
-                if tuple(self._params[pfx + ".noise_const"].shape) != (h, w):
+            if self._net is None:
+                self._handle()  # builds the object, applies the resize and uploads what noise there is
+            else:
+                self._apply_resize()
+            self._upload_noise(noise_generator)
+
+    def _upload_noise(self, noise_generator):
+        """After every maua_synth_set_resize: (re-)upload the noise buffer of every layer - the network's own
+        noise_const where the layer runs at its native size, a resized layer's buffer otherwise (drawn fresh from
+        ``noise_generator`` when there is none of the right size yet, wrappers/stylegan2.py:139-150)."""
+        for l, (pfx, _, _, res, _) in enumerate(self.layer_shapes()):
+            h, w = self.layer_size(l)
+            key = pfx + ".noise_const"
+            if (h, w) == (res, res):
+                nz = self._params[key]
+                self._resized_noise.pop(key, None)
+            else:
+                nz = self._resized_noise.get(key)
+                if nz is None or tuple(nz.shape) != (h, w):
                     nz = torch.randn((h, w), generator=noise_generator)
-                    self._params[pfx + ".noise_const"] = nz
-                    a = np.ascontiguousarray(nz.numpy(), dtype=np.float32)
-                    L.check(L.lib().maua_synth_load(self._net, (pfx + ".noise_const").encode(),
-                                                    a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+                    self._resized_noise[key] = nz
+            a = np.ascontiguousarray(nz.numpy(), dtype=np.float32)
+            L.check(L.lib().maua_synth_load(self._net, key.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+
+    def clone(self):
+        """An independent network with the same parameters (own device object, own resize state): what every wrapper
+        built from one cached checkpoint gets."""
+        other = SynthesisNetwork(self.w_dim, self.img_resolution, self.img_channels, self.channel_base, self.channel_max,
+                                 dtype=self.dtype, nv_compat=self.nv_compat)
+        other._params = dict(self._params)
+        return other
 
     def _apply_resize(self):
         r = self._resize
@@ -304,9 +335,17 @@ class MappingNetwork(torch.nn.Module):
         return dict(self._params)
 
     def load_state_dict(self, sd, strict=True):
+        # strict like torch's: a conditional checkpoint (embed.*, fc0 fed with z_dim + embedding) must not load into
+        # this unconditional network silently
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and unexpected:
+            raise KeyError(f"unexpected mapping-network keys {unexpected[:4]} (conditional networks are not supported)")
         for k in self._params:
             if k in sd:
-                self._params[k] = sd[k].detach().float().cpu()
+                v = sd[k].detach().float().cpu()
+                if tuple(v.shape) != tuple(self._params[k].shape):
+                    raise ValueError(f"mapping.{k}: shape {tuple(v.shape)} != {tuple(self._params[k].shape)}")
+                self._params[k] = v
             elif strict:
                 raise KeyError(k)
 
@@ -432,7 +471,7 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
             self.G_synth = SynthesisNetwork(w_dim=512, img_resolution=img_resolution, img_channels=3, dtype=dtype,
                                             generator=generator)
         else:
-            self.G_synth = _load_generator(model_file, inference, dtype).synthesis
+            self.G_synth = _load_generator(model_file, inference, dtype).synthesis.clone()
         R = self.G_synth.img_resolution
         if output_size is None:
             output_size = (R, R)
@@ -492,11 +531,25 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
         M = torch.as_tensor(matrix, dtype=torch.float32).reshape(-1, 2, 3).cpu()
         A, t = M[:, :, :2], M[:, :, 2:]
         Ainv = torch.linalg.inv(A)
-        minv = L.dev_tensor(torch.cat([Ainv, -Ainv @ t], dim=2).reshape(-1, 6).contiguous(), torch.float32)
+        minv = torch.cat([Ainv, -Ainv @ t], dim=2).reshape(-1, 6).contiguous()
         if not hasattr(self, "_warps"):
             self._warps = {}
-        self._warps[slot] = minv  # keeps the device buffer alive
-        L.check(L.lib().maua_synth_set_warp(self.G_synth._handle(), slot, int(layer), L.ptr(minv)))
+        # layer_names[0] and [1] both name bs.0.conv1 (the reference lists every block twice): a hook on either lands
+        # on synthesis layer 1
+        self._warps[slot] = dict(layer=max(1, int(layer)), host=minv, dev=None)
+        self._install_warp(slot, len(minv))
+
+    def _install_warp(self, slot, B):
+        """Upload slot's matrices for a batch of B frames: one row per frame; a single row is broadcast (the kernel
+        reads B rows); any other count is an error instead of an out-of-bounds read."""
+        w = self._warps[slot]
+        n = len(w["host"])
+        if n != B and n != 1:
+            raise ValueError(f"transform hook holds {n} matrices, the batch has {B} frames")
+        rows = w["host"] if n == B else w["host"].expand(B, 6).contiguous()
+        if w["dev"] is None or len(w["dev"]) != B:
+            w["dev"] = L.dev_tensor(rows, torch.float32)  # (kept alive here: the library stores the pointer)
+            L.check(L.lib().maua_synth_set_warp(self.G_synth._handle(), slot, w["layer"], L.ptr(w["dev"])))
 
     def _layer_hw(self, layer):
         h, w = self.G_synth.layer_size(layer - 1)
@@ -546,6 +599,8 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
             self.apply_zoom(zoom_layer, zoom, zoom_center)
         if rotation is not None:
             self.apply_rotation(rotation_layer, rotation, rotation_center)
+        for slot in getattr(self, "_warps", {}):  # hooks persist across calls: re-check them against this batch
+            self._install_warp(slot, len(latents))
         # noise kwargs are consumed in dict order as layer 0..16 (wrappers/stylegan2.py:86-100)
         nz = list(noise.values()) if noise else None
         return self.G_synth.forward(latents, noise_mode="const", noise=nz, rgb8_out=rgb8_out)

@@ -124,3 +124,35 @@ def test_generate_non_native_size(wav, tmp_path, monkeypatch):
         assert meta["frames"] == 32 and (meta["width"], meta["height"]) == (200, 136)
         raw = np.fromfile(out + ".rgb24", dtype=np.uint8).reshape(32, 136, 200, 3)
         assert raw.std() > 1.0
+
+
+def test_ffmpeg_renderer_runs_the_patch_postprocess(wav, tmp_path, monkeypatch):
+    """(advisor, round 1) A patch that overrides process_outputs is honoured at the native size too: the renderer
+    packs u8 inside the synthesis call only when the postprocess is known to be the identity (the reference always
+    calls postprocess(frame_batch) before writing, render/ffmpeg.py:72-73)."""
+    import os
+    import shutil
+    from maua_amd.audiovisual.generate import generate_audiovisal_from_patch
+    if shutil.which("ffmpeg"):
+        pytest.skip("compares the raw-frame fallback of the writer")
+    monkeypatch.chdir(tmp_path)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(repo)
+    os.symlink(os.path.join(repo, "maua_amd"), tmp_path / "maua_amd")
+    (tmp_path / "inv_patch.py").write_text(
+        "from maua_amd.audiovisual.patches.examples.stylegan2 import ExampleSG2Patch\n"
+        "class Inverted(ExampleSG2Patch):\n"
+        "    def process_outputs(self, video):\n"
+        "        return 1 - video\n")
+    common = dict(audio_file=wav, model_file="None", patch_name=None, fps=30, out_size=(256, 256),
+                  resize_strategy="pad-zero", resize_layer=0, renderer="ffmpeg")
+    torch.manual_seed(0)
+    plain = generate_audiovisal_from_patch(patch_file="maua_amd/audiovisual/patches/examples/stylegan2.py",
+                                           renderer_kwargs=dict(output_file=str(tmp_path / "a.mp4")), **common)[0]
+    torch.manual_seed(0)
+    inv = generate_audiovisal_from_patch(patch_file=str(tmp_path / "inv_patch.py"),
+                                         renderer_kwargs=dict(output_file=str(tmp_path / "b.mp4")), **common)[0]
+    a = np.fromfile(plain + ".rgb24", dtype=np.uint8).astype(int)
+    b = np.fromfile(inv + ".rgb24", dtype=np.uint8).astype(int)
+    assert a.shape == b.shape and a.std() > 1.0
+    assert np.abs((255 - a) - b).max() <= 1

@@ -127,6 +127,53 @@ def test_wrapper_output_size_and_noise_kwargs():
     assert G.output_hw == (64, 64)
 
 
+def test_resize_state_survives_repeats_and_is_per_instance(tmp_path):
+    """(advisor, round 1) host and device noise stay in step: the same non-native size twice, back to native, a rebuilt
+    device object and two wrappers over one cached checkpoint all give the images they should."""
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer, SynthesisNetwork
+    from oracle import stylegan2 as OS
+    gen = torch.Generator().manual_seed(2)
+    syn = StyleGAN2Synthesizer(None, False, (64, 64), "stretch", 0, img_resolution=64, dtype=torch.float32, generator=gen)
+    G = syn.G_synth
+    ws = torch.randn(2, syn.num_ws, 512, generator=gen)
+    native = syn.forward(ws).cpu()
+    ref = OS.synthesis_network(G.state_dict(), ws)
+    assert rel(native, ref) <= 2e-5
+    syn.change_output_resolution((96, 64), "stretch", 2, add_noise=False)
+    a = syn.forward(ws).cpu()
+    syn.change_output_resolution((96, 64), "stretch", 2, add_noise=False)   # same size again: new noise, never zeros
+    b = syn.forward(ws).cpu()
+    assert tuple(a.shape) == tuple(b.shape) == (2, 3, 64, 96)
+    for key, nz in G._resized_noise.items():
+        assert float(nz.abs().max()) > 0 and tuple(nz.shape) != tuple(G._params[key].shape)
+    # the later layers' noise reaches the image: a zeroed buffer would make the frame independent of it
+    nzs = dict(G._resized_noise)
+    G._resized_noise = {k: torch.zeros_like(v) for k, v in nzs.items()}
+    G._upload_noise(None)
+    z = syn.forward(ws).cpu()
+    assert rel(z, b) > 1e-3
+    G._resized_noise = nzs
+    G._upload_noise(None)
+    assert torch.equal(syn.forward(ws).cpu(), b)
+    # a rebuilt device object (new device / stream) re-applies resize and noise
+    G._destroy()
+    assert torch.equal(syn.forward(ws).cpu(), b)
+    # back to native: the network's own noise_const is uploaded again
+    syn.change_output_resolution((64, 64), "stretch", 0)
+    assert torch.equal(syn.forward(ws).cpu(), native)
+    # two wrappers over one cached checkpoint do not share resize state
+    from maua_amd import load as ML
+    path = tmp_path / "ros.pt"
+    torch.save(ML.synthetic_rosinality_checkpoint(), path)
+    s1 = StyleGAN2Synthesizer(str(path), True, None, dtype=torch.float32)
+    s2 = StyleGAN2Synthesizer(str(path), True, (24, 16), "stretch", 2, dtype=torch.float32,
+                              generator=torch.Generator().manual_seed(1))
+    assert s1.G_synth is not s2.G_synth
+    ws16 = torch.randn(2, s1.num_ws, 512, generator=gen)
+    assert tuple(s1.forward(ws16).shape) == (2, 3, 16, 16) and tuple(s2.forward(ws16).shape) == (2, 3, 16, 24)
+    assert rel(s1.forward(ws16).cpu(), OS.synthesis_network(s1.G_synth.state_dict(), ws16)) <= 2e-4
+
+
 def test_resample_matches_reference(golden):
     """lanczos pre-filter + bicubic(align_corners=True) (maua/ops/image.py:214-240) vs the reference's outputs (g17)."""
     from maua_amd import ops

@@ -57,11 +57,12 @@ def test_synth_bf16_vs_oracle():
     noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
     img = net(ws, noise=noise).cpu()
     ref = OS.synthesis_network(p, ws, noise=noise)
-    # bf16 operands / f32 accumulate vs the fp32 oracle: PSNR >= 40 dB over the image range and
-    # max-abs <= 3e-2 of the range
+    # bf16 operands / f32 accumulate vs the fp32 oracle: measured 60-68 dB on nets of this size; the bar is set so
+    # that a regression of more than a few dB (one layer rounding twice, a wrong tap) fails.  max-abs <= 1e-2 of the
+    # image range.
     rng = float(ref.max() - ref.min())
-    assert psnr(img, ref) >= 40.0
-    assert float((img - ref).abs().max()) <= 3e-2 * rng
+    assert psnr(img, ref) >= 55.0, psnr(img, ref)
+    assert float((img - ref).abs().max()) <= 1e-2 * rng
 
 
 def test_synth_rgb8_and_determinism():
@@ -222,8 +223,80 @@ def test_full_size_network_properties_and_oracle_frame():
     finally:
         torch.set_num_threads(nthr)
     rng = float(ref.max() - ref.min())
-    assert psnr(img[:1].cpu(), ref) >= 40.0
-    assert float((img[:1].cpu() - ref).abs().max()) <= 3e-2 * rng
+    print(f"full-size bf16 frame vs oracle: PSNR {psnr(img[:1].cpu(), ref):.1f} dB, "
+          f"max-abs {float((img[:1].cpu() - ref).abs().max()) / rng:.2e} of the range")
+    assert psnr(img[:1].cpu(), ref) >= 55.0, psnr(img[:1].cpu(), ref)  # 17 layers, 512 channels: measured 65.9 dB
+    assert float((img[:1].cpu() - ref).abs().max()) <= 1e-2 * rng
+
+
+def test_bench_shape_batch_equals_single_frames():
+    """The shape bench.py times: B = 32 frames of the 1024^2 bf16 net in one call (512-channel layers through the
+    batch-wide low-resolution GEMM, the LDS-direct-load and register-stationary kernels at full grids).  Frames
+    0, 15 and 31 of that batch equal the same frames rendered alone, bit for bit (what frame-range sharding relies
+    on), and frame 15 matches the fp32 CPU oracle."""
+    from maua_amd.noise import Loop, loop_batch
+    from maua_amd.stylegan2 import SynthesisNetwork
+    net = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(77)
+    B = 32
+    ws = torch.randn(B, net.num_ws, 512, generator=g).cuda()
+    sizes = [s[3] for s in net.layer_shapes()]
+    rng_n = torch.Generator().manual_seed(42)
+    mods = [Loop(rng_n, 64, (s, s), n_loops=2, sigma=5) for s in sizes]
+    nz = loop_batch(mods, 3, B)  # the bench's noise path: frames 3 .. 34 of a 64-frame loop
+    img = torch.empty((B, 3, 1024, 1024), device="cuda")
+    u8 = torch.empty((B, 1024, 1024, 3), dtype=torch.uint8, device="cuda")
+    net(ws, noise=nz, out=img, rgb8_out=u8)
+    for i in (0, 15, 31):
+        one = torch.empty((1, 3, 1024, 1024), device="cuda")
+        one8 = torch.empty((1, 1024, 1024, 3), dtype=torch.uint8, device="cuda")
+        net(ws[i:i + 1], noise=[n[i:i + 1].contiguous() for n in nz], out=one, rgb8_out=one8)
+        assert torch.equal(one[0], img[i]), i
+        assert torch.equal(one8[0], u8[i]), i
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(32, nthr))
+    try:
+        ref = OS.synthesis_network(net.state_dict(), ws[15:16].cpu(), noise=[n[15:16].cpu() for n in nz])
+    finally:
+        torch.set_num_threads(nthr)
+    got = img[15:16].cpu()
+    assert psnr(got, ref) >= 55.0, psnr(got, ref)
+    # (a random-init net's image spans ~ +-60, so one u8 step is 1e-4 of its range: the u8 frame is checked against the
+    #  pack of the f32 image of the same call, exactly, rather than against the fp32 oracle's frame)
+    want8 = ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)
+    assert torch.equal(u8, want8)
+
+
+def test_warp_hook_on_layers_with_fused_torgb():
+    """A translate / rotate hook on a conv1 whose toRGB normally rides on the conv epilogue (register-stationary
+    kernels, LDS-direct kernel) - including the LAST conv1, whose features are normally not stored at all: the hook
+    replaces the layer output before toRGB reads it (wrappers/stylegan2.py:153-194), so the fused path must step
+    aside.  256^2 bf16 net with 128 / 64 / 32 channels at 64^2 / 128^2 / 256^2, against the oracle."""
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer
+    gen = torch.Generator().manual_seed(14)
+    G, _ = build(256, 8192, 128, torch.bfloat16)
+    syn = StyleGAN2Synthesizer.__new__(StyleGAN2Synthesizer)
+    torch.nn.Module.__init__(syn)
+    syn.G_synth, syn.num_ws, syn.w_dim = G, G.num_ws, G.w_dim
+    assert [s[2] for s in G.layer_shapes()][-3:] == [64, 32, 32]
+    B = 2
+    ws = torch.randn(B, syn.num_ws, 64, generator=gen)
+    plain = OS.synthesis_network(G.state_dict(), ws)
+    last = G.num_layers          # layer_names index of bs.6.conv1 (1-based count of synthesis layers)
+    for layer in (last, last - 2):
+        rotation = torch.tensor([10.0, -25.0])
+        h, w = G.layer_size(layer - 1)
+        img = syn.forward(ws, rotation=rotation, rotation_layer=layer).cpu()
+        u8 = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
+        G(ws, rgb8_out=u8)  # hooks persist: the u8-only call takes the same route
+        Mr = StyleGAN2Synthesizer._rotation_scale_matrix(rotation, torch.ones(B), None, h, w, B)
+        ref = OS.synthesis_network(G.state_dict(), ws, warps=[(layer, Mr)])
+        assert psnr(img, ref) >= 45.0, (layer, psnr(img, ref))
+        assert psnr(plain, ref) < 35.0  # the hook does something
+        want = ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)
+        assert int((u8.cpu().int() - want.int()).abs().max()) <= 1
+        syn.forward(ws, rotation=torch.zeros(B), rotation_layer=layer)  # identity warp: back to the plain image
+    assert psnr(syn.forward(ws).cpu(), plain) >= 55.0
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
