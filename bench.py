@@ -11,6 +11,9 @@ range over the ranks.  One "step" = one batch of B frames through the per-batch 
 selfsupervised/sample.py:90-98 (reference): 17 index-addressed Loop noise maps -> StyleGAN2 synthesis forward ->
 (x+1)/2 -> u8 HWC pack.  Latents (spline-loop schedule blended by the onset envelope) and network weights are
 resident in HBM before the timed region, as the reference has them resident before its render loop.
+After the K timed steps every rank renders its WHOLE frame range once (the "clip" leg: sustained rate over
+3600 / N frames, then the one RCCL gather of the u8 shards to rank 0, timed) - reported as extra keys `sustained`,
+`e2e` (SURVEY 8(d) metric (ii): set-up + render of the whole clip) and `gather_ms`; `value` stays the K-step rate.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -19,6 +22,7 @@ import json
 import os
 import sys
 import time
+from pathlib import Path
 
 import torch
 
@@ -42,13 +46,17 @@ def parse():
 
 
 def kernel_of(ci, co, res, up):
-    """Which kernel instantiation synth.hip launches for a layer (mirrors launch_modconv_t / hires_supported);
-    names match the rocprofv3 kernel-trace rows."""
+    """Which kernel instantiation synth.hip launches for a layer (mirrors launch_modconv_t / hires_supported /
+    dma_conv_supported); names match the rocprofv3 kernel-trace rows."""
     hin = res // up
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
     if up == 2 and 32 <= hin <= 512:
         return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
+    if up == 1 and 64 <= hin <= 512 and ci % 64 == 0 and co % 128 == 0:  # conv1 behind a tconv + upfir up-layer
+        if co % 256 == 0:
+            return "modconv_dma_kernel<2,4,4,2,1,0>"
+        return "modconv_dma_kernel<4,2,2,2,%d,0>" % (2 if (ci // 64) % 2 == 0 else 1)
     cov = co * up * up
     if hin * hin <= 64 and ci % 64 == 0 and cov % 128 == 0:
         return "lowres_conv_kernel<bf16> (+premod, +epilogue)"  # one profile slot covers the three launches
@@ -60,6 +68,14 @@ def kernel_of(ci, co, res, up):
             return "modconv3x3_kernel<bf16,4,4,2,1,3,%d>" % (128 if k128 else 64)
         return "modconv3x3_kernel<bf16,2,4,2,1,3,%d>" % (128 if (k128 and hin * hin < 256) else 64)
     return "modconv3x3_kernel<bf16,4,1,2,2,9,64>" if cov % 64 == 0 else "modconv3x3_kernel<bf16,4,1,2,1,9,64>"
+
+
+def rgb_fused(c, r):
+    """does the block's toRGB ride on its conv1 epilogue?  (register-stationary kernels; the LDS-direct kernel and the
+    generic kernel when all channels sit in one N tile)"""
+    k = kernel_of(c, c, r, 1)
+    return k.startswith("modconv_hires") or (k.startswith("modconv_dma") and c in (128, 256)) or \
+        (k.startswith("modconv3x3") and c == 128 and r * r >= 4096)
 
 
 def layer_table(net):
@@ -77,7 +93,7 @@ def layer_table(net):
             gflop = 2 * hin * hin * 9 * ci * co / 1e9
             byts = (hin * hin * ci + res * res * co) * 2 + res * res * 4  # bf16 in/out + f32 noise
             kern = kernel_of(ci, co, res, up)
-            if up == 1 and (kern.startswith("modconv_hires") or (co == 128 and res * res >= 4096)):  # + fused toRGB: img write + upsampled skip read
+            if up == 1 and rgb_fused(co, res):  # + fused toRGB: img write + upsampled skip read
                 gflop += 2 * r * r * co * 3 / 1e9
                 byts += r * r * 12 + (r // 2) ** 2 * 12
                 if i == len(net.block_resolutions) - 1:  # last block: the features are not stored and the image
@@ -89,8 +105,7 @@ def layer_table(net):
             else:
                 rows.append((pfx, kern, gflop, byts))
         c = shapes[li - 1][2]
-        # toRGB rides on the conv1 epilogue: register-stationary kernels, and the generic kernel when Co == its N tile
-        fused = kernel_of(c, c, r, 1).startswith("modconv_hires") or (c == 128 and r * r >= 4096)
+        fused = rgb_fused(c, r)
         rows.append((f"bs.{i}.torgb", "torgb(fused)" if fused else "torgb_kernel",
                      0.0 if fused else 2 * r * r * c * 3 / 1e9,
                      0.0 if fused else r * r * c * 2 + r * r * 12 + (r // 2) ** 2 * 12))
@@ -134,11 +149,34 @@ def cpu_baseline(seconds):
                 break
     dt = time.time() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "threads_capped": torch.get_num_threads() < (os.cpu_count() or 1),
+            "threads_note": "oneDNN convolutions stop scaling (and regress) well below the host's hardware threads; "
+                            "32 threads measured fastest on the 256-thread host",
             "sample": f"{n} frame(s) of the same 1024x1024 workload (B=1, fp32 oracle: noise + synthesis + u8), {dt:.1f} s"}
+
+
+def measured_traffic(kernel_name, batch=None):
+    """HBM bytes per launch measured with rocprofv3 --pmc in an EARLIER run of this same command: profiles/traffic.json,
+    written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the corrections of
+    MI355X_MICROARCH.md section HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  The file records the frames per step it was
+    collected at; activations scale with the batch, so another `batch` is scaled linearly.  (None, reason) if absent."""
+    p = Path(__file__).resolve().parent / "profiles" / "traffic.json"
+    if not p.exists():
+        return None, "profiles/traffic.json absent"
+    try:
+        v = json.loads(p.read_text()).get(kernel_name)
+        if v is None:
+            return None, "kernel not in profiles/traffic.json"
+        scale = (batch / v["batch"]) if (batch and v.get("batch")) else 1.0
+        return float(v["bytes_per_launch"]) * scale, \
+            "replayed from profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
+    except Exception as e:
+        return None, f"profiles/traffic.json unreadable: {e}"
 
 
 def main():
     a = parse()
+    t_start = time.perf_counter()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -158,7 +196,13 @@ def main():
     from maua_amd import _lib as L
     from maua_amd import pipeline
     from maua_amd.noise import loop_batch
+    torch.zeros(1, device=device)
+    torch.cuda.synchronize()
+    t_ctx = time.perf_counter()  # HIP context up; everything after this is the clip's own set-up
     net, latents, noise, info = build_inputs(device, rank, world)
+    net._handle()
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_ctx
     B = a.batch
     lo, hi = pipeline.frame_range(T_FRAMES, rank, world)
     # every timed step packs its frames into its own slot; the slots form a ring so that a long run (--steps in the
@@ -196,18 +240,37 @@ def main():
     L.check(lib.maua_synth_get_profile(h, ms, cnt.value, C.byref(cnt)))
     L.check(lib.maua_synth_set_option(h, b"profile", 0))
 
-    # final gather of the u8 frames to rank 0 (one RCCL gather over xGMI, not part of the per-step rate)
-    gather_ms = None
     if dist is not None:
-        fence()
-        tg = time.perf_counter()
-        bufs = [torch.empty_like(out_u8) for _ in range(world)] if rank == 0 else None
-        dist.gather(out_u8, bufs, dst=0)
-        fence()
-        gather_ms = (time.perf_counter() - tg) * 1e3
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- clip leg: this rank's whole frame range once (3600 / N frames, ceil((hi - lo) / B) steps), frames kept
+    # resident; then the ONE gather of the u8 shards to rank 0 (RCCL over xGMI) - the real end of a sharded render
+    del out_u8
+    n_local = hi - lo
+    shard = torch.empty((n_local, RES, RES, 3), dtype=torch.uint8, device=device)
+    fence()
+    tc = time.perf_counter()
+    for i in range(lo, hi, B):
+        b = min(B, hi - i)
+        net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=shard[i - lo:i - lo + b])
+    fence()
+    clip_s = time.perf_counter() - tc
+    gather_ms = None
+    if dist is not None:
+        from maua_amd.distributed import gather_frames
+        t = torch.tensor([clip_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        clip_s = float(t.item())
+        fence()
+        tg = time.perf_counter()
+        full = gather_frames(shard, T_FRAMES, rank, world)
+        fence()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        if rank == 0:
+            assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
+        del full
 
     if rank == 0:
         frames = world * B * a.steps
@@ -241,8 +304,9 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f_hbm}
         roof.update({"frac_mfma": f_mfma, "frac_hbm": f_hbm})
+        traffic, traffic_source = measured_traffic(dom, B)
         roof.update({"kernel": dom, "avg_launch_ms": gd["ms"] / gd["launches"], "launches_timed": gd["launches"],
-                     "traffic": pipeline.measured_traffic(dom, B)})
+                     "traffic": traffic, "traffic_source": traffic_source})
         res = {
             "metric": "frames/sec (whole node), 1024x1024 StyleGAN2 audio-reactive render",
             "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -253,6 +317,17 @@ def main():
                        "frames_per_step_per_gpu": B, "clip_frames": T_FRAMES, "frame_sharding": f"contiguous x{world}",
                        "latents": info},
             "roofline": roof, "kernels": roof_all, "gather_ms": gather_ms,
+            # sustained: every rank's whole shard once, after the timed steps (max over ranks); e2e adds the set-up of
+            # rank 0 (weight init + upload, synthetic audio, audio pre-pass, latent schedule, mapper, noise planes)
+            "sustained": {"clip_frames": T_FRAMES, "frames_per_gpu": n_local, "seconds": clip_s,
+                          "fps": T_FRAMES / clip_s},
+            "e2e": {"clip_frames": T_FRAMES, "setup_s": setup_s, "render_s": clip_s,
+                    "gather_s": (gather_ms or 0.0) / 1e3,
+                    "seconds": setup_s + clip_s + (gather_ms or 0.0) / 1e3,
+                    "fps": T_FRAMES / (setup_s + clip_s + (gather_ms or 0.0) / 1e3),
+                    "includes": "weight init + upload, synthetic audio, HPSS onset pre-pass, latent schedule, mapper, "
+                                "noise planes, render + u8 pack of every frame, gather (N > 1); excludes the HIP "
+                                "context / first import"},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)

@@ -1,0 +1,1 @@
+"""Drop-in name for maua/audiovisual/audioreactive/selfsupervised/features/: re-exports the MI355X-native implementation in maua_amd."""

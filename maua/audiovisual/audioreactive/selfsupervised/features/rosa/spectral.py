@@ -1,0 +1,3 @@
+"""Drop-in name for .../features/rosa/spectral.py: re-exports the MI355X-native implementation in maua_amd."""
+from maua_amd.audio import (dct, hpss, istft, magphase, median_filter2d, mel, melspectrogram, power_to_db,  # noqa: F401
+                            spectrogram, stft)

@@ -1,0 +1,2 @@
+"""Drop-in name for maua/audiovisual/audioreactive/selfsupervised/mir.py:24-45: re-exports the MI355X-native implementation in maua_amd."""
+from maua_amd.audiovisual.sample import retrieve_music_information  # noqa: F401

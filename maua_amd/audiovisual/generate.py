@@ -1,8 +1,9 @@
 """Patch-driven audio-reactive render entry point (drop-in for maua/audiovisual/generate.py:16-98:
 same function name, arguments and CLI flags).
 
-    python -m maua_amd.audiovisual.generate --audio_file clip.wav --model_file None \
-        --patch_file maua_amd/audiovisual/patches/examples/stylegan2.py
+    python -m maua.audiovisual.generate --audio_file clip.wav --model_file None \
+        --patch_file maua/audiovisual/patches/examples/stylegan2.py
+(`maua/` is the reference's import surface for this path; it re-exports `maua_amd`)
 """
 import argparse
 from pathlib import Path
@@ -51,7 +52,7 @@ def generate_audiovisal_from_patch(audio_file: str, model_file: str, patch_file:
 _FLAGS = [
     ("audio_file", dict(required=True, type=str, help="Path to audio file")),
     ("model_file", dict(required=True, type=str, help="Checkpoint (rosinality / NVIDIA state dict), or 'None' for random init")),
-    ("patch_file", dict(default="maua_amd/audiovisual/patches/examples/stylegan2.py", type=str,
+    ("patch_file", dict(default="maua/audiovisual/patches/examples/stylegan2.py", type=str,
                         help="Python file defining the MauaPatch that modulates the generator's inputs")),
     ("patch_name", dict(default=None, type=str, help="Patch class to use when the file defines several")),
     ("renderer", dict(default="ffmpeg", type=str, help="'ffmpeg' (video file) or 'memmap' (uint8 array)")),

@@ -1,8 +1,6 @@
-"""Clip-level plumbing shared by bench.py, the entry points and the tests: frame-range sharding, the synthetic
-BASELINE clip, and the profile-file lookup for measured HBM traffic."""
-import json
+"""Clip-level plumbing shared by bench.py, the entry points and the tests: frame-range sharding and the synthetic
+BASELINE clip."""
 import math
-from pathlib import Path
 
 import torch
 
@@ -42,21 +40,3 @@ def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4
     lat = latent.sequence_weighted(low, high, env)
     lat = audio.gaussian_filter(lat, 2)
     return lat.contiguous(), {"seeds": seeds, "schedule": f"spline_loops(n_loops={n_loops}) x2 blended by onsets, gaussian sigma=2"}
-
-
-def measured_traffic(kernel_name, batch=None):
-    """HBM bytes per launch measured with rocprofv3 --pmc: profiles/traffic.json, written by
-    scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes over bench.py with the corrections of
-    MI355X_MICROARCH.md §HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  The file records the frames per step it was
-    collected at; activations scale with the batch, so another `batch` is scaled linearly.  None if absent."""
-    p = Path(__file__).resolve().parent.parent / "profiles" / "traffic.json"
-    if not p.exists():
-        return None
-    try:
-        v = json.loads(p.read_text()).get(kernel_name)
-        if v is None:
-            return None
-        scale = (batch / v["batch"]) if (batch and v.get("batch")) else 1.0
-        return float(v["bytes_per_launch"]) * scale
-    except Exception:
-        return None

@@ -187,3 +187,30 @@ def test_pass_filters_match_reference(golden):
     for fn, key, args in [(ar.low_pass, "low", (200,)), (ar.high_pass, "high", (3000,)), (ar.band_pass, "band", (200, 3000))]:
         y = fn(x, 30720, *args)
         assert np.allclose(y, g[key].numpy(), rtol=1e-9, atol=1e-12), key
+
+
+def test_maua_namespace_resolves_to_the_native_package():
+    """the reference's module paths for this path import unchanged and name the maua_amd objects."""
+    import importlib
+    import pkgutil
+    import maua
+    for m in pkgutil.walk_packages(maua.__path__, "maua."):
+        importlib.import_module(m.name)
+    import maua_amd.ops as native_ops
+    import maua_amd.stylegan2 as native_sg
+    from maua.GAN.wrappers.inference import ops
+    from maua.GAN.wrappers.stylegan2 import StyleGAN2, StyleGAN2Synthesizer
+    from maua.audiovisual import audioreactive as ar
+    from maua.audiovisual.audioreactive.selfsupervised.features import audio as FA, processing as FP
+    from maua.audiovisual.audioreactive.selfsupervised.sample import generate
+    from maua.audiovisual.generate import generate_audiovisal_from_patch
+    from maua.audiovisual.patches.base import MauaPatch, get_patch_from_file
+    from maua.audiovisual.patches.base.stylegan2 import StyleGAN2Patch
+    assert ops.modulated_conv2d is native_ops.modulated_conv2d and ops.upfirdn2d is native_ops.upfirdn2d
+    assert StyleGAN2 is native_sg.StyleGAN2 and StyleGAN2Synthesizer is native_sg.StyleGAN2Synthesizer
+    assert callable(ar.onsets) and callable(ar.spline_loops) and callable(FA.mfcc) and callable(FP.gaussian_filter)
+    assert callable(generate) and callable(generate_audiovisal_from_patch)
+    # the reference's default patch file resolves through the namespace to a class defined in that module
+    cls = get_patch_from_file("maua/audiovisual/patches/examples/stylegan2.py")
+    assert issubclass(cls, StyleGAN2Patch) and issubclass(cls, MauaPatch)
+    assert cls.__module__ == "maua.audiovisual.patches.examples.stylegan2"

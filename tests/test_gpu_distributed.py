@@ -1,0 +1,67 @@
+"""world_size-2 render over RCCL ("nccl" backend on ROCm): each rank renders its contiguous frame range of a small clip
+on its own GPU, one gather to rank 0, compared with the single-GPU render.  Needs two visible GPUs; the 1-GPU test box
+skips it (the sharding / gather logic itself is covered on CPU by tests/test_distributed_gloo.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _render(lo, hi, T, B=4):
+    from maua_amd.noise import Loop, loop_batch
+    from maua_amd.stylegan2 import SynthesisNetwork
+    net = SynthesisNetwork(64, 64, 3, channel_base=2048, channel_max=128, dtype=torch.bfloat16,
+                           generator=torch.Generator().manual_seed(0))
+    g = torch.Generator().manual_seed(1)
+    ws = torch.randn(T, net.num_ws, 64, generator=g).cuda()
+    rng = torch.Generator().manual_seed(42)
+    mods = [Loop(rng, T, (s[3], s[3]), n_loops=2, sigma=5) for s in net.layer_shapes()]
+    out = torch.empty((hi - lo, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    for i in range(lo, hi, B):
+        b = min(B, hi - i)
+        net(ws[i:i + b], noise=loop_batch(mods, i, b), rgb8_out=out[i - lo:i - lo + b])
+    return out
+
+
+def _worker(rank, world, port, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from maua_amd.distributed import gather_frames, maybe_init_process_group
+    from maua_amd.pipeline import frame_range
+    assert maybe_init_process_group("nccl") == (rank, world)
+    lo, hi = frame_range(T, rank, world)
+    full = gather_frames(_render(lo, hi, T), T, rank, world)
+    if rank == 0:
+        q.put(full.cpu())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL gather)")
+def test_two_rank_render_equals_single_gpu():
+    T = 13  # uneven shards: 7 + 6 frames
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    torch.cuda.set_device(0)
+    want = _render(0, T, T).cpu()
+    assert torch.equal(got, want)

@@ -156,3 +156,23 @@ def test_ffmpeg_renderer_runs_the_patch_postprocess(wav, tmp_path, monkeypatch):
     b = np.fromfile(inv + ".rgb24", dtype=np.uint8).astype(int)
     assert a.shape == b.shape and a.std() > 1.0
     assert np.abs((255 - a) - b).max() <= 1
+
+
+def test_python_m_maua_audiovisual_generate(wav, tmp_path):
+    """`python -m maua.audiovisual.generate ...` (the reference's command line, generate.py:57-98) runs from any
+    directory with the repo on PYTHONPATH, with the reference's default patch file."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=repo + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "maua.audiovisual.generate", "--audio_file", wav, "--model_file", "None",
+                        "--out_size", "256,256", "--fps", "30", "--resize_strategy", "stretch", "--out_dir", str(tmp_path)],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = [f for f in os.listdir(tmp_path) if f.startswith("clip_None_stretch_256x256")]
+    assert outs, os.listdir(tmp_path)
+    if not shutil.which("ffmpeg"):
+        meta = json.loads(open(tmp_path / "clip_None_stretch_256x256.mp4.json").read())
+        assert meta["frames"] == 32 and (meta["width"], meta["height"]) == (256, 256)
