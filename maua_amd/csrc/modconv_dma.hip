@@ -29,9 +29,8 @@ namespace maua {
 namespace {
 
 constexpr int TH = 8, TW = 32, HW2 = TW + 2, HALO_PX = (TH + 2) * HW2;  // 8 x 32 output pixels, 10 x 34 halo
-constexpr int KCB = 128;                                                // bytes of K per LDS row = 64 bf16 channels
-constexpr int KC = 64;
-constexpr int HB = HALO_PX * KCB;                                       // one halo buffer: 43 520 B
+// K bytes per LDS row (KB, template parameter): 128 (64 bf16 channels; one workgroup per CU) or 64 (32 channels: half
+// the halo, two workgroups per CU - the short-K layers, whose per-tile prologue / epilogue otherwise idles the CU)
 
 __device__ __forceinline__ unsigned lds_off(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
@@ -83,18 +82,24 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
   return MAUA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN, int ABL = 0>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(ConvArgs a) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, int PIN, int ABL = 0>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
   constexpr int BM = TH * TW, BN = WAVES_N * WN * 32;
+  constexpr int KCB = KB, KC = KB / 2;                  // bytes / bf16 channels of K per LDS row (= per chunk)
+  constexpr int PPR = KB / 16, PSH = KB == 128 ? 3 : 2; // 16-byte pieces per row
+  constexpr int HB = HALO_PX * KCB;                     // one halo buffer
   constexpr int TB = BN * KCB;                          // bytes of one tap's weight slice (BN rows)
   constexpr int WB = TPS * TB;                          // bytes of one weight stage (TPS taps)
   constexpr int WJ = TB / 1024 / NW;                    // weight load instructions per wave per tap
-  constexpr int HJ = (HALO_PX * 8 + NT - 1) / NT;       // halo load instructions per wave per chunk
-  constexpr int Q = 4 * TPS;                            // 32-byte k-steps per stage
-  static_assert(TB % (1024 * NW) == 0 && HJ == 6 && (TPS == 1 || TPS == 2), "stage split");
+  constexpr int HJ = (HALO_PX * PPR + NT - 1) / NT;     // halo load instructions per wave per chunk
+  constexpr int KSPT = KB / 32;                         // 32-byte k-steps per tap
+  constexpr int Q = KSPT * TPS;                         // k-steps per stage
+  static_assert(TB % (1024 * NW) == 0 && (HJ == 6 || HJ == 3) && (TPS == 1 || TPS == 2) && (Q == 4 || Q == 8), "stage split");
   constexpr int OFF_H = 2 * WB;
+  // piece p of row n sits at piece index p ^ swz(n): 8 rows x 8 pieces or 16 rows x 4 pieces tile one 1 KB bank period
+#define MAUA_SWZ(N_) (KB == 128 ? (((N_) >> 1) & 7) : (((N_) >> 2) & 3))
   constexpr int ES = BN * 2 + 16, PPP = BN / 8;         // epilogue tile row stride, 16-byte pieces per pixel
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
@@ -117,13 +122,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
 #pragma unroll
   for (int j = 0; j < HJ; j++) {
     const int P = (wave + NW * j) * 64 + lane;
-    const int hp = P >> 3, q = (P & 7) ^ ((hp >> 1) & 7);
+    const int hp = P >> PSH, q = (P & (PPR - 1)) ^ MAUA_SWZ(hp);
     const int py = (hp * 1928) >> 16;  // hp / 34 for hp < 340
     const int px = hp - py * HW2;
     const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
     const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     hoff[j] = 0xffffffffu;
-    if (P < HALO_PX * 8) {
+    if (P < HALO_PX * PPR) {
       if (in) {
         hoff[j] = (unsigned)(((gy * a.W + gx) * a.Ci + q * 8) * 2);
       } else {
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
   unsigned woff[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; j++) {
-    const int row = 8 * (wave + NW * j) + (lane >> 3);
-    const int q = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = (1024 / KB) * (wave + NW * j) + (lane >> PSH);
+    const int q = (lane & (PPR - 1)) ^ MAUA_SWZ(row);
     woff[j] = (unsigned)((row * a.Ci + q * 8) * 2);
   }
   const long tap_stride = (long)a.Co * a.Ci * 2;  // bytes between taps ([tap][Co][Ci])
@@ -168,19 +173,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
 
   // ---- fragment addresses: A (pixels) from the halo, B (channels) from the weight stage
   const int hp00 = (wm * WM + 1) * HW2 + r + 1;                          // halo pixel of block row 0, centre tap
-  const unsigned b0 = (unsigned)(((wn * WN) * 32 + r) * KCB + ((((r >> 1) & 7) ^ h) << 4));
+  const unsigned b0 = (unsigned)(((wn * WN) * 32 + r) * KCB + ((MAUA_SWZ(r) ^ h) << 4));
   // k-step Q_ of the stage at position K_ of the period starting at chunk CC_ (weight stage buffer WBUF_)
 #define MAUA_LOAD_FRAGS(AF_, BF_, CC_, K_, Q_, WBUF_)                                                    \
   if (ABL != 3 || ((CC_) == 0 && (K_) == 0 && (Q_) < 2)) {                                               \
-    const int lp_ = (K_) * TPS + (Q_) / 4, t_ = lp_ % 9, ks_ = (Q_) % 4;                                 \
+    const int lp_ = (K_) * TPS + (Q_) / KSPT, t_ = lp_ % 9, ks_ = (Q_) % KSPT;                           \
     const int hb_ = ((CC_) + lp_ / 9) & 1;                                                               \
     _Pragma("unroll") for (int i = 0; i < WM; i++) {                                                    \
       const int hp_ = hpv + (i + t_ / 3 - 1) * HW2 + (t_ % 3 - 1);                                       \
-      const unsigned o_ = OFF_H + hb_ * HB + hp_ * KCB + ((((hp_ >> 1) & 7) ^ h) << 4);                  \
+      const unsigned o_ = OFF_H + hb_ * HB + hp_ * KCB + ((MAUA_SWZ(hp_) ^ h) << 4);                     \
       AF_[i] = *reinterpret_cast<const u32x4*>(smem + (o_ ^ (ks_ << 5)));                                \
     }                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < WN; j++)                                                      \
-        BF_[j] = *reinterpret_cast<const u32x4*>(smem + (WBUF_) * WB + ((Q_) / 4) * TB + j * 32 * KCB + (b0 ^ (ks_ << 5))); \
+        BF_[j] = *reinterpret_cast<const u32x4*>(smem + (WBUF_) * WB + ((Q_) / KSPT) * TB + j * 32 * KCB + (b0 ^ (ks_ << 5))); \
   }
 #define MAUA_MMA(AF_, BF_)                                                                               \
   _Pragma("unroll") for (int i = 0; i < WM; i++) _Pragma("unroll") for (int j = 0; j < WN; j++)         \
@@ -197,7 +202,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
   // ---- prologue: halo of chunk 0 (and, with two taps per stage, the first third of chunk 1's), weight stages 0 and 1
 #pragma unroll
   for (int j = 0; j < HJ; j++) MAUA_ISSUE_H(j, 0)
-  if constexpr (TPS == 2) { MAUA_ISSUE_H(0, 1) MAUA_ISSUE_H(1, 1) }
+  if constexpr (TPS == 2) {
+#pragma unroll
+    for (int j = 0; j < HJ / 3; j++) MAUA_ISSUE_H(j, 1)
+  }
   MAUA_ISSUE_WSTAGE(0, 0, 0)
   MAUA_ISSUE_WSTAGE(0, 1, 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
         MAUA_MMA(af1, bf1)                                                                               \
       }
       MAUA_STEP2(0)
-      if constexpr (TPS == 2) { MAUA_STEP2(2) MAUA_STEP2(4) }
+      if constexpr (Q == 8) { MAUA_STEP2(2) MAUA_STEP2(4) }
       MAUA_STEP2(Q - 2)
 #undef MAUA_STEP2
       // here: MFMAs of k-steps 0 .. Q-2 issued, fragments of k-step Q-1 in af1 / bf1.
@@ -245,16 +253,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
       if constexpr (TPS == 1) {
         if (k < HJ) MAUA_ISSUE_H(k, cc + 1)
       } else {
-        // chunk cc+1 -> H[1]: free since the previous period's last stage, first read by the second tap of stage 4
-        if (k == 0) { MAUA_ISSUE_H(2, cc + 1) MAUA_ISSUE_H(3, cc + 1) }
-        if (k == 1) MAUA_ISSUE_H(4, cc + 1)
-        if (k == 2) MAUA_ISSUE_H(5, cc + 1)
-        // chunk cc+2 -> H[0]: free once stage 4 has read tap 8, first read by the next period's stage 0
-        if (k == 4) { MAUA_ISSUE_H(0, cc + 2) MAUA_ISSUE_H(1, cc + 2) }
-        if (k == 5) { MAUA_ISSUE_H(2, cc + 2) MAUA_ISSUE_H(3, cc + 2) }
-        if (k == 6) MAUA_ISSUE_H(4, cc + 2)
-        if (k == 7) MAUA_ISSUE_H(5, cc + 2)
-        if (k == 8) { MAUA_ISSUE_H(0, cc + 3) MAUA_ISSUE_H(1, cc + 3) }
+        // chunk cc+1 -> H[1]: free since the previous period's last stage (whose post-barrier block issues the first
+        // third), first read by the second tap of stage 4; chunk cc+2 -> H[0]: free once stage 4 has read tap 8, first
+        // read by the next period's stage 0.  HJ / 3 load instructions per wave at each of the six points.
+#pragma unroll
+        for (int j = 0; j < HJ / 3; j++) {
+          if (k == 0) MAUA_ISSUE_H(HJ / 3 + j, cc + 1)
+          if (k == 1) MAUA_ISSUE_H(2 * (HJ / 3) + j, cc + 1)
+          if (k == 4) MAUA_ISSUE_H(j, cc + 2)
+          if (k == 5) MAUA_ISSUE_H(HJ / 3 + j, cc + 2)
+          if (k == 6) MAUA_ISSUE_H(2 * (HJ / 3) + j, cc + 2)
+          if (k == 8) MAUA_ISSUE_H(j, cc + 3)
+        }
       }
       if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       MAUA_MMA(af1, bf1)
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
 #undef MAUA_ISSUE_H
 #undef MAUA_LOAD_FRAGS
 #undef MAUA_MMA
+#undef MAUA_SWZ
 
   // ---- epilogue: demod, noise, bias, activation, gain, clamp -> LDS tile [pixel][channel] -> coalesced NHWC rows
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
@@ -390,17 +401,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv_dma_kernel(Conv
 }
 
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
-  return dtype == MAUA_BF16 && up == 1 && Ci % KC == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
+  return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int PIN, int ABL = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, int PIN, int ABL = 0>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
-  const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KCB + 2 * HB, (size_t)TH * TW * (BN * 2 + 16));
+  const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KB + 2 * HALO_PX * KB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
-  MAUA_REQUIRE((a.Ci / KC) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
+  MAUA_REQUIRE((a.Ci / (KB / 2)) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, PIN, ABL>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PIN, ABL>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -414,20 +425,20 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");
   if (a.B == 0) return MAUA_OK;
   MAUA_REQUIRE((long)a.H * a.W * a.Ci * 2 < (1L << 32), "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
-  const bool two = (a.Ci / KC) % 2 == 0;
+  const bool two = (a.Ci / 64) % 2 == 0;
   if (a.variant >= 3 && a.variant <= 5 && a.Co % 256 == 0) {  // ablation arms (wrong results, timing only)
-    if (a.variant == 3) return launch_dma_variant<2, 4, 4, 2, 1, 0, 1>(stream, a);
-    if (a.variant == 4) return launch_dma_variant<2, 4, 4, 2, 1, 0, 2>(stream, a);
-    return launch_dma_variant<2, 4, 4, 2, 1, 0, 3>(stream, a);
+    if (a.variant == 3) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 1>(stream, a);
+    if (a.variant == 4) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 2>(stream, a);
+    return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 3>(stream, a);
   }
-  if (a.variant == 2) {  // experiment arm
-    if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 1>(stream, a);
-    if (two) return launch_dma_variant<4, 2, 2, 2, 2, 1>(stream, a);
-    return launch_dma_variant<4, 2, 2, 2, 1, 1>(stream, a);
+  if (a.variant == 6) return launch_dma_variant<4, 2, 2, 2, 2, 64, 0>(stream, a);  // experiment: two workgroups per CU everywhere
+  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0>(stream, a);
+  if (a.variant == 2) {  // experiment arm: one workgroup per CU also for the 128-channel N tile
+    if (two) return launch_dma_variant<4, 2, 2, 2, 2, 128, 0>(stream, a);
+    return launch_dma_variant<4, 2, 2, 2, 1, 128, 0>(stream, a);
   }
-  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 0>(stream, a);
-  if (two) return launch_dma_variant<4, 2, 2, 2, 2, 0>(stream, a);
-  return launch_dma_variant<4, 2, 2, 2, 1, 0>(stream, a);
+  // 128-channel N tile: 64-byte K rows, two taps per stage, 75.5 KB of LDS -> two workgroups per CU
+  return launch_dma_variant<4, 2, 2, 2, 2, 64, 0>(stream, a);
 }
 
 bool dma_rgb_fusable(int Co) { return Co == 128 || Co == 256; }

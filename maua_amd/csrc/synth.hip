@@ -584,7 +584,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 1;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
-        if (fuse_rgb_ok && dma_rgb_fusable(c.Co) && (c.ih % 2) == 0 && (c.iw % 2) == 0) {
+        if (fuse_rgb_ok && dma_rgb_fusable(c.Co) && (n->dma_conv != 6 || c.Co == 128) && (c.ih % 2) == 0 && (c.iw % 2) == 0) {
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;

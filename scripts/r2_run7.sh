@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_synth.py -x -q 2>&1 | tail -5
+timeout 600 python scripts/ab_synth.py dma_conv 32 5 0,1,2 > gpurun_out/r7_ab.log 2>&1
+cat gpurun_out/r7_ab.log

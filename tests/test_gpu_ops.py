@@ -163,7 +163,7 @@ def test_modconv_dma_equals_generic_kernel(M, case):
         y1 = M.modulated_conv2d(xd, wt, s, **kw)
     finally:
         L.check(L.lib().maua_ctx_set_option(ctx, b"dma_conv", 1))
-    if h * w >= 4096:
+    if h * w >= 4096 and co % 256 == 0:  # (the 128-channel N tile walks K in 32-channel chunks)
         assert torch.equal(y0, y1), float((y0.float() - y1.float()).abs().max())
     else:
         assert relerr(y1, y0) <= 4e-3
