@@ -185,6 +185,11 @@ int maua_istft_general(maua_ctx* ctx, const float* spec_frames_bins_complex, int
  * by finfo.tiny ** 0.5 + the frame's largest magnitude. */
 int maua_plp_select(maua_ctx* ctx, float* tempogram_frames_bins_complex, int n_frames, int n_bins,
                     const float* tempo_freq_dev, float tempo_min, float tempo_max);
+/* the autocorrelation tempogram behind selfsupervised/mir.py:27-30 (rosa.beat.tempo -> librosa.feature.tempogram,
+ * un-vendored: published algorithm): ac[f][l] = sum_n (w[n] e[f+n]) (w[n+l] e[f+n+l]) for l < n_lags <= win, over the
+ * n_frames hop-1 frames of env_padded [n_frames + win - 1] (the caller pads the envelope by win/2 ramp samples). */
+int maua_autocorr_frames(maua_ctx* ctx, const float* env_padded, const float* window, int n_frames, int win,
+                         int n_lags, float* ac_frames_lags);
 /* replaces processing.py:53-56 normalize (eps = 1e-8) and signal.py:27-38 normalize (eps = 0):
  * y = (x - min) / ((max - min) + eps) over all n elements. */
 int maua_normalize(maua_ctx* ctx, const float* x, long n, float eps, float* y);

@@ -503,3 +503,45 @@ def plp(y, sr, hop_length=1024, win_length=1024, tempo_min=60, tempo_max=180):
 def pulse(audio, sr):
     """features/audio.py:72-73 -> [T, 1]."""
     return plp(percussive(audio), sr).unsqueeze(-1)
+
+
+# ------------------------------------------------------------------------------------------------ tempo
+def tempo_frequencies(n_bins, hop_length=512, sr=22050):
+    """librosa.tempo_frequencies: BPM of autocorrelation lag i = 60 sr / (hop i); lag 0 -> inf."""
+    bpm = torch.full((n_bins,), float("inf"), dtype=torch.float64)
+    bpm[1:] = 60.0 * sr / (hop_length * torch.arange(1, n_bins, dtype=torch.float64))
+    return bpm
+
+
+def tempo(onset_envelope, sr=22050, hop_length=1024, max_tempo=240.0, ac_size=120.0, prior_scale=400.0, prior_s=1.0):
+    """selfsupervised/mir.py:27-30: ``rosa.beat.tempo(onset_envelope=env, max_tempo=240, prior=lognorm(loc=0, scale=400,
+    s=1), ac_size=120, hop_length=1024)`` - librosa is un-vendored and unpinned (setup.py:60), so this restates its
+    published algorithm (librosa.beat.tempo / feature.tempogram, 0.9-0.10): hop-1 frames of ``ac_size`` seconds of the
+    envelope (padded by half a window of linear ramp to zero), Hann-windowed autocorrelation per frame, max-normalised,
+    averaged over time, log1p(1e6 x) + log-prior over the lag BPMs, lags faster than ``max_tempo`` excluded, argmax.
+    Reference quirk kept (Q11): the call does not pass ``sr``, so lags are converted with librosa's default 22 050 Hz
+    although the envelope's true frame rate is that of the video.  Returns a float (BPM).  Parity unpinned."""
+    import math
+    env = _f32(onset_envelope).reshape(-1)
+    T = env.numel()
+    W = int(math.floor(ac_size * sr / hop_length))          # time_to_frames
+    W = max(2, min(W, 16384))
+    half = W // 2
+    dev = env.device
+    ramp_l = torch.linspace(0, 1, half + 1, device=dev)[:-1] * env[0]       # np.pad(mode="linear_ramp", end_values=0)
+    ramp_r = torch.linspace(1, 0, half + 1, device=dev)[1:] * env[-1]
+    padded = torch.cat([ramp_l, env, ramp_r, torch.zeros(W, device=dev)]).contiguous()
+    n = torch.arange(W, dtype=torch.float64)
+    window = (0.5 - 0.5 * torch.cos(2 * math.pi * n / W)).float().to(dev)   # scipy get_window("hann", fftbins=True)
+    ac = torch.empty((T, W), dtype=torch.float32, device=dev)
+    L.check(L.lib().maua_autocorr_frames(L.ctx(dev), L.ptr(padded), L.ptr(window), T, W, W, L.ptr(ac)))
+    tg = ac / ac.abs().amax(1, keepdim=True).clamp_min(torch.finfo(torch.float32).tiny)   # util.normalize(norm=inf)
+    tg = tg.mean(0).double().cpu()
+    bpms = tempo_frequencies(W, hop_length=hop_length, sr=sr)
+    x = bpms.clamp_min(1e-300)
+    logprior = -torch.log(x * prior_s * math.sqrt(2 * math.pi)) - torch.log(x / prior_scale) ** 2 / (2 * prior_s ** 2)
+    logprior[0] = float("-inf")                                              # lognorm.logpdf(inf)
+    if max_tempo is not None:
+        logprior[: int(torch.argmax((bpms < max_tempo).to(torch.int8)))] = float("-inf")
+    best = int(torch.argmax(torch.log1p(1e6 * tg) + logprior))
+    return float(bpms[best])

@@ -1,10 +1,11 @@
 """Hop-aligned audio-reactive sampler (drop-in for
 maua/audiovisual/audioreactive/selfsupervised/sample.py:36-107 ``generate`` and patch.py:34-197 ``Patch``).
 
-Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  The feature set is the in-scope part
-of the reference's (SURVEY 8f N3 lists the rest): ``onsets`` and ``rms``; tempo / beat tracking (librosa) and
-Laplacian segmentation (torch_geometric) are un-vendored, so ``tempo`` is an argument and "segmentation" patches are
-not drawn.  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
+Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  Features: every function of the
+reference's AFEATFNS except the two constant-Q ones: mfcc, spectral_contrast, spectral_flatness, rms,
+drop_strength, onsets.  The tempo is estimated from the onset envelope (the autocorrelation-tempogram estimate the
+reference takes from librosa); beat tracking + Laplacian segmentation (librosa / torch_geometric, un-vendored) are not
+implemented, so "segmentation" sub-patches are not drawn (latent_patch itself supports them when given labels).  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
 rank 0 with one RCCL gather at the end.
 
     python -m maua_amd.audiovisual.sample --audio_file clip.wav --stylegan2_checkpoint None --downscale_factor 4
@@ -26,15 +27,22 @@ from ..pipeline import frame_range
 from ..stylegan2 import StyleGAN2
 from ..video import VideoWriter
 
-AFEATFNS = ["rms", "onsets"]
-UNITFEATS = ["rms", "onsets"]
-ALLFEATS = UNITFEATS
+# selfsupervised/mir.py:9-11 minus the two features that need the constant-Q transform (chromagram, tonnetz: their
+# resampler is torchaudio's, un-vendored - SURVEY 8(f) N3)
+AFEATFNS = [A.mfcc, A.spectral_contrast, A.spectral_flatness, A.rms, A.drop_strength, A.onsets]
+UNITFEATS = ["rms", "drop_strength", "onsets", "spectral_flatness"]
+ALLFEATS = ["mfcc", "spectral_contrast"] + UNITFEATS
 
 
 def retrieve_music_information(audio, sr):
-    """selfsupervised/mir.py:24-45 for the in-scope features: raw feature -> gaussian(2) -> salience -> normalize."""
-    raw = {"rms": A.rms(audio, sr), "onsets": A.onsets(audio, sr)}
-    return {k: A.normalize(A.salience_weighted(A.gaussian_filter(v, sigma=2))) for k, v in raw.items()}
+    """selfsupervised/mir.py:24-45: every feature function on the clip -> gaussian(2) -> salience -> normalize.
+    Returns (features, tempo): tempo from the onset envelope (audio.tempo, the autocorrelation estimate the
+    reference takes from librosa, :27-30).  Beat-synchronous Laplacian segmentation (:31-41) is not implemented."""
+    raw = {fn.__name__: fn(audio, sr) for fn in AFEATFNS}
+    raw = {k: (v if v.dim() > 1 else v.unsqueeze(-1)) for k, v in raw.items()}
+    tempo = A.tempo(raw["onsets"].squeeze())
+    feats = {k: A.normalize(A.salience_weighted(A.gaussian_filter(v, sigma=2))) for k, v in raw.items()}
+    return feats, tempo
 
 
 def random_choice(rng, options, weights=None):
@@ -119,9 +127,10 @@ class Patch(torch.nn.Module):
 def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_file: Optional[str] = None,
              seed: Optional[int] = None, latent_seeds: Optional[str] = None, fps: float = 30, audio_offset: float = 0,
              audio_duration: Optional[float] = None, downscale_factor: float = 4, aspect_ratio: float = 1,
-             batch_size: int = 32, device: str = "cuda", tempo: float = 120.0, out_dir: str = "output",
+             batch_size: int = 32, device: str = "cuda", tempo: Optional[float] = None, out_dir: str = "output",
              reference_tail: bool = False, dtype=torch.bfloat16):
-    """sample.py:36-101.  ``reference_tail=True`` reproduces the reference loop's dropped tail."""
+    """sample.py:36-101.  ``reference_tail=True`` reproduces the reference loop's dropped tail.
+    ``tempo``: BPM for the "loop" sub-patches; None = estimated from the onset envelope like the reference (mir.py:27-30)."""
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31, size=()).item())
     rank, world = world_info()
@@ -129,7 +138,8 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     out_size = (round(aspect_ratio * 1024 / downscale_factor), res)   # (width, height), sample.py:53
     out_file = f"{out_dir}/{Path(audio_file).stem}_RandomPatches++_seed{seed}_{out_size[0]}x{out_size[1]}.mp4"
     audio, sr = load_audio(audio_file, audio_offset, audio_duration, fps)
-    features = retrieve_music_information(audio, sr)
+    features, est_tempo = retrieve_music_information(audio, sr)
+    tempo = est_tempo if tempo is None else tempo
     if patch_file is None:
         patch = Patch(features=features, tempo=tempo, seed=seed, fps=fps)
     else:  # sample.py:62-66
@@ -184,7 +194,7 @@ def main(argv=None):
     ap.add_argument("--aspect_ratio", type=float, default=1)
     ap.add_argument("--batch_size", type=int, default=32)
     ap.add_argument("--device", default="cuda")
-    ap.add_argument("--tempo", type=float, default=120.0)
+    ap.add_argument("--tempo", type=float, default=None, help="BPM of the loop sub-patches (default: estimated from the onset envelope)")
     ap.add_argument("--reference_tail", action="store_true")
     a = ap.parse_args(argv)
     from ..distributed import maybe_init_process_group

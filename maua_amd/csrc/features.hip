@@ -154,6 +154,30 @@ __global__ __launch_bounds__(256) void eerp_kernel(const float* __restrict__ a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- tempo
+// Windowed local autocorrelation of an onset envelope = librosa's autocorrelation tempogram (librosa.feature.tempogram,
+// published algorithm; the reference calls it through rosa.beat.tempo in selfsupervised/mir.py:27-30):
+//   ac[f][l] = sum_{n=0}^{W-1-l} (w[n] e[f+n]) (w[n+l] e[f+n+l]),  e = the envelope padded by W/2 linear-ramp samples.
+// One workgroup per frame: the windowed frame sits in LDS, each thread owns lags l, l + 256, ...
+__global__ __launch_bounds__(256) void autocorr_frames_kernel(const float* __restrict__ env_padded,
+                                                              const float* __restrict__ window, int W, int n_lags,
+                                                              float* __restrict__ ac) {
+  extern __shared__ float fr[];
+  const float* e = env_padded + blockIdx.x;
+  for (int n = threadIdx.x; n < W; n += 256) fr[n] = window[n] * e[n];
+  __syncthreads();
+  for (int l = threadIdx.x; l < n_lags; l += 256) {
+    float a0 = 0.f, a1 = 0.f;  // two chains; fixed order -> deterministic
+    int n = 0;
+    for (; n + 1 < W - l; n += 2) {
+      a0 = fmaf(fr[n], fr[n + l], a0);
+      a1 = fmaf(fr[n + 1], fr[n + 1 + l], a1);
+    }
+    if (n < W - l) a0 = fmaf(fr[n], fr[n + l], a0);
+    ac[(long)blockIdx.x * n_lags + l] = a0 + a1;
+  }
+}
+
 }  // namespace maua
 
 using namespace maua;
@@ -231,3 +255,14 @@ int maua_eerp(maua_ctx* ctx, const float* a, const float* b, const float* t, lon
 }
 
 }  // extern "C"
+
+extern "C" int maua_autocorr_frames(maua_ctx* ctx, const float* env_padded, const float* window, int n_frames, int win,
+                                    int n_lags, float* ac) {
+  MAUA_REQUIRE(ctx && env_padded && window && ac, "maua_autocorr_frames: NULL argument");
+  MAUA_REQUIRE(win >= 1 && n_lags >= 1 && n_lags <= win && (size_t)win * 4 <= 64 * 1024, "maua_autocorr_frames: bad window");
+  if (n_frames == 0) return MAUA_OK;
+  hipLaunchKernelGGL(maua::autocorr_frames_kernel, dim3(n_frames), dim3(256), (size_t)win * 4, ctx->stream, env_padded,
+                     window, win, n_lags, ac);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}

@@ -273,8 +273,7 @@ class SynthesisNetwork(torch.nn.Module):
             rh, rw = self.layer_size(l)
             t = L.dev_tensor(t, torch.float32)
             if tuple(t.shape[-2:]) != (rh, rw):  # wrappers/stylegan2.py:92-98: resize mismatching noise
-                t = torch.nn.functional.interpolate(t.reshape(-1, 1, *t.shape[-2:]), (rh, rw), mode="bicubic",
-                                                    align_corners=False).contiguous()
+                t = ops.interpolate_bicubic(t.reshape(-1, 1, *t.shape[-2:]).contiguous(), (rh, rw))
             nb = t.numel() // (rh * rw)
             if nb not in (1, B):
                 raise ValueError(f"noise{l}: batch {nb} does not match latents batch {B}")
@@ -615,7 +614,7 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
             if l > layer_limit:
                 continue
             h, w = self.G_synth.layer_size(l)
-            n = torch.nn.functional.interpolate(noise, (h, w), mode="bicubic", align_corners=False)
+            n = ops.interpolate_bicubic(noise, (h, w))  # maua_resize2d: F.interpolate(bicubic, align_corners=False)
             noises[f"noise{l}"] = n / n.std((1, 2, 3), keepdim=True)
         return noises
 

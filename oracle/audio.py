@@ -352,3 +352,26 @@ def plp(y, sr, hop=HOP, win_length=1024, tempo_min=60, tempo_max=180):
 def pulse(audio, sr):
     """features/audio.py:72-73"""
     return plp(percussive(audio), sr).unsqueeze(-1)
+
+
+def tempo(onset_envelope, sr=22050, hop=1024, max_tempo=240.0, ac_size=120.0, prior_scale=400.0, prior_s=1.0):
+    """selfsupervised/mir.py:27-30 -> librosa.beat.tempo (un-vendored, unpinned: published algorithm restated with
+    numpy, the autocorrelation by FFT as librosa.autocorrelate does).  Parity unpinned."""
+    import numpy as np
+    from scipy import stats
+    env = np.asarray(onset_envelope, dtype=np.float64).reshape(-1)
+    W = int(np.floor(ac_size * sr / hop))
+    W = max(2, min(W, 16384))
+    padded = np.pad(env, (W // 2, W // 2), mode="linear_ramp", end_values=0)
+    padded = np.concatenate([padded, np.zeros(W)])
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(W) / W)
+    frames = np.lib.stride_tricks.sliding_window_view(padded, W)[: len(env)] * win
+    nfft = 2 * W - 1
+    spec = np.fft.rfft(frames, n=nfft, axis=1)
+    ac = np.fft.irfft(np.abs(spec) ** 2, n=nfft, axis=1)[:, :W]
+    tg = (ac / np.maximum(np.abs(ac).max(1, keepdims=True), np.finfo(np.float32).tiny)).mean(0)
+    bpms = np.full(W, np.inf)
+    bpms[1:] = 60.0 * sr / (hop * np.arange(1, W))
+    logprior = stats.lognorm(loc=0, scale=prior_scale, s=prior_s).logpdf(bpms)
+    logprior[: int(np.argmax(bpms < max_tempo))] = -np.inf
+    return float(bpms[int(np.argmax(np.log1p(1e6 * tg) + logprior))])

@@ -123,3 +123,29 @@ def merge(latents, sequence, merge_type, merge_depth, modulation=None):
     else:
         lat[:, lays] = sequence[:, lays]
     return lat
+
+
+def latent_patch(permutation, latents, palette, segmentations, features, tempo, fps, patch_type, segments, loop_bars,
+                 seq_feat, seq_feat_weight, mod_feat, mod_feat_weight, merge_type, merge_depth):
+    """selfsupervised/latent.py:16-80 with the permutation the sub-patch draws (``torch.randperm(len(palette),
+    generator=rng)``, :36) passed in explicitly; returns a new tensor."""
+    from .audio import gaussian_filter
+    feature = seq_feat_weight * features[seq_feat]
+    if patch_type == "segmentation":                                   # :38-42
+        selection = permutation[:segments]
+        sequence = gaussian_filter(palette[selection[segmentations[(seq_feat, segments)]]], 5)
+    elif patch_type == "feature":                                      # :43-50
+        n_select = feature.shape[1]
+        if n_select == 1:
+            sel = palette[permutation[:2]]
+            sequence = feature[..., None] * sel[[0]] + (1 - feature[..., None]) * sel[[1]]
+        else:
+            sequence = torch.einsum("TN,NWL->TWL", feature, palette[permutation[:n_select]])
+    elif patch_type == "loop":                                         # :51-54
+        n_loops = len(latents) / fps / 60 / tempo / 4 / loop_bars
+        sequence = spline_loop_latents(palette[permutation[:segments]], len(latents), n_loops=n_loops)
+    else:
+        raise ValueError(patch_type)
+    sequence = gaussian_filter(sequence, 1)                            # :55
+    modulation = mod_feat_weight * features[mod_feat] if merge_type == "modulate" else None
+    return merge(latents, sequence, merge_type, merge_depth, modulation)

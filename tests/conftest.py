@@ -18,7 +18,7 @@ def pytest_configure(config):
 def load_golden(name):
     import torch
     z = np.load(GOLDEN / f"{name}.npz")
-    return {k: (torch.from_numpy(z[k]) if z[k].ndim else z[k][()]) for k in z.files}
+    return {k: (z[k] if z[k].dtype.kind in "US" else torch.from_numpy(z[k]) if z[k].ndim else z[k][()]) for k in z.files}
 
 
 @pytest.fixture(scope="session")

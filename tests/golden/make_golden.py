@@ -447,6 +447,66 @@ def golden_resample():
          mixed=OI.resample(x, (28, 17)), short12=OI.resample(x, 12), lanczos_taps=OI.lanczos(OI.ramp(16 / 20, 2), 2))
 
 
+def golden_patches():
+    """The sub-patch graphs of the sampler: selfsupervised/latent.py:16-80 latent_patch and
+    selfsupervised/noise.py:89-140 noise_patch, run on explicit features / segmentations.  The permutation each
+    latent sub-patch draws and the planes each noise module draws are stored with the outputs, so the fixture does not
+    depend on torch's RNG stream ("loop" latent patches need torchcubicspline, un-vendored: pinned by g12_spline)."""
+    from maua.audiovisual.audioreactive.selfsupervised import latent as RL
+    from maua.audiovisual.audioreactive.selfsupervised import noise as RN
+    g = torch.Generator().manual_seed(77)
+    T_, P, Lw, D = 40, 9, 18, 16
+    palette = torch.randn(P, Lw, D, generator=g)
+    base = torch.randn(T_, Lw, D, generator=g)
+    features = {"onsets": torch.rand(T_, 1, generator=g), "rms": torch.rand(T_, 1, generator=g),
+                "mfcc": torch.rand(T_, 4, generator=g), "chromagram": torch.rand(T_, 3, generator=g)}
+    seg = torch.randint(0, 4, (T_,), generator=g)
+    segmentations = {(k, 4): seg for k in features}  # (looked up for every patch type, latent.py:35)
+    out = {"palette": palette, "base": base, "seg": seg, **{"feat_" + k: v for k, v in features.items()}}
+    cases = [("segmentation", "mfcc", "average", "low"), ("segmentation", "onsets", "modulate", "midhigh"),
+             ("feature", "onsets", "modulate", "mid"), ("feature", "mfcc", "average", "all"),
+             ("feature", "chromagram", "overwrite", "lowmid"), ("feature", "rms", "modulate", "high")]
+    for i, (ptype, sf, mt, md) in enumerate(cases):
+        rng = torch.Generator("cpu").manual_seed(100 + i)
+        perm = torch.randperm(P, generator=torch.Generator("cpu").manual_seed(100 + i))
+        lat = RL.latent_patch(rng, base.clone(), palette, segmentations, features, tempo=120.0, fps=24, patch_type=ptype,
+                              segments=4, loop_bars=4, seq_feat=sf, seq_feat_weight=0.8, mod_feat="rms",
+                              mod_feat_weight=0.6, merge_type=mt, merge_depth=md)
+        out[f"lat{i}"] = lat
+        out[f"perm{i}"] = perm
+    out["cases"] = np.array(["|".join(c) for c in cases])
+
+    # noise graphs: 17 base Loop modules of tiny sizes, two stacked sub-patches; outputs of layers 0, 7, 13, 16
+    sizes = [(3 + (l % 3), 4 + (l % 2)) for l in range(17)]
+    rng = torch.Generator("cpu").manual_seed(5)
+    noise = [RN.Loop(rng, T_, sz, n_loops=2, sigma=3 + l % 4) for l, sz in enumerate(sizes)]
+    out["nsizes"] = np.array(sizes)
+    for l, m in enumerate(noise):
+        out[f"nbase_planes{l}"] = m.noise
+    subs = [dict(patch_type="blend", loop_bars=4, seq_feat="mfcc", seq_feat_weight=0.7, mod_feat="onsets",
+                 mod_feat_weight=0.9, merge_type="modulate", merge_depth="all", noise_mean=0.1, noise_std=0.8),
+            dict(patch_type="multiply", loop_bars=8, seq_feat="chromagram", seq_feat_weight=1.0, mod_feat="rms",
+                 mod_feat_weight=1.0, merge_type="average", merge_depth="midhigh", noise_mean=0.0, noise_std=1.2),
+            dict(patch_type="loop", loop_bars=16, seq_feat="onsets", seq_feat_weight=1.0, mod_feat="rms",
+                 mod_feat_weight=0.5, merge_type="overwrite", merge_depth="low", noise_mean=-0.2, noise_std=0.5)]
+    for sub in subs:
+        noise = RN.noise_patch(rng, noise, features, 120.0, 24, **sub)
+
+    def planes_of(m, acc):  # every random tensor of the graph, in construction (depth-first, left before right) order
+        for name in ("base", "left", "right"):
+            if hasattr(m, name):
+                planes_of(getattr(m, name), acc)
+        if hasattr(m, "noise"):
+            acc.append(m.noise)
+        return acc
+    for l in (0, 7, 13, 16):
+        out[f"ny{l}"] = noise[l].forward(5, 6)
+        for j, pl in enumerate(planes_of(noise[l], [])):
+            out[f"nplanes{l}_{j}"] = pl
+    out["subs"] = np.array([repr(sorted(s.items())) for s in subs])
+    save("g20_patches", **out)
+
+
 def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
     """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
     maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""

@@ -214,3 +214,34 @@ def test_maua_namespace_resolves_to_the_native_package():
     cls = get_patch_from_file("maua/audiovisual/patches/examples/stylegan2.py")
     assert issubclass(cls, StyleGAN2Patch) and issubclass(cls, MauaPatch)
     assert cls.__module__ == "maua.audiovisual.patches.examples.stylegan2"
+
+
+def test_video_writer_pipes_frames_to_ffmpeg(tmp_path, monkeypatch):
+    """maua/ops/video.py:15-128: producer -> bounded queue -> writer thread -> ffmpeg stdin.  Neither image has an
+    ffmpeg binary, so a stand-in named `ffmpeg` on PATH records its command line and copies stdin to the output file:
+    the pipe path (rawvideo rgb24 on stdin, -s WxH, -r fps, audio input, back-pressure through a 2-slot queue, close /
+    wait on exit) runs for real."""
+    import os
+    import stat
+    import numpy as np
+    from maua_amd.video import VideoWriter
+    fake = tmp_path / "bin" / "ffmpeg"
+    fake.parent.mkdir()
+    fake.write_text("#!/bin/sh\nfor a in \"$@\"; do out=\"$a\"; done\necho \"$@\" > \"$out.cmd\"\nsleep 0.2\ncat > \"$out\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(fake.parent) + os.pathsep + os.environ["PATH"])
+    out = tmp_path / "clip.mp4"
+    rng = np.random.default_rng(0)
+    frames = [torch.from_numpy(rng.integers(0, 256, (3, 8, 12, 3), dtype=np.uint8)) for _ in range(7)]
+    with VideoWriter(str(out), (12, 8), 30, audio_file="song.wav", audio_offset=1.5, audio_duration=2.0,
+                     ffmpeg_preset="fast", max_queue=2) as vw:
+        for f in frames:
+            vw.write(f)               # blocks while the 2-slot queue is full (the consumer sleeps first)
+        with pytest.raises(TypeError):
+            vw.write(torch.zeros(8, 12, 3))
+    got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(21, 8, 12, 3)
+    assert np.array_equal(got, torch.cat(frames).numpy()) and vw.frames_written == 21
+    cmd = (tmp_path / "clip.mp4.cmd").read_text().split()
+    assert cmd[cmd.index("-s") + 1] == "12x8" and cmd[cmd.index("-r") + 1] == "30" and cmd[cmd.index("-f") + 1] == "rawvideo"
+    assert cmd[cmd.index("-ss") + 1] == "1.5" and cmd[cmd.index("-t") + 1] == "2.0" and "song.wav" in cmd
+    assert cmd[cmd.index("-preset") + 1] == "fast" and cmd[-1] == str(out)

@@ -287,3 +287,47 @@ def test_classic_compress_eerp(golden):
     assert rel(ar.expand(g["e"].cuda(), 0.3, 2.0, invert=True), g["comp_lo"]) < 2e-6
     assert rel(ar.eerp(g["a"].cuda(), g["b"].cuda(), g["t"].cuda()), g["eerp"]) < 5e-6
     assert rel(ar.copeerp(g["a"].cuda(), g["b"].cuda(), g["t"].cuda()), g["copeerp"]) < 5e-5
+
+
+def test_latent_and_noise_patch_graphs(golden):
+    """L6 / N-2 on the HIP path against the reference's own outputs (g20, explicit selections): every latent
+    sub-patch type the reference can run here x merge type x depth, and three stacked noise sub-patches."""
+    import maua_amd.latent as LT
+    import maua_amd.noise as N
+    g = golden("g20_patches")
+    feats = {k[5:]: g[k].cuda() for k in g if k.startswith("feat_")}
+    segs = {(k, 4): g["seg"] for k in feats}
+    for i, case in enumerate(g["cases"]):
+        kw = dict(zip(("patch_type", "seq_feat", "merge_type", "merge_depth"), str(case).split("|")))
+        rng = torch.Generator("cpu").manual_seed(100 + i)   # the sub-patch draws its permutation like the reference
+        out = LT.latent_patch(rng, g["base"].clone().cuda(), g["palette"].cuda(), segs, feats, tempo=120.0, fps=24, segments=4,
+                              loop_bars=4, seq_feat_weight=0.8, mod_feat="rms", mod_feat_weight=0.6, **kw)
+        assert rel(out, g[f"lat{i}"]) <= 5e-6, case
+    # noise: same construction order and generator as the reference -> same planes, then same frames
+    T_ = len(g["base"])
+    sizes = [tuple(int(v) for v in s) for s in g["nsizes"]]
+    rng = torch.Generator("cpu").manual_seed(5)
+    noise = [N.Loop(rng, T_, sz, n_loops=2, sigma=3 + l % 4) for l, sz in enumerate(sizes)]
+    for l in (0, 7, 13, 16):
+        assert torch.equal(noise[l].noise, g[f"nbase_planes{l}"])
+    for s in g["subs"]:
+        noise = N.noise_patch(rng, noise, feats, 120.0, 24, **dict(eval(str(s))))
+    for l in (0, 7, 13, 16):
+        assert rel(noise[l].forward(5, 6), g[f"ny{l}"]) <= 1e-5, l
+
+
+def test_tempo_estimate(clip):
+    """selfsupervised/mir.py:27-30 tempo: HIP autocorrelation tempogram vs the oracle's numpy/FFT restatement of
+    librosa's published algorithm (librosa itself is un-vendored: parity unpinned), on a 2 Hz click train and on the
+    clip's own onset envelope."""
+    import numpy as np
+    import maua_amd.audio as A
+    T = 1800
+    env = np.zeros(T, dtype=np.float32)
+    env[::15] = 1.0
+    env += 0.01 * np.random.default_rng(0).random(T).astype(np.float32)
+    want = OA.tempo(env)
+    assert abs(want - 60 * 22050 / (1024 * 15)) < 1e-9      # period 15 frames at the sample rate librosa assumes
+    assert A.tempo(torch.from_numpy(env)) == want            # same lag bin -> the same float
+    e = A.onsets(clip, 30720).squeeze(-1)                   # the g09 clip (40 frames: a window longer than the clip)
+    assert A.tempo(e) == OA.tempo(e.cpu().numpy())

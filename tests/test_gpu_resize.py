@@ -116,8 +116,14 @@ def test_wrapper_output_size_and_noise_kwargs():
     ws = torch.randn(2, syn.num_ws, 512, generator=gen)
     img = syn.forward(ws)
     assert tuple(img.shape) == (2, 3, 40, 96) and bool(torch.isfinite(img).all())
-    pyr = syn.make_noise_pyramid(torch.randn(2, 1, 16, 16, generator=gen))
+    base = torch.randn(2, 1, 16, 16, generator=gen)
+    pyr = syn.make_noise_pyramid(base)
     assert tuple(pyr["noise3"].shape[-2:]) == G.layer_size(3)
+    # wrappers/stylegan2.py:196-213 (N-3): bicubic resize of the base to every layer size, / per-frame std
+    for l in (0, 3, 6):
+        want = torch.nn.functional.interpolate(base, G.layer_size(l), mode="bicubic", align_corners=False)
+        want = want / want.std((1, 2, 3), keepdim=True)
+        assert rel(pyr[f"noise{l}"], want) <= 1e-5
     img2 = syn.forward(ws, **pyr)
     assert tuple(img2.shape) == (2, 3, 40, 96) and not torch.equal(img, img2)
     with pytest.warns(UserWarning):                                          # 100 is not a multiple of 8

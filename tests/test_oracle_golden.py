@@ -279,6 +279,49 @@ def test_noise(golden):
     close(ON.scale_bias(md, 0.7, 0.1), g["scalebias_y"], 2e-6)
 
 
+PATCH_KEYS = ("patch_type", "seq_feat", "merge_type", "merge_depth")
+
+
+def _patch_features(g):
+    return {k[5:]: g[k] for k in g if k.startswith("feat_")}
+
+
+def test_latent_patch_graphs(golden):
+    """L6: selfsupervised/latent.py:16-80 on explicit selections (fixture = the reference's latent_patch run here)."""
+    g = golden("g20_patches")
+    feats = _patch_features(g)
+    segs = {(k, 4): g["seg"] for k in feats}
+    for i, case in enumerate(g["cases"]):
+        kw = dict(zip(PATCH_KEYS, str(case).split("|")))
+        out = OL.latent_patch(g[f"perm{i}"], g["base"], g["palette"], segs, feats, tempo=120.0, fps=24, segments=4,
+                              loop_bars=4, seq_feat_weight=0.8, mod_feat="rms", mod_feat_weight=0.6, **kw)
+        close(out, g[f"lat{i}"], 2e-6)
+
+
+def patch_subs(g):
+    return [dict(eval(str(s))) for s in g["subs"]]  # repr(sorted(dict.items())) written by make_golden.py
+
+
+def test_noise_patch_graphs(golden):
+    """N-2: selfsupervised/noise.py:89-140 - three stacked sub-patches over the 17 base Loop modules."""
+    g = golden("g20_patches")
+    feats = _patch_features(g)
+    T_ = len(g["base"])
+    sizes = [tuple(int(v) for v in s) for s in g["nsizes"]]
+    idx = torch.linspace(0, 2 * 2 * torch.pi, T_)
+    layers = (0, 7, 13, 16)
+    noise = [(lambda l: lambda i, b: ON.loop(g[f"nbase_planes{l}"], idx, i, b, 3 + l % 4))(l) for l in range(17)]
+    planes = {l: iter([g[k] for k in sorted((k for k in g if k.startswith(f"nplanes{l}_")),
+                                            key=lambda k: int(k.split("_")[1]))][1:]) for l in layers}
+    # layer 0 ends on an "overwrite" sub-patch: only that last module survives in the reference's graph (its planes are
+    # entry 0 of the fixture); the blend module it replaces gets placeholder planes
+    planes[0] = iter([torch.zeros(2, 4, *sizes[0]), g["nplanes0_0"]])
+    for sub in patch_subs(g):
+        noise = ON.noise_patch(planes, noise, sizes, feats, 120.0, 24, only=layers, **sub)
+    for l in layers:
+        close(noise[l](5, 6), g[f"ny{l}"], 3e-6)
+
+
 def test_tensor2bytes(golden):
     g = golden("g14_tensor2bytes")
     assert np.array_equal(OIO.tensor2bytes(g["img"]), g["bytes"].numpy())
