@@ -39,6 +39,7 @@ enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLI
 
 typedef struct maua_ctx maua_ctx;
 typedef struct maua_synth maua_synth;
+typedef struct maua_rrdbnet maua_rrdbnet;
 
 /* ---- context (library plumbing: no reference counterpart — the reference relies on torch's current device and
  * stream; a maua_ctx carries exactly that: device ordinal, HIP stream, a scratch arena) --------------------------- */
@@ -281,6 +282,19 @@ int maua_noise_mix(maua_ctx* ctx, const float* noise, const float* noise2, const
  * :78-86 ScaleBias (mode 2: scale*x + bias).  x, y, out [B,h,w]. */
 int maua_noise_combine(maua_ctx* ctx, const float* x, const float* y, const float* mod, int mode, float scale,
                        float bias, int B, int h, int w, float* out);
+
+/* ---- N4 (first slice): RealESRGAN x4 generator, the per-frame up-scaler of "StyleGAN2 render -> RealESRGAN 4x" ----
+ * replaces maua/super/image/models/realesrgan.py:22-49 (basicsr RRDBNet(3, 3, num_feat, num_block, num_grow_ch, scale 4)
+ * run by RealESRGANer.enhance: [0,1] image -> network -> clamp(0,1) -> round(x * 255)) and the per-frame loop of
+ * maua/super/video/frame_by_frame.py:22-33.  basicsr / realesrgan are un-vendored: published architecture. */
+int maua_rrdb_create(maua_ctx* ctx, int num_feat, int num_block, int num_grow_ch, int dtype, maua_rrdbnet** out);
+void maua_rrdb_destroy(maua_rrdbnet* net);
+/* name: a key of basicsr's RRDBNet state dict (conv_first.weight, body.3.rdb2.conv4.bias, conv_last.weight, ...);
+ * weights are [Co][Ci][3][3], biases [Co], f32 on the host. */
+int maua_rrdb_load(maua_rrdbnet* net, const char* name, const float* host_data, size_t count);
+/* img: device f32 [B][3][H][W] in [0,1].  out_nchw: device f32 [B][3][4H][4W] clamped to [0,1] (or NULL);
+ * out_rgb8: device u8 [B][4H][4W][3] = round(clamp * 255) (or NULL). */
+int maua_rrdb_forward(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, float* out_nchw, uint8_t* out_rgb8);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,13 @@ struct ConvArgs {
   float rgb_clamp;
   float fir[16];
   int variant;            // kernel-variant selector for same-process A/B measurements (0 = default)
+  // channel-sliced operands (modconv3x3_kernel only; 0 = dense): elements between consecutive pixels of x / y, first
+  // output channel inside a y pixel (dense-block buffers of the RRDB network, super.hip)
+  int x_pstride, y_pstride, y_coff;
+  long y_bstride;         // elements between samples of y (0 = Ho * Wo * Co)
+  const void* res;        // optional residual added after activation / gain / clamp: NHWC, res_pstride elements per pixel
+  int res_pstride;
+  long res_bstride;
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);

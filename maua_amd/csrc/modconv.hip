@@ -148,7 +148,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
       int py = (int)(((unsigned)p * g.inv_hw2) >> 20);
       int px = p - py * g.hw2;
       int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = ((long)gy * a.W + gx) * a.Ci + q * EPC;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) hoff[i] = ((long)gy * a.W + gx) * (a.x_pstride ? a.x_pstride : a.Ci) + q * EPC;
     }
   }
 
@@ -316,6 +316,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
             v[k] = t;
           }
         }
+        if (a.res && inside) {  // residual connection (RRDB blocks): added after activation, gain and clamp
+          const T* rp = reinterpret_cast<const T*>(a.res) + (long)b * a.res_bstride +
+                        ((long)gy * a.W + gx) * a.res_pstride + co;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] += Elem<T>::load(rp + k);
+        }
         char* dst = epi + m * ES + nl * (int)sizeof(T);
         if constexpr (sizeof(T) == 2)
           *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -413,7 +419,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
       }
     }
   }
-  char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ho * Wo * a.Co * (long)sizeof(T);
+  const long ypix = a.y_pstride ? a.y_pstride : a.Co;
+  char* yb = reinterpret_cast<char*>(a.y) +
+             ((long)b * (a.y_bstride ? a.y_bstride : (long)Ho * Wo * a.Co) + a.y_coff) * (long)sizeof(T);
   // (with the fused toRGB the waves that did not take part in it write the whole tile meanwhile)
   const bool rgb_split = sizeof(T) == 2 && a.rgb_out && NT > (BM / 32) * 64;
   const int ro_tid = rgb_split ? tid - (BM / 32) * 64 : tid, ro_nt = rgb_split ? NT - (BM / 32) * 64 : NT;
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
       const int co = nv - ph * a.Co;
       const int pa = ph >> (a.up - 1), pb = ph & (a.up - 1);
       const long pix = (long)(gy * a.up + pa) * Wo + gx * a.up + pb;
-      *reinterpret_cast<uint4*>(yb + (pix * a.Co + co) * (long)sizeof(T)) =
+      *reinterpret_cast<uint4*>(yb + (pix * ypix + co) * (long)sizeof(T)) =
           *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
     }
   }

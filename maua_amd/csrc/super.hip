@@ -1,0 +1,318 @@
+// RealESRGAN x4 generator (RRDBNet) forward: the per-frame 4x up-scaler of BASELINE configs[4] ("StyleGAN2 render ->
+// RealESRGAN 4x"), first slice.
+//
+// Replaces (reference): maua/super/image/models/realesrgan.py:22-49 (load_model builds basicsr's RRDBNet(3, 3, 64, 23 |
+// 6, 32, scale 4) and runs it through RealESRGANer.enhance: [0,1] input -> network -> clamp -> x255 round -> u8) and the
+// per-frame loop of maua/super/video/frame_by_frame.py:22-33.  basicsr / realesrgan are un-vendored (setup.py:32,85,
+// unpinned): the architecture is the published ESRGAN / Real-ESRGAN one; oracle/super.py restates it.  Parity unpinned.
+//
+//   RDB :  x1 = lrelu(c1(x)); x2 = lrelu(c2([x,x1])); x3 = lrelu(c3([x,x1,x2])); x4 = lrelu(c4([x..x3]));
+//          out = c5([x..x4]) * 0.2 + x                       (growth 32, lrelu slope 0.2)
+//   RRDB:  out = rdb3(rdb2(rdb1(x))) * 0.2 + x
+//   net :  f = conv_first(img); f = f + conv_body(RRDB^n(f)); f = lrelu(conv_up1(up2(f))); f = lrelu(conv_up2(up2(f)));
+//          out = conv_last(lrelu(conv_hr(f)))                (up2 = nearest neighbour x2)
+//
+// MI355X design: activations stay NHWC in the network dtype for the whole forward; a dense block is ONE buffer of
+// num_feat + 4 * grow channels per pixel - every convolution reads a channel prefix of it and writes its own channel
+// slice (no torch.cat copies: the conv kernels take pixel strides), the block's scaled residual is fused into conv5's
+// epilogue.  The 3x3 convolutions run on the MFMA implicit-GEMM kernel of modconv.hip with unit styles (a plain
+// convolution is a modulated one with s = 1 and no demodulation).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+using namespace maua;
+
+namespace {
+
+struct PlainConv {
+  int Ci, Co, Cip, Cop;   // real / padded-to-32 channel counts
+  void* wt = nullptr;     // prepared [9][Cop][Cip]
+  float* bias = nullptr;  // [Cop] (zero padded)
+};
+
+// dst[p][c] = a * x[p][c] + b * y[p][c] over n_pix pixels x C channels (16-byte pieces), each operand with its own pixel
+// stride; y may be NULL (b ignored).  The RRDB-level residual and the block-input copy.
+template <typename T>
+__global__ __launch_bounds__(256) void lincomb_nhwc_kernel(T* __restrict__ dst, int dps, float a, const T* __restrict__ x,
+                                                           int xps, float bsc, const T* __restrict__ y, int yps,
+                                                           long n_pix, int C) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int ppp = C / EPC;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_pix * ppp) return;
+  const long p = idx / ppp;
+  const int c = (int)(idx - p * ppp) * EPC;
+  float v[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) v[e] = a * Elem<T>::load(x + p * xps + c + e);
+  if (y) {
+#pragma unroll
+    for (int e = 0; e < EPC; e++) v[e] += bsc * Elem<T>::load(y + p * yps + c + e);
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; e++) Elem<T>::store(dst + p * dps + c + e, v[e]);
+}
+
+// nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest")) on NHWC, 16-byte pieces
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_nearest_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H,
+                                                                     int W, int C) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int ppp = C / EPC;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 4 * H * W * ppp;
+  if (idx >= total) return;
+  const int pc = (int)(idx % ppp);
+  long p = idx / ppp;
+  const int ox = (int)(p % (2 * W)); p /= 2 * W;
+  const int oy = (int)(p % (2 * H));
+  const int b = (int)(p / (2 * H));
+  const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + (oy >> 1)) * W + (ox >> 1)) * C + pc * EPC);
+  *reinterpret_cast<uint4*>(y + (((long)b * 2 * H + oy) * 2 * W + ox) * C + pc * EPC) = v;
+}
+
+// final image: NHWC network dtype (first 3 of Cp channels) -> planar f32 [B][3][H][W] and / or u8 HWC, clamped to [0,1]
+// (RealESRGANer.enhance: output.clamp_(0, 1), then (x * 255).round() for 8-bit images)
+template <typename T>
+__global__ __launch_bounds__(256) void rrdb_output_kernel(const T* __restrict__ x, int Cp, long HW, int B,
+                                                          float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * HW) return;
+  const long b = idx / HW, p = idx - b * HW;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float v = Elem<T>::load(x + idx * Cp + c);
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    if (out_f32) out_f32[(b * 3 + c) * HW + p] = v;
+    if (out_u8) out_u8[idx * 3 + c] = (uint8_t)__float2int_rn(v * 255.0f);
+  }
+}
+
+}  // namespace
+
+struct maua_rrdbnet {
+  maua_ctx* ctx;
+  int num_feat, num_block, grow, dtype;
+  size_t esize;
+  PlainConv conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last;
+  std::vector<PlainConv> rdb;  // [block][3 rdb][5 conv]
+  float* ones = nullptr;       // unit styles [bcap][max Ci]
+  int ones_b = 0;
+  // workspace (grow-only)
+  size_t cap_px = 0;           // B * H * W the buffers were sized for
+  void *in32 = nullptr, *feat0 = nullptr, *dense[2] = {nullptr, nullptr}, *rsave = nullptr, *f1 = nullptr, *up1 = nullptr,
+       *f2 = nullptr, *up2 = nullptr, *f3 = nullptr, *f4 = nullptr, *f5 = nullptr;
+};
+
+static int alloc_conv(PlainConv& c, int Ci, int Co, size_t esize) {
+  c.Ci = Ci; c.Co = Co; c.Cip = (Ci + 31) / 32 * 32; c.Cop = (Co + 31) / 32 * 32;
+  MAUA_HIP_CHECK(hipMalloc(&c.wt, (size_t)9 * c.Cop * c.Cip * esize));
+  MAUA_HIP_CHECK(hipMemset(c.wt, 0, (size_t)9 * c.Cop * c.Cip * esize));
+  MAUA_HIP_CHECK(hipMalloc((void**)&c.bias, (size_t)c.Cop * 4));
+  MAUA_HIP_CHECK(hipMemset(c.bias, 0, (size_t)c.Cop * 4));
+  return MAUA_OK;
+}
+
+static void free_ws(maua_rrdbnet* n) {
+  void** ps[] = {&n->in32, &n->feat0, &n->dense[0], &n->dense[1], &n->rsave, &n->f1, &n->up1, &n->f2, &n->up2, &n->f3,
+                 &n->f4, &n->f5};
+  for (void** p : ps) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+  }
+  n->cap_px = 0;
+}
+
+extern "C" {
+
+int maua_rrdb_create(maua_ctx* ctx, int num_feat, int num_block, int num_grow_ch, int dtype, maua_rrdbnet** out) {
+  MAUA_REQUIRE(ctx && out, "maua_rrdb_create: NULL argument");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_rrdb_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(num_feat % 32 == 0 && num_grow_ch % 32 == 0 && num_feat > 0 && num_grow_ch > 0 && num_block > 0,
+               "maua_rrdb_create: num_feat / num_grow_ch must be positive multiples of 32");
+  maua_rrdbnet* n = new maua_rrdbnet();
+  n->ctx = ctx; n->num_feat = num_feat; n->num_block = num_block; n->grow = num_grow_ch; n->dtype = dtype;
+  n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  int rc = alloc_conv(n->conv_first, 3, num_feat, n->esize);
+  n->rdb.resize((size_t)num_block * 15);
+  for (int i = 0; i < num_block * 3 && !rc; i++)
+    for (int k = 0; k < 5 && !rc; k++)
+      rc = alloc_conv(n->rdb[(size_t)i * 5 + k], num_feat + k * num_grow_ch, k == 4 ? num_feat : num_grow_ch, n->esize);
+  if (!rc) rc = alloc_conv(n->conv_body, num_feat, num_feat, n->esize);
+  if (!rc) rc = alloc_conv(n->conv_up1, num_feat, num_feat, n->esize);
+  if (!rc) rc = alloc_conv(n->conv_up2, num_feat, num_feat, n->esize);
+  if (!rc) rc = alloc_conv(n->conv_hr, num_feat, num_feat, n->esize);
+  if (!rc) rc = alloc_conv(n->conv_last, num_feat, 3, n->esize);
+  if (rc) {
+    maua_rrdb_destroy(n);
+    return rc;
+  }
+  *out = n;
+  return MAUA_OK;
+}
+
+void maua_rrdb_destroy(maua_rrdbnet* n) {
+  if (!n) return;
+  hipStreamSynchronize(n->ctx->stream);
+  free_ws(n);
+  auto fc = [](PlainConv& c) {
+    if (c.wt) hipFree(c.wt);
+    if (c.bias) hipFree(c.bias);
+  };
+  fc(n->conv_first); fc(n->conv_body); fc(n->conv_up1); fc(n->conv_up2); fc(n->conv_hr); fc(n->conv_last);
+  for (auto& c : n->rdb) fc(c);
+  if (n->ones) hipFree(n->ones);
+  delete n;
+}
+
+// parameter names of basicsr's RRDBNet state dict: conv_first | conv_body | conv_up1 | conv_up2 | conv_hr | conv_last
+// | body.<i>.rdb<1..3>.conv<1..5>, each .weight ([Co][Ci][3][3]) or .bias ([Co])
+int maua_rrdb_load(maua_rrdbnet* n, const char* name, const float* host, size_t count) {
+  MAUA_REQUIRE(n && name && host, "maua_rrdb_load: NULL argument");
+  std::string s(name);
+  const size_t dot = s.rfind('.');
+  MAUA_REQUIRE(dot != std::string::npos, "maua_rrdb_load: unknown parameter name");
+  const std::string mod = s.substr(0, dot), par = s.substr(dot + 1);
+  PlainConv* c = nullptr;
+  int blk = -1, r = -1, k = -1;
+  if (mod == "conv_first") c = &n->conv_first;
+  else if (mod == "conv_body") c = &n->conv_body;
+  else if (mod == "conv_up1") c = &n->conv_up1;
+  else if (mod == "conv_up2") c = &n->conv_up2;
+  else if (mod == "conv_hr") c = &n->conv_hr;
+  else if (mod == "conv_last") c = &n->conv_last;
+  else if (sscanf(mod.c_str(), "body.%d.rdb%d.conv%d", &blk, &r, &k) == 3 && blk >= 0 && blk < n->num_block && r >= 1 &&
+           r <= 3 && k >= 1 && k <= 5)
+    c = &n->rdb[((size_t)blk * 3 + (r - 1)) * 5 + (k - 1)];
+  if (!c) return fail("maua_rrdb_load: unknown parameter name: " + s);
+  hipStream_t st = n->ctx->stream;
+  if (par == "bias") {
+    if (count != (size_t)c->Co) return fail("maua_rrdb_load: " + s + ": wrong size");
+    MAUA_HIP_CHECK(hipMemcpy(c->bias, host, count * 4, hipMemcpyHostToDevice));
+    return MAUA_OK;
+  }
+  if (par != "weight") return fail("maua_rrdb_load: unknown parameter name: " + s);
+  if (count != (size_t)c->Co * c->Ci * 9) return fail("maua_rrdb_load: " + s + ": wrong size");
+  float* tmp;
+  MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+  MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+  MAUA_HIP_CHECK(hipMemsetAsync(c->wt, 0, (size_t)9 * c->Cop * c->Cip * n->esize, st));
+  int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, nullptr, c->Co, c->Ci, 3, 1, 0, c->Cop, c->Cip);
+  hipStreamSynchronize(st);
+  hipFree(tmp);
+  return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <typename T>
+int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, float* out_f32, uint8_t* out_u8) {
+  hipStream_t st = n->ctx->stream;
+  const int F = n->num_feat, G = n->grow, D = F + 4 * G;
+  const size_t es = n->esize;
+  const size_t px = (size_t)B * H * W;
+  if (px > n->cap_px) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    free_ws(n);
+    MAUA_HIP_CHECK(hipMalloc(&n->in32, px * 32 * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->feat0, px * F * es));
+    for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->dense[i], px * D * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->rsave, px * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->f1, px * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->up1, px * 4 * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->f2, px * 4 * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->up2, px * 16 * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->f3, px * 16 * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->f4, px * 16 * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->f5, px * 16 * 32 * es));
+    n->cap_px = px;
+  }
+  if (B > n->ones_b) {  // unit styles: [B][D] floats of 1
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    if (n->ones) hipFree(n->ones);
+    std::vector<float> h((size_t)B * D, 1.f);
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->ones, h.size() * 4));
+    MAUA_HIP_CHECK(hipMemcpy(n->ones, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    n->ones_b = B;
+  }
+  // a plain 3x3 convolution on channel slices: x = first c.Cip channels of a buffer with xps channels per pixel,
+  // y = c.Cop channels at channel offset ycoff of a buffer with yps per pixel (+ optional residual, yps-strided source)
+  auto conv = [&](const PlainConv& c, const void* x, int xps, void* y, int yps, int ycoff, int h, int w, bool lrelu,
+                  float gain, const void* res, int rps) -> int {
+    ConvArgs a{};
+    a.x = x; a.x_bstride = (long)h * w * xps; a.x_pstride = xps; a.w = c.wt; a.s = n->ones; a.d = nullptr;
+    a.noise = nullptr; a.bias = c.bias; a.y = y; a.y_pstride = yps; a.y_coff = ycoff; a.y_bstride = (long)h * w * yps;
+    a.B = B; a.H = h; a.W = w; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
+    a.act = lrelu ? MAUA_ACT_LRELU : MAUA_ACT_LINEAR; a.alpha = 0.2f; a.gain = gain; a.clamp = -1.f;
+    a.res = res; a.res_pstride = rps; a.res_bstride = (long)h * w * rps;
+    return launch_modconv3x3(st, n->dtype, a);
+  };
+  auto lincomb = [&](void* dst, int dps, float aa, const void* x, int xps, float bb, const void* y, int yps, long npix,
+                     int C) -> int {
+    const long total = npix * (C / (16 / (int)sizeof(T)));
+    hipLaunchKernelGGL(lincomb_nhwc_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (T*)dst, dps, aa,
+                       (const T*)x, xps, bb, (const T*)y, yps, npix, C);
+    MAUA_HIP_CHECK(hipGetLastError());
+    return MAUA_OK;
+  };
+  auto up2 = [&](const void* x, void* y, int h, int w) -> int {
+    const long total = (long)B * 4 * h * w * (F / (16 / (int)sizeof(T)));
+    hipLaunchKernelGGL(upsample2_nearest_nhwc_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const T*)x, (T*)y, B, h, w, F);
+    MAUA_HIP_CHECK(hipGetLastError());
+    return MAUA_OK;
+  };
+
+  int rc = launch_nchw_to_nhwc<float, T>(st, img, n->in32, B, 3, H * W, 32);
+  if (rc) return rc;
+  if ((rc = conv(n->conv_first, n->in32, 32, n->feat0, F, 0, H, W, false, 1.f, nullptr, 0))) return rc;
+  // the trunk: block input in channels [0, F) of dense[0]
+  if ((rc = lincomb(n->dense[0], D, 1.f, n->feat0, F, 0.f, nullptr, 0, (long)px, F))) return rc;
+  for (int blk = 0; blk < n->num_block; blk++) {
+    if ((rc = lincomb(n->rsave, F, 1.f, n->dense[0], D, 0.f, nullptr, 0, (long)px, F))) return rc;
+    int cur = 0;
+    for (int r = 0; r < 3; r++) {
+      const PlainConv* cs = &n->rdb[((size_t)blk * 3 + r) * 5];
+      char* db = (char*)n->dense[cur];
+      for (int k = 0; k < 4; k++)  // x_{k+1} = lrelu(conv_{k+1}(prefix)) -> its own channel slice of the same buffer
+        if ((rc = conv(cs[k], db, D, db, D, F + k * G, H, W, true, 1.f, nullptr, 0))) return rc;
+      // out = conv5(all) * 0.2 + x  -> the next dense block's input slice
+      if ((rc = conv(cs[4], db, D, n->dense[cur ^ 1], D, 0, H, W, false, 0.2f, db, D))) return rc;
+      cur ^= 1;
+    }
+    // RRDB: out * 0.2 + x (three blocks later the data sit in dense[1]); result back into dense[0]
+    if ((rc = lincomb(n->dense[0], D, 0.2f, n->dense[1], D, 1.f, n->rsave, F, (long)px, F))) return rc;
+  }
+  // feat = feat0 + conv_body(trunk)
+  if ((rc = conv(n->conv_body, n->dense[0], D, n->f1, F, 0, H, W, false, 1.f, n->feat0, F))) return rc;
+  if ((rc = up2(n->f1, n->up1, H, W))) return rc;
+  if ((rc = conv(n->conv_up1, n->up1, F, n->f2, F, 0, 2 * H, 2 * W, true, 1.f, nullptr, 0))) return rc;
+  if ((rc = up2(n->f2, n->up2, 2 * H, 2 * W))) return rc;
+  if ((rc = conv(n->conv_up2, n->up2, F, n->f3, F, 0, 4 * H, 4 * W, true, 1.f, nullptr, 0))) return rc;
+  if ((rc = conv(n->conv_hr, n->f3, F, n->f4, F, 0, 4 * H, 4 * W, true, 1.f, nullptr, 0))) return rc;
+  if ((rc = conv(n->conv_last, n->f4, F, n->f5, 32, 0, 4 * H, 4 * W, false, 1.f, nullptr, 0))) return rc;
+  const long opx = (long)B * 16 * H * W;
+  hipLaunchKernelGGL(rrdb_output_kernel<T>, dim3((unsigned)((opx + 255) / 256)), dim3(256), 0, st, (const T*)n->f5, 32,
+                     (long)16 * H * W, B, out_f32, out_u8);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // namespace
+
+extern "C" int maua_rrdb_forward(maua_rrdbnet* n, const float* img_nchw, int B, int H, int W, float* out_nchw,
+                                 uint8_t* out_rgb8) {
+  MAUA_REQUIRE(n && img_nchw, "maua_rrdb_forward: NULL argument");
+  MAUA_REQUIRE(out_nchw || out_rgb8, "maua_rrdb_forward: no output buffer");
+  MAUA_REQUIRE(B >= 0 && H > 0 && W > 0, "maua_rrdb_forward: bad shape");
+  if (B == 0) return MAUA_OK;
+  return n->dtype == MAUA_BF16 ? forward_t<bf16_t>(n, img_nchw, B, H, W, out_nchw, out_rgb8)
+                               : forward_t<float>(n, img_nchw, B, H, W, out_nchw, out_rgb8);
+}
