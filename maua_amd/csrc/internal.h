@@ -40,6 +40,7 @@ struct ConvArgs {
   // output channel inside a y pixel (dense-block buffers of the RRDB network, super.hip)
   int x_pstride, y_pstride, y_coff;
   long y_bstride;         // elements between samples of y (0 = Ho * Wo * Co)
+  const float* out_scale; // modconv_dma: [B][Co] or NULL - the stored features are multiplied by the NEXT layer's styles
   const void* res;        // optional residual added after activation / gain / clamp: NHWC, res_pstride elements per pixel
   int res_pstride;
   long res_bstride;
@@ -93,6 +94,10 @@ int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt,
 // modconv_tconv.hip: up-layer as the minimal stride-2 transposed convolution; writes the raw tensor
 // t [B][2H+1][2W+1][Co] (uses x, x_bstride, w (from launch_prep_tconv_weights), s, y, B, H, W, Ci, Co of ConvArgs)
 int launch_tconv2(hipStream_t stream, int dtype, const ConvArgs& a);
+constexpr int TCONV_EDGES_ONLY = 100;  // ConvArgs.variant: launch_tconv2 covers only the last row / column of positions
+// modconv_tconv_dma.hip: the main H x W block on LDS-direct loads; x already multiplied by the styles (bf16)
+bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W);
+int launch_tconv_dma(hipStream_t stream, const ConvArgs& a);
 int launch_prep_tconv_weights(hipStream_t stream, int dtype, const float* w, void* wt, int Co, int Ci, int flip);
 
 // second half of the minimal up-layer: out = act(d * FIR4x4(t) + noise + bias) (ops.py:225 upfirdn2d pad 1 gain 4,

@@ -393,10 +393,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     }
   }
   char* yb = reinterpret_cast<char*>(a.y) + (long)b * a.H * a.W * a.Co * 2;
+  // The stored features may carry the NEXT layer's styles (that layer's kernel then needs no modulation on its load
+  // path); the fused toRGB above read the unscaled tile.  A thread always copies the same piece column (NT % PPP == 0).
+  static_assert(NT % PPP == 0, "piece column per thread");
+  float osc[8];
+  if (a.out_scale) {
+    const float* sp = a.out_scale + (long)b * a.Co + n0 + (tid % PPP) * 8;
+    const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+    osc[0] = s0.x; osc[1] = s0.y; osc[2] = s0.z; osc[3] = s0.w; osc[4] = s1.x; osc[5] = s1.y; osc[6] = s1.z; osc[7] = s1.w;
+  }
   for (int p = tid; p < BM * PPP; p += NT) {
     const int m = p / PPP, pc = p - m * PPP;
     const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
-    *reinterpret_cast<uint4*>(yb + (pix * a.Co + n0 + pc * 8) * 2) = *reinterpret_cast<const uint4*>(epi + m * ES + pc * 16);
+    u32x4 v = *reinterpret_cast<const u32x4*>(epi + m * ES + pc * 16);
+    if (a.out_scale) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * osc[2 * k], bf2f((bf16_t)(v[k] >> 16)) * osc[2 * k + 1]);
+    }
+    *reinterpret_cast<u32x4*>(yb + (pix * a.Co + n0 + pc * 8) * 2) = v;
   }
 }
 

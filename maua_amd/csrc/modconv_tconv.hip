@@ -253,6 +253,7 @@ static int launch_tconv_t(hipStream_t stream, const ConvArgs& a) {
   // main H x W block, then the last column (n = W) and the last row (m = H) of the (H+1) x (W+1) position grid
   TconvRegions regs;
   int nt = make_region(regs.r[0], 0, 0, a.H, a.W, 0);
+  if (a.variant == TCONV_EDGES_ONLY) nt = 0;  // the main block is somebody else's (modconv_tconv_dma.hip): thin regions only
   nt += make_region(regs.r[1], 0, a.W, a.H + 1, 1, nt);
   nt += make_region(regs.r[2], a.H, 0, 1, a.W, nt);
   regs.halo_max = std::max(regs.r[0].halo_px, std::max(regs.r[1].halo_px, regs.r[2].halo_px));

@@ -1,0 +1,229 @@
+// Minimal-MAC up-layer, first half (t = conv_transpose2d(x * s, W, stride 2): reference ops.py:211-224), on the
+// LDS-direct-load pipeline of modconv_dma.hip - the main H x W block of the (H+1) x (W+1) position grid; the thin
+// last row / last column keep the register-staged kernel of modconv_tconv.hip.
+//
+// Same arithmetic and the same K order as tconv2_kernel (chunks of 32 channels, 9 (shift, class) weight blocks per
+// 16-channel k-step, classes accumulate their taps in the same order), so both produce bit-identical t from the same
+// bf16 operands.  What changes is the data path:
+//   * the input is ALREADY multiplied by the styles (the producing conv1's epilogue, or a premod pass), so the halo
+//     (9 x 33 pixels x 64 B per chunk) and the weights (9 blocks x 32 rows x 64 B per chunk) both arrive by
+//     global_load_lds_dwordx4 into double buffers - no staging registers, no ds_write, no style multiplication;
+//   * ONE barrier per chunk (tconv2_kernel: two), placed before the chunk's last k-step so that the refill of the
+//     buffers and the first fragment reads of the next chunk overlap the last MFMAs;
+//   * a wave owns TWO position rows (64 positions x 4 classes x 32 channels = 128 accumulator registers): the 9 weight
+//     fragments of a k-step feed 18 MFMAs instead of 9, the 6 distinct halo fragments (3 rows x 2 column shifts) are
+//     shared by the two rows - 0.83 ds_read_b128 per MFMA instead of 1.44;
+//   * 4 waves / 75 KB of LDS per workgroup: two workgroups per CU run out of phase.
+#include "common.h"
+#include "internal.h"
+
+namespace maua {
+
+namespace {
+
+constexpr int PTH = 8, PTW = 32;                   // positions per workgroup: 8 rows x 32 columns
+constexpr int HW1 = PTW + 1, HPX = (PTH + 1) * HW1;  // 9 x 33 halo pixels
+constexpr int KB = 64;                             // bytes of K per LDS row (32 bf16 channels = one chunk)
+constexpr int HBUF = HPX * KB;                     // 19 008
+constexpr int WROWS = 9 * 32;                      // weight rows per chunk: 9 (shift, class) blocks of 32 channels
+constexpr int WBUF = WROWS * KB;                   // 18 432
+constexpr int OFF_H = 2 * WBUF;
+constexpr int NW = 4, NT = NW * 64;
+constexpr int WJ = (WBUF / 1024 + NW - 1) / NW;    // 5 weight instructions per wave per chunk (18 in all)
+constexpr int HJ = (HPX * 4 + NT - 1) / NT;        // 5 halo instructions per wave per chunk (1188 pieces)
+
+__device__ __constant__ const int kSlot[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};  // as modconv_tconv.hip
+__device__ __constant__ const int kCls[9] = {0, 0, 1, 0, 2, 0, 1, 2, 3};
+
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+__device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
+
+}  // namespace
+
+__global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
+  constexpr int ES = 128 * 2 + 16, PPP = 16;  // epilogue tile row stride, 16-byte pieces per position (128 virtual ch)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int tiles_x = a.W >> 5;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int ty0 = tyi * PTH, tx0 = txi * PTW;
+  const int b = blockIdx.y, cb = blockIdx.z, CB = a.Co >> 5;
+  const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.x_bstride * 2;
+  const char* wp = reinterpret_cast<const char*>(a.w);
+
+  // halo sources (pixels above / left of the image are never loaded: zeroed once)
+  unsigned hoff[HJ];
+#pragma unroll
+  for (int j = 0; j < HJ; j++) {
+    const int P = (wave + NW * j) * 64 + lane;
+    const int hp = P >> 2, q = (P & 3) ^ swz(hp);
+    const int py = (hp * 1986) >> 16;  // hp / 33 for hp < 297
+    const int px = hp - py * HW1;
+    const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+    hoff[j] = 0xffffffffu;
+    if (P < HPX * 4) {
+      if (gy >= 0 && gx >= 0) {
+        hoff[j] = (unsigned)(((gy * a.W + gx) * a.Ci + q * 8) * 2);
+      } else {
+        *reinterpret_cast<u32x4*>(smem + OFF_H + P * 16) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(smem + OFF_H + HBUF + P * 16) = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  // weight sources: LDS row R = 32 k + n of the chunk's [288][64 B] image <- global row of block k, channel n
+  unsigned woff[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; j++) {
+    const int ii = wave + NW * j;
+    const int R = min(16 * ii + (lane >> 2), WROWS - 1);
+    const int k = R >> 5, n = R & 31;
+    const int q = (lane & 3) ^ swz(R);
+    woff[j] = (unsigned)((((((kSlot[k] * CB + cb) * 4 + kCls[k]) * 32 + n) * a.Ci) + q * 8) * 2);
+  }
+#define TD_ISSUE(C_, BUF_)                                                                               \
+  {                                                                                                      \
+    const char* ws_ = wp + (long)(C_) * KB;                                                              \
+    _Pragma("unroll") for (int j = 0; j < WJ; j++)                                                      \
+      if (wave + NW * j < WBUF / 1024) dma16_s(ws_, woff[j], lds0 + (BUF_) * WBUF + (wave + NW * j) * 1024); \
+    const char* xs_ = xb + (long)(C_) * KB;                                                              \
+    _Pragma("unroll") for (int j = 0; j < HJ; j++)                                                      \
+      if (hoff[j] != 0xffffffffu) dma16_s(xs_, hoff[j], lds0 + OFF_H + (BUF_) * HBUF + (wave + NW * j) * 1024); \
+  }
+
+  // fragment addresses.  A: halo pixel of (local row 2 wave + R, column r) under shift (p, q) = row + 1 - p, r + 1 - q
+  const int hp00 = (2 * wave) * HW1 + r;   // halo row 2 wave, halo column r  (= shift (1,1) of the wave's first row)
+  const unsigned b0 = (unsigned)(r * KB + ((swz(r) ^ h) << 4));
+#define TD_A(HR_, Q1_, KS_, BUF_)                                                                        \
+  ({                                                                                                     \
+    const int hp_ = hpv + (HR_) * HW1 + (Q1_);                                                           \
+    *reinterpret_cast<const u32x4*>(smem + ((OFF_H + (BUF_) * HBUF + hp_ * KB + ((swz(hp_) ^ h) << 4)) ^ ((KS_) << 5))); \
+  })
+#define TD_B(K_, KS_, BUF_) (*reinterpret_cast<const u32x4*>(smem + (BUF_) * WBUF + (K_) * 32 * KB + (b0 ^ ((KS_) << 5))))
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int R = 0; R < 2; R++)
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[R][c][e] = 0.f;
+
+  const int n_chunks = a.Ci >> 5;
+  TD_ISSUE(0, 0)
+  if (n_chunks > 1) TD_ISSUE(1, 1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int hpv = hp00;
+  // one k-step: 6 halo fragments (rows 2w .. 2w+2 of the halo x column shifts q = 1, 0), 9 weight fragments, 18 MFMAs;
+  // per class the taps accumulate in the order of tconv2_kernel (shift slots 0, 1, 2, 3)
+#define TD_STEP(KS_, BUF_)                                                                               \
+  {                                                                                                      \
+    u32x4 A00 = TD_A(0, 0, KS_, BUF_), A01 = TD_A(0, 1, KS_, BUF_);   /* halo row 2w:   q = 1, q = 0 */   \
+    u32x4 A10 = TD_A(1, 0, KS_, BUF_), A11 = TD_A(1, 1, KS_, BUF_);   /* halo row 2w+1 */                 \
+    u32x4 A20 = TD_A(2, 0, KS_, BUF_), A21 = TD_A(2, 1, KS_, BUF_);   /* halo row 2w+2 */                 \
+    {                                                                                                    \
+      const u32x4 B0 = TD_B(0, KS_, BUF_), B1 = TD_B(1, KS_, BUF_), B2 = TD_B(2, KS_, BUF_);              \
+      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);            /* shift (1,1) */                     \
+      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);            /* shift (1,0), class 1 */            \
+      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);            /* shift (1,0), class 0 */            \
+    }                                                                                                    \
+    {                                                                                                    \
+      const u32x4 B3 = TD_B(3, KS_, BUF_), B4 = TD_B(4, KS_, BUF_);                                       \
+      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);            /* shift (0,1), class 2 */            \
+      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);            /* shift (0,1), class 0 */            \
+    }                                                                                                    \
+    {                                                                                                    \
+      const u32x4 B5 = TD_B(5, KS_, BUF_), B6 = TD_B(6, KS_, BUF_), B7 = TD_B(7, KS_, BUF_), B8 = TD_B(8, KS_, BUF_); \
+      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);            /* shift (0,0) */                     \
+      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);                                                  \
+      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);                                                  \
+      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);                                                  \
+    }                                                                                                    \
+  }
+  for (int c = 0; c < n_chunks; c++) {
+    const int buf = c & 1;
+    asm volatile("" : "+v"(hpv));  // (keeps the fragment addresses out of loop-invariant registers)
+    TD_STEP(0, buf)
+    // the chunk's last fragment reads are issued inside the next step; the barrier that frees the buffers comes after
+    // they have returned, so it splits that step by hand: loads, wait, barrier, refill, MFMAs
+    {
+      u32x4 A00 = TD_A(0, 0, 1, buf), A01 = TD_A(0, 1, 1, buf), A10 = TD_A(1, 0, 1, buf), A11 = TD_A(1, 1, 1, buf);
+      u32x4 A20 = TD_A(2, 0, 1, buf), A21 = TD_A(2, 1, 1, buf);
+      const u32x4 B0 = TD_B(0, 1, buf), B1 = TD_B(1, 1, buf), B2 = TD_B(2, 1, buf), B3 = TD_B(3, 1, buf), B4 = TD_B(4, 1, buf);
+      const u32x4 B5 = TD_B(5, 1, buf), B6 = TD_B(6, 1, buf), B7 = TD_B(7, 1, buf), B8 = TD_B(8, 1, buf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
+      __syncthreads();                                  // ... for everybody; chunk c's buffers are free
+      if (c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
+      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);
+      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);
+      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);
+      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);
+      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);
+      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);
+      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);
+      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);
+      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);
+    }
+  }
+#undef TD_ISSUE
+#undef TD_A
+#undef TD_B
+#undef TD_STEP
+
+  // ---- raw t tile -> LDS [position][class * 32 + ch] -> 16-byte NHWC pieces of t [2H+1][2W+1][Co]
+  const int Wt = 2 * a.W + 1, Ht = 2 * a.H + 1;
+  __syncthreads();
+  char* epi = smem;
+#pragma unroll
+  for (int R = 0; R < 2; R++) {
+    const int m = (2 * wave + R) * 32 + r;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++)
+        *reinterpret_cast<uint2*>(epi + m * ES + (c * 32 + 8 * qd + 4 * h) * 2) =
+            make_uint2(pack2bf(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), pack2bf(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
+  }
+  __syncthreads();
+  char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ht * Wt * a.Co * 2;
+  for (int p = tid; p < PTH * PTW * PPP; p += NT) {
+    const int mm = p / PPP, pc = p - mm * PPP;
+    const int gy = ty0 + (mm >> 5), gx = tx0 + (mm & 31);
+    const int nv = pc * 8, cls = nv >> 5, ch = nv & 31;
+    const int oy = 2 * gy + (cls >> 1), ox = 2 * gx + (cls & 1);
+    *reinterpret_cast<uint4*>(yb + (((long)oy * Wt + ox) * a.Co + cb * 32 + ch) * 2) =
+        *reinterpret_cast<const uint4*>(epi + mm * ES + pc * 16);
+  }
+}
+
+bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W) {
+  return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H % PTH == 0 && W % PTW == 0 &&
+         (long)H * W * Ci * 2 < (1L << 32) && 16L * Co * Ci * 2 < (1L << 32);
+}
+
+// main H x W block of the position grid; a.x must already carry the styles.  The caller adds the last row / column with
+// launch_tconv2 (variant = TCONV_EDGES_ONLY, unit styles).
+int launch_tconv_dma(hipStream_t stream, const ConvArgs& a) {
+  MAUA_REQUIRE(tconv_dma_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W), "tconv_dma: unsupported shape");
+  MAUA_REQUIRE(a.B <= 65535, "tconv_dma: grid too large");
+  if (a.B == 0) return MAUA_OK;
+  const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * HBUF, (size_t)PTH * PTW * (128 * 2 + 16));
+  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tconv_dma_kernel, dim3((a.H / PTH) * (a.W / PTW), a.B, a.Co / 32), dim3(NT), smem, stream, a);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // namespace maua

@@ -67,6 +67,9 @@ struct maua_synth {
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
+  int tconv_dma = 1;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
+  float* ones = nullptr;   // [Bcap][max channels] unit styles (kernels that take already-modulated input)
+  void* xm = nullptr;      // [Bcap] pre-modulated copy of an up-layer's input when its producer could not scale it
   void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
   void* lowres_xm = nullptr;   // [Bcap] modconv_lowres workspaces (premodulated input, split-K partial sums)
   float* lowres_ws = nullptr;
@@ -112,8 +115,6 @@ static void compute_dims(maua_synth* n) {
   int h = 4, w = 4;
   if (n->rs_layer == 0) { h = n->rs_th; w = n->rs_tw; }
   size_t li = 0;
-  bool rgb8_done = false;
-  bool x_premod = false;  // the current x already carries the styles of the layer that reads it (modconv_dma.hip)
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     for (int k = 0; k < nconv; k++, li++) {
@@ -152,6 +153,10 @@ static int free_workspace(maua_synth* n) {
   n->style_table_dev = nullptr;
   if (n->tbuf) hipFree(n->tbuf);
   n->tbuf = nullptr;
+  if (n->ones) hipFree(n->ones);
+  if (n->xm) hipFree(n->xm);
+  n->ones = nullptr;
+  n->xm = nullptr;
   if (n->lowres_xm) hipFree(n->lowres_xm);
   if (n->lowres_ws) hipFree(n->lowres_ws);
   n->lowres_xm = nullptr;
@@ -202,6 +207,20 @@ static int ensure_workspace(maua_synth* n, int B) {
       lowres_workspace(n->dtype, B, c.ih, c.iw, c.Ci, c.Co, c.up, &x1, &w1);
       lx = std::max(lx, x1); lw = std::max(lw, w1);
     }
+  {
+    int maxc = 0;
+    size_t xm_elems = 0;
+    for (auto& c : n->convs) {
+      maxc = std::max(maxc, std::max(c.Ci, c.Co));
+      // (only the up-layers whose producer has no fused toRGB need the copy: inputs up to 64^2 at 1024^2 networks;
+      //  sized for any up-layer so that hooks / options can fall back to it)
+      if (c.up == 2 && tconv_dma_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw)) xm_elems = std::max(xm_elems, (size_t)c.ih * c.iw * c.Ci);
+    }
+    std::vector<float> h1((size_t)B * maxc, 1.f);
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->ones, h1.size() * sizeof(float)));
+    MAUA_HIP_CHECK(hipMemcpy(n->ones, h1.data(), h1.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (xm_elems) MAUA_HIP_CHECK(hipMalloc(&n->xm, (size_t)B * xm_elems * n->esize));
+  }
   if (lx) MAUA_HIP_CHECK(hipMalloc(&n->lowres_xm, lx));
   if (lw) MAUA_HIP_CHECK(hipMalloc((void**)&n->lowres_ws, lw));
   for (int i = 0; i < 2; i++)
@@ -406,6 +425,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->tconv_up = value;
     return MAUA_OK;
   }
+  if (!strcmp(key, "tconv_dma")) {
+    n->tconv_dma = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "dma_conv")) {
     n->dma_conv = value;
     return MAUA_OK;
@@ -506,6 +529,14 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
   return fail("maua_synth_load: unknown parameter name: " + s);
 }
 
+// does this up-layer run the LDS-direct transposed-conv kernel?  (same routing conditions as in the forward below)
+static bool up_uses_tconv_dma(const maua_synth* n, const ConvLayer& c) {
+  if (!n->tconv_dma || n->tconv_up != 1 || c.up != 2) return false;
+  const bool hires_up = n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw);
+  const int hin = std::min(c.ih, c.iw), hmax = std::max(c.ih, c.iw);
+  return !hires_up && hin >= 32 && hmax <= 512 && tconv_dma_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw);
+}
+
 int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* noise, const long* noise_bstride, int B,
                            float* img_out, uint8_t* rgb8_out) {
   MAUA_REQUIRE(n && ws, "maua_synth_forward: NULL argument");
@@ -541,7 +572,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   int img_cur = 0;
   size_t li = 0;
   bool rgb8_done = false;
-  bool x_premod = false;  // the current x already carries the styles of the layer that reads it (modconv_dma.hip)
+  bool x_premod = false;       // the current x already carries the styles of the conv1 that reads it (modconv_dma.hip)
+  bool premod_for_up = false;  // ... of the up-layer that reads it (modconv_tconv_dma.hip)
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     RgbLayer& g = n->rgbs[blk];
@@ -572,6 +604,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       // output by that layer's styles; nothing else reads an up-layer's output)
       const bool premod_in = x_premod;
       x_premod = false;
+      const bool premod_up_in = premod_for_up;   // x carries this up-layer's styles (set by the conv1 that produced it)
+      premod_for_up = false;
       bool premod_out = false;
       if (via_tconv && n->dma_conv && !hooked && !warped && !n->keep_features && c.which == 0 && li + 1 < n->convs.size()) {
         const ConvLayer& nx = n->convs[li + 1];
@@ -590,6 +624,15 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           rgb_fused = true;
         }
         a.variant = n->dma_conv;
+        // the up-layer that follows reads only these features (the block's toRGB is fused right here): store them
+        // already multiplied by its styles when it runs the LDS-direct transposed-conv kernel
+        if (rgb_fused && !hooked && !warped && !n->keep_features && li + 1 < n->convs.size()) {
+          const ConvLayer& nx = n->convs[li + 1];
+          if (nx.up == 2 && up_uses_tconv_dma(n, nx)) {
+            a.out_scale = nx.s;
+            premod_for_up = true;
+          }
+        }
         if (int rc = launch_modconv_dma(st, a)) return rc;
       } else if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};
@@ -617,6 +660,18 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;
         a.y = n->tbuf; a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 2;
+        if (up_uses_tconv_dma(n, c)) {
+          // main block on the LDS-direct kernel (input already multiplied by the styles: by the producing conv1, or by
+          // a pass over the - small - input here), last row / column of positions on the register-staged kernel
+          if (!premod_up_in) {
+            if (int rc = launch_premod_nhwc(st, x, x_bstride, c.s, n->xm, B, (long)c.ih * c.iw, c.Ci)) return rc;
+            a.x = n->xm;
+            a.x_bstride = (long)c.ih * c.iw * c.Ci;
+          }
+          a.s = n->ones;
+          if (int rc = launch_tconv_dma(st, a)) return rc;
+          a.variant = TCONV_EDGES_ONLY;
+        }
         if (int rc = launch_tconv2(st, n->dtype, a)) return rc;
         prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
         UpfirArgs u{};

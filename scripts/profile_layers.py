@@ -24,7 +24,7 @@ print(f"setup+first forward {time.time()-t0:.1f}s")
 h = net._handle()
 lib = L.lib()
 import os
-for opt in ("use_hires", "fuse_torgb", "tconv_up", "lowres", "dma_conv"):
+for opt in ("use_hires", "fuse_torgb", "tconv_up", "lowres", "dma_conv", "tconv_dma"):
     if os.environ.get("MAUA_" + opt.upper()) is not None:
         L.check(lib.maua_synth_set_option(h, opt.encode(), int(os.environ["MAUA_" + opt.upper()])))
 for it in range(3):

@@ -209,6 +209,13 @@ def test_full_size_network_properties_and_oracle_frame():
     L.check(L.lib().maua_synth_set_option(h, b"use_hires", 1))
     L.check(L.lib().maua_synth_set_option(h, b"tconv_up", 1))
     assert psnr(img.cpu(), img_g.cpu()) >= 45.0
+    # the LDS-direct-load kernels (conv1 on pre-modulated input, transposed conv of the up-layers) vs the register-staged
+    # ones: the same operands except that a pre-modulated activation is rounded once instead of twice
+    for opt in (b"dma_conv", b"tconv_dma"):
+        L.check(L.lib().maua_synth_set_option(h, opt, 0))
+        img_o = net(ws, noise=noise_d)
+        L.check(L.lib().maua_synth_set_option(h, opt, 1))
+        assert psnr(img.cpu(), img_o.cpu()) >= 60.0, (opt, psnr(img.cpu(), img_o.cpu()))
     # toRGB fused into the conv1 epilogues (register-stationary kernels at 512^2 / 1024^2, the generic kernel at 256^2
     # where Co == its N tile) vs the stand-alone toRGB kernels: same image up to f32 summation order
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
