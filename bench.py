@@ -52,11 +52,14 @@ def kernel_of(ci, co, res, up):
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
     if up == 2 and 32 <= hin <= 512:
-        return "tconv2_kernel<bf16>"  # + upfir_epilogue_kernel (second profile slot)
+        # main position block on LDS-direct loads; the profile slot also holds the thin last row / column
+        # (tconv2_kernel) and, where the producing conv1 could not pre-scale its output, the premod pass;
+        # + upfir_epilogue_kernel in a second profile slot
+        return "tconv_dma_kernel (+edges, +premod)"
     if up == 1 and 64 <= hin <= 512 and ci % 64 == 0 and co % 128 == 0:  # conv1 behind a tconv + upfir up-layer
         if co % 256 == 0:
-            return "modconv_dma_kernel<2,4,4,2,1,0>"
-        return "modconv_dma_kernel<4,2,2,2,%d,0>" % (2 if (ci // 64) % 2 == 0 else 1)
+            return "modconv_dma_kernel<2,4,4,2,1,128>"   # 256-channel N tile, 128-byte K rows, one workgroup per CU
+        return "modconv_dma_kernel<4,2,2,2,2,64>"        # 128-channel N tile, 64-byte K rows, two workgroups per CU
     cov = co * up * up
     if hin * hin <= 64 and ci % 64 == 0 and cov % 128 == 0:
         return "lowres_conv_kernel<bf16> (+premod, +epilogue)"  # one profile slot covers the three launches
@@ -98,7 +101,7 @@ def layer_table(net):
                 byts += r * r * 12 + (r // 2) ** 2 * 12
                 if i == len(net.block_resolutions) - 1:  # last block: the features are not stored and the image
                     byts += r * r * 3 - res * res * co * 2 - r * r * 12  # leaves as u8 (no f32 image, no pack pass)
-            if kern.startswith("tconv2"):  # two launches: MACs on the first, the output write on the second
+            if kern.startswith("tconv_dma"):  # two profile slots: MACs on the first, the output write on the second
                 t_bytes = (res + 1) * (res + 1) * co * 2
                 rows.append((pfx + ".tconv", kern, gflop, hin * hin * ci * 2 + t_bytes))
                 rows.append((pfx + ".upfir", "upfir_epilogue_kernel<bf16>", 0.0, t_bytes + res * res * co * 2 + res * res * 4))

@@ -49,6 +49,7 @@ __device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
 
 }  // namespace
 
+template <int ABL>
 __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
   constexpr int ES = 128 * 2 + 16, PPP = 16;  // epilogue tile row stride, 16-byte pieces per position (128 virtual ch)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -56,10 +57,19 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int tiles_x = a.W >> 5;
-  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  // Workgroup order (1-D grid): the dispatcher places block L on XCD L % 8, each XCD has its own L2.  The channel
+  // blocks of one (tile, sample) read the same input halo, so they run back to back ON ONE XCD (cb fastest inside an
+  // XCD, in groups of <= 8 blocks = <= 2.4 MB of weights, which stay L2-resident next to the halos): x is fetched from
+  // HBM once per group instead of once per channel block.  Placement is a speed matter only.
+  const int tiles_x = a.W >> 5, tiles = tiles_x * (a.H >> 3), CB = a.Co >> 5;
+  const int cbg = CB < 8 ? CB : 8, n_ts = tiles * a.B, per_group = ((n_ts + 7) >> 3) * 8 * cbg;
+  const int L = blockIdx.x, grp = L / per_group, Lg = L - grp * per_group;
+  const int xcd = Lg & 7, idx = Lg >> 3;
+  const int cb = grp * cbg + idx % cbg, ts = (idx / cbg) * 8 + xcd;
+  if (ts >= n_ts) return;
+  const int b = ts / tiles, tile = ts - b * tiles;
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
   const int ty0 = tyi * PTH, tx0 = txi * PTW;
-  const int b = blockIdx.y, cb = blockIdx.z, CB = a.Co >> 5;
   const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.x_bstride * 2;
   const char* wp = reinterpret_cast<const char*>(a.w);
 
@@ -163,9 +173,11 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
       u32x4 A20 = TD_A(2, 0, 1, buf), A21 = TD_A(2, 1, 1, buf);
       const u32x4 B0 = TD_B(0, 1, buf), B1 = TD_B(1, 1, buf), B2 = TD_B(2, 1, buf), B3 = TD_B(3, 1, buf), B4 = TD_B(4, 1, buf);
       const u32x4 B5 = TD_B(5, 1, buf), B6 = TD_B(6, 1, buf), B7 = TD_B(7, 1, buf), B8 = TD_B(8, 1, buf);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
-      __syncthreads();                                  // ... for everybody; chunk c's buffers are free
-      if (c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
+      if (ABL != 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
+        __syncthreads();                                  // ... for everybody; chunk c's buffers are free
+      }
+      if (ABL != 1 && c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
       mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);
       mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);
       mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);
@@ -217,11 +229,15 @@ bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W) {
 // launch_tconv2 (variant = TCONV_EDGES_ONLY, unit styles).
 int launch_tconv_dma(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(tconv_dma_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W), "tconv_dma: unsupported shape");
-  MAUA_REQUIRE(a.B <= 65535, "tconv_dma: grid too large");
   if (a.B == 0) return MAUA_OK;
+  const int tiles = (a.H / PTH) * (a.W / PTW), CB = a.Co / 32, cbg = CB < 8 ? CB : 8;
+  MAUA_REQUIRE(CB % cbg == 0, "tconv_dma: channel blocks must split into groups of 8");
+  const long n_ts = (long)tiles * a.B, grid = ((n_ts + 7) / 8) * 8 * cbg * (CB / cbg);
+  MAUA_REQUIRE(grid < (1L << 31), "tconv_dma: grid too large");
   const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * HBUF, (size_t)PTH * PTW * (128 * 2 + 16));
-  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(tconv_dma_kernel, dim3((a.H / PTH) * (a.W / PTW), a.B, a.Co / 32), dim3(NT), smem, stream, a);
+  auto kern = a.variant == 3 ? tconv_dma_kernel<1> : a.variant == 4 ? tconv_dma_kernel<2> : tconv_dma_kernel<0>;  // (ablation arms)
+  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, stream, a);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

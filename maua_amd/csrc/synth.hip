@@ -669,10 +669,16 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             a.x_bstride = (long)c.ih * c.iw * c.Ci;
           }
           a.s = n->ones;
+          // (the thin edges first, the main block behind them; running the edges on a side stream beside the main block
+          //  measured no different: 8.06 vs 8.08 ms per forward)
+          ConvArgs e = a;
+          e.variant = TCONV_EDGES_ONLY;
+          if (int rc = launch_tconv2(st, n->dtype, e)) return rc;
+          a.variant = n->tconv_dma;
           if (int rc = launch_tconv_dma(st, a)) return rc;
-          a.variant = TCONV_EDGES_ONLY;
+        } else if (int rc = launch_tconv2(st, n->dtype, a)) {
+          return rc;
         }
-        if (int rc = launch_tconv2(st, n->dtype, a)) return rc;
         prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
         UpfirArgs u{};
         u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;

@@ -40,8 +40,13 @@ def bench_name(k):
     m = re.search(r"modconv3x3_kernel<unsigned short, (\d), (\d), (\d), (\d), (\d), (\d+)>", k)
     if m:
         return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s,%s>" % m.groups()
+    if "tconv_dma_kernel" in k:
+        return "tconv_dma_kernel (+edges, +premod)"
+    m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+), 0, 0>", k)
+    if m:
+        return "modconv_dma_kernel<%s,%s,%s,%s,%s,%s>" % m.groups()
     if "tconv2_kernel<unsigned short>" in k:
-        return "tconv2_kernel<bf16>"
+        return "tconv2_kernel<bf16> (edges)"
     if "upfir_epilogue_kernel<unsigned short" in k:
         return "upfir_epilogue_kernel<bf16>"
     m = re.search(r"modconv_hires_kernel<(\d+), (\d+), (\d)>", k)

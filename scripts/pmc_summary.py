@@ -4,7 +4,10 @@
 
 Runs `rocprofv3 --kernel-trace --pmc <set>` once per counter set (PMC only, no other trace domains) over
 scripts/profile_layers.py, averages every counter per kernel name over the warmed-up launches, and derives
-  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE)   (share of matrix-pipe cycles in use)
+  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8)   (share of matrix-pipe cycles in
+              use; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs - checked against a kernel of known MFMA
+              count and duration: 18.9 M MFMAs x 32 cycles / (1024 SIMDs x 1.04 M cycles) = 0.57)
+  clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration (needs the kernel-trace durations; printed when available)
   valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES-like denominators where available
   lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES counts cycles
@@ -60,11 +63,11 @@ for name, cd in agg.items():
     m = {c: sum(v) / len(v) for c, v in cd.items()}
     g = m.get("GRBM_GUI_ACTIVE", 0.0)
     if g and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-        m["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * g)
+        m["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * g / 8)
     if m.get("SQ_LDS_IDX_ACTIVE"):
         m["lds_conflict_share"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
         if g:
-            m["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (256 * g)
+            m["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (256 * g / 8)
     if m.get("SQ_WAVE_CYCLES"):
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in m:
