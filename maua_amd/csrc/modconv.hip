@@ -316,6 +316,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
             v[k] = t;
           }
         }
+        if (a.out_scale) {  // the layer that reads these features wants them pre-multiplied by its styles
+          const float4 sv4 = *reinterpret_cast<const float4*>(a.out_scale + (long)b * a.Co + co);
+          v[0] *= sv4.x; v[1] *= sv4.y; v[2] *= sv4.z; v[3] *= sv4.w;
+        }
         if (a.res && inside) {  // residual connection (RRDB blocks): added after activation, gain and clamp
           const T* rp = reinterpret_cast<const T*>(a.res) + (long)b * a.res_bstride +
                         ((long)gy * a.W + gx) * a.res_pstride + co;

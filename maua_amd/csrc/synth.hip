@@ -607,7 +607,11 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       const bool premod_up_in = premod_for_up;   // x carries this up-layer's styles (set by the conv1 that produced it)
       premod_for_up = false;
       bool premod_out = false;
-      if (via_tconv && n->dma_conv && !hooked && !warped && !n->keep_features && c.which == 0 && li + 1 < n->convs.size()) {
+      // (producers that can scale their output: the FIR pass of a tconv up-layer, the generic kernel's epilogue)
+      const bool generic_up = c.up == 2 && !via_tconv && !hires_up &&
+                              !(n->lowres && lowres_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw));
+      if ((via_tconv || generic_up) && n->dma_conv && !hooked && !warped && !n->keep_features && c.which == 0 &&
+          li + 1 < n->convs.size()) {
         const ConvLayer& nx = n->convs[li + 1];
         premod_out = nx.block == blk && dma_conv_supported(n->dtype, nx.Ci, nx.Co, nx.up, nx.ih, nx.iw);
       }
@@ -700,6 +704,10 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           // <= 8x8 input pixels: one GEMM over all samples, split-K (modconv_lowres.hip)
           if (int rc = launch_modconv_lowres(st, n->dtype, a, n->lowres_xm, n->lowres_ws)) return rc;
         } else {
+        if (premod_out) {
+          a.out_scale = n->convs[li + 1].s;
+          x_premod = true;
+        }
         if (fuse_rgb_ok && modconv_rgb_fusable(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // the block's toRGB + skip in the epilogue
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
