@@ -56,7 +56,7 @@ def kernel_of(ci, co, res, up):
         # (tconv2_kernel) and, where the producing conv1 could not pre-scale its output, the premod pass;
         # + upfir_epilogue_kernel in a second profile slot
         return "tconv_dma_kernel (+edges, +premod)"
-    if up == 1 and 64 <= hin <= 512 and ci % 64 == 0 and co % 128 == 0:  # conv1 behind a tconv + upfir up-layer
+    if up == 1 and 32 <= hin <= 512 and ci % 64 == 0 and co % 128 == 0:  # conv1 behind an up-layer that pre-scales its output
         if co % 256 == 0:
             return "modconv_dma_kernel<2,4,4,2,1,128>"   # 256-channel N tile, 128-byte K rows, one workgroup per CU
         return "modconv_dma_kernel<4,2,2,2,2,64>"        # 128-channel N tile, 64-byte K rows, two workgroups per CU

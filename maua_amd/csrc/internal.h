@@ -35,7 +35,7 @@ struct ConvArgs {
   float* rgb_out;         // [B][3][H][W]
   float rgb_clamp;
   float fir[16];
-  int variant;            // kernel-variant selector for same-process A/B measurements (0 = default)
+  int variant;            // launch_tconv2: TCONV_EDGES_ONLY restricts the launch to the thin regions (0 = everything)
   // channel-sliced operands (modconv3x3_kernel only; 0 = dense): elements between consecutive pixels of x / y, first
   // output channel inside a y pixel (dense-block buffers of the RRDB network, super.hip)
   int x_pstride, y_pstride, y_coff;

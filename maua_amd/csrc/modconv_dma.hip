@@ -82,7 +82,7 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
   return MAUA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, int PIN, int ABL = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   }
   // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
 #define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
-  if (ABL != 1 || (K_) < 2) {                                                                            \
+  {                                                                                                      \
     _Pragma("unroll") for (int j_ = 0; j_ < TPS; j_++) {                                                \
       const int lp_ = ((K_) % 9) * TPS + j_;                                                             \
       const int c_ = (CC_) + ((K_) / 9) * TPS + lp_ / 9;                                                 \
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   }
 #define MAUA_ISSUE_H(J_, C_)                                                                             \
   {                                                                                                      \
-    if ((ABL != 1 || (C_) == 0) && (C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
+    if ((C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
       dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (wave + NW * (J_)) * 1024); \
   }
 
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const unsigned b0 = (unsigned)(((wn * WN) * 32 + r) * KCB + ((MAUA_SWZ(r) ^ h) << 4));
   // k-step Q_ of the stage at position K_ of the period starting at chunk CC_ (weight stage buffer WBUF_)
 #define MAUA_LOAD_FRAGS(AF_, BF_, CC_, K_, Q_, WBUF_)                                                    \
-  if (ABL != 3 || ((CC_) == 0 && (K_) == 0 && (Q_) < 2)) {                                               \
+  {                                                                                                      \
     const int lp_ = (K_) * TPS + (Q_) / KSPT, t_ = lp_ % 9, ks_ = (Q_) % KSPT;                           \
     const int hb_ = ((CC_) + lp_ / 9) & 1;                                                               \
     _Pragma("unroll") for (int i = 0; i < WM; i++) {                                                    \
@@ -239,11 +239,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       // Every load this wave issued behind the previous barrier (the next stage's weights, pieces of a coming halo)
       // has landed; the barrier publishes them and tells everybody that this stage's buffers have been read for the
       // last time.
-      if constexpr (ABL != 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (k + 1 < 9) {
         MAUA_LOAD_FRAGS(af, bf, cc, (k + 1) % 9, 0, wbuf ^ 1)
       } else if (cc + TPS < n_chunks) {
@@ -266,7 +263,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
           if (k == 8) MAUA_ISSUE_H(j, cc + 3)
         }
       }
-      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       MAUA_MMA(af1, bf1)
     }
   }
@@ -419,14 +415,14 @@ bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, int PIN, int ABL = 0>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
   const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KB + 2 * HALO_PX * KB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
   MAUA_REQUIRE((a.Ci / (KB / 2)) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PIN, ABL>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -440,20 +436,12 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");
   if (a.B == 0) return MAUA_OK;
   MAUA_REQUIRE((long)a.H * a.W * a.Ci * 2 < (1L << 32), "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
-  const bool two = (a.Ci / 64) % 2 == 0;
-  if (a.variant >= 3 && a.variant <= 5 && a.Co % 256 == 0) {  // ablation arms (wrong results, timing only)
-    if (a.variant == 3) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 1>(stream, a);
-    if (a.variant == 4) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 2>(stream, a);
-    return launch_dma_variant<2, 4, 4, 2, 1, 128, 0, 3>(stream, a);
-  }
-  if (a.variant == 6) return launch_dma_variant<4, 2, 2, 2, 2, 64, 0>(stream, a);  // experiment: two workgroups per CU everywhere
-  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 128, 0>(stream, a);
-  if (a.variant == 2) {  // experiment arm: one workgroup per CU also for the 128-channel N tile
-    if (two) return launch_dma_variant<4, 2, 2, 2, 2, 128, 0>(stream, a);
-    return launch_dma_variant<4, 2, 2, 2, 1, 128, 0>(stream, a);
-  }
-  // 128-channel N tile: 64-byte K rows, two taps per stage, 75.5 KB of LDS -> two workgroups per CU
-  return launch_dma_variant<4, 2, 2, 2, 2, 64, 0>(stream, a);
+  // 256-channel N tile: 128-byte K rows, one tap per stage, 149 KB of LDS, one workgroup per CU.
+  // 128-channel N tile: 64-byte K rows, two taps per stage, 75 KB -> two workgroups per CU (measured on the 256^2 layer,
+  // K = 1152: 0.90 -> 0.65 ms against the same tile with 128-byte rows and one workgroup per CU; for the 256-channel
+  // layers the two-workgroup shape measured the same as the big tile, which also keeps their toRGB fused)
+  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 128>(stream, a);
+  return launch_dma_variant<4, 2, 2, 2, 2, 64>(stream, a);
 }
 
 bool dma_rgb_fusable(int Co) { return Co == 128 || Co == 256; }

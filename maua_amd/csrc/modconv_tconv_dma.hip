@@ -49,7 +49,6 @@ __device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
 
 }  // namespace
 
-template <int ABL>
 __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
   constexpr int ES = 128 * 2 + 16, PPP = 16;  // epilogue tile row stride, 16-byte pieces per position (128 virtual ch)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -173,11 +172,9 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
       u32x4 A20 = TD_A(2, 0, 1, buf), A21 = TD_A(2, 1, 1, buf);
       const u32x4 B0 = TD_B(0, 1, buf), B1 = TD_B(1, 1, buf), B2 = TD_B(2, 1, buf), B3 = TD_B(3, 1, buf), B4 = TD_B(4, 1, buf);
       const u32x4 B5 = TD_B(5, 1, buf), B6 = TD_B(6, 1, buf), B7 = TD_B(7, 1, buf), B8 = TD_B(8, 1, buf);
-      if (ABL != 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
-        __syncthreads();                                  // ... for everybody; chunk c's buffers are free
-      }
-      if (ABL != 1 && c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
+      __syncthreads();                                  // ... for everybody; chunk c's buffers are free
+      if (c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
       mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);
       mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);
       mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);
@@ -235,9 +232,8 @@ int launch_tconv_dma(hipStream_t stream, const ConvArgs& a) {
   const long n_ts = (long)tiles * a.B, grid = ((n_ts + 7) / 8) * 8 * cbg * (CB / cbg);
   MAUA_REQUIRE(grid < (1L << 31), "tconv_dma: grid too large");
   const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * HBUF, (size_t)PTH * PTW * (128 * 2 + 16));
-  auto kern = a.variant == 3 ? tconv_dma_kernel<1> : a.variant == 4 ? tconv_dma_kernel<2> : tconv_dma_kernel<0>;  // (ablation arms)
-  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, stream, a);
+  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tconv_dma_kernel, dim3((unsigned)grid), dim3(NT), smem, stream, a);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

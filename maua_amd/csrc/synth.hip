@@ -622,12 +622,11 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 1;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
-        if (fuse_rgb_ok && dma_rgb_fusable(c.Co) && (n->dma_conv != 6 || c.Co == 128) && (c.ih % 2) == 0 && (c.iw % 2) == 0) {
+        if (fuse_rgb_ok && dma_rgb_fusable(c.Co) && (c.ih % 2) == 0 && (c.iw % 2) == 0) {
           a.rgb_wmod = g.wmod; a.rgb_bias = g.bias; a.rgb_prev = prev_img; a.rgb_out = rgb_out; a.rgb_clamp = 256.f;
           memcpy(a.fir, n->fir, sizeof(a.fir));
           rgb_fused = true;
         }
-        a.variant = n->dma_conv;
         // the up-layer that follows reads only these features (the block's toRGB is fused right here): store them
         // already multiplied by its styles when it runs the LDS-direct transposed-conv kernel
         if (rgb_fused && !hooked && !warped && !n->keep_features && li + 1 < n->convs.size()) {
@@ -678,7 +677,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           ConvArgs e = a;
           e.variant = TCONV_EDGES_ONLY;
           if (int rc = launch_tconv2(st, n->dtype, e)) return rc;
-          a.variant = n->tconv_dma;
+          a.variant = 0;
           if (int rc = launch_tconv_dma(st, a)) return rc;
         } else if (int rc = launch_tconv2(st, n->dtype, a)) {
           return rc;

@@ -42,7 +42,7 @@ def bench_name(k):
         return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s,%s>" % m.groups()
     if "tconv_dma_kernel" in k:
         return "tconv_dma_kernel (+edges, +premod)"
-    m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+), 0, 0>", k)
+    m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+)>", k)
     if m:
         return "modconv_dma_kernel<%s,%s,%s,%s,%s,%s>" % m.groups()
     if "tconv2_kernel<unsigned short>" in k:
