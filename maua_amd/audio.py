@@ -26,17 +26,19 @@ def _f32(t):
     return L.dev_tensor(torch.as_tensor(t), torch.float32)
 
 
-def _check_framing(n_fft, hop_length):
-    if n_fft != N_FFT or hop_length != HOP:
-        raise NotImplementedError("the HIP STFT is specialised to n_fft=2048, hop_length=1024 (the reference features' framing)")
+def _default_framing(n_fft, hop_length):
+    """the features' own framing (n_fft 2048, hop 1024: one hop per video frame) runs the specialised kernels; every other
+    power-of-two n_fft <= 2048 / hop (librosa's 2048 / 512 of the classic API) the general ones"""
+    return n_fft == N_FFT and hop_length == HOP
 
 
 # ------------------------------------------------------------------------------------------------ spectra
 def stft(y, n_fft=2048, hop_length=1024, center=True, window=None, pad_mode="reflect", return_complex=True):
-    """-> complex64 [1025, 1 + len(y)//1024] (a transposed view of the frame-major device buffer)."""
-    _check_framing(n_fft, hop_length)
+    """-> complex64 [n_fft//2 + 1, 1 + len(y)//hop] (a transposed view of the frame-major device buffer)."""
     if not center or pad_mode != "reflect":
         raise NotImplementedError("center=True / reflect padding only")
+    if not _default_framing(n_fft, hop_length):
+        return stft_general(y, n_fft, hop_length, window)
     y = _f32(y).reshape(-1)
     frames = 1 + y.numel() // HOP
     out = torch.empty((frames, N_BINS, 2), dtype=torch.float32, device=y.device)
@@ -51,7 +53,8 @@ def _frame_major(spec):
 
 
 def istft(spec, n_fft=2048, hop_length=1024, center=True, window=None, length=None):
-    _check_framing(n_fft, hop_length)
+    if not _default_framing(n_fft, hop_length):
+        return istft_general(spec, n_fft, hop_length, hop_length * (spec.shape[1] - 1) if length is None else length, window)
     spec = L.dev_tensor(spec, torch.complex64) if not spec.is_cuda else spec
     buf = _frame_major(spec)
     frames = buf.shape[0]
@@ -155,9 +158,12 @@ def power_to_db(magnitude, ref_value=1.0, amin=1e-10, top_db=80.0):
     return log_spec
 
 
-def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None):
-    """beat.py:10-23 -> [T] on device.  ``aggregate``: None / torch.mean, or "median" (what plp passes, beat.py:44)."""
-    S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=11025.0)
+def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None, fmax=11025.0):
+    """beat.py:10-23 -> [T] on device.  ``aggregate``: None / torch.mean, or "median" (what plp passes, beat.py:44).
+    ``fmax``: the in-tree function fixes 11 025 Hz; librosa's own default (the classic mir.onsets) is sr / 2."""
+    if n_fft != N_FFT:
+        raise NotImplementedError("onset_strength: n_fft must be 2048 (the mel kernel's bin count)")
+    S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=fmax)
     n_mels, T = S.shape
     env = torch.empty((T,), dtype=torch.float32, device=S.device)
     pad_width = 1 + n_fft // (2 * hop_length)
@@ -209,14 +215,14 @@ def median_filter2d(x, k=(3, 3), s=(1, 1), p=(1, 1, 1, 1), mode="reflect"):
     return out.T.reshape(x.shape)
 
 
-def harmonic(audio, margin=8.0):
+def harmonic(audio, margin=8.0, hop_length=1024):
     y = _f32(audio)
-    return istft(hpss(stft(y), margin=margin)[0], length=y.numel())
+    return istft(hpss(stft(y, hop_length=hop_length), margin=margin)[0], hop_length=hop_length, length=y.numel())
 
 
-def percussive(audio, margin=8.0):
+def percussive(audio, margin=8.0, hop_length=1024):
     y = _f32(audio)
-    return istft(hpss(stft(y), margin=margin)[1], length=y.numel())
+    return istft(hpss(stft(y, hop_length=hop_length), margin=margin)[1], hop_length=hop_length, length=y.numel())
 
 
 # ------------------------------------------------------------------------------------------------ envelopes

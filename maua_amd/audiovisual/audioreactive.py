@@ -16,15 +16,19 @@ def load_audio(audio_file, offset=0, duration=-1, cache=True):
     return audio, sr, len(audio) / sr
 
 
-def onsets(audio, sr, type="rosa", prepercussive=4):
-    """audioreactive/mir.py:16-61.  type="rosa" semantics (HPSS -> mel onset strength -> percentile_clip(95)) at the
-    in-tree framing (n_fft 2048, hop 1024); type="mm" needs madmom (un-vendored) and is rejected."""
+def onsets(audio, sr, type="rosa", prepercussive=4, hop_length=512):
+    """audioreactive/mir.py:16-61, type="rosa": ``rosa.effects.percussive(audio, margin)`` then
+    ``rosa.onset.onset_strength(y, sr)`` then ``percentile_clip(95)`` at librosa's own framing (n_fft 2048, hop 512, 128
+    mels up to sr / 2, lag 1, centre compensation) - librosa is un-vendored, its published algorithm is what the HIP
+    kernels implement (HPSS medians / soft masks / mel / dB / rectified difference; parity unpinned).  Pass
+    ``hop_length=1024`` for the hop-aligned framing of the selfsupervised features.  type="mm" needs madmom's filterbank
+    and five spectral-flux variants (un-vendored) and is rejected."""
     if type != "rosa":
         raise NotImplementedError('onsets(type="mm") needs madmom, which the reference does not vendor; use type="rosa"')
     a = torch.as_tensor(audio)
     if prepercussive:
-        a = percussive(a, margin=float(prepercussive))
-    return percentile_clip(onset_strength(a, sr), 95).squeeze()
+        a = percussive(a, margin=float(prepercussive), hop_length=hop_length)
+    return percentile_clip(onset_strength(a, sr, hop_length=hop_length, fmax=sr / 2), 95).squeeze()
 
 
 def rms(audio, sr):

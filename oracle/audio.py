@@ -61,9 +61,9 @@ def istft(spec, n_fft=N_FFT, hop=HOP, length=None):
     return y
 
 
-def spectrogram(y, power=1):
+def spectrogram(y, power=1, hop=HOP):
     """spectral.py:59-62 — drops the LAST stft column."""
-    return stft(y)[:, :-1].abs() ** power
+    return stft(y, hop=hop)[:, :-1].abs() ** power
 
 
 def hz_to_mel(f):
@@ -119,9 +119,9 @@ def mel_basis(sr, n_fft=N_FFT, n_mels=128, fmin=0.0, fmax=None):
     return w * enorm[:, None]
 
 
-def melspectrogram(y, sr, power=2.0, fmax=None):
+def melspectrogram(y, sr, power=2.0, fmax=None, hop=HOP):
     """spectral.py:65-70."""
-    return mel_basis(sr, fmax=fmax) @ spectrogram(y, power=power)
+    return mel_basis(sr, fmax=fmax) @ spectrogram(y, power=power, hop=hop)
 
 
 def power_to_db(S, amin=1e-10, top_db=80.0):
@@ -131,10 +131,10 @@ def power_to_db(S, amin=1e-10, top_db=80.0):
     return torch.maximum(log_spec, log_spec.max() - top_db)
 
 
-def onset_strength(y, sr, n_fft=N_FFT, hop=HOP, aggregate="mean"):
+def onset_strength(y, sr, n_fft=N_FFT, hop=HOP, aggregate="mean", fmax=11025.0):
     """beat.py:10-23 — mean (or, for plp :44, torch.median = lower middle) over mels of the rectified lag-1 dB
     difference, left-padded by 1 + n_fft // (2*hop) zeros and cropped to the spectrogram length."""
-    S = power_to_db(melspectrogram(y, sr, fmax=11025.0).abs())
+    S = power_to_db(melspectrogram(y, sr, fmax=fmax, hop=hop).abs())
     d = torch.clamp(S[:, 1:] - S[:, :-1], min=0)
     d = d.mean(0) if aggregate == "mean" else torch.median(d, dim=0).values
     pad_width = 1 + n_fft // (2 * hop)
@@ -172,14 +172,22 @@ def hpss(D, ks=31, power=2.0, margin=1.0):
     return (S * mh) * phase, (S * mp) * phase
 
 
-def harmonic(audio, margin=8.0):
+def harmonic(audio, margin=8.0, hop=HOP):
     """audio.py:13-17"""
-    return istft(hpss(stft(audio), margin=margin)[0], length=len(audio))
+    return istft(hpss(stft(audio, hop=hop), margin=margin)[0], hop=hop, length=len(audio))
 
 
-def percussive(audio, margin=8.0):
+def percussive(audio, margin=8.0, hop=HOP):
     """audio.py:20-24"""
-    return istft(hpss(stft(audio), margin=margin)[1], length=len(audio))
+    return istft(hpss(stft(audio, hop=hop), margin=margin)[1], hop=hop, length=len(audio))
+
+
+def classic_onsets(audio, sr, prepercussive=4, hop=512):
+    """audioreactive/mir.py:16-61 with type="rosa": librosa's percussive separation and onset_strength (un-vendored;
+    published algorithm, librosa's default framing n_fft 2048 / hop 512 / fmax sr/2), then percentile_clip(95)."""
+    from .signal import percentile_clip
+    a = percussive(audio, float(prepercussive), hop) if prepercussive else audio
+    return percentile_clip(onset_strength(a, sr, hop=hop, fmax=sr / 2), 95).squeeze()
 
 
 def normalize(x):

@@ -331,3 +331,18 @@ def test_tempo_estimate(clip):
     assert A.tempo(torch.from_numpy(env)) == want            # same lag bin -> the same float
     e = A.onsets(clip, 30720).squeeze(-1)                   # the g09 clip (40 frames: a window longer than the clip)
     assert A.tempo(e) == OA.tempo(e.cpu().numpy())
+
+
+def test_classic_onsets_at_librosa_framing(clip):
+    """A16: ar.onsets(type="rosa") = percussive -> onset_strength -> percentile_clip(95) at librosa's framing (hop 512,
+    mel up to sr / 2) and at the hop-aligned one, against the oracle's composition (librosa un-vendored: unpinned)."""
+    from maua_amd.audiovisual import audioreactive as ar
+    sr = 30720
+    for hop in (512, 1024):
+        got = ar.onsets(clip, sr, type="rosa", prepercussive=4, hop_length=hop).cpu()
+        want = OA.classic_onsets(clip, sr, 4, hop)
+        assert got.shape == want.shape == (len(clip) // hop,)
+        assert float((got - want).abs().max()) <= 2e-3, hop   # values in [0, 1]; dB of near-silent bins amplifies 1e-6
+    assert ar.onsets(clip, sr, prepercussive=0).shape == (len(clip) // 512,)
+    with pytest.raises(NotImplementedError):
+        ar.onsets(clip, sr, type="mm")
