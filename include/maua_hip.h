@@ -191,6 +191,21 @@ int maua_plp_select(maua_ctx* ctx, float* tempogram_frames_bins_complex, int n_f
  * n_frames hop-1 frames of env_padded [n_frames + win - 1] (the caller pads the envelope by win/2 ramp samples). */
 int maua_autocorr_frames(maua_ctx* ctx, const float* env_padded, const float* window, int n_frames, int win,
                          int n_lags, float* ac_frames_lags);
+/* ---- constant-Q features (rosa/constantq.py:13-115, rosa/spectral.py:164-325, rosa/pitch.py) ----
+ * out[i] = scale * sum_k taps[k] x[i * stride + k - left] (zero outside the signal): one phase of torchaudio's sinc
+ * resampler - what constantq.py:92 `resample(y, sr, sr / 2, "kaiser_window")` computes (torchaudio un-vendored:
+ * published kernel, built by the caller). */
+int maua_fir_decimate(maua_ctx* ctx, const float* x, long n, const float* taps, int ntaps, int stride, int left,
+                      float scale, float* out, long n_out);
+/* spectral.py:193-232 spline_eval (+ step_function when apply_step): out = step(a + f (b + f (c + f d))) with the
+ * interval picked like torch.bucketize; knots [n_knots], coef [4][n_knots - 1] (a, b, c, d rows), all device f32. */
+int maua_spline_step(maua_ctx* ctx, const float* x, long n, const float* knots, const float* coef, int n_knots, float h,
+                     float alpha, int apply_step, float* out);
+/* pitch.py:27-87 piptrack on the frame-major magnitude [n_frames][n_bins]; frame_max [n_frames] = max over bins,
+ * freqs [n_bins] = the bin frequencies the band test compares (the caller's linspace), bin_hz = sr / n_fft;
+ * pitch / mag [n_frames][n_bins] receive the interpolated frequency (Hz) and magnitude at accepted peaks, 0 elsewhere. */
+int maua_piptrack(maua_ctx* ctx, const float* mag_frames_bins, int n_frames, int n_bins, const float* frame_max,
+                  float threshold, const float* freqs, float bin_hz, float fmin, float fmax, float* pitch, float* mag);
 /* replaces processing.py:53-56 normalize (eps = 1e-8) and signal.py:27-38 normalize (eps = 0):
  * y = (x - min) / ((max - min) + eps) over all n elements. */
 int maua_normalize(maua_ctx* ctx, const float* x, long n, float eps, float* y);

@@ -17,7 +17,7 @@ HEADER = _HERE.parent / "include" / "maua_hip.h"
 
 F32, BF16 = 0, 1
 ACTS = {"linear": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "elu": 5, "selu": 6, "softplus": 7, "swish": 8}
-PAD_MODES = {"circular": 0, "reflect": 1, "replicate": 2}
+PAD_MODES = {"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}
 
 
 class MauaHipError(RuntimeError):

@@ -377,11 +377,17 @@ def mfcc(y, sr, n_mfcc=20, norm=False, **kwargs):
     return M
 
 
-def tonnetz(y=None, sr=None, chroma=None):
-    """features/audio.py:50-62 given a chromagram [12 (or n_chroma), T] (chroma_cens / CQT are not implemented:
-    pass ``chroma``) -> [T, 6]."""
+def chromagram(audio, sr):
+    """features/audio.py:44-45 -> [T, 12] (constant-Q chain: maua_amd/cqt.py)."""
+    from .cqt import chromagram as _chromagram
+    return _chromagram(audio, sr)
+
+
+def tonnetz(y=None, sr=None, chroma_fn=None, chroma=None):
+    """features/audio.py:50-62 -> [T, 6]: tonal centroids of the chromagram (``chroma_fn(y, sr)`` -> [12, T], default the
+    CENS chromagram like the reference; ``chroma`` hands a ready one in)."""
     if chroma is None:
-        raise NotImplementedError("tonnetz needs a chromagram: chroma_cens (constant-Q stack) is not implemented")
+        chroma = chroma_fn(y, sr) if chroma_fn is not None else chromagram(y, sr).T
     ch = _f32(chroma)
     n = ch.shape[0]
     dim_map = torch.linspace(0, 12, n)

@@ -1,9 +1,8 @@
 """Hop-aligned audio-reactive sampler (drop-in for
 maua/audiovisual/audioreactive/selfsupervised/sample.py:36-107 ``generate`` and patch.py:34-197 ``Patch``).
 
-Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  Features: every function of the
-reference's AFEATFNS except the two constant-Q ones: mfcc, spectral_contrast, spectral_flatness, rms,
-drop_strength, onsets.  The tempo is estimated from the onset envelope (the autocorrelation-tempogram estimate the
+Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  Features: the reference's AFEATFNS (chromagram, tonnetz, mfcc,
+spectral_contrast, spectral_flatness, rms, drop_strength, onsets).  The tempo is estimated from the onset envelope (the autocorrelation-tempogram estimate the
 reference takes from librosa); beat tracking + Laplacian segmentation (librosa / torch_geometric, un-vendored) are not
 implemented, so "segmentation" sub-patches are not drawn (latent_patch itself supports them when given labels).  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
 rank 0 with one RCCL gather at the end.
@@ -27,11 +26,10 @@ from ..pipeline import frame_range
 from ..stylegan2 import StyleGAN2
 from ..video import VideoWriter
 
-# selfsupervised/mir.py:9-11 minus the two features that need the constant-Q transform (chromagram, tonnetz: their
-# resampler is torchaudio's, un-vendored - SURVEY 8(f) N3)
-AFEATFNS = [A.mfcc, A.spectral_contrast, A.spectral_flatness, A.rms, A.drop_strength, A.onsets]
+# selfsupervised/mir.py:9-11
+AFEATFNS = [A.chromagram, A.tonnetz, A.mfcc, A.spectral_contrast, A.spectral_flatness, A.rms, A.drop_strength, A.onsets]
 UNITFEATS = ["rms", "drop_strength", "onsets", "spectral_flatness"]
-ALLFEATS = ["mfcc", "spectral_contrast"] + UNITFEATS
+ALLFEATS = ["chromagram", "tonnetz", "mfcc", "spectral_contrast"] + UNITFEATS
 
 
 def retrieve_music_information(audio, sr):

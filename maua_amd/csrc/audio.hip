@@ -452,6 +452,7 @@ __device__ __forceinline__ int pad_src(int j, int T, int radius, int mode) {
   if (i >= 0 && i < T) return i;
   if (mode == MAUA_PAD_CIRCULAR) return ((i % T) + T) % T;
   if (mode == MAUA_PAD_REFLECT) return i < 0 ? -i : 2 * (T - 1) - i;
+  if (mode == MAUA_PAD_CONSTANT) return -1;  // zero padding (conv1d(padding="same"), chroma_cens smoothing)
   return i < 0 ? 0 : T - 1;
 }
 
@@ -461,7 +462,10 @@ __global__ __launch_bounds__(256) void gauss1d_kernel(const float* __restrict__ 
   int t = blockIdx.y;
   if (c >= C) return;
   float acc = 0.f;
-  for (int k = 0; k <= 2 * radius; k++) acc += taps[k] * x[(long)pad_src(t + k, T, radius, mode) * C + c];
+  for (int k = 0; k <= 2 * radius; k++) {
+    const int src = pad_src(t + k, T, radius, mode);
+    if (src >= 0) acc += taps[k] * x[(long)src * C + c];
+  }
   y[(long)t * C + c] = acc;
 }
 
@@ -834,7 +838,7 @@ int maua_gaussian_filter1d(maua_ctx* ctx, const float* x, const float* taps, int
   MAUA_REQUIRE(ctx, "maua_gaussian_filter1d: ctx is NULL");
   if (T == 0 || C == 0) return MAUA_OK;
   MAUA_REQUIRE(x && taps && y && x != y, "maua_gaussian_filter1d: NULL or aliased argument");
-  MAUA_REQUIRE(mode >= 0 && mode <= 2, "maua_gaussian_filter1d: unknown padding mode");
+  MAUA_REQUIRE(mode >= 0 && mode <= 3, "maua_gaussian_filter1d: unknown padding mode");
   // torch's F.pad(mode="reflect") rejects a pad >= the sequence length; the reference pads min(radius, T) with `mode`
   MAUA_REQUIRE(mode != MAUA_PAD_REFLECT || std::min(radius, T) < T,
                "maua_gaussian_filter1d: reflect padding must be smaller than the sequence (lower sigma)");

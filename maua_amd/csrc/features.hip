@@ -178,6 +178,83 @@ __global__ __launch_bounds__(256) void autocorr_frames_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------- constant-Q support
+// out[i] = scale * sum_k taps[k] * x[i * stride + k - left]  (zero outside [0, n)): the polyphase form of a sinc
+// resampler for integer down-sampling (rosa/constantq.py:92 resample(y, sr, sr / 2): torchaudio's kernel, one phase).
+__global__ __launch_bounds__(256) void fir_decimate_kernel(const float* __restrict__ x, long n, const float* __restrict__ taps,
+                                                           int ntaps, int stride, int left, float scale,
+                                                           float* __restrict__ out, long n_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const long base = i * stride - left;
+  float acc = 0.f;
+  for (int k = 0; k < ntaps; k++) {
+    const long j = base + k;
+    if (j >= 0 && j < n) acc = fmaf(taps[k], x[j], acc);
+  }
+  out[i] = acc * scale;
+}
+
+// y = step(spline(x)): the soft quantiser of chroma_cens (rosa/spectral.py:164-232).  spline = piecewise cubic
+// a + f (b + f (c + f d)), f = x - knot[idx], idx = (number of knots < x) - 1 clamped to [0, nk - 2] (torch.bucketize);
+// step(w) = h (floor(w - 0.5) + 1 / (2 m) / (1 + exp(-2 alpha r(w)))), r(w) = (w - 0.5) - floor(w - 0.5) - 0.5.
+__global__ __launch_bounds__(256) void spline_step_kernel(const float* __restrict__ x, long n, const float* __restrict__ knots,
+                                                          const float* __restrict__ coef /* [4][nk-1]: a, b, c, d */,
+                                                          int nk, float h, float alpha, float inv2m, int apply_step,
+                                                          float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t = x[i];
+  int lo = 0, hi = nk;  // first index with knots[idx] >= t  (bucketize, right = False)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (knots[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  int idx = lo - 1;
+  idx = idx < 0 ? 0 : (idx > nk - 2 ? nk - 2 : idx);
+  const float f = t - knots[idx];
+  const int m = nk - 1;
+  float w = coef[idx] + (coef[m + idx] + (coef[2 * m + idx] + coef[3 * m + idx] * f) * f) * f;
+  if (apply_step) {
+    const float fl = floorf(w - 0.5f);
+    const float r = (w - 0.5f) - fl - 0.5f;
+    w = h * (fl + inv2m / (1.f + expf(-2.f * alpha * r)));
+  }
+  out[i] = w;
+}
+
+// piptrack core (rosa/pitch.py:27-87) on the frame-major magnitude S [n_frames][n_bins]: per bin the parabolic
+// interpolation shift, the local-max / threshold / band test, pitch (Hz) and interpolated magnitude (0 where rejected).
+__global__ __launch_bounds__(256) void piptrack_kernel(const float* __restrict__ S, int n_frames, int n_bins,
+                                                       const float* __restrict__ frame_max, float threshold,
+                                                       const float* __restrict__ freqs, float bin_hz, float fmin,
+                                                       float fmax, float* __restrict__ pitch, float* __restrict__ mag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_frames * n_bins) return;
+  const int f = (int)(idx / n_bins), b = (int)(idx - (long)f * n_bins);
+  const float* row = S + (long)f * n_bins;
+  const float s0 = row[b];
+  const float ref = threshold * frame_max[f];
+  auto gated = [&](int k) { return (k < 0 || k >= n_bins) ? 0.f : (row[k] > ref ? row[k] : 0.f); };
+  float p = 0.f, m = 0.f;
+  const float freq = freqs[b];    // the caller's torch.linspace(0, sr / 2, n_bins): compared exactly like the reference
+  const float g = gated(b);
+  const bool lmax = g > gated(b - 1) && g >= gated(b + 1);
+  if (lmax && fmin <= freq && freq < fmax) {
+    float avg = 0.f, shift = 0.f;
+    if (b >= 1 && b + 1 < n_bins) {
+      avg = 0.5f * (row[b + 1] - row[b - 1]);
+      float sh = 2.f * s0 - row[b + 1] - row[b - 1];
+      sh = sh + (fabsf(sh) < 1.17549435e-38f ? 1.f : 0.f);
+      shift = avg / sh;
+    }
+    p = (b + shift) * bin_hz;
+    m = s0 + 0.5f * avg * shift;
+  }
+  pitch[idx] = p;
+  mag[idx] = m;
+}
+
 }  // namespace maua
 
 using namespace maua;
@@ -263,6 +340,41 @@ extern "C" int maua_autocorr_frames(maua_ctx* ctx, const float* env_padded, cons
   if (n_frames == 0) return MAUA_OK;
   hipLaunchKernelGGL(maua::autocorr_frames_kernel, dim3(n_frames), dim3(256), (size_t)win * 4, ctx->stream, env_padded,
                      window, win, n_lags, ac);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+extern "C" int maua_fir_decimate(maua_ctx* ctx, const float* x, long n, const float* taps, int ntaps, int stride, int left,
+                                 float scale, float* out, long n_out) {
+  MAUA_REQUIRE(ctx && x && taps && out, "maua_fir_decimate: NULL argument");
+  MAUA_REQUIRE(ntaps >= 1 && stride >= 1 && n >= 0 && n_out >= 0, "maua_fir_decimate: bad sizes");
+  if (n_out == 0) return MAUA_OK;
+  hipLaunchKernelGGL(maua::fir_decimate_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, x, n, taps,
+                     ntaps, stride, left, scale, out, n_out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+extern "C" int maua_spline_step(maua_ctx* ctx, const float* x, long n, const float* knots, const float* coef, int n_knots,
+                                float h, float alpha, int apply_step, float* out) {
+  MAUA_REQUIRE(ctx && x && knots && coef && out, "maua_spline_step: NULL argument");
+  MAUA_REQUIRE(n_knots >= 2, "maua_spline_step: need at least two knots");
+  if (n == 0) return MAUA_OK;
+  const float m = 1.f / (1.f + expf(-alpha)) - 0.5f;
+  hipLaunchKernelGGL(maua::spline_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, knots, coef,
+                     n_knots, h, alpha, 1.f / (2.f * m), apply_step, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+extern "C" int maua_piptrack(maua_ctx* ctx, const float* mag_frames_bins, int n_frames, int n_bins, const float* frame_max,
+                             float threshold, const float* freqs, float bin_hz, float fmin, float fmax, float* pitch,
+                             float* mag) {
+  MAUA_REQUIRE(ctx && mag_frames_bins && frame_max && freqs && pitch && mag, "maua_piptrack: NULL argument");
+  const long n = (long)n_frames * n_bins;
+  if (n == 0) return MAUA_OK;
+  hipLaunchKernelGGL(maua::piptrack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, mag_frames_bins,
+                     n_frames, n_bins, frame_max, threshold, freqs, bin_hz, fmin, fmax, pitch, mag);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

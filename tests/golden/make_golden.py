@@ -507,6 +507,34 @@ def golden_patches():
     save("g20_patches", **out)
 
 
+def golden_cqt():
+    """The parts of the constant-Q chain the reference can run here (rosa/constantq.py, rosa/pitch.py, rosa/convert.py):
+    filter bank, sparsified FFT basis, the top octave's response, piptrack / estimate_tuning, cq_to_chroma.  The rest
+    (torchaudio.resample between octaves, the torchcubicspline coefficients behind spline_quantize) is un-vendored."""
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import spectral as _SP  # noqa: F401 (first: its import cycle)
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import constantq as CQ
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import convert as CV
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import pitch as PT
+    a = np.load(HERE / "g09_audio_clip.npz")["audio"]
+    y = torch.from_numpy(a)
+    sr = 30720
+    fmin = torch.tensor(32.70319566257483).float()
+    top = CQ.cqt_frequencies(252, fmin, bins_per_octave=36)[-36:]
+    filters, lengths = CQ.constant_q(sr, fmin=top.min(), n_bins=36, bins_per_octave=36)
+    fft_basis, n_fft, _ = getattr(CQ, "__cqt_filter_fft")(sr, top.min(), 36, 36, 1, 0.01, gamma=0)
+    dense = fft_basis.to_dense()
+    resp = getattr(CQ, "__cqt_response")(y, n_fft, 1024, fft_basis)
+    pitch, mag = PT.piptrack(y, sr)
+    tuning = PT.estimate_tuning(y, sr, bins_per_octave=36)
+    m = CV.cq_to_chroma(252, "cpu", bins_per_octave=36, n_chroma=12, fmin=fmin)
+    nz = torch.nonzero(pitch)
+    save("g21_cqt", top_freqs=top, lengths=lengths, filt_rows=torch.view_as_real(filters[[0, 17, 35]]), filt_abs_sum=filters.abs().sum(1),
+         n_fft=np.int64(n_fft), basis_nnz=(dense != 0).sum(1), basis_rows=torch.view_as_real(dense[[0, 17, 35]]),
+         basis_abs_sum=dense.abs().sum(1), resp=torch.view_as_real(resp), pitch_idx=nz, pitch_val=pitch[nz[:, 0], nz[:, 1]],
+         mag_val=mag[nz[:, 0], nz[:, 1]], tuning=np.float32(float(tuning)), cq_to_chroma=m,
+         lengths_full=CQ.constant_q_lengths(sr, fmin, n_bins=252, bins_per_octave=36))
+
+
 def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
     """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
     maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""

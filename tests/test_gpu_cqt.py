@@ -1,0 +1,96 @@
+"""Constant-Q chain (maua_amd/cqt.py) on the device against oracle/cqt.py and the reference fixture g21."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SR = 30720
+
+
+def close(a, b, tol):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert err <= tol, err
+
+
+@pytest.fixture(scope="module")
+def clip(golden):
+    return torch.from_numpy(np.asarray(golden("g09_audio_clip")["audio"]))
+
+
+def test_resample_half_equals_oracle(clip):
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    for n in (len(clip), 4097, 31):
+        y = clip[:n]
+        close(Q.resample_half(y), OC.resample(y, 2, 1) * np.sqrt(2.0), 2e-6)
+
+
+def test_piptrack_and_tuning_match_reference_fixture(clip, golden):
+    from maua_amd import cqt as Q
+    g = golden("g21_cqt")
+    pitch, mag = Q.piptrack(clip, SR)
+    pitch, mag = pitch.cpu(), mag.cpu()
+    nz = torch.nonzero(pitch)
+    want = torch.as_tensor(g["pitch_idx"])
+    # which bins are peaks: the comparisons sit on the device FFT's magnitudes (1e-6 off torch.stft's), so allow the few
+    # peaks whose threshold / local-max test is a tie at that precision to differ
+    a = {tuple(r) for r in nz.tolist()}
+    b = {tuple(r) for r in want.tolist()}
+    assert len(a ^ b) <= max(2, len(b) // 100), (len(a ^ b), len(b))
+    both = sorted(a & b)
+    idx = torch.tensor(both)
+    pos = {tuple(r): i for i, r in enumerate(want.tolist())}
+    sel = torch.tensor([pos[r] for r in both])
+    close(pitch[idx[:, 0], idx[:, 1]], torch.as_tensor(g["pitch_val"])[sel], 1e-5)
+    close(mag[idx[:, 0], idx[:, 1]], torch.as_tensor(g["mag_val"])[sel], 1e-4)
+    assert abs(Q.estimate_tuning(clip, SR, bins_per_octave=36) - float(g["tuning"])) < 1e-6
+
+
+def test_top_octave_response_matches_reference_fixture(clip, golden):
+    """one-octave CQT (no resampling involved) = the reference's __cqt_response on its own sparsified basis, up to the
+    1 / sqrt(length) scaling the full cqt applies at the end."""
+    from maua_amd import cqt as Q
+    g = golden("g21_cqt")
+    top = float(np.asarray(g["top_freqs"]).min())
+    got = Q.cqt(clip, SR, 1024, fmin=top, n_bins=36, bins_per_octave=36, magnitude=False).cpu()
+    want = torch.view_as_complex(torch.as_tensor(g["resp"]).contiguous()) / torch.sqrt(torch.as_tensor(g["lengths"]))[:, None]
+    close(torch.view_as_real(got), torch.view_as_real(want), 5e-5)
+
+
+def test_cqt_equals_oracle(clip):
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    got = Q.cqt(clip, SR, 1024, n_bins=252, bins_per_octave=36).cpu()
+    want = OC.cqt(clip, SR, 1024, n_bins=252, bins_per_octave=36).abs()
+    assert got.shape == want.shape
+    close(got, want, 1e-4)
+    with pytest.raises(Exception, match="hop_length"):
+        Q.cqt(clip, SR, 1000, n_bins=252, bins_per_octave=36)
+
+
+def test_spline_quantize_equals_oracle():
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.rand(4000, generator=g) * 1.3 - 0.15, torch.tensor([-0.1, 0.0, 0.025, 0.05, 0.1, 0.2, 0.4, 0.5, 1.0, 1.1])])
+    close(Q.spline_quantize(x.reshape(-1, 10)).cpu(), OC.spline_quantize(x.reshape(-1, 10)), 2e-5)
+
+
+def test_chromagram_equals_oracle(clip):
+    from maua_amd import cqt as Q
+    from maua_amd import audio as A
+    from oracle import cqt as OC
+    got = Q.chromagram(clip, SR).cpu()
+    want = OC.chromagram(clip, SR)
+    assert got.shape == want.shape == (len(clip) // 1024, 12)
+    close(got, want, 2e-3)
+    close(got.norm(dim=1), torch.ones(len(got)), 1e-5)
+    # chroma_cqt / chroma_cens on the same harmonic part: isolates the chain after HPSS
+    h = A.harmonic(clip).cpu()
+    close(Q.chroma_cqt(h, SR, bins_per_octave=36).cpu(), OC.chroma_cqt(h, SR), 5e-4)
+    close(Q.chroma_cens(h, SR).cpu(), OC.chroma_cens(h, SR), 5e-4)
+    t = A.tonnetz(chroma=Q.chroma_cens(h, SR))
+    assert t.shape == (len(clip) // 1024, 6) and bool(torch.isfinite(t).all())

@@ -365,3 +365,67 @@ def test_pulse(golden):
     a = synthetic_audio(int(g["n"]), sr, int(g["seed"]))
     close(A.onset_strength(A.percussive(a), sr, aggregate="median"), g["env_median"], 2e-4)
     close(A.pulse(a, sr), g["pulse"], 2e-3)
+
+
+def test_cqt_pieces(golden):
+    """N3 constant-Q chain: every piece the reference can run here (g21, make_golden.py:golden_cqt)."""
+    from oracle import cqt as OC
+    g = golden("g21_cqt")
+    y = golden("g09_audio_clip")["audio"]
+    sr = 30720
+    fmin = torch.tensor(OC.C1_HZ).float()
+    top = OC.cqt_frequencies(252, fmin, 36)[-36:]
+    close(top, g["top_freqs"], 1e-6)
+    filters, lengths = OC.constant_q(sr, top.min(), 36, 36)
+    close(lengths, g["lengths"], 1e-6)
+    close(torch.view_as_real(filters[[0, 17, 35]]), g["filt_rows"], 1e-5)
+    close(filters.abs().sum(1), g["filt_abs_sum"], 1e-5)
+    basis, n_fft, _ = OC.cqt_filter_fft(sr, top.min(), 36, 36)
+    assert n_fft == int(g["n_fft"]) == 1024
+    assert torch.equal((basis != 0).sum(1), g["basis_nnz"])          # the sparsity pattern: integer-exact
+    close(torch.view_as_real(basis[[0, 17, 35]]), g["basis_rows"], 1e-5)
+    close(basis.abs().sum(1), g["basis_abs_sum"], 1e-5)
+    resp = basis @ OC.stft_rect(y, n_fft, 1024)[:, :-1]
+    close(torch.view_as_real(resp), g["resp"], 2e-5)
+    pitch, mag = OC.piptrack(y, sr)
+    nz = torch.nonzero(pitch)
+    assert torch.equal(nz, g["pitch_idx"])                            # which bins are peaks: exact
+    close(pitch[nz[:, 0], nz[:, 1]], g["pitch_val"], 1e-6)
+    close(mag[nz[:, 0], nz[:, 1]], g["mag_val"], 1e-6)
+    assert abs(float(OC.estimate_tuning(y, sr, bins_per_octave=36)) - float(g["tuning"])) < 1e-7
+    assert torch.equal(OC.cq_to_chroma(252, 36, 12), g["cq_to_chroma"])
+    close(OC.constant_q_lengths(sr, fmin, 252, 36), g["lengths_full"], 1e-6)
+    # the un-vendored pieces, against independent statements of what they are: the resampler halves a band-limited tone
+    # (amplitude kept, frequency kept), the quantiser's spline passes through its knots
+    t = torch.arange(8192) / 8192.0
+    tone = torch.sin(2 * torch.pi * 200 * t)
+    half = OC.resample(tone, 8192, 4096)
+    want = torch.sin(2 * torch.pi * 200 * torch.arange(4096) / 4096.0)
+    assert half.shape == (4096,) and float((half[64:-64] - want[64:-64]).abs().max()) < 2e-3
+    xs, coef = OC.quantiser_coeffs()
+    _, ys = OC.quantiser_knots()
+    close(torch.from_numpy(coef[0]), ys[:-1], 1e-6)
+    out = OC.chromagram(y, sr)
+    assert out.shape == (len(y) // 1024, 12) and bool(torch.isfinite(out).all())
+    close(out.norm(dim=1), torch.ones(len(out)), 1e-5)                # CENS rows are L2-normalised
+
+
+def test_cqt_host_setup_matches_oracle_and_fixture(golden):
+    """the host-built constants of maua_amd/cqt.py (no device needed): filter FFT basis against the reference fixture, the
+    half-band resampling taps and the quantiser's spline rows against the oracle's restatements."""
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    g = golden("g21_cqt")
+    basis, n_fft, lengths = Q.cqt_filter_fft(30720, float(g["top_freqs"].min()), 36, 36)
+    assert n_fft == 1024 and torch.equal((basis != 0).sum(1), g["basis_nnz"])
+    close(torch.view_as_real(basis[[0, 17, 35]]), g["basis_rows"], 1e-5)
+    close(lengths, g["lengths"], 1e-6)
+    assert torch.equal(Q.cq_to_chroma(252, 36, 12), g["cq_to_chroma"])
+    taps, width = Q._kaiser_half_band()
+    k, w, _, _ = OC.sinc_resample_kernel(2, 1)
+    assert width == w and taps.numel() == k.numel()
+    close(taps, k.reshape(-1), 1e-6)
+    xs, coef = Q._quantiser()
+    oxs, ocoef = OC.quantiser_coeffs()
+    close(xs, oxs, 0)
+    close(coef, torch.as_tensor(ocoef, dtype=torch.float32), 1e-6)
