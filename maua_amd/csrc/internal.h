@@ -86,6 +86,17 @@ struct HiresArgs {
 };
 bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W);
 int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);
+// modconv_upwalk.hip: the 64 -> 32 channel up-layer in half-folded form (horizontal FIR in the weights, vertical FIR on
+// the accumulators of a row walk); a.w = weights from launch_prep_upwalk_weights ([3][2][3][Co][Ci] bf16)
+bool upwalk_supported(int dtype, int Ci, int Co, int up, int H, int W);
+size_t upwalk_weight_elems(int Co, int Ci);
+int launch_upwalk(hipStream_t stream, const HiresArgs& a);
+int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int Co, int Ci, int flip);
+// ... and the whole block (that up-layer, the 3x3 conv1 behind it, toRGB + skip, optional u8 pack) in one walk: the
+// block's features never reach HBM.  up = conv0's arguments (w from launch_prep_upwalk_weights, y unused), c1 = conv1's
+// (w from launch_prep_weights, rgb_* set, y unused)
+bool upwalk_fused_supported(int dtype, int Ci, int Cm, int H, int W);
+int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1);
 
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,

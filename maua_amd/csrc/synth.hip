@@ -29,6 +29,7 @@ struct ConvLayer {
   float noise_strength = 0.f;    // loaded value (used under nv_compat bit1)
   void* wt = nullptr;            // prepared weights (up-layers: 4 phase kernels, 9 taps each)
   void* wt_t = nullptr;          // up-layers: transposed-conv class weights (minimal MACs; FIR done afterwards)
+  void* wt_h = nullptr;          // up-layers on the row-walk kernel: half-folded weights (modconv_upwalk.hip)
   float* wsq = nullptr;          // [Co][Ci]
   float* s = nullptr;            // [Bcap][Ci]
   float* d = nullptr;            // [Bcap][Co]
@@ -64,6 +65,8 @@ struct maua_synth {
   int keep_features = 0;
   int lowres = 1;      // <= 8x8 layers as one batch-wide split-K GEMM (option "lowres")
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
+  int upwalk = 1;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
+                       // 2: the last block as one fused walk when nothing else reads its features
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
@@ -299,6 +302,7 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
     A((void**)&c.noise_const, (size_t)c.res * c.res * 4);
     A(&c.wt, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
     if (c.up == 2) A(&c.wt_t, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
+    if (upwalk_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) A(&c.wt_h, upwalk_weight_elems(c.Co, c.Ci) * 2);
     A((void**)&c.wsq, (size_t)c.Co * c.Ci * 4);
   }
   for (auto& g : n->rgbs) {
@@ -327,6 +331,7 @@ void maua_synth_destroy(maua_synth* n) {
   for (auto& c : n->convs) {
     hipFree(c.affine_w); hipFree(c.affine_b); hipFree(c.bias); hipFree(c.noise_const); hipFree(c.wt); hipFree(c.wsq);
     if (c.wt_t) hipFree(c.wt_t);
+    if (c.wt_h) hipFree(c.wt_h);
   }
   for (auto& g : n->rgbs) {
     hipFree(g.affine_w); hipFree(g.affine_b); hipFree(g.wrgb); hipFree(g.bias);
@@ -419,6 +424,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
   }
   if (!strcmp(key, "use_hires")) {
     n->use_hires = value;
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "upwalk")) {
+    n->upwalk = value;
     return MAUA_OK;
   }
   if (!strcmp(key, "tconv_up")) {
@@ -522,6 +531,7 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
                                  (c->up == 2) ? (n->nv_compat & 1) : 0, c->Co, c->Ci);
     if (!rc && c->up == 2)
       rc = launch_prep_tconv_weights(st, n->dtype, tmp, c->wt_t, c->Co, c->Ci, n->nv_compat & 1);
+    if (!rc && c->wt_h) rc = launch_prep_upwalk_weights(st, tmp, c->wt_h, c->Co, c->Ci, n->nv_compat & 1);
     hipStreamSynchronize(st);
     hipFree(tmp);
     return rc;
@@ -572,6 +582,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   int img_cur = 0;
   size_t li = 0;
   bool rgb8_done = false;
+  bool walk_skip = false;      // the previous up-layer ran the whole block (modconv_upwalk.hip): its conv1 is done
   bool x_premod = false;       // the current x already carries the styles of the conv1 that reads it (modconv_dma.hip)
   bool premod_for_up = false;  // ... of the up-layer that reads it (modconv_tconv_dma.hip)
   for (int blk = 0; blk < n->nblocks; blk++) {
@@ -655,7 +666,48 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           // the last block's features have no reader besides the toRGB fused here: skip their HBM store
           if (last && !n->keep_features && !hooked) a.y = nullptr;
         }
-        if (int rc = launch_modconv_hires(st, a)) return rc;
+        if (walk_skip) {
+          // (conv1 of a block that ran as one fused walk: nothing left to launch)
+          rgb_fused = true;
+          rgb8_done = rgb8_done || (last && rgb8_out);
+          walk_skip = false;
+        } else if (c.up == 2 && n->upwalk && c.wt_h && !fuse_rgb_ok) {  // half the matrix work of the phase form
+          a.w = c.wt_h;
+          // the last block as ONE walk (conv0 up -> conv1 -> toRGB + skip -> image / u8): when nothing else reads its
+          // features (no hooks, no feature capture) they never reach HBM
+          bool fused_walk = false;
+          if (n->upwalk >= 2 && last && li + 1 < n->convs.size() && !hooked && !warped && !n->keep_features &&
+              n->fuse_torgb && !rs_block) {
+            ConvLayer& c1 = n->convs[li + 1];
+            bool warped1 = n->rs_layer == (int)li + 2;
+            for (int wsl = 0; wsl < 3; wsl++) warped1 = warped1 || (n->warp_layer[wsl] == (int)li + 2 && n->warp_minv[wsl]);
+            if (c1.block == blk && c1.up == 1 && c1.Ci == c.Co && c1.Co == c.Co && c1.ih == c.oh && c1.iw == c.ow &&
+                !warped1 && upwalk_fused_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw)) {
+              const float* nz1 = (noise && noise[li + 1]) ? noise[li + 1] : c1.noise_const;
+              HiresArgs f{};
+              f.x = nullptr; f.w = c1.wt; f.s = c1.s; f.d = c1.d; f.noise = nz1;
+              f.noise_bstride = (noise && noise[li + 1]) ? (noise_bstride ? noise_bstride[li + 1] : (long)c1.oh * c1.ow) : 0;
+              f.noise_strength = (n->nv_compat & 2) ? c1.noise_strength : 1.f;
+              f.bias = c1.bias; f.y = nullptr;
+              f.B = B; f.H = c1.ih; f.W = c1.iw; f.Ci = c1.Ci; f.Co = c1.Co; f.up = 1;
+              f.act = MAUA_ACT_LRELU; f.alpha = 0.2f; f.gain = std::sqrt(2.0f); f.clamp = 256.f;
+              f.rgb_wmod = g.wmod; f.rgb_bias = g.bias; f.rgb_prev = prev_img; f.rgb_out = rgb_out; f.rgb_clamp = 256.f;
+              memcpy(f.fir, n->fir, sizeof(f.fir));
+              if (rgb8_out) {
+                f.rgb8_out = rgb8_out;
+                f.rgb_skip_f32 = img_out == nullptr;
+              }
+              a.y = nullptr;
+              if (int rc = launch_upwalk_fused(st, a, f)) return rc;
+              fused_walk = true;
+              walk_skip = true;
+            }
+          }
+          if (!fused_walk)
+            if (int rc = launch_upwalk(st, a)) return rc;
+        } else if (int rc = launch_modconv_hires(st, a)) {
+          return rc;
+        }
       } else if (via_tconv) {
         // (measured: pays off from 32^2 inputs up; below, the extra launch costs more than the MACs it saves,
         //  a tconv_up value > 1 sets the largest routed input size)

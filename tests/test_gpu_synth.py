@@ -131,12 +131,21 @@ def test_hires_kernels_match_generic_and_oracle():
     # same image, same u8 frame, bit for bit
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 1))
     net.keep_features(False)
+    L.check(L.lib().maua_synth_set_option(h, b"upwalk", 2))
     img_e = torch.empty_like(img_d)
     u8c = torch.empty_like(u8a)
     u8d = torch.empty_like(u8a)
     net(ws, noise=noise, out=img_e, rgb8_out=u8c)
     net(ws, noise=noise, rgb8_out=u8d)
-    assert torch.equal(img_e, img_d) and torch.equal(u8c, u8a) and torch.equal(u8d, u8a)
+    # (the last block then runs as ONE walk - modconv_upwalk.hip - whose conv1 folds demodulation into the weights:
+    #  equal to the unfused kernels up to bf16 weight rounding, and bit-identical with / without the f32 image)
+    assert psnr(img_e.cpu(), img_h) >= 60.0 and float((img_e.cpu() - img_h).abs().max()) <= 2e-3 * rng
+    assert torch.equal(u8c, ((img_e + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1))
+    assert torch.equal(u8d, u8c)
+    L.check(L.lib().maua_synth_set_option(h, b"upwalk", 1))   # the same block as separate kernels: bit-identical to capture mode
+    net(ws, noise=noise, out=img_e, rgb8_out=u8c)
+    assert torch.equal(img_e, img_d) and torch.equal(u8c, u8a)
+    L.check(L.lib().maua_synth_set_option(h, b"upwalk", 2))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
