@@ -65,7 +65,7 @@ struct maua_synth {
   int keep_features = 0;
   int lowres = 1;      // <= 8x8 layers as one batch-wide split-K GEMM (option "lowres")
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
-  int upwalk = 1;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
+  int upwalk = 2;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
                        // 2: the last block as one fused walk when nothing else reads its features
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
@@ -302,7 +302,8 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
     A((void**)&c.noise_const, (size_t)c.res * c.res * 4);
     A(&c.wt, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
     if (c.up == 2) A(&c.wt_t, prepped_weight_elems(3, c.up, c.Co, c.Ci) * n->esize);
-    if (upwalk_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) A(&c.wt_h, upwalk_weight_elems(c.Co, c.Ci) * 2);
+    // (the half-folded weights do not depend on the layer's size - it can change with a resize hook - only the routing does)
+    if (upwalk_supported(n->dtype, c.Ci, c.Co, c.up, 64, 64)) A(&c.wt_h, upwalk_weight_elems(c.Co, c.Ci) * 2);
     A((void**)&c.wsq, (size_t)c.Co * c.Ci * 4);
   }
   for (auto& g : n->rgbs) {
@@ -671,7 +672,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           rgb_fused = true;
           rgb8_done = rgb8_done || (last && rgb8_out);
           walk_skip = false;
-        } else if (c.up == 2 && n->upwalk && c.wt_h && !fuse_rgb_ok) {  // half the matrix work of the phase form
+        } else if (c.up == 2 && n->upwalk && c.wt_h && !fuse_rgb_ok &&
+                   upwalk_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {  // half the matrix work of the phase form
           a.w = c.wt_h;
           // the last block as ONE walk (conv0 up -> conv1 -> toRGB + skip -> image / u8): when nothing else reads its
           // features (no hooks, no feature capture) they never reach HBM

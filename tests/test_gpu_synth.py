@@ -227,10 +227,16 @@ def test_full_size_network_properties_and_oracle_frame():
         assert psnr(img.cpu(), img_o.cpu()) >= 60.0, (opt, psnr(img.cpu(), img_o.cpu()))
     # toRGB fused into the conv1 epilogues (register-stationary kernels at 512^2 / 1024^2, the generic kernel at 256^2
     # where Co == its N tile) vs the stand-alone toRGB kernels: same image up to f32 summation order
+    # (with the last block as separate kernels, upwalk = 1: its one-walk form folds conv1's demodulation into the weights
+    #  - a different bf16 rounding, compared below)
+    L.check(L.lib().maua_synth_set_option(h, b"upwalk", 1))
+    img_sep = net(ws, noise=noise_d)
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
     img_nf = net(ws, noise=noise_d)
     L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 1))
-    assert float((img_nf - img).abs().max()) <= 1e-4 * float(img.max() - img.min())
+    L.check(L.lib().maua_synth_set_option(h, b"upwalk", 2))
+    assert float((img_nf - img_sep).abs().max()) <= 1e-4 * float(img.max() - img.min())
+    assert psnr(img.cpu(), img_sep.cpu()) >= 65.0, psnr(img.cpu(), img_sep.cpu())   # fused walk vs separate kernels
     # one full-size frame against the oracle (fp32, CPU): same bar as the small bf16 nets
     nthr = torch.get_num_threads()
     torch.set_num_threads(min(32, nthr))
@@ -337,3 +343,54 @@ def test_lowres_gemm_matches_per_sample_kernels(dt):
     for l, (a, b) in enumerate(zip(feats_l, feats_g)):
         assert float((a - b).abs().max()) <= tol * float(b.abs().max()), f"layer {l}"
     assert float((img_l - img_g).abs().max()) <= tol * float(img_g.abs().max())
+
+
+@pytest.mark.parametrize("res,B", [(128, 1), (256, 3), (512, 2)])
+def test_upwalk_block_walks_match_phase_form_and_oracle(res, B):
+    """The last block's 64 -> 32 channel up-layer as a half-folded row walk (modconv_upwalk.hip), alone (upwalk = 1) and
+    fused with conv1 + toRGB + skip + u8 pack into one walk whose features never reach HBM (upwalk = 2), against the
+    register-stationary phase-form kernels (upwalk = 0) and the fp32 oracle.  Sizes: 1 / 3 / 5 strips of 126 output
+    pixels (the last one partial), several row segments per strip; rows / columns at every image edge."""
+    from maua_amd import _lib as L
+    from maua_amd.stylegan2 import SynthesisNetwork
+    cbase = 32 * res                    # 64 channels up to res / 2, 32 at res
+    g = torch.Generator().manual_seed(res)
+    net = SynthesisNetwork(64, res, 3, channel_base=cbase, channel_max=64, dtype=torch.bfloat16, generator=g)
+    p = net.state_dict()
+    g2 = torch.Generator().manual_seed(res + 1)
+    for k in p:
+        if k.endswith(".bias") and "affine" not in k:
+            p[k] = torch.randn(p[k].shape, generator=g2) * 0.1
+    net.load_state_dict(p)
+    shapes = net.layer_shapes()
+    assert shapes[-1][1:3] == (32, 32) and shapes[-2][1:3] == (64, 32), shapes[-2:]
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in shapes]
+    h = net._handle()
+    imgs, u8s = {}, {}
+    for mode in (0, 1, 2):
+        L.check(L.lib().maua_synth_set_option(h, b"upwalk", mode))
+        img = torch.empty((B, 3, res, res), device="cuda")
+        u8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device="cuda")
+        u8_only = torch.empty_like(u8)
+        net(ws, noise=noise, out=img, rgb8_out=u8)
+        net(ws, noise=noise, rgb8_out=u8_only)               # no f32 image requested: same frame
+        assert torch.equal(u8, u8_only), mode
+        assert torch.equal(u8, ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)), mode
+        img2 = torch.empty_like(img)
+        net(ws, noise=noise, out=img2)
+        assert torch.equal(img, img2), mode                  # bit-identical re-run
+        imgs[mode], u8s[mode] = img.cpu(), u8.cpu()
+    rng = float(imgs[0].max() - imgs[0].min())
+    for mode in (1, 2):   # same bf16 operands, different summation order / weight folding
+        assert psnr(imgs[mode], imgs[0]) >= 60.0, (mode, psnr(imgs[mode], imgs[0]))
+        assert float((imgs[mode] - imgs[0]).abs().max()) <= 5e-3 * rng, mode
+    ref = OS.synthesis_network(p, ws, noise=noise)
+    for mode in (0, 1, 2):
+        assert psnr(imgs[mode], ref) >= 50.0, (mode, psnr(imgs[mode], ref))
+    # a frame alone equals the same frame inside the batch (frame-range sharding relies on it), fused walk included
+    if B > 1:
+        L.check(L.lib().maua_synth_set_option(h, b"upwalk", 2))
+        one = torch.empty((1, 3, res, res), device="cuda")
+        net(ws[B - 1:], noise=[n[B - 1:] for n in noise], out=one)
+        assert torch.equal(one[0].cpu(), imgs[2][B - 1])
