@@ -49,6 +49,10 @@ def kernel_of(ci, co, res, up):
     """Which kernel instantiation synth.hip launches for a layer (mirrors launch_modconv_t / hires_supported /
     dma_conv_supported); names match the rocprofv3 kernel-trace rows."""
     hin = res // up
+    if (ci, co, up) == (64, 32, 2) and hin % 64 == 0:
+        # the last block as one walk (modconv_upwalk.hip): conv0 up -> conv1 -> toRGB + skip -> u8, features stay in LDS;
+        # its conv1 / toRGB profile slots measure ~0
+        return "upwalk_fused_kernel<64,32>"
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
     if up == 2 and 32 <= hin <= 512:
@@ -88,6 +92,7 @@ def layer_table(net):
     rows = [("styles", "styles", 0.0, 0.0)]
     shapes = net.layer_shapes()
     li = 0
+    walk_fused = False
     for i, r in enumerate(net.block_resolutions):
         for _ in range(1 if i == 0 else 2):
             pfx, ci, co, res, up = shapes[li]
@@ -96,6 +101,17 @@ def layer_table(net):
             gflop = 2 * hin * hin * 9 * ci * co / 1e9
             byts = (hin * hin * ci + res * res * co) * 2 + res * res * 4  # bf16 in/out + f32 noise
             kern = kernel_of(ci, co, res, up)
+            last = i == len(net.block_resolutions) - 1
+            if last and kern.startswith("upwalk_fused"):
+                # whole block: + conv1 (co -> co at res) + toRGB; HBM: input, both noise maps, skip image, u8 frame
+                gflop += 2 * res * res * 9 * co * co / 1e9 + 2 * res * res * co * 3 / 1e9
+                byts = hin * hin * ci * 2 + 2 * res * res * 4 + (res // 2) ** 2 * 12 + res * res * 3
+                rows.append((pfx, kern, gflop, byts))
+                walk_fused = True
+                continue
+            if last and up == 1 and walk_fused:
+                rows.append((pfx, "(in the fused walk)", 0.0, 0.0))
+                continue
             if up == 1 and rgb_fused(co, res):  # + fused toRGB: img write + upsampled skip read
                 gflop += 2 * r * r * co * 3 / 1e9
                 byts += r * r * 12 + (r // 2) ** 2 * 12

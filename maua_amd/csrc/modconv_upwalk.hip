@@ -334,7 +334,9 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       const int px = X0 - 1 + p;
       const bool px_ok = px >= 0 && px < Wo;
       const unsigned nzoff = (unsigned)(h * Wo + min(max(px, 0), Wo - 1)) * 4u;
-      const int ring_off = p * (CM * 2) + h * 8, esw = (p >> 2) & 3;
+      // ring rows keep even and odd pixels in separate halves (slot = (p & 1) * 66 + (p >> 1)) with the 16-byte pieces
+      // XOR-swizzled by (p >> 2) & 3: the consumers' ds_read_b128 are conflict-free, these 8-byte writes 2-way
+      const int ring_off = ((p & 1) * (RPX / 2) + (p >> 1)) * (CM * 2) + h * 8, esw = (p >> 2) & 3;
       // DMA descriptors: piece j of this wave = positions 8 (widx + 4 j) .. + 7; lane = (position, 16-byte slot); the
       // lane fetches the source piece that belongs in its slot after the XOR swizzle
       unsigned xoff[3];
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) {
           const int pp = pcol + dx;
-          foff[dx][ks] = pp * (CM * 2) + (((2 * ks + h) ^ ((pp >> 2) & 3)) * 16);
+          foff[dx][ks] = ((pp & 1) * (RPX / 2) + (pp >> 1)) * (CM * 2) + (((2 * ks + h) ^ ((pp >> 2) & 3)) * 16);
         }
       // skip image = upsample2d of the previous image in its branch-free 2x2 form (modconv_hires.hip): output pixel
       // (y, x) reads rows (y - 1) >> 1, + 1 and columns (x - 1) >> 1, + 1 with the FIR taps its parities select.  The

@@ -49,6 +49,10 @@ def bench_name(k):
         return "tconv2_kernel<bf16> (edges)"
     if "upfir_epilogue_kernel<unsigned short" in k:
         return "upfir_epilogue_kernel<bf16>"
+    if "upwalk_fused_kernel" in k:
+        return "upwalk_fused_kernel<64,32>"
+    if "upwalk_kernel" in k:
+        return "upwalk_kernel<64,32>"
     m = re.search(r"modconv_hires_kernel<(\d+), (\d+), (\d)>", k)
     if m:
         return "modconv_hires_kernel<%s,%s,%s>" % m.groups()
