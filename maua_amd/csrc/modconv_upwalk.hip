@@ -258,8 +258,8 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
   char* xrow = smem;                                            // [2][XROWB]
   char* ring = smem + 2 * XROWB;                                // [3 slots][2 rows][RROW]
   u32x4* wl = reinterpret_cast<u32x4*>(ring + 6 * RROW);        // [pb 2][chain i 3][kx 3][KS][64 lanes]: conv0's A fragments
-  float* pvs = reinterpret_cast<float*>(wl + 2 * 3 * 3 * KS * 64);   // [4 slots][PVW]
-  float* bias0_s = pvs + 4 * PVW;
+  float* pvs = reinterpret_cast<float*>(wl + 2 * 3 * 3 * KS * 64);   // [3 slots][PVW]
+  float* bias0_s = pvs + 3 * PVW;
   float* bias1_s = bias0_s + CM;
   // (both in accumulator order: lane half h, element e = channel 8 (e >> 2) + 4 h + (e & 3); conv0's halved: its four
   //  FIR taps sum to 2)
@@ -390,12 +390,11 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         MAUA_TICK(if (k) dsum[2] += tz - tlast)
         MAUA_TICK(dsum[3] += ta - tz)
         if (k == nsteps - 1) continue;   // (the consumers' last step; the loop ends right after)
-        // ---- staging: input row rho + 1 for the next step; row rho - 1 of the previous image (slot k % 4) for the
-        // consumers' epilogue two steps on (their last epilogue runs after the last barrier)
+        // ---- staging: input row rho + 1 and row rho - 1 of the previous image (slot k % 3) for the next step
         MAUA_UWF_STAGE_X(rho + 1, (k + 1) & 1)
         if (pvbase) {
           const int m = rho - 1;
-          float* dst = pvs + (k % 4) * PVW;
+          float* dst = pvs + (k % 3) * PVW;
           if (m >= 0 && m < Hp) {
             if (pvoff != 0xffffffffu) lds_dma_b32(pvbase + (long)m * Wp * 4, pvoff, dst + widx * 64);
           } else {
@@ -577,91 +576,35 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
             fc[dy * 2 + dx] = !okk ? 0.f : uh ? (vh ? c.fir[5] : c.fir[4]) : (vh ? c.fir[1] : c.fir[0]);
           }
       }
-      float nz_next = 0.f, nz_use = 0.f;
       const f32x16* bias1_p = reinterpret_cast<const f32x16*>(bias1_s + 16 * h);   // the accumulators start from bias * gain
-      f32x16 accA = *bias1_p, accB = accA;
       long long ta = 0;
-      // The consumers run half a step out of phase with the producers on the same SIMD: a step starts with the EPILOGUE
-      // of the rows multiplied in the previous step (VALU, while the producers multiply) and ends with this step's MFMAs
-      // (while the producers run their FIR / epilogue).
+      // A consumer step has the producers' phase order - multiply, then VALU - because that is how two waves share a SIMD
+      // best here (scripts/ubench/issue_mix.hip: a VALU stream beside a partner that multiplies with LDS operands runs at
+      // ~14 cycles per instruction, beside a partner's VALU stream at ~5; two LDS-fed MFMA streams barely slow each other:
+      // each is bound by its own wave's LDS read rate, ~50 cycles per ds_read_b128):
+      //   M  conv1 of rows arow - 1 (accA), arow (accB), arow = 2 (rho - 2), from ring rows arow - 2 .. arow + 1
+      //   A  noise + lrelu + clamp in registers -> bf16 B fragments -> the four toRGB MFMAs
+      //   B  + bias, clamp, + skip taps from LDS, store the pixel (lanes h == 0: row arow - 1, h == 1: row arow)
 #pragma unroll 1
-      for (int k = 0; k <= nsteps; k++) {
+      for (int k = 0; k < nsteps; k++) {
         const int rho = r0 - 2 + k;
-        nz_use = nz_next;
+        const int arow = 2 * (rho - 2);
         const long long tz = MAUA_NOW();
         MAUA_TICK(if (k) dsum[4] += tz - tlast)
-        if (k < nsteps) {
-          __syncthreads();
-          ta = MAUA_NOW();
-          MAUA_TICK(dsum[0] += ta - tz)
-          // noise of the rows multiplied in THIS step (arow - 1 + h, arow = 2 (rho - 2)): used by the next step's epilogue
-          if (nbase) {
-            const int nrow = min(max(2 * (rho - 2) - 1 + h, 0), Ho - 1);
-            nz_next = *reinterpret_cast<const float*>(nbase + (unsigned)(nrow * Wo) * 4u + nzoff);
-          }
+        __syncthreads();
+        ta = MAUA_NOW();
+        MAUA_TICK(dsum[0] += ta - tz)
+        f32x2_t nz = {0.f, 0.f};   // noise of the lane's column in rows arow - 1, arow (needed after the multiply)
+        if (nbase) {               // (rows clamped into the image: the clamped ones are never stored)
+          nz[0] = *reinterpret_cast<const float*>(nbase + (long)min(max(arow - 1, 0), Ho - 1) * Wo * 4 + nzoff);
+          nz[1] = *reinterpret_cast<const float*>(nbase + (long)min(max(arow, 0), Ho - 1) * Wo * 4 + nzoff);
         }
         const long long tb = MAUA_NOW();
         MAUA_TICK(dsum[1] += tb - ta)
-        if (k > 0) {
-          // ---- epilogue of step k - 1 (output rows arow - 1: lanes h == 0, arow: h == 1) in registers -> toRGB MFMA
-          const int arow = 2 * (rho - 3);
-          const int oy = arow - 1 + h;
-          const float nz_other = __shfl_xor(nz_use, 32);
-          const float nzA = (h ? nz_other : nz_use) * nz_scale, nzB = (h ? nz_use : nz_other) * nz_scale;
-          u32x4 fa[KS1], fb[KS1];
-          const f32x2_t nA = nzA, nB = nzB, al = c.alpha;
-#pragma unroll
-          for (int e = 0; e < 16; e += 2) {       // (the bias rides in the accumulators)
-            const f32x2_t ya = f32x2_t{accA[e], accA[e + 1]} + nA, yb = f32x2_t{accB[e], accB[e + 1]} + nB;
-            const f32x2_t sa = ya * al, sb = yb * al;
-            fa[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(ya[0], sa[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(ya[1], sa[1]), -cl, cl));
-            fb[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(yb[0], sb[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(yb[1], sb[1]), -cl, cl));
-          }
-          f32x16 ra, rb;
-#pragma unroll
-          for (int e = 0; e < 16; e++) { ra[e] = 0.f; rb[e] = 0.f; }
-#pragma unroll
-          for (int ks = 0; ks < KS1; ks++) {
-            ra = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fa[ks]), ra, 0, 0, 0);
-            rb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fb[ks]), rb, 0, 0, 0);
-          }
-          // skip: rows m - 1 (staged at step k - 3) and m (step k - 2) of the previous image, m = rho - 3
-          float u3[3] = {0.f, 0.f, 0.f};
-          if (pv_on) {
-            const float* sA = pvs + ((k + 1) % 4) * PVW + pvi;
-            const float* sB = pvs + ((k + 2) % 4) * PVW + pvi;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++)
-              u3[ch] = sA[ch * PVP] * fc[0] + sA[ch * PVP + 1] * fc[1] + sB[ch * PVP] * fc[2] + sB[ch * PVP + 1] * fc[3];
-          }
-          float o3[3];
-          o3[0] = (h ? rb[0] + rb[4] : ra[0] + ra[4]) + rgb_b0;
-          o3[1] = (h ? rb[1] + rb[5] : ra[1] + ra[5]) + rgb_b1;
-          o3[2] = (h ? rb[2] + rb[6] : ra[2] + ra[6]) + rgb_b2;
-          if (c.rgb_clamp >= 0.f) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) o3[ch] = fminf(fmaxf(o3[ch], -c.rgb_clamp), c.rgb_clamp);
-          }
-          o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
-          if (px_ok && oy >= 2 * r0 && oy < 2 * r1) {
-            if (!c.rgb_skip_f32) {
-              float* ob = c.rgb_out + (long)b * 3 * HWl + (unsigned)(oy * Wo + px);
-              ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
-            }
-            if (c.rgb8_out) {
-              uint8_t* o8 = c.rgb8_out + ((long)b * HWl + (unsigned)(oy * Wo + px)) * 3;
-              o8[0] = (uint8_t)to_u8(o3[0]); o8[1] = (uint8_t)to_u8(o3[1]); o8[2] = (uint8_t)to_u8(o3[2]);
-            }
-          }
-        }
-        const long long tc = MAUA_NOW();
-        MAUA_TICK(dsum[2] += tc - tb)
-        if (k == nsteps) break;
-        // ---- conv1 of rows arow - 1 (accA) and arow (accB): ring rows arow - 2 .. arow + 1 = slots (k - 2) % 3 and
-        // (k - 1) % 3.  Row arow - 2 feeds only accA and row arow + 1 only accB: those two are interleaved so no two
-        // consecutive MFMAs share an accumulator; the fragments are requested a stage ahead
-        accA = *bias1_p;
-        accB = accA;
+        // ---- M: ring rows arow - 2 .. arow + 1 = slots (k - 2) % 3 and (k - 1) % 3.  Row arow - 2 feeds only accA and
+        // row arow + 1 only accB: those two are interleaved so no two consecutive MFMAs share an accumulator; the
+        // fragments are requested a stage ahead
+        f32x16 accA = *bias1_p, accB = accA;
         const char* s2 = ring + ((k + 1) % 3) * (2 * RROW);
         const char* s1 = ring + ((k + 2) % 3) * (2 * RROW);
         u32x4 f0[3 * KS1], f3[3 * KS1], f1[3 * KS1];
@@ -694,8 +637,59 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
           accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[3 * KS1 + i]), __builtin_bit_cast(bf16x8, f0[i]), accB, 0, 0, 0);
         }
 #undef MAUA_UWF_CLOAD
+        const long long tc = MAUA_NOW();
+        MAUA_TICK(dsum[3] += tc - tb)
+        // ---- A: epilogue in registers (the bias rides in the accumulators) -> toRGB MFMAs
+        u32x4 fa[KS1], fb[KS1];
+        {
+          const f32x2_t nA = nz[0] * nz_scale, nB = nz[1] * nz_scale, al = c.alpha;
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const f32x2_t ya = f32x2_t{accA[e], accA[e + 1]} + nA, yb = f32x2_t{accB[e], accB[e + 1]} + nB;
+            const f32x2_t sa = ya * al, sb = yb * al;
+            fa[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(ya[0], sa[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(ya[1], sa[1]), -cl, cl));
+            fb[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(yb[0], sb[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(yb[1], sb[1]), -cl, cl));
+          }
+        }
+        f32x16 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { ra[e] = 0.f; rb[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) {
+          ra = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fa[ks]), ra, 0, 0, 0);
+          rb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fb[ks]), rb, 0, 0, 0);
+        }
+        // ---- B: skip = rows m - 1 (staged at step k - 2) and m (step k - 1) of the previous image, m = rho - 2
+        const int oy = arow - 1 + h;
+        float u3[3] = {0.f, 0.f, 0.f};
+        if (pv_on) {
+          const float* sA = pvs + ((k + 1) % 3) * PVW + pvi;
+          const float* sB = pvs + ((k + 2) % 3) * PVW + pvi;
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++)
+            u3[ch] = sA[ch * PVP] * fc[0] + sA[ch * PVP + 1] * fc[1] + sB[ch * PVP] * fc[2] + sB[ch * PVP + 1] * fc[3];
+        }
+        float o3[3];
+        o3[0] = (h ? rb[0] + rb[4] : ra[0] + ra[4]) + rgb_b0;
+        o3[1] = (h ? rb[1] + rb[5] : ra[1] + ra[5]) + rgb_b1;
+        o3[2] = (h ? rb[2] + rb[6] : ra[2] + ra[6]) + rgb_b2;
+        if (c.rgb_clamp >= 0.f) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) o3[ch] = fminf(fmaxf(o3[ch], -c.rgb_clamp), c.rgb_clamp);
+        }
+        o3[0] = u3[0] + o3[0]; o3[1] = u3[1] + o3[1]; o3[2] = u3[2] + o3[2];
+        if (px_ok && oy >= 2 * r0 && oy < 2 * r1) {
+          if (!c.rgb_skip_f32) {
+            float* ob = c.rgb_out + (long)b * 3 * HWl + (unsigned)(oy * Wo + px);
+            ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
+          }
+          if (c.rgb8_out) {
+            uint8_t* o8 = c.rgb8_out + ((long)b * HWl + (unsigned)(oy * Wo + px)) * 3;
+            o8[0] = (uint8_t)to_u8(o3[0]); o8[1] = (uint8_t)to_u8(o3[1]); o8[2] = (uint8_t)to_u8(o3[2]);
+          }
+        }
         tlast = MAUA_NOW();
-        MAUA_TICK(dsum[3] += tlast - tc)
+        MAUA_TICK(dsum[2] += tlast - tc)
       }
       MAUA_TICK(steps_total += nsteps)
     }
@@ -732,7 +726,7 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
     MAUA_REQUIRE(q->alpha >= 0.f && q->alpha <= 1.f && q->gain > 0.f, "upwalk_fused: needs 0 <= alpha <= 1 and gain > 0");
   }
   constexpr int CI = 64, CM = 32;
-  const size_t smem = 2 * 9 * 1024 + 6 * 132 * (CM * 2) + 2 * 3 * 3 * (CI / 16) * 64 * 16 + 4 * 256 * 4 + 2 * CM * 4;
+  const size_t smem = 2 * 9 * 1024 + 6 * 132 * (CM * 2) + 2 * 3 * 3 * (CI / 16) * 64 * 16 + 3 * 256 * 4 + 2 * CM * 4;
   static const bool want_dbg = getenv("MAUA_UW_DBG") != nullptr;
   auto kern = want_dbg ? upwalk_fused_kernel<CI, CM, true> : upwalk_fused_kernel<CI, CM, false>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
