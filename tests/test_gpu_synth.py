@@ -252,24 +252,30 @@ def test_full_size_network_properties_and_oracle_frame():
 
 
 def test_bench_shape_batch_equals_single_frames():
-    """The shape bench.py times: B = 32 frames of the 1024^2 bf16 net in one call (512-channel layers through the
-    batch-wide low-resolution GEMM, the LDS-direct-load and register-stationary kernels at full grids).  Frames
-    0, 15 and 31 of that batch equal the same frames rendered alone, bit for bit (what frame-range sharding relies
+    """The shape bench.py times: its default batch of frames of the 1024^2 bf16 net in one call (512-channel layers through
+    the batch-wide low-resolution GEMM, the LDS-direct-load kernels and the fused last-block walk at full grids).  Frames
+    0, 15 and B - 1 of that batch equal the same frames rendered alone, bit for bit (what frame-range sharding relies
     on), and frame 15 matches the fp32 CPU oracle."""
+    import importlib.util
+    import pathlib
+    spec = importlib.util.spec_from_file_location("maua_bench", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
     from maua_amd.noise import Loop, loop_batch
     from maua_amd.stylegan2 import SynthesisNetwork
     net = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(0))
     g = torch.Generator().manual_seed(77)
-    B = 32
+    B = bench.DEFAULT_BATCH
+    assert B >= 32
     ws = torch.randn(B, net.num_ws, 512, generator=g).cuda()
     sizes = [s[3] for s in net.layer_shapes()]
     rng_n = torch.Generator().manual_seed(42)
-    mods = [Loop(rng_n, 64, (s, s), n_loops=2, sigma=5) for s in sizes]
-    nz = loop_batch(mods, 3, B)  # the bench's noise path: frames 3 .. 34 of a 64-frame loop
+    mods = [Loop(rng_n, 2 * B, (s, s), n_loops=2, sigma=5) for s in sizes]
+    nz = loop_batch(mods, 3, B)  # the bench's noise path: frames 3 .. B + 2 of a 2 B-frame loop
     img = torch.empty((B, 3, 1024, 1024), device="cuda")
     u8 = torch.empty((B, 1024, 1024, 3), dtype=torch.uint8, device="cuda")
     net(ws, noise=nz, out=img, rgb8_out=u8)
-    for i in (0, 15, 31):
+    for i in (0, 15, B - 1):
         one = torch.empty((1, 3, 1024, 1024), device="cuda")
         one8 = torch.empty((1, 1024, 1024, 3), dtype=torch.uint8, device="cuda")
         net(ws[i:i + 1], noise=[n[i:i + 1].contiguous() for n in nz], out=one, rgb8_out=one8)
