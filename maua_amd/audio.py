@@ -557,3 +557,43 @@ def tempo(onset_envelope, sr=22050, hop_length=1024, max_tempo=240.0, ac_size=12
         logprior[: int(torch.argmax((bpms < max_tempo).to(torch.int8)))] = float("-inf")
     best = int(torch.argmax(torch.log1p(1e6 * tg) + logprior))
     return float(bpms[best])
+
+
+# ---- torchaudio.functional.resample (selfsupervised/sample.py:7,29; audioreactive/audio.py:53-59) --------------------
+def sinc_resample_kernel(orig, new, lowpass_filter_width=6, rolloff=0.99, resampling_method="sinc_interp_hann", beta=None):
+    """torchaudio's polyphase filter bank [new, 2 * width + orig] for the reduced rates (float64 index arithmetic, float32
+    result) - built on the host once per (rate pair): the published _get_sinc_resample_kernel (torchaudio un-vendored)."""
+    import math
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx
+    t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+    if resampling_method in ("sinc_interp_hann", "sinc_interpolation"):
+        window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    elif resampling_method in ("sinc_interp_kaiser", "kaiser_window"):
+        beta = 14.769656459379492 if beta is None else beta
+        window = torch.i0(beta * torch.sqrt(1 - (t / lowpass_filter_width) ** 2)) / torch.i0(torch.tensor(float(beta), dtype=torch.float64))
+    else:
+        raise ValueError(f"Invalid resampling method: {resampling_method}")
+    t = t * math.pi
+    return (torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)).float(), width
+
+
+def resample_sinc(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99, resampling_method="sinc_interp_hann",
+                  beta=None):
+    """Drop-in for ``torchaudio.functional.resample`` on a mono signal, on the HIP device: the strided correlation with
+    the filter bank is ONE exact-f32 GEMM - rows = hops of `orig` input samples (windows of 2 * width + orig), columns = the
+    `new` output phases (``maua_matmul_nt``); window extraction is a strided view of the padded signal."""
+    import math
+    y = _f32(waveform).reshape(-1)
+    if int(orig_freq) == int(new_freq):
+        return y
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    kern, width = sinc_resample_kernel(orig, new, lowpass_filter_width, rolloff, resampling_method, beta)
+    n = y.numel()
+    xp = torch.nn.functional.pad(y, (width, width + orig))
+    frames = xp.unfold(0, kern.shape[1], orig).contiguous()          # [hops, 2 * width + orig]
+    out = _matmul_nt(frames, kern.to(y.device))                       # [hops, new]
+    return out.reshape(-1)[: int(math.ceil(new * n / orig))].contiguous()

@@ -1,8 +1,8 @@
-"""Audio decode (host plumbing).  The reference decodes with torchaudio / librosa and resamples with
-torchaudio.functional.resample (sample.py:16-32, audioreactive/audio.py:15-48) — un-vendored and unpinned, so
-there is no arithmetic to be bit-compatible with ("parity unpinned").  Here: PCM/float WAV via scipy,
-``.npy`` / ``.pt`` float arrays, mono mean, slice, and scipy's polyphase resampler to the target rate."""
-from math import gcd
+"""Audio decode (host plumbing) + resampling (device).  The reference decodes with torchaudio / librosa and resamples with
+torchaudio.functional.resample (sample.py:16-32, audioreactive/audio.py:15-48) — un-vendored, so "parity unpinned" (SURVEY A1).
+Here: PCM/float WAV via scipy, ``.npy`` / ``.pt`` float arrays, mono mean, slice on the host; the resampler is torchaudio's
+published windowed-sinc polyphase algorithm as one GEMM on the HIP device (``audio.resample_sinc``; no host fallback).  MP3 /
+other compressed formats need a decoder the image does not have."""
 from pathlib import Path
 
 import numpy as np
@@ -43,8 +43,7 @@ def load_audio(audio_file, offset=0, duration=None, fps=None, sr=None):
     if fps is not None:
         new_sr = int(1024 * fps)
         if new_sr != file_sr:
-            from scipy.signal import resample_poly
-            g = gcd(new_sr, file_sr)
-            audio = torch.from_numpy(resample_poly(audio.numpy(), new_sr // g, file_sr // g).astype(np.float32))
+            from .audio import resample_sinc
+            audio = resample_sinc(audio, file_sr, new_sr).cpu()
         file_sr = new_sr
     return audio.contiguous(), file_sr

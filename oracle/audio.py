@@ -383,3 +383,32 @@ def tempo(onset_envelope, sr=22050, hop=1024, max_tempo=240.0, ac_size=120.0, pr
     logprior = stats.lognorm(loc=0, scale=prior_scale, s=prior_s).logpdf(bpms)
     logprior[: int(np.argmax(bpms < max_tempo))] = -np.inf
     return float(bpms[int(np.argmax(np.log1p(1e6 * tg) + logprior))])
+
+
+def sinc_resample(waveform, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99, resampling_method="sinc_interp_hann",
+                  beta=None):
+    """torchaudio.functional.resample as the reference calls it (selfsupervised/sample.py:7,29; audio.py:53-59) - torchaudio
+    is un-vendored: its published algorithm (functional.py _get_sinc_resample_kernel / _apply_sinc_resample_kernel, index
+    arithmetic in float64 = the ``dtype=None`` branch) restated; parity unpinned.  1-D float tensor in, 1-D out."""
+    import math
+    import torch.nn.functional as F
+    x = torch.as_tensor(waveform, dtype=torch.float32).reshape(-1)
+    if int(orig_freq) == int(new_freq):
+        return x
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+    if resampling_method in ("sinc_interp_hann", "sinc_interpolation"):
+        window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    else:
+        beta = 14.769656459379492 if beta is None else beta
+        window = torch.i0(beta * torch.sqrt(1 - (t / lowpass_filter_width) ** 2)) / torch.i0(torch.tensor(float(beta), dtype=torch.float64))
+    t = t * math.pi
+    kernel = (torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)).float()
+    xp = F.pad(x[None, None], (width, width + orig))
+    out = F.conv1d(xp, kernel, stride=orig).transpose(1, 2).reshape(-1)
+    return out[: int(math.ceil(new * x.numel() / orig))]

@@ -346,3 +346,43 @@ def test_classic_onsets_at_librosa_framing(clip):
     assert ar.onsets(clip, sr, prepercussive=0).shape == (len(clip) // 512,)
     with pytest.raises(NotImplementedError):
         ar.onsets(clip, sr, type="mm")
+
+
+def test_sinc_resample_and_load_audio(tmp_path):
+    """torchaudio.functional.resample restated (A1): the device GEMM form equals the oracle's strided correlation for the
+    rate pairs the sampler meets (44.1 / 48 / 22.05 kHz -> 1024 * fps), hann and kaiser windows, odd lengths; a band-limited
+    tone keeps its amplitude and frequency (what the resampler is for); load_audio resamples on the device."""
+    import wave
+    import numpy as np
+    from maua_amd import audio as A
+    from maua_amd.audio_io import load_audio
+    from oracle import audio as OA
+    g = torch.Generator().manual_seed(5)
+    for orig, new, n in ((44100, 30720, 44100 * 3 + 17), (48000, 24576, 48000), (22050, 30720, 22050 * 2 + 1), (8000, 10240, 4001)):
+        x = torch.randn(n, generator=g)
+        want = OA.sinc_resample(x, orig, new)
+        got = A.resample_sinc(x, orig, new).cpu()
+        assert got.shape == want.shape == (int(np.ceil(new * n / orig)),)
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    x = torch.randn(30000, generator=g)
+    want = OA.sinc_resample(x, 44100, 30720, resampling_method="sinc_interp_kaiser")
+    got = A.resample_sinc(x, 44100, 30720, resampling_method="sinc_interp_kaiser").cpu()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert torch.equal(A.resample_sinc(x, 44100, 44100).cpu(), x)
+    t = torch.arange(44100) / 44100.0
+    tone = torch.sin(2 * torch.pi * 1000 * t)
+    got = A.resample_sinc(tone, 44100, 30720).cpu()
+    ref = torch.sin(2 * torch.pi * 1000 * torch.arange(30720) / 30720.0)
+    assert got.shape == (30720,) and float((got[64:-64] - ref[64:-64]).abs().max()) < 2e-3
+    # 16-bit stereo wav -> mono float, sliced, resampled to 1024 * fps
+    sr = 8000
+    tt = np.arange(sr * 2) / sr
+    pcm = (np.stack([np.sin(2 * np.pi * 440 * tt), np.zeros_like(tt)], 1) * 32767).astype(np.int16)
+    f = tmp_path / "a.wav"
+    with wave.open(str(f), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr); w.writeframes(pcm.tobytes())
+    a, s = load_audio(str(f), offset=0.5, duration=1.0, fps=10)
+    assert s == 10240 and len(a) == 10240 and a.dtype == torch.float32
+    assert 0.45 < float(a.abs().max()) <= 0.51  # mono mean of (sine, 0)
+    mono = torch.from_numpy(pcm[:, 0].astype(np.float32) / 32768.0 / 2)[sr // 2: sr // 2 + sr]
+    assert float((a - OA.sinc_resample(mono, sr, 10240)).abs().max()) < 1e-5

@@ -429,3 +429,19 @@ def test_cqt_host_setup_matches_oracle_and_fixture(golden):
     oxs, ocoef = OC.quantiser_coeffs()
     close(xs, oxs, 0)
     close(coef, torch.as_tensor(ocoef, dtype=torch.float32), 1e-6)
+
+
+def test_sinc_resample_oracle_properties():
+    """oracle.audio.sinc_resample = torchaudio.functional.resample's published algorithm (un-vendored: parity unpinned) -
+    checked by what it must do: length ceil(n new / orig), a band-limited tone survives with its amplitude and frequency,
+    and the kaiser / 2:1 case equals the constant-Q chain's own half-band restatement (oracle/cqt.py)."""
+    from oracle import audio as OA
+    from oracle import cqt as OC
+    t = torch.arange(44100) / 44100.0
+    tone = torch.sin(2 * torch.pi * 1000 * t)
+    out = OA.sinc_resample(tone, 44100, 30720)
+    ref = torch.sin(2 * torch.pi * 1000 * torch.arange(30720) / 30720.0)
+    assert out.shape == (30720,) and float((out[64:-64] - ref[64:-64]).abs().max()) < 2e-3
+    x = torch.randn(4097, generator=torch.Generator().manual_seed(1))
+    close(OA.sinc_resample(x, 2, 1, resampling_method="sinc_interp_kaiser"), OC.resample(x, 2, 1), 1e-6)
+    assert OA.sinc_resample(x, 8000, 10240).shape == (int(np.ceil(10240 * 4097 / 8000)),)
