@@ -311,6 +311,21 @@ int maua_rrdb_load(maua_rrdbnet* net, const char* name, const float* host_data, 
  * out_rgb8: device u8 [B][4H][4W][3] = round(clamp * 255) (or NULL). */
 int maua_rrdb_forward(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, float* out_nchw, uint8_t* out_rgb8);
 
+/* ---- multi-GPU: the one exchange step of the frame-sharded render ------------------------------------
+ * One process per GPU; frames are sharded by contiguous range (no data-path collective).  maua_gather_frames moves every
+ * rank's packed u8 shard to `root`, ordered by rank, as grouped RCCL point-to-point transfers on the context's stream
+ * (replaces the single-process frame list of maua/audiovisual/generate.py:57-98; process layout as
+ * maua/super/image/bulk.py:31-109).  Bootstrap: rank 0 calls maua_comm_unique_id and hands the 128 bytes to the other
+ * ranks out of band (torch.distributed broadcast, a file, MPI ...); every rank then calls maua_comm_init.  RCCL is bound
+ * at first use (dlopen): single-GPU hosts never load it. */
+typedef struct { char internal[128]; } maua_comm_id;   /* = ncclUniqueId */
+typedef struct maua_comm maua_comm;
+int maua_comm_unique_id(maua_comm_id* id);
+int maua_comm_init(maua_ctx* ctx, const maua_comm_id* id, int rank, int world, maua_comm** out);
+/* bytes_per_rank [world]: shard sizes (host array); send: this rank's shard (device); recv: root only, sum of the sizes. */
+int maua_gather_frames(maua_comm* comm, const uint8_t* send, const long* bytes_per_rank, uint8_t* recv, int root);
+int maua_comm_destroy(maua_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

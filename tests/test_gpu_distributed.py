@@ -42,8 +42,13 @@ def _worker(rank, world, port, T, q):
     from maua_amd.pipeline import frame_range
     assert maybe_init_process_group("nccl") == (rank, world)
     lo, hi = frame_range(T, rank, world)
-    full = gather_frames(_render(lo, hi, T), T, rank, world)
+    shard = _render(lo, hi, T)
+    full = gather_frames(shard, T, rank, world)
+    from maua_amd.distributed import gather_frames_cabi
+    full2 = gather_frames_cabi(shard, T, rank, world)     # the library's own entry point (maua_gather_frames)
+    torch.cuda.synchronize()
     if rank == 0:
+        assert torch.equal(full, full2)
         q.put(full.cpu())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -65,3 +70,14 @@ def test_two_rank_render_equals_single_gpu():
     torch.cuda.set_device(0)
     want = _render(0, T, T).cpu()
     assert torch.equal(got, want)
+
+
+
+def test_cabi_gather_single_rank():
+    """maua_comm_* / maua_gather_frames on one GPU (world 1: RCCL is bound and a communicator created, the root's own shard
+    is copied into place); the two-rank exchange is the test above wherever two GPUs exist."""
+    from maua_amd.distributed import gather_frames_cabi
+    x = torch.randint(0, 255, (5, 8, 8, 3), dtype=torch.uint8, device="cuda")
+    out = gather_frames_cabi(x, 5, rank=0, world=1)
+    torch.cuda.synchronize()
+    assert out.data_ptr() != x.data_ptr() and torch.equal(out, x)
