@@ -227,6 +227,11 @@ int maua_order_stat(maua_ctx* ctx, const float* x, const uint8_t* mask, long n, 
  * c [M][N] = a [M][K] x b [N][K]^T (f32).  Replaces rosa/spectral.py:35-56 dct (as a cosine-basis product, used by
  * audio.py:65-70 mfcc) and the phi @ chroma product of audio.py:50-62 tonnetz. */
 int maua_matmul_nt(maua_ctx* ctx, const float* a, const float* b, float* c, int M, int N, int K);
+/* mapping network (inference/stylegan2.py:116-192) around its matmul_nt + bias_act layers: the prologue normalize_2nd_moment
+ * (ops.py:142-143: y = x / sqrt(mean(x^2, dim 1) + eps), x [P][D]) and the epilogue w.unsqueeze(1).repeat(1, n, 1)
+ * (:183; out [P][n][D]) - so that the once-per-clip mapper needs no kernel outside this library. */
+int maua_normalize_2nd_moment(maua_ctx* ctx, const float* x, int P, int D, float eps, float* y);
+int maua_repeat_rows(maua_ctx* ctx, const float* x, int P, int D, int n, float* out);
 /* replaces audio.py:118-126 spectral_flatness on the frame-major complex STFT spec [n_frames][n_bins]:
  * out[f] = exp(mean(log(max(amin, |z|^power)))) / mean(max(amin, |z|^power)). */
 int maua_spectral_flatness(maua_ctx* ctx, const float* spec, int n_frames, int n_bins, float amin, float power,

@@ -378,3 +378,48 @@ extern "C" int maua_piptrack(maua_ctx* ctx, const float* mag_frames_bins, int n_
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
+
+// ---- mapping-network prologue / epilogue (inference/stylegan2.py:142-143, :183): rows of a [P][D] matrix ----------------
+namespace {
+// y[p][:] = x[p][:] / sqrt(mean(x[p][:]^2) + eps): one wave per row, fixed summation order (lane-strided partial sums,
+// xor-butterfly)
+__global__ __launch_bounds__(64) void normalize_2nd_moment_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
+                                                                   float eps) {
+  const float* xr = x + (long)blockIdx.x * D;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < D; i += 64) s += xr[i] * xr[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float inv = 1.0f / sqrtf(s / (float)D + eps);
+  for (int i = threadIdx.x; i < D; i += 64) y[(long)blockIdx.x * D + i] = xr[i] * inv;
+}
+// out[p][k][:] = x[p][:] for k < n  (ws = w.unsqueeze(1).repeat(1, num_ws, 1))
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int D, int n,
+                                                          long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const long row = idx / D;
+  out[idx] = x[(row / n) * D + (idx - row * D)];
+}
+}  // namespace
+
+extern "C" {
+
+int maua_normalize_2nd_moment(maua_ctx* ctx, const float* x, int P, int D, float eps, float* y) {
+  MAUA_REQUIRE(ctx && x && y && P >= 0 && D > 0, "maua_normalize_2nd_moment: bad argument");
+  if (P == 0) return MAUA_OK;
+  hipLaunchKernelGGL(normalize_2nd_moment_kernel, dim3(P), dim3(64), 0, ctx->stream, x, y, D, eps);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_repeat_rows(maua_ctx* ctx, const float* x, int P, int D, int n, float* out) {
+  MAUA_REQUIRE(ctx && x && out && P >= 0 && D > 0 && n > 0, "maua_repeat_rows: bad argument");
+  const long total = (long)P * n * D;
+  if (total == 0) return MAUA_OK;
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, out, D, n, total);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // extern "C"

@@ -116,8 +116,21 @@ def matmul_nt(a, b):
 
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
-    """ops.py:142-143 — a [P,512] prologue of the mapper; plain torch on the caller's device."""
-    return x / ((x * x).mean(dim=dim, keepdim=True) + eps).sqrt()
+    """ops.py:142-143 - the [P, D] prologue of the mapper (maua_normalize_2nd_moment: one wave per row)."""
+    if x.dim() != 2 or dim not in (1, -1):
+        return x / ((x * x).mean(dim=dim, keepdim=True) + eps).sqrt()
+    x = L.dev_tensor(x, torch.float32)
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_normalize_2nd_moment(L.ctx(x.device), L.ptr(x), x.shape[0], x.shape[1], C.c_float(eps), L.ptr(y)))
+    return y
+
+
+def repeat_rows(x, n):
+    """x [P, D] -> [P, n, D] (w.unsqueeze(1).repeat(1, n, 1) of the mapper, inference/stylegan2.py:183)."""
+    x = L.dev_tensor(x, torch.float32)
+    out = torch.empty((x.shape[0], n, x.shape[1]), dtype=torch.float32, device=x.device)
+    L.check(L.lib().maua_repeat_rows(L.ctx(x.device), L.ptr(x), x.shape[0], x.shape[1], n, L.ptr(out)))
+    return out
 
 
 def _check_resample_filter(f):

@@ -353,12 +353,15 @@ class MappingNetwork(torch.nn.Module):
         x = L.dev_tensor(z, torch.float32)
         x = ops.normalize_2nd_moment(x)
         for i in range(self.num_layers):
-            w = self._params[f"fcs.{i}.weight"].to(x.device) * (self.lr_multiplier / sqrt(self._params[f"fcs.{i}.weight"].shape[1]))
-            b = self._params[f"fcs.{i}.bias"].to(x.device) * self.lr_multiplier
+            # (gain and layout of the 512 x 512 matrices are prepared on the host: the once-per-clip mapper then runs only
+            #  library kernels - the first elementwise PyTorch kernel of a process costs ~0.3 s of code-object loading)
+            wh = self._params[f"fcs.{i}.weight"]
+            w = wh * (self.lr_multiplier / sqrt(wh.shape[1]))
+            b = (self._params[f"fcs.{i}.bias"] * self.lr_multiplier).to(x.device)
             # F.linear(x, w) upstream; the in-tree layer multiplies by the un-transposed matrix
-            y = ops.matmul_nt(x, w if self.nv_compat else w.T)
+            y = ops.matmul_nt(x, (w if self.nv_compat else w.T.contiguous()).to(x.device))
             x = ops.bias_act(y[:, :, None, None], b, act="lrelu")[:, :, 0, 0]
-        x = x.unsqueeze(1).repeat(1, self.num_ws, 1)
+        x = ops.repeat_rows(x, self.num_ws)
         if truncation_psi != 1:  # stylegan2.py:185-190: lerp towards w_avg, all ws or only the first `cutoff`
             w_avg = self._params["w_avg"].to(x.device)
             if truncation_cutoff is None:

@@ -1,0 +1,24 @@
+"""Where bench.py's e2e set-up time goes (after the HIP context is up): python scripts/e2e_setup_phases.py"""
+import sys, time, torch
+sys.path.insert(0, ".")
+torch.cuda.init(); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+t = [time.perf_counter()]
+def lap(msg):
+    torch.cuda.synchronize(); n = time.perf_counter(); print(f"{msg:44s} {n - t[0]:.3f} s"); t[0] = n
+from maua_amd import _lib as L, audio, latent, pipeline
+from maua_amd.noise import Loop
+from maua_amd.stylegan2 import SynthesisNetwork, MappingNetwork, get_z_latents
+lap("imports")
+g = torch.Generator().manual_seed(0)
+net = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, generator=g); lap("SynthesisNetwork init (host RNG)")
+net._handle(); lap("weights upload + prep (net._handle)")
+wav = pipeline.synthetic_audio(3600 * 1024, 30720); lap("synthetic audio (host)")
+env = audio.onsets(wav, 30720).squeeze(-1); lap("onsets (STFT, HPSS, mel, ...)")
+mapper = MappingNetwork(512, 0, 512, 18, generator=torch.Generator().manual_seed(0)); lap("mapper init (host RNG)")
+pal = mapper(get_z_latents("0-60", 512).float()); lap("mapper forward")
+half = pal.shape[0] // 2
+low = latent.spline_loops(pal[:half], 3600, 4); high = latent.spline_loops(pal[half:2 * half], 3600, 4); lap("spline loops x2")
+lat = latent.sequence_weighted(low, high, env); lat = audio.gaussian_filter(lat, 2); lap("blend + gaussian")
+rng = torch.Generator().manual_seed(42)
+sizes = [s[3] for s in net.layer_shapes()]
+noise = [Loop(rng, 3600, (s, s), n_loops=4, sigma=5) for s in sizes]; lap("17 Loop noise modules (host RNG + upload)")
