@@ -109,6 +109,7 @@ constexpr int TCONV_EDGES_ONLY = 100;  // ConvArgs.variant: launch_tconv2 covers
 // modconv_tconv_dma.hip: the main H x W block on LDS-direct loads; x already multiplied by the styles (bf16)
 bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W);
 int launch_tconv_dma(hipStream_t stream, const ConvArgs& a);
+int launch_tconv_edges(hipStream_t stream, const ConvArgs& a);   // the thin last row / column of positions (bf16, pre-modulated x)
 int launch_prep_tconv_weights(hipStream_t stream, int dtype, const float* w, void* wt, int Co, int Ci, int flip);
 
 // second half of the minimal up-layer: out = act(d * FIR4x4(t) + noise + bias) (ops.py:225 upfirdn2d pad 1 gain 4,

@@ -217,6 +217,79 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
   }
 }
 
+// ---- the thin last row (i = H) and last column (j = W) of the (H + 1) x (W + 1) position grid ---------------------------
+// Beyond the image only the taps that reach back inside contribute: the row edge sees x[H - 1][.] through the shift slots
+// (1,1) / (1,0) and produces the classes (0,0), (0,1) (t row 2H); the column edge sees x[.][W - 1] through (1,1) / (0,1)
+// and produces (0,0), (1,0) (t column 2W).  That is 3 weight blocks and 2 input fragments per k-step instead of 9 and 4,
+// on 32 consecutive edge positions per wave - no tile of mostly-absent neighbours, no LDS: both operands come straight
+// from global memory (L2) as MFMA fragments.  One wave per (32 positions, 32 channels, sample); K runs over all input
+// channels in 16-channel steps.  (tconv2_kernel's thin regions did this work in 8 x 32 / 64 x 4 tiles at 12 - 25 % use
+// with all nine blocks: 0.06 ms per layer at B = 32 for 0.4 % of the layer's MACs.)
+__global__ __launch_bounds__(64) void tconv_edges_kernel(ConvArgs a, int row_tiles) {
+  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y, cb = blockIdx.z, CB = a.Co >> 5;
+  const bool row_edge = (int)blockIdx.x < row_tiles;
+  const int e0 = (row_edge ? (int)blockIdx.x : (int)blockIdx.x - row_tiles) * 32 + r;   // j (row edge) or i (column edge)
+  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * a.x_bstride;
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w);
+  // input fragments: X0 = shift (1,1), X1 = shift (1,0) [row edge] or (0,1) [column edge]
+  long x0 = -1, x1 = -1;
+  if (row_edge) {
+    if (e0 >= 1 && e0 <= a.W) x0 = ((long)(a.H - 1) * a.W + (e0 - 1)) * a.Ci;
+    if (e0 < a.W) x1 = ((long)(a.H - 1) * a.W + e0) * a.Ci;
+  } else {
+    if (e0 >= 1 && e0 <= a.H - 1) x0 = ((long)(e0 - 1) * a.W + (a.W - 1)) * a.Ci;
+    if (e0 < a.H) x1 = ((long)e0 * a.W + (a.W - 1)) * a.Ci;
+  }
+  // weight blocks [slot][CB][class][32][Ci]: W0 = (slot 0, class 0); row edge: W1 = (1, 0), W2 = (1, 1); column: (2, 0), (2, 2)
+  const int s1 = row_edge ? 1 : 2, c2 = row_edge ? 1 : 2;
+  const bf16_t* w0 = wp + ((((long)0 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
+  const bf16_t* w1 = wp + ((((long)s1 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
+  const bf16_t* w2 = wp + ((((long)s1 * CB + cb) * 4 + c2) * 32 + r) * a.Ci + 8 * h;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll 4
+  for (int k = 0; k < a.Ci; k += 16) {
+    const u32x4 A0 = *reinterpret_cast<const u32x4*>(w0 + k), A1 = *reinterpret_cast<const u32x4*>(w1 + k),
+                A2 = *reinterpret_cast<const u32x4*>(w2 + k);
+    const u32x4 X0 = x0 >= 0 ? *reinterpret_cast<const u32x4*>(xb + x0 + k + 8 * h) : zero;
+    const u32x4 X1 = x1 >= 0 ? *reinterpret_cast<const u32x4*>(xb + x1 + k + 8 * h) : zero;
+    mma(acc0, A0, X0);
+    mma(acc1, A2, X1);
+    mma(acc0, A1, X1);
+  }
+  const int Wt = 2 * a.W + 1, Ht = 2 * a.H + 1;
+  bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long)b * Ht * Wt * a.Co + cb * 32 + 4 * h;
+  long o0 = -1, o1 = -1;   // class (0,0) and the edge's second class
+  if (row_edge) {
+    if (e0 <= a.W) o0 = ((long)(2 * a.H) * Wt + 2 * e0) * a.Co;
+    if (e0 < a.W) o1 = ((long)(2 * a.H) * Wt + 2 * e0 + 1) * a.Co;
+  } else if (e0 < a.H) {
+    o0 = ((long)(2 * e0) * Wt + 2 * a.W) * a.Co;
+    o1 = ((long)(2 * e0 + 1) * Wt + 2 * a.W) * a.Co;
+  }
+#pragma unroll
+  for (int qd = 0; qd < 4; qd++) {
+    if (o0 >= 0)
+      *reinterpret_cast<uint2*>(yb + o0 + 8 * qd) = make_uint2(pack2bf(acc0[qd * 4], acc0[qd * 4 + 1]), pack2bf(acc0[qd * 4 + 2], acc0[qd * 4 + 3]));
+    if (o1 >= 0)
+      *reinterpret_cast<uint2*>(yb + o1 + 8 * qd) = make_uint2(pack2bf(acc1[qd * 4], acc1[qd * 4 + 1]), pack2bf(acc1[qd * 4 + 2], acc1[qd * 4 + 3]));
+  }
+}
+
+// last row / column of positions; a.x must already carry the styles (as for launch_tconv_dma)
+int launch_tconv_edges(hipStream_t stream, const ConvArgs& a) {
+  MAUA_REQUIRE(a.Ci % 16 == 0 && a.Co % 32 == 0, "tconv_edges: Ci % 16, Co % 32");
+  if (a.B == 0) return MAUA_OK;
+  const int row_tiles = (a.W + 1 + 31) / 32, col_tiles = (a.H + 31) / 32;
+  MAUA_REQUIRE(a.B <= 65535 && a.Co / 32 <= 65535, "tconv_edges: grid too large");
+  hipLaunchKernelGGL(tconv_edges_kernel, dim3(row_tiles + col_tiles, a.B, a.Co / 32), dim3(64), 0, stream, a, row_tiles);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W) {
   return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H % PTH == 0 && W % PTW == 0 &&
          (long)H * W * Ci * 2 < (1L << 32) && 16L * Co * Ci * 2 < (1L << 32);

@@ -70,7 +70,7 @@ struct maua_synth {
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
-  int tconv_dma = 1;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
+  int tconv_dma = 2;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
   float* ones = nullptr;   // [Bcap][max channels] unit styles (kernels that take already-modulated input)
   void* xm = nullptr;      // [Bcap] pre-modulated copy of an up-layer's input when its producer could not scale it
   void* tbuf = nullptr;  // [Bcap] transposed-conv tensor of the largest up-layer
@@ -728,9 +728,13 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           a.s = n->ones;
           // (the thin edges first, the main block behind them; running the edges on a side stream beside the main block
           //  measured no different: 8.06 vs 8.08 ms per forward)
-          ConvArgs e = a;
-          e.variant = TCONV_EDGES_ONLY;
-          if (int rc = launch_tconv2(st, n->dtype, e)) return rc;
+          if (n->tconv_dma >= 2) {          // dedicated edge kernel (3 of 9 weight blocks, no tile waste)
+            if (int rc = launch_tconv_edges(st, a)) return rc;
+          } else {
+            ConvArgs e = a;
+            e.variant = TCONV_EDGES_ONLY;
+            if (int rc = launch_tconv2(st, n->dtype, e)) return rc;
+          }
           a.variant = 0;
           if (int rc = launch_tconv_dma(st, a)) return rc;
         } else if (int rc = launch_tconv2(st, n->dtype, a)) {

@@ -42,6 +42,8 @@ def bench_name(k):
         return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s,%s>" % m.groups()
     if "tconv_dma_kernel" in k:
         return "tconv_dma_kernel (+edges, +premod)"
+    if "tconv_edges_kernel" in k:
+        return "tconv_edges_kernel"
     m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+)>", k)
     if m:
         return "modconv_dma_kernel<%s,%s,%s,%s,%s,%s>" % m.groups()
