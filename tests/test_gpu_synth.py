@@ -402,10 +402,12 @@ def test_upwalk_block_walks_match_phase_form_and_oracle(res, B):
         assert torch.equal(one[0].cpu(), imgs[2][B - 1])
 
 
-def test_upwalk_block_walks_on_a_resized_non_square_grid():
-    """The same three forms of the last block behind a feature-space resize (get_hook's resize: 64^2 -> 40 x 96 after
-    bs.4.conv1, so the last block's up-layer runs on 80 x 192 inputs and renders 160 x 384): non-square, rows not a
-    multiple of the row segments, 4 strips with a partial last one - against each other and the oracle."""
+@pytest.mark.parametrize("target", [(40, 96), (33, 64), (7, 32)])
+def test_upwalk_block_walks_on_a_resized_non_square_grid(target):
+    """The same three forms of the last block behind a feature-space resize (get_hook's resize: 64^2 -> target after
+    bs.4.conv1, so the last block's up-layer runs on 2 target inputs and renders 4 target): non-square, odd row counts,
+    rows not a multiple of the row segments, partial last strips - against each other and the oracle."""
+    th, tw = target
     from maua_amd import _lib as L
     from maua_amd.stylegan2 import SynthesisNetwork
     g = torch.Generator().manual_seed(21)
@@ -417,15 +419,15 @@ def test_upwalk_block_walks_on_a_resized_non_square_grid():
     net.load_state_dict(p)
     B = 2
     ws = torch.randn(B, net.num_ws, 64, generator=g)
-    fill = torch.randn((64, 40, 96), generator=g) * 0.5
-    net.set_resize(8, target=(40, 96), fill_noise=fill, noise_generator=torch.Generator().manual_seed(5), mode="stretch")
-    assert net.output_hw == (160, 384)
+    fill = torch.randn((64, th, tw), generator=g) * 0.5
+    net.set_resize(8, target=(th, tw), fill_noise=fill, noise_generator=torch.Generator().manual_seed(5), mode="stretch")
+    assert net.output_hw == (4 * th, 4 * tw)
     h = net._handle()
     imgs = {}
     for mode in (0, 1, 2):
         L.check(L.lib().maua_synth_set_option(h, b"upwalk", mode))
-        img = torch.empty((B, 3, 160, 384), device="cuda")
-        u8 = torch.empty((B, 160, 384, 3), dtype=torch.uint8, device="cuda")
+        img = torch.empty((B, 3, 4 * th, 4 * tw), device="cuda")
+        u8 = torch.empty((B, 4 * th, 4 * tw, 3), dtype=torch.uint8, device="cuda")
         net(ws, out=img, rgb8_out=u8)
         assert torch.equal(u8, ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1)), mode
         imgs[mode] = img.cpu()
@@ -433,7 +435,7 @@ def test_upwalk_block_walks_on_a_resized_non_square_grid():
     for mode in (1, 2):
         assert psnr(imgs[mode], imgs[0]) >= 60.0, (mode, psnr(imgs[mode], imgs[0]))
         assert float((imgs[mode] - imgs[0]).abs().max()) <= 5e-3 * rng, mode
-    ref = OS.synthesis_network(net.state_dict(), ws, resize=dict(layer=8, mode="stretch", target=(40, 96), fill=fill, padding=(0, 0, 0, 0)))
+    ref = OS.synthesis_network(net.state_dict(), ws, resize=dict(layer=8, mode="stretch", target=(th, tw), fill=fill, padding=(0, 0, 0, 0)))
     for mode in (0, 1, 2):
         assert psnr(imgs[mode], ref) >= 50.0, (mode, psnr(imgs[mode], ref))
     net.set_resize(None)
