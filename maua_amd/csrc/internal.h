@@ -51,6 +51,7 @@ bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
 // modconv_dma.hip: up = 1, bf16, input already multiplied by the styles (x * s); both operands by LDS-direct loads
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W);
 bool dma_rgb_fusable(int Co);
+bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W);  // 32 / 64 output channels (plain convs: x_pstride / y_pstride / y_coff / res honoured)
 int launch_modconv_dma(hipStream_t stream, const ConvArgs& a);
 int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci);
 

@@ -92,11 +92,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   constexpr int HB = HALO_PX * KCB;                     // one halo buffer
   constexpr int TB = BN * KCB;                          // bytes of one tap's weight slice (BN rows)
   constexpr int WB = TPS * TB;                          // bytes of one weight stage (TPS taps)
-  constexpr int WJ = TB / 1024 / NW;                    // weight load instructions per wave per tap
+  constexpr int WPIECES = TB / 1024;                    // 1 KB weight load instructions per tap (all waves together)
+  constexpr int WJ = (WPIECES + NW - 1) / NW;           // ... per wave (narrow N tiles: only the first WPIECES waves load)
   constexpr int HJ = (HALO_PX * PPR + NT - 1) / NT;     // halo load instructions per wave per chunk
   constexpr int KSPT = KB / 32;                         // 32-byte k-steps per tap
   constexpr int Q = KSPT * TPS;                         // k-steps per stage
-  static_assert(TB % (1024 * NW) == 0 && (HJ == 6 || HJ == 3) && (TPS == 1 || TPS == 2) && (Q == 4 || Q == 8), "stage split");
+  static_assert(TB % 1024 == 0 && (WPIECES % NW == 0 || WPIECES < NW) && (HJ == 6 || HJ == 3) && (TPS == 1 || TPS == 2) &&
+                    (Q == 4 || Q == 8), "stage split");
   constexpr int OFF_H = 2 * WB;
   // piece p of row n sits at piece index p ^ swz(n): 8 rows x 8 pieces or 16 rows x 4 pieces tile one 1 KB bank period
 #define MAUA_SWZ(N_) (KB == 128 ? (((N_) >> 1) & 7) : (((N_) >> 2) & 3))
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const int b = blockIdx.y, n0 = blockIdx.z * BN;
   const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.x_bstride * 2;
   const char* wp = reinterpret_cast<const char*>(a.w);
+  const int xps = a.x_pstride ? a.x_pstride : a.Ci;   // elements between pixels (channel-sliced inputs: a prefix of a wider buffer)
 
   // ---- sources of this lane's LDS-direct loads (fixed for the whole K loop apart from the chunk offset)
   // halo: instruction ii = wave + NW j covers pieces [64 ii, 64 ii + 64) of the [340 px][8 pieces] buffer
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     hoff[j] = 0xffffffffu;
     if (P < HALO_PX * PPR) {
       if (in) {
-        hoff[j] = (unsigned)(((gy * a.W + gx) * a.Ci + q * 8) * 2);
+        hoff[j] = (unsigned)(((gy * a.W + gx) * xps + q * 8) * 2);
       } else {
         *reinterpret_cast<u32x4*>(smem + OFF_H + P * 16) = u32x4{0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(smem + OFF_H + HB + P * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   unsigned woff[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; j++) {
-    const int row = (1024 / KB) * (wave + NW * j) + (lane >> PSH);
+    const int row = min((1024 / KB) * (wave + NW * j) + (lane >> PSH), BN - 1);
     const int q = (lane & (PPR - 1)) ^ MAUA_SWZ(row);
     woff[j] = (unsigned)((row * a.Ci + q * 8) * 2);
   }
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   {                                                                                                      \
     const char* ws_ = wtile + (long)(T_) * tap_stride + (long)(C_) * (KC * 2);                           \
     _Pragma("unroll") for (int jj = 0; jj < WJ; jj++)                                                   \
-        dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024);                \
+        if (WPIECES >= NW || wave + NW * jj < WPIECES)                                                   \
+          dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024);              \
   }
   // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
 #define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   __syncthreads();
   // ---- fused toRGB + upsampled skip (conv1 layers whose channels all sit in this N tile): [32 px x Co] x [Co x 3(+3)]
   // on the matrix cores straight from the epilogue tile, as in modconv.hip (weights split hi + lo to ~2^-17)
-  if (a.rgb_out) {
+  if (NW == 8 && a.rgb_out) {   // (wave w owns image row w of the tile)
     const int c_rgb = r < 3 ? r : (r >= 8 && r < 11 ? r - 8 : -1);
     const int mrow = wave * 32 + r;  // wave w owns image row w of the tile
     const int y = ty0 + wave, x = tx0 + r;
@@ -388,7 +392,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
     }
   }
-  char* yb = reinterpret_cast<char*>(a.y) + (long)b * a.H * a.W * a.Co * 2;
+  const int yps = a.y_pstride ? a.y_pstride : a.Co;   // channel-sliced outputs: Co channels at offset y_coff of a wider pixel
+  char* yb = reinterpret_cast<char*>(a.y) + ((long)b * (a.y_bstride ? a.y_bstride : (long)a.H * a.W * yps) + a.y_coff) * 2;
+  const char* rb = a.res ? reinterpret_cast<const char*>(a.res) + (long)b * a.res_bstride * 2 : nullptr;
   // The stored features may carry the NEXT layer's styles (that layer's kernel then needs no modulation on its load
   // path); the fused toRGB above read the unscaled tile.  A thread always copies the same piece column (NT % PPP == 0).
   static_assert(NT % PPP == 0, "piece column per thread");
@@ -407,12 +413,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       for (int k = 0; k < 4; k++)
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * osc[2 * k], bf2f((bf16_t)(v[k] >> 16)) * osc[2 * k + 1]);
     }
-    *reinterpret_cast<u32x4*>(yb + (pix * a.Co + n0 + pc * 8) * 2) = v;
+    if (rb) {   // residual added to the activated output (RRDB: out = conv5(..) * 0.2 + x); both operands bf16
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(rb + (pix * a.res_pstride + n0 + pc * 8) * 2);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
+    }
+    *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
   }
 }
 
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
+}
+// ... and the narrow plain convolutions of the RRDB up-scaler (super.hip): 32 or 64 output channels, K a multiple of 64
+bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W) {
+  return dtype == MAUA_BF16 && Ci % 64 == 0 && (Co == 32 || Co == 64) && H % TH == 0 && W % TW == 0;
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB>
@@ -432,10 +448,18 @@ static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
 
 // a.x must already carry the styles (x * s[b, ci]); a.s is not read
 int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
-  MAUA_REQUIRE(dma_conv_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_dma: unsupported shape");
+  const bool narrow = dma_conv_narrow_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W) && a.up == 1;
+  MAUA_REQUIRE(narrow || dma_conv_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_dma: unsupported shape");
   MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");
   if (a.B == 0) return MAUA_OK;
-  MAUA_REQUIRE((long)a.H * a.W * a.Ci * 2 < (1L << 32), "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
+  MAUA_REQUIRE((long)a.H * a.W * (a.x_pstride ? a.x_pstride : a.Ci) * 2 < (1L << 32),
+               "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
+  // narrow N tiles (4 waves, 64-byte K rows, two taps per stage): 64 channels = 2 x 2 blocks per wave, 32 = 2 x 1
+  if (narrow) {
+    MAUA_REQUIRE(!a.rgb_out && !a.out_scale, "modconv_dma: the narrow tiles carry no toRGB / style scaling");
+    return a.Co == 64 ? launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
+  }
+  MAUA_REQUIRE(!a.x_pstride && !a.y_pstride && !a.y_coff && !a.res, "modconv_dma: channel-sliced operands are for the narrow tiles");
   // 256-channel N tile: 128-byte K rows, one tap per stage, 149 KB of LDS, one workgroup per CU.
   // 128-channel N tile: 64-byte K rows, two taps per stage, 75 KB -> two workgroups per CU (measured on the 256^2 layer,
   // K = 1152: 0.90 -> 0.65 ms against the same tile with 128-byte rows and one workgroup per CU; for the 256-channel

@@ -15,9 +15,11 @@
 // MI355X design: activations stay NHWC in the network dtype for the whole forward; a dense block is ONE buffer of
 // num_feat + 4 * grow channels per pixel - every convolution reads a channel prefix of it and writes its own channel
 // slice (no torch.cat copies: the conv kernels take pixel strides), the block's scaled residual is fused into conv5's
-// epilogue.  The 3x3 convolutions run on the MFMA implicit-GEMM kernel of modconv.hip with unit styles (a plain
-// convolution is a modulated one with s = 1 and no demodulation).
+// epilogue.  The 3x3 convolutions run on the MFMA implicit-GEMM kernels with unit styles (a plain convolution is a
+// modulated one with s = 1 and no demodulation): bf16 at H % 8 == 0, W % 32 == 0 on the narrow N tiles of the LDS-direct
+// kernel (modconv_dma.hip), everything else on the generic kernel (modconv.hip).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,6 +103,7 @@ struct maua_rrdbnet {
   size_t esize;
   PlainConv conv_first, conv_body, conv_up1, conv_up2, conv_hr, conv_last;
   std::vector<PlainConv> rdb;  // [block][3 rdb][5 conv]
+  int use_dma = 1;             // bf16 trunk convolutions on the LDS-direct kernel (MAUA_RRDB_DMA=0: the generic kernel)
   float* ones = nullptr;       // unit styles [bcap][max Ci]
   int ones_b = 0;
   // workspace (grow-only)
@@ -111,6 +114,9 @@ struct maua_rrdbnet {
 
 static int alloc_conv(PlainConv& c, int Ci, int Co, size_t esize) {
   c.Ci = Ci; c.Co = Co; c.Cip = (Ci + 31) / 32 * 32; c.Cop = (Co + 31) / 32 * 32;
+  // bf16: K in whole 64-channel chunks (zero weights beyond Ci) so that the trunk runs on the LDS-direct kernel; the
+  // channels read beyond Ci belong to the same dense-block buffer (zero-initialised, only ever finite)
+  if (esize == 2 && Ci >= 64) c.Cip = (Ci + 63) / 64 * 64;
   MAUA_HIP_CHECK(hipMalloc(&c.wt, (size_t)9 * c.Cop * c.Cip * esize));
   MAUA_HIP_CHECK(hipMemset(c.wt, 0, (size_t)9 * c.Cop * c.Cip * esize));
   MAUA_HIP_CHECK(hipMalloc((void**)&c.bias, (size_t)c.Cop * 4));
@@ -138,6 +144,7 @@ int maua_rrdb_create(maua_ctx* ctx, int num_feat, int num_block, int num_grow_ch
   maua_rrdbnet* n = new maua_rrdbnet();
   n->ctx = ctx; n->num_feat = num_feat; n->num_block = num_block; n->grow = num_grow_ch; n->dtype = dtype;
   n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  if (const char* e = getenv("MAUA_RRDB_DMA")) n->use_dma = atoi(e);
   int rc = alloc_conv(n->conv_first, 3, num_feat, n->esize);
   n->rdb.resize((size_t)num_block * 15);
   for (int i = 0; i < num_block * 3 && !rc; i++)
@@ -223,7 +230,10 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, float* out
     free_ws(n);
     MAUA_HIP_CHECK(hipMalloc(&n->in32, px * 32 * es));
     MAUA_HIP_CHECK(hipMalloc(&n->feat0, px * F * es));
-    for (int i = 0; i < 2; i++) MAUA_HIP_CHECK(hipMalloc(&n->dense[i], px * D * es));
+    for (int i = 0; i < 2; i++) {
+      MAUA_HIP_CHECK(hipMalloc(&n->dense[i], px * D * es));
+      MAUA_HIP_CHECK(hipMemsetAsync(n->dense[i], 0, px * D * es, st));
+    }
     MAUA_HIP_CHECK(hipMalloc(&n->rsave, px * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f1, px * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->up1, px * 4 * F * es));
@@ -252,6 +262,8 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, float* out
     a.B = B; a.H = h; a.W = w; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
     a.act = lrelu ? MAUA_ACT_LRELU : MAUA_ACT_LINEAR; a.alpha = 0.2f; a.gain = gain; a.clamp = -1.f;
     a.res = res; a.res_pstride = rps; a.res_bstride = (long)h * w * rps;
+    // 32 / 64 output channels with K in 64-channel chunks: both operands by LDS-direct loads (modconv_dma.hip narrow tiles)
+    if (n->use_dma && dma_conv_narrow_supported(n->dtype, c.Cip, c.Cop, h, w)) return launch_modconv_dma(st, a);
     return launch_modconv3x3(st, n->dtype, a);
   };
   auto lincomb = [&](void* dst, int dps, float aa, const void* x, int xps, float bb, const void* y, int yps, long npix,

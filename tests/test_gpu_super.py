@@ -59,3 +59,32 @@ def test_realesrgan_wrapper_and_render_pipeline():
     assert float(outs[0].min()) >= 0.0 and float(outs[0].max()) <= 1.0
     big = model.model(frames)                                # batched, on-device form of the same thing
     assert float((big[0].cpu() - outs[0][0]).abs().max()) <= 1 / 255 + 1e-3   # upscale() goes through u8 images
+
+
+def test_rrdb_trunk_on_lds_direct_kernel_matches_generic_and_oracle(monkeypatch):
+    """bf16, image sizes the LDS-direct kernel takes (H % 8 == 0, W % 32 == 0): every 3x3 convolution of the trunk and the
+    up-sampling tail runs on modconv_dma's narrow N tiles (32 / 64 output channels, channel-sliced dense-block operands,
+    residual in the copy-out) - against the generic MFMA kernel on the same weights and the fp32 oracle."""
+    from maua_amd.super import RRDBNet
+    from oracle import super as OSR
+    g = torch.Generator().manual_seed(8)
+    blocks = 2
+    ref_net = RRDBNet(num_block=blocks, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(5))
+    p = ref_net.state_dict()
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    p["conv_last.bias"] = torch.full((3,), 0.5)
+    p["conv_last.weight"] = p["conv_last.weight"] * 0.1
+    x = torch.rand(2, 3, 32, 64, generator=g)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAUA_RRDB_DMA", mode)
+        net = RRDBNet(num_block=blocks, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(5))
+        net.load_state_dict(p)
+        outs[mode] = net(x).cpu()
+        del net
+    ref = OSR.rrdbnet(p, x, blocks)
+    assert outs["1"].shape == ref.shape == (2, 3, 128, 256)
+    assert _psnr(outs["1"], ref) >= 40.0 and _psnr(outs["0"], ref) >= 40.0, (_psnr(outs["1"], ref), _psnr(outs["0"], ref))
+    assert _psnr(outs["1"], outs["0"]) >= 50.0, _psnr(outs["1"], outs["0"])   # same bf16 operands, residual rounded once more
