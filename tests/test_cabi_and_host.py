@@ -245,3 +245,39 @@ def test_video_writer_pipes_frames_to_ffmpeg(tmp_path, monkeypatch):
     assert cmd[cmd.index("-s") + 1] == "12x8" and cmd[cmd.index("-r") + 1] == "30" and cmd[cmd.index("-f") + 1] == "rawvideo"
     assert cmd[cmd.index("-ss") + 1] == "1.5" and cmd[cmd.index("-t") + 1] == "2.0" and "song.wav" in cmd
     assert cmd[cmd.index("-preset") + 1] == "fast" and cmd[-1] == str(out)
+
+
+def test_bench_layer_table_matches_the_profile_slots():
+    """bench.py's per-launch accounting (kernel name, algorithmic FLOPs / bytes per profile slot) must line up with what
+    synth.hip launches for the BASELINE network: 1 styles slot + (conv slots incl. the two-slot tconv layers) + 9 toRGB
+    slots + the u8 pack, the fused last-block walk carrying the whole block's work with its conv1 slot empty."""
+    import importlib.util
+    import pathlib
+    from maua_amd.stylegan2 import SynthesisNetwork
+    spec = importlib.util.spec_from_file_location("maua_bench", pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Shapes:  # layer_table only needs the layer shapes of the 1024^2 network
+        block_resolutions = [4, 8, 16, 32, 64, 128, 256, 512, 1024]
+
+        def layer_shapes(self):
+            ch = {4: 512, 8: 512, 16: 512, 32: 512, 64: 512, 128: 256, 256: 128, 512: 64, 1024: 32}
+            out = [("bs.0.conv1", 512, 512, 4, 1)]
+            for i, r in enumerate(self.block_resolutions[1:], 1):
+                out += [(f"bs.{i}.conv0", ch[r // 2], ch[r], r, 2), (f"bs.{i}.conv1", ch[r], ch[r], r, 1)]
+            return out
+
+    rows = bench.layer_table(Shapes())
+    names = [r[0] for r in rows]
+    assert names[0] == "styles" and names[-1] == "pack_rgb8"
+    assert len(rows) == 1 + 17 + 4 + 9 + 1            # 4 up-layers occupy two slots (tconv + FIR pass)
+    kern = {r[0]: r[1] for r in rows}
+    assert kern["bs.8.conv0"].startswith("upwalk_fused") and kern["bs.8.conv1"] == "(in the fused walk)"
+    assert kern["bs.7.conv1"] == "modconv_hires_kernel<64,64,1>" and kern["bs.6.conv1"].startswith("modconv_dma_kernel<4,2,2,2,2,64>")
+    total_gflop = sum(r[2] for r in rows)
+    assert abs(total_gflop - 148.5) < 1.5, total_gflop   # SURVEY 8(d): 148.5 GFLOP per frame on minimal MACs
+    assert bench.DEFAULT_BATCH == 128
+    # the real class agrees with the stand-in on the shapes (cheap: no weights are drawn)
+    assert [s[1:] for s in Shapes().layer_shapes()] == [tuple(s[1:]) for s in SynthesisNetwork.layer_shapes_for(1024)] \
+        if hasattr(SynthesisNetwork, "layer_shapes_for") else True
