@@ -16,11 +16,14 @@ def frame_range(n_frames, rank, world):
 def synthetic_audio(n_samples, sr, seed=1234):
     """SURVEY 8(d) synthetic clip: 220 Hz tone + 2 Hz click train + noise, float32 mono."""
     g = torch.Generator().manual_seed(seed)
-    t = torch.arange(n_samples, dtype=torch.float64) / sr
+    t = torch.arange(n_samples, dtype=torch.float64).div_(sr)
     u = torch.rand(n_samples, generator=g, dtype=torch.float64)
     nz = torch.randn(n_samples, generator=g, dtype=torch.float64)
-    click = ((2 * t) % 1 < 0.05).double()
-    return (0.3 * torch.sin(2 * math.pi * 220 * t) + 0.2 * (u - 0.5) * click + 0.01 * nz).float()
+    # 0.3 sin(2 pi 220 t) + 0.2 (u - 0.5) [2t mod 1 < 0.05] + 0.01 nz, in place (eight 29 MB temporaries cost the
+    # 3600-frame clip 0.25 s of page faults)
+    u.sub_(0.5).mul_(0.2).mul_(t.mul(2).remainder_(1).lt_(0.05))
+    t.mul_(2 * math.pi * 220).sin_().mul_(0.3).add_(u).add_(nz.mul_(0.01))
+    return t.float()
 
 
 def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4):
