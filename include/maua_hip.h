@@ -191,6 +191,29 @@ int maua_plp_select(maua_ctx* ctx, float* tempogram_frames_bins_complex, int n_f
  * n_frames hop-1 frames of env_padded [n_frames + win - 1] (the caller pads the envelope by win/2 ramp samples). */
 int maua_autocorr_frames(maua_ctx* ctx, const float* env_padded, const float* window, int n_frames, int win,
                          int n_lags, float* ac_frames_lags);
+/* ---- beats and Laplacian segmentation (selfsupervised/mir.py:31-41; features/rosa/segment.py) ----
+ * mir.py:31 rosa.beat.beat_track(onset_envelope, trim=False, hop_length=1024, bpm=tempo): librosa is un-vendored, this is
+ * its published dynamic program (librosa.beat.__beat_local_score + __beat_track_dp).  onset_norm [T] = envelope / its
+ * std(ddof=1); period = round(60 * frame_rate / bpm) frames.  Outputs (device): localscore [T] f64 = the envelope
+ * smoothed by exp(-0.5 (32 m / period)^2), cumscore [T] f64, backlink [T] i32 (best predecessor frame, negative = none).
+ * The caller walks the links back from the last beat (host; maua_amd.segment.beats_from_links). */
+int maua_beat_dp(maua_ctx* ctx, const float* onset_norm, int T, int period, double tightness, double* localscore,
+                 double* cumscore, int* backlink);
+/* segment.py:152-155 beat-synchronous feature: out[s][c] = lower median (mode 0, torch.median) or mean (mode 1,
+ * librosa.util.sync of :241) of x[bounds[s] .. bounds[s+1])[c]; x [T][C] f32, bounds [n_segments + 1] i32 on the device */
+int maua_segment_reduce(maua_ctx* ctx, const float* x, int T, int C, const int* bounds, int n_segments, int mode,
+                        float* out);
+/* segment.py:23-57 recurrence_matrix(data, k, width, sym=True): rec [n][n] = exp(-d / bandwidth) on the k nearest rows of
+ * every column (|i - j| < width excluded), symmetrised by the minimum, bandwidth = lower median of the row maxima */
+int maua_recurrence_affinity(maua_ctx* ctx, const float* data, int n, int d, int k, int width, float* rec);
+/* segment.py:74-82 timelag_median_filter: median of 7 along the diagonals (time-lag domain), out != rec */
+int maua_timelag_median(maua_ctx* ctx, const float* rec, int n, float* out);
+/* segment.py:60-64 median_filter1d as :193 applies it: window k (odd, <= 15) along the rows of x [n][m], reflect padding */
+int maua_median_filter_rows(maua_ctx* ctx, const float* x, int n, int m, int k, float* out);
+/* segment.py:106-131 differentiable_k_means on unit-norm rows data [n][k] from centres mu0 [k][k] (k <= 16): `iters`
+ * updates mu = (r^T data) / sum r, r = softmax(temp * data mu^T); r_out [n][k], mu_out [k][k] */
+int maua_soft_kmeans(maua_ctx* ctx, const float* data, int n, int k, const float* mu0, int iters, float temp, float* r_out,
+                     float* mu_out);
 /* ---- constant-Q features (rosa/constantq.py:13-115, rosa/spectral.py:164-325, rosa/pitch.py) ----
  * out[i] = scale * sum_k taps[k] x[i * stride + k - left] (zero outside the signal): one phase of torchaudio's sinc
  * resampler - what constantq.py:92 `resample(y, sr, sr / 2, "kaiser_window")` computes (torchaudio un-vendored:

@@ -3,8 +3,8 @@ maua/audiovisual/audioreactive/selfsupervised/sample.py:36-107 ``generate`` and 
 
 Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  Features: the reference's AFEATFNS (chromagram, tonnetz, mfcc,
 spectral_contrast, spectral_flatness, rms, drop_strength, onsets).  The tempo is estimated from the onset envelope (the autocorrelation-tempogram estimate the
-reference takes from librosa); beat tracking + Laplacian segmentation (librosa / torch_geometric, un-vendored) are not
-implemented, so "segmentation" sub-patches are not drawn (latent_patch itself supports them when given labels).  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
+reference takes from librosa), beats by librosa's published dynamic program and the beat-synchronous Laplacian segmentations
+by maua_amd.segment (device kernels; librosa / torch_geometric / sklearn are un-vendored).  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
 rank 0 with one RCCL gather at the end.
 
     python -m maua_amd.audiovisual.sample --audio_file clip.wav --stylegan2_checkpoint None --downscale_factor 4
@@ -20,6 +20,7 @@ import torch
 from .. import audio as A
 from .. import latent as LT
 from .. import noise as N
+from .. import segment as SG
 from ..audio_io import load_audio
 from ..distributed import gather_frames, world_info
 from ..pipeline import frame_range
@@ -32,15 +33,32 @@ UNITFEATS = ["rms", "drop_strength", "onsets", "spectral_flatness"]
 ALLFEATS = ["chromagram", "tonnetz", "mfcc", "spectral_contrast"] + UNITFEATS
 
 
-def retrieve_music_information(audio, sr):
-    """selfsupervised/mir.py:24-45: every feature function on the clip -> gaussian(2) -> salience -> normalize.
-    Returns (features, tempo): tempo from the onset envelope (audio.tempo, the autocorrelation estimate the
-    reference takes from librosa, :27-30).  Beat-synchronous Laplacian segmentation (:31-41) is not implemented."""
+def retrieve_music_information(audio, sr, ks=(2, 4, 6, 8, 12, 16), device="cuda"):
+    """selfsupervised/mir.py:24-45 -> (features, segmentations, tempo).  Every feature function on the clip; tempo from the
+    onset envelope (audio.tempo: the autocorrelation estimate the reference takes from librosa, :27-30); beats at that
+    tempo (segment.beat_track, :31-33, a leading beat at frame 0 dropped); per feature and per k the argmax of the
+    Laplacian segmentation (:35-38) plus the CQT / MFCC "rosa" segmentation (:40-41); then gaussian(2) -> salience ->
+    normalize on the features (:43)."""
     raw = {fn.__name__: fn(audio, sr) for fn in AFEATFNS}
     raw = {k: (v if v.dim() > 1 else v.unsqueeze(-1)) for k, v in raw.items()}
-    tempo = A.tempo(raw["onsets"].squeeze())
+    onset_env = raw["onsets"].squeeze()
+    tempo = A.tempo(onset_env)
+    beats = [int(b) for b in SG.beat_track(onset_env, tempo)]
+    if beats and beats[0] == 0:
+        del beats[0]
+    # (a clip with fewer beat-synchronous frames than segments cannot be cut that finely - the reference fails on such
+    #  clips; here the affected k are left out, and a clip of <= 7 beats gets no segmentations at all)
+    n_sync = len(beats) + 1
+    ks = [k for k in ks if k <= n_sync] if n_sync > 7 else []
+    segmentations = {}
+    for name, feature in raw.items():
+        for k, s in zip(ks, SG.laplacian_segmentation(feature, beats, ks=ks)):
+            segmentations[(name, k)] = s.argmax(1)
+    n_frames = raw[AFEATFNS[0].__name__].shape[0]
+    for k, seg in zip(ks, SG.laplacian_segmentation_rosa(audio, sr, n_frames, ks=ks, beats=beats).unbind(1)):
+        segmentations[("rosa", k)] = seg
     feats = {k: A.normalize(A.salience_weighted(A.gaussian_filter(v, sigma=2))) for k, v in raw.items()}
-    return feats, tempo
+    return feats, segmentations, tempo
 
 
 def random_choice(rng, options, weights=None):
@@ -49,13 +67,15 @@ def random_choice(rng, options, weights=None):
 
 
 class Patch(torch.nn.Module):
-    """patch.py:34-197 restricted to in-scope sub-patch types ("feature", "loop")."""
+    """patch.py:34-197.  The generator lives on the host (the reference's is a device generator whose stream is
+    device / version specific, SURVEY L6: parity is on explicit selections, not on torch's stream)."""
 
-    def __init__(self, features, tempo, fps=24, seed=42, min_subpatches=2, max_subpatches=20, device="cuda"):
+    def __init__(self, features, segmentations, tempo, fps=24, seed=42, min_subpatches=2, max_subpatches=20, device="cuda"):
         super().__init__()
         rng = torch.Generator("cpu").manual_seed(seed)
         self.seed, self.rng, self.fps, self.tempo = seed, rng, fps, tempo
-        self.features = features
+        self.features, self.segmentations = features, segmentations
+        self.ks = np.unique([k for (_, k) in segmentations]).tolist()
         self.length = features[list(features.keys())[0]].shape[0]
         self.n_base_latents = torch.randint(3, 15, size=(), generator=rng).item()
         self.sigma_base_noise = 1 + 9 * torch.rand((), generator=rng).item()
@@ -72,8 +92,11 @@ class Patch(torch.nn.Module):
                     merge_depth=random_choice(r, ["low", "mid", "high", "lowmid", "midhigh", "all"], weights=[3, 3, 3, 2, 2, 1]))
 
     def random_latent_patch(self):
-        return dict(patch_type=random_choice(self.rng, ["feature", "loop"]), segments=random_choice(self.rng, [2, 4, 6, 8, 12, 16]),
-                    **self._common())
+        if not self.ks:  # no segmentations (clip too short to segment): only the sub-patch types that need none
+            return dict(patch_type=random_choice(self.rng, ["feature", "loop"]),
+                        segments=random_choice(self.rng, [2, 4, 6, 8, 12, 16]), **self._common())
+        return dict(patch_type=random_choice(self.rng, ["segmentation", "feature", "loop"]),
+                    segments=random_choice(self.rng, self.ks), **self._common())
 
     def random_noise_patch(self):
         return dict(patch_type=random_choice(self.rng, ["blend", "multiply", "loop"]), **self._common(), noise_mean=0, noise_std=1)
@@ -83,7 +106,7 @@ class Patch(torch.nn.Module):
         base = torch.randperm(len(latent_palette), generator=self.rng)[: self.n_base_latents]
         latents = LT.spline_loop_latents(latent_palette[base.to(latent_palette.device)], self.length).contiguous()
         for sub in self.latent_patches:
-            latents = LT.latent_patch(self.rng, latents, latent_palette, {}, self.features, self.tempo, self.fps, **sub)
+            latents = LT.latent_patch(self.rng, latents, latent_palette, self.segmentations, self.features, self.tempo, self.fps, **sub)
         sizes = [4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024]
         noise = [N.Loop(rng=self.rng, length=self.length,
                         size=(round(aspect_ratio * s / downscale_factor), round(s / downscale_factor)),
@@ -106,10 +129,10 @@ class Patch(torch.nn.Module):
                 + "\n  )\n)")
 
     @staticmethod
-    def load(path, features, tempo, fps, device="cuda"):
+    def load(path, features, segmentations, tempo, fps, device="cuda"):
         """patch.py:190-197: a fresh Patch whose attributes are overwritten by the saved JSON (seed, sub-patch lists,
         base-noise parameters), so the same file reproduces the same latent / noise sequences."""
-        patch = Patch(features=features, tempo=tempo, fps=fps, device=device)
+        patch = Patch(features=features, segmentations=segmentations, tempo=tempo, fps=fps, device=device)
         for key, val in json.loads(Path(path).read_text()).items():
             setattr(patch, key, val)
         return patch
@@ -136,12 +159,12 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     out_size = (round(aspect_ratio * 1024 / downscale_factor), res)   # (width, height), sample.py:53
     out_file = f"{out_dir}/{Path(audio_file).stem}_RandomPatches++_seed{seed}_{out_size[0]}x{out_size[1]}.mp4"
     audio, sr = load_audio(audio_file, audio_offset, audio_duration, fps)
-    features, est_tempo = retrieve_music_information(audio, sr)
+    features, segmentations, est_tempo = retrieve_music_information(audio, sr)
     tempo = est_tempo if tempo is None else tempo
     if patch_file is None:
-        patch = Patch(features=features, tempo=tempo, seed=seed, fps=fps)
+        patch = Patch(features=features, segmentations=segmentations, tempo=tempo, seed=seed, fps=fps)
     else:  # sample.py:62-66
-        patch = Patch.load(patch_file, features=features, tempo=tempo, fps=fps)
+        patch = Patch.load(patch_file, features=features, segmentations=segmentations, tempo=tempo, fps=fps)
     G = StyleGAN2(model_file=stylegan2_checkpoint, output_size=out_size, dtype=dtype,
                   generator=torch.Generator().manual_seed(seed))
     if latent_seeds is None:

@@ -535,6 +535,47 @@ def golden_cqt():
          lengths_full=CQ.constant_q_lengths(sr, fmin, n_bins=252, bins_per_octave=36))
 
 
+def segment_inputs(seed=3, T=640, C=12, n_sections=5):
+    """a feature with section structure (repeated random section templates + noise) and a jittered beat grid"""
+    g = torch.Generator().manual_seed(seed)
+    templates = torch.randn(3, C, generator=g)
+    order = [0, 1, 0, 2, 1]
+    bounds = torch.linspace(0, T, n_sections + 1).long()
+    env = torch.empty(T, C)
+    for s in range(n_sections):
+        lo, hi = int(bounds[s]), int(bounds[s + 1])
+        env[lo:hi] = templates[order[s]] + 0.3 * torch.randn(hi - lo, C, generator=g)
+    beats, b = [], 0
+    while True:
+        b += int(torch.randint(6, 11, (), generator=g))
+        if b >= T - 2:
+            break
+        beats.append(b)
+    return env, beats
+
+
+def golden_segment():
+    """features/rosa/segment.py pieces the reference can run here (torch_geometric / librosa / sklearn are stubs: the
+    get_laplacian call of laplacian_segmentation itself cannot run)."""
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import segment as SG
+    env, beats = segment_inputs()
+    Csync = torch.stack([torch.median(env[b1:b2], dim=0).values for b1, b2 in zip([0] + beats, beats + [len(env)])])
+    R = SG.recurrence_matrix(Csync, width=3, sym=True)
+    Rf = SG.timelag_median_filter(R)
+    g = torch.Generator().manual_seed(11)
+    ev = torch.randn(len(Csync), 16, generator=g)
+    evf = SG.median_filter1d(ev.T, k=9, s=1, p=4).T
+    out = dict(env=env, beats=np.array(beats), Csync=Csync, R=R, Rf=Rf, ev=ev, evf=evf)
+    for k in (2, 6, 16):
+        X = torch.randn(len(Csync), k, generator=g) + 2.0 * torch.nn.functional.one_hot(torch.arange(len(Csync)) * k // len(Csync), k)
+        Xn = torch.diag(1.0 / torch.norm(X, p=2, dim=1)) @ X
+        out[f"km{k}_X"] = X
+        out[f"km{k}_init"] = SG.init_plus_plus(Xn.numpy(), k)
+        mu, r, dist = SG.differentiable_k_means(X, k, 100)
+        out[f"km{k}_mu"], out[f"km{k}_r"], out[f"km{k}_dist"] = mu, r, dist
+    save("g22_segment", **out)
+
+
 def synthetic_rosinality_checkpoint(res=16, n_map=2, seed=7, const_input=True):
     """A random state dict with the key/shape structure of a rosinality StyleGAN2 ``g_ema`` (the structure is what
     maua/GAN/load.py:18-127 consumes); shared with tests/test_load.py, which rebuilds the same tensors."""

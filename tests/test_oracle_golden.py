@@ -445,3 +445,66 @@ def test_sinc_resample_oracle_properties():
     x = torch.randn(4097, generator=torch.Generator().manual_seed(1))
     close(OA.sinc_resample(x, 2, 1, resampling_method="sinc_interp_kaiser"), OC.resample(x, 2, 1), 1e-6)
     assert OA.sinc_resample(x, 8000, 10240).shape == (int(np.ceil(10240 * 4097 / 8000)),)
+
+
+def _segment_inputs(seed=3, T=640, C=12, n_sections=5):
+    """same construction as tests/golden/make_golden.py:segment_inputs (a feature with section structure + a beat grid)"""
+    g = torch.Generator().manual_seed(seed)
+    templates = torch.randn(3, C, generator=g)
+    order = [0, 1, 0, 2, 1]
+    bounds = torch.linspace(0, T, n_sections + 1).long()
+    env = torch.empty(T, C)
+    for s in range(n_sections):
+        lo, hi = int(bounds[s]), int(bounds[s + 1])
+        env[lo:hi] = templates[order[s]] + 0.3 * torch.randn(hi - lo, C, generator=g)
+    beats, b = [], 0
+    while True:
+        b += int(torch.randint(6, 11, (), generator=g))
+        if b >= T - 2:
+            break
+        beats.append(b)
+    return env, beats, order, bounds
+
+
+def test_segment_oracle_matches_reference_fixture(golden):
+    """oracle/segment.py against g22 (the reference's own recurrence_matrix / timelag_median_filter / median_filter1d /
+    init_plus_plus / differentiable_k_means on seeded inputs)."""
+    from oracle import segment as O
+    g = {k: np.asarray(v) for k, v in golden("g22_segment").items()}
+    env, beats, _, _ = _segment_inputs()
+    assert np.array_equal(env.numpy(), g["env"]) and np.array_equal(np.array(beats), g["beats"])
+    assert np.array_equal(O.sync(g["env"], g["beats"]), g["Csync"])
+    R = O.recurrence_matrix(g["Csync"], width=3)
+    assert np.array_equal(R != 0, g["R"] != 0) and np.abs(R - g["R"]).max() < 1e-6
+    assert np.array_equal(O.timelag_median_filter(g["R"]), g["Rf"])
+    assert np.array_equal(O.median_filter1d(g["ev"].T, 9, 4).T, g["evf"])
+    for k in (2, 6, 16):
+        X = g[f"km{k}_X"]
+        Xn = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+        assert np.abs(O.init_plus_plus(Xn, k) - g[f"km{k}_init"]).max() < 1e-6
+        mu, r, dist = O.soft_kmeans(X, k, 100)
+        assert np.abs(mu - g[f"km{k}_mu"]).max() < 5e-6 and np.abs(r - g[f"km{k}_r"]).max() < 5e-6
+        assert np.abs(dist - g[f"km{k}_dist"]).max() < 5e-6
+
+
+def test_segment_oracle_recovers_sections_and_beats():
+    """what the un-pinned pieces must do: the beat tracker locks onto a click train at the given tempo (librosa's
+    published dynamic program), and the full chain (dense sym Laplacian = torch_geometric's get_laplacian) separates the
+    A B A C B sections of the fixture feature."""
+    from oracle import segment as O
+    # 21.5 frames/s (sr 22050 / hop 1024), 129 BPM -> period 10 frames
+    T, period = 900, 10
+    env = np.zeros(T, dtype=np.float32)
+    env[7::period] = 1.0
+    env += 0.05 * np.random.RandomState(0).rand(T).astype(np.float32)
+    beats, local, cum, back = O.beat_track(env, bpm=60.0 * (22050 / 1024) / period)
+    assert len(beats) > 80 and np.all(np.diff(beats) == period) and np.all(beats % period == 7)
+    assert O.beat_track(np.zeros(50, dtype=np.float32), 120.0)[0].size == 0
+    env2, bts, order, bounds = _segment_inputs()
+    segs = O.laplacian_segmentation(env2.numpy(), bts, ks=(2, 4, 6))
+    assert [s.shape for s in segs] == [(640, 2), (640, 4), (640, 6)]
+    lab = segs[1].argmax(1)
+    mids = [int((bounds[s] + bounds[s + 1]) // 2) for s in range(5)]
+    # sections with the same template share a label, different templates differ (k = 4 over 3 templates)
+    assert lab[mids[0]] == lab[mids[2]] and lab[mids[1]] == lab[mids[4]]
+    assert len({int(lab[mids[0]]), int(lab[mids[1]]), int(lab[mids[3]])}) == 3
