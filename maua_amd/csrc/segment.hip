@@ -160,11 +160,17 @@ __global__ __launch_bounds__(256) void recurrence_sym_kernel(const float* __rest
   if (threadIdx.x == 0) rowmax[i] = sh[0];
 }
 
-// lower median of x[0..n) (torch.median) by rank counting -> out[0]
-__global__ __launch_bounds__(256) void lower_median_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+// lower median of x[0..n) (torch.median) by rank counting -> out[0].  `positive`: a zero median (more than half of the
+// rows kept no neighbour: constant features) is replaced by the largest value, or 1 - the reference divides by it and
+// carries NaNs into its eigensolver
+__global__ __launch_bounds__(256) void lower_median_kernel(const float* __restrict__ x, int n, int positive,
+                                                           float* __restrict__ out) {
+  __shared__ float sh[256];
   const int want = (n - 1) / 2;
+  float mx = -INFINITY;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float v = x[i];
+    mx = fmaxf(mx, v);
     int rank = 0;
     for (int m = 0; m < n; m++) {
       const float u = x[m];
@@ -172,6 +178,13 @@ __global__ __launch_bounds__(256) void lower_median_kernel(const float* __restri
     }
     if (rank == want) *out = v;
   }
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && positive && !(*out > 0.f)) *out = sh[0] > 0.f ? sh[0] : 1.f;
 }
 
 // segment.py:51-57: negatives to zero, exp(rec / -bandwidth), entries that were zero (exp = 1) back to zero
@@ -350,7 +363,7 @@ int maua_recurrence_affinity(maua_ctx* ctx, const float* data, int n, int d, int
   hipLaunchKernelGGL(recurrence_topk_kernel, dim3(n), dim3(256), (size_t)n * 4, s, data, n, d, k, width, (float*)(base + oraw));
   hipLaunchKernelGGL(recurrence_sym_kernel, dim3(n), dim3(256), 0, s, (const float*)(base + oraw), n, rec,
                      (float*)(base + omax));
-  hipLaunchKernelGGL(lower_median_kernel, dim3(1), dim3(256), 0, s, (const float*)(base + omax), n, (float*)(base + obw));
+  hipLaunchKernelGGL(lower_median_kernel, dim3(1), dim3(256), 0, s, (const float*)(base + omax), n, 1, (float*)(base + obw));
   const long n2 = (long)n * n;
   hipLaunchKernelGGL(recurrence_affinity_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, rec, n2,
                      (const float*)(base + obw));
