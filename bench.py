@@ -201,6 +201,10 @@ def measured_traffic(kernel_name, batch=None):
 def main():
     a = parse()
     t_start = time.perf_counter()
+    # host side = small tensors (seeds, 512 x 512 matrices, one 3.7 M-sample waveform): torch's intra-op pool sized for
+    # the box's 128+ hardware threads costs more in fork/join than it saves (set-up 0.48 s -> 0.29 s on the GPU box;
+    # with N ranks on one node the ranks would also oversubscribe each other); the CPU-baseline leg sets its own count
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

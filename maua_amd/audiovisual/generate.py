@@ -67,6 +67,7 @@ _FLAGS = [
 
 
 def main(argv=None):
+    torch.set_num_threads(min(torch.get_num_threads(), 8))   # host side = small tensors (see _lib.host_threads)
     parser = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     for name, kw in _FLAGS:
         parser.add_argument(f"--{name}", **kw)

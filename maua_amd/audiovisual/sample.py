@@ -202,6 +202,7 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
 
 
 def main(argv=None):
+    torch.set_num_threads(min(torch.get_num_threads(), 8))   # host side = small tensors (see _lib.host_threads)
     ap = argparse.ArgumentParser(description="argparse shim for the reference's fire.Fire(generate): same names/defaults")
     ap.add_argument("--audio_file", required=True)
     ap.add_argument("--stylegan2_checkpoint", default=None)

@@ -135,18 +135,6 @@ def estimate_tuning(y, sr, n_fft=2048, resolution=0.01, bins_per_octave=12):
 _BASIS_CACHE = {}
 
 
-class _one_host_thread:
-    """The filter banks are dozens of tiny host tensors: with torch's intra-op thread pool every small operator pays a
-    fork/join (measured 0.29 s -> 0.04 s for the seven octaves of one CQT); results are identical."""
-
-    def __enter__(self):
-        self.n = torch.get_num_threads()
-        torch.set_num_threads(1)
-
-    def __exit__(self, *exc):
-        torch.set_num_threads(self.n)
-
-
 def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, sparsity=0.01,
         magnitude=True):
     """constantq.py:13-115 (vqt with gamma = 0) -> |CQT| [n_bins, frames] on the device (``magnitude=False``: complex)."""
@@ -175,7 +163,7 @@ def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning
         key = (float(my_sr), float(fmin_t * 2.0 ** -i), n_filters, bins_per_octave, filter_scale, sparsity, lo, hi, i,
                float(fmin), n_bins, str(dev))
         if key not in _BASIS_CACHE:
-            with _one_host_thread():
+            with L.host_threads(1):   # dozens of tiny host tensors (0.29 s -> 0.04 s for the seven octaves of one CQT)
                 basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity)
                 if n_fft > 2048:
                     raise NotImplementedError(f"cqt: the filters need a {n_fft}-point FFT at sr={sr}; the HIP FFT stops at 2048")

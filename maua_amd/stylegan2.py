@@ -79,6 +79,7 @@ def parse_seeds(seeds):
     return out
 
 
+@L.host_threads(1)
 def get_z_latents(seeds, z_dim=512):
     """wrappers/stylegan.py:58-69: float64 [P, z_dim] from numpy's MT19937 (host)."""
     return torch.cat([torch.from_numpy(np.random.RandomState(s).randn(1, z_dim)) for s in parse_seeds(seeds)])
@@ -316,6 +317,7 @@ class MappingNetwork(torch.nn.Module):
     the library's own `maua_matmul_nt` (initialising a BLAS library for it would cost the clip 0.5 s); in-tree semantics
     incl. the x @ w quirk."""
 
+    @L.host_threads(1)
     def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, lr_multiplier=0.01, nv_compat=False,
                  generator=None):
         super().__init__()
@@ -348,6 +350,7 @@ class MappingNetwork(torch.nn.Module):
             elif strict:
                 raise KeyError(k)
 
+    @L.host_threads(1)
     def forward(self, z, c=None, truncation_psi=1.0, truncation_cutoff=None):
         L.require_device()
         x = L.dev_tensor(z, torch.float32)

@@ -1,5 +1,6 @@
 """Where bench.py's e2e set-up time goes (after the HIP context is up): python scripts/e2e_setup_phases.py"""
-import sys, time, torch
+import os, sys, time, torch
+if os.environ.get("NT"): torch.set_num_threads(int(os.environ["NT"]))
 sys.path.insert(0, ".")
 torch.cuda.init(); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
 t = [time.perf_counter()]
