@@ -16,18 +16,24 @@ def load_audio(audio_file, offset=0, duration=-1, cache=True):
     return audio, sr, len(audio) / sr
 
 
-def onsets(audio, sr, type="rosa", prepercussive=4, hop_length=512):
-    """audioreactive/mir.py:16-61, type="rosa": ``rosa.effects.percussive(audio, margin)`` then
-    ``rosa.onset.onset_strength(y, sr)`` then ``percentile_clip(95)`` at librosa's own framing (n_fft 2048, hop 512, 128
-    mels up to sr / 2, lag 1, centre compensation) - librosa is un-vendored, its published algorithm is what the HIP
-    kernels implement (HPSS medians / soft masks / mel / dB / rectified difference; parity unpinned).  Pass
-    ``hop_length=1024`` for the hop-aligned framing of the selfsupervised features.  type="mm" needs madmom's filterbank
-    and five spectral-flux variants (un-vendored) and is rejected."""
-    if type != "rosa":
-        raise NotImplementedError('onsets(type="mm") needs madmom, which the reference does not vendor; use type="rosa"')
+def onsets(audio, sr, type="mm", prepercussive=4, hop_length=512):
+    """audioreactive/mir.py:16-61 -> onset envelope, hop 512.  Both back ends of the reference are un-vendored; their
+    published algorithms are what the device code implements (parity unpinned):
+    type="mm" (the reference's default): madmom's framed STFT -> 24-bands-per-octave filterbank -> mean of five
+    normalised onset detection functions (maua_amd/mmonsets.py);
+    type="rosa": ``rosa.onset.onset_strength(y, sr)`` at librosa's own framing (n_fft 2048, hop 512, 128 mels up to
+    sr / 2, lag 1, centre compensation).  Pass ``hop_length=1024`` for the hop-aligned framing of the selfsupervised
+    features (type="rosa" only).  Before either: ``percussive(audio, margin=prepercussive)``; after: percentile_clip(95)."""
     a = torch.as_tensor(audio)
     if prepercussive:
         a = percussive(a, margin=float(prepercussive), hop_length=hop_length)
+    if type == "mm":
+        if hop_length != 512:
+            raise NotImplementedError('onsets(type="mm") runs at madmom\'s framing of the reference (hop 512)')
+        from ..mmonsets import mm_onset_envelope
+        return percentile_clip(mm_onset_envelope(a, sr), 95).squeeze()
+    if type != "rosa":
+        raise ValueError(f"unknown onset type {type!r}")
     return percentile_clip(onset_strength(a, sr, hop_length=hop_length, fmax=sr / 2), 95).squeeze()
 
 

@@ -343,9 +343,45 @@ def test_classic_onsets_at_librosa_framing(clip):
         want = OA.classic_onsets(clip, sr, 4, hop)
         assert got.shape == want.shape == (len(clip) // hop,)
         assert float((got - want).abs().max()) <= 2e-3, hop   # values in [0, 1]; dB of near-silent bins amplifies 1e-6
-    assert ar.onsets(clip, sr, prepercussive=0).shape == (len(clip) // 512,)
-    with pytest.raises(NotImplementedError):
-        ar.onsets(clip, sr, type="mm")
+    assert ar.onsets(clip, sr, type="rosa", prepercussive=0).shape == (len(clip) // 512,)
+    with pytest.raises(ValueError):
+        ar.onsets(clip, sr, type="other")
+
+
+def test_classic_onsets_madmom_chain(clip):
+    """A16, type="mm" (the reference's default): the five onset detection functions on madmom's framed STFT / log filterbank
+    against oracle/mmonsets.py (numpy / scipy restatement of the published chain; madmom un-vendored: unpinned), and what
+    they must do on a click train: every function peaks on the clicks."""
+    from maua_amd import mmonsets as MM
+    from maua_amd.audiovisual import audioreactive as ar
+    from oracle import mmonsets as OM
+    sr = 30720
+    fb, lo, hi = MM.log_filterbank(sr)
+    ofb, corners = OM.log_filterbank(sr)
+    assert np.array_equal(fb, ofb) and list(zip(lo, hi)) == corners
+    assert fb.shape[0] == 1024 and 120 < fb.shape[1] < 220 and np.allclose(fb.sum(0), 1.0, atol=1e-6)
+    y = clip[: 30 * 1024 + 300]                              # a ragged length: ceil(len / hop) frames
+    got = MM.onset_functions(y, sr)
+    want = OM.onset_functions(y.numpy(), sr)
+    for name in want:
+        g, w = got[name].cpu().double().numpy(), want[name]
+        assert g.shape == w.shape == (int(np.ceil(len(y) / 512)),)
+        assert np.abs(g - w).max() <= 2e-3 * np.abs(w).max() + 1e-6, name
+    env = ar.onsets(y, sr, type="mm", prepercussive=0).cpu().numpy()
+    from oracle.signal import percentile_clip
+    wenv = percentile_clip(torch.from_numpy(OM.mm_onset_envelope(y.numpy(), sr)).float(), 95).squeeze().numpy()
+    assert env.shape == wenv.shape and np.abs(env - wenv).max() <= 5e-3
+    # clicks every 4096 samples = every 8 frames, on a quiet noise floor
+    g = torch.Generator().manual_seed(2)
+    z = 1e-3 * torch.randn(40 * 512, generator=g)
+    z[2048::4096] += 1.0
+    f = MM.onset_functions(z, sr)
+    for name, v in f.items():
+        v = v.cpu().numpy()
+        peaks = np.argsort(v)[-5:]
+        # (frame 8 k + 4 is centred on a click; the ratio-based function fires when the click enters the window, a frame early)
+        assert all(int(p) % 8 in (3, 4, 5) for p in peaks) and len({int(p) // 8 for p in peaks}) == 5, (name, sorted(peaks))
+    assert ar.onsets(clip, sr, prepercussive=4).shape == (int(np.ceil(len(clip) / 512)),)   # default type = "mm"
 
 
 def test_sinc_resample_and_load_audio(tmp_path):

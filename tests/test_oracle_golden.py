@@ -508,3 +508,25 @@ def test_segment_oracle_recovers_sections_and_beats():
     # sections with the same template share a label, different templates differ (k = 4 over 3 templates)
     assert lab[mids[0]] == lab[mids[2]] and lab[mids[1]] == lab[mids[4]]
     assert len({int(lab[mids[0]]), int(lab[mids[1]]), int(lab[mids[3]])}) == 3
+
+
+def test_mm_onset_oracle_properties():
+    """oracle/mmonsets.py (madmom's published onset chain; un-vendored -> parity unpinned) does what the chain must: unit-sum
+    triangular filters on strictly increasing bins, frame count ceil(len / hop), silence -> zeros, every detection function
+    peaks on the frames of a click train, the envelope lies in [0, 1]."""
+    from oracle import mmonsets as OM
+    fb, corners = OM.log_filterbank(30720)
+    assert fb.shape[0] == 1024 and np.allclose(fb.sum(0), 1.0, atol=1e-6) and (fb >= 0).all()
+    centres = fb.argmax(0)
+    assert np.all(np.diff(centres) > 0) and all(lo <= c <= hi for c, (lo, hi) in zip(centres, corners))
+    f0 = OM.onset_functions(np.zeros(3000, dtype=np.float32), 30720)
+    assert all(v.shape == (6,) and not v.any() for v in f0.values())
+    g = torch.Generator().manual_seed(2)
+    z = 1e-3 * torch.randn(40 * 512, generator=g)
+    z[2048::4096] += 1.0
+    f = OM.onset_functions(z.numpy(), 30720)
+    for name, v in f.items():
+        peaks = np.argsort(v)[-5:]
+        assert all(int(p) % 8 in (3, 4, 5) for p in peaks) and len({int(p) // 8 for p in peaks}) == 5, name
+    env = OM.mm_onset_envelope(z.numpy(), 30720)
+    assert env.shape == (40,) and env.min() >= 0 and env.max() <= 1
