@@ -61,6 +61,9 @@ def onset_functions(audio, sr, frame_size=2048, hop=512, num_bands=24):
     """-> dict of the five onset detection functions, float32 [n_frames] on the device, n_frames = ceil(len / hop)."""
     y = A._f32(audio).reshape(-1)
     n = int(math.ceil(y.numel() / float(hop)))
+    if n == 0:
+        z = torch.zeros(0, dtype=torch.float32, device=y.device)
+        return {k: z.clone() for k in ("spectral_diff", "spectral_flux", "superflux", "complex_flux", "modified_kullback_leibler")}
     half = frame_size // 2
     if half % hop:
         raise NotImplementedError("half a frame must be a whole number of hops")
@@ -107,4 +110,6 @@ def onset_functions(audio, sr, frame_size=2048, hop=512, num_bands=24):
 def mm_onset_envelope(audio, sr):
     """mir.py:48-56: mean of the five functions, each divided by its maximum (percentile_clip(95) is the caller's)."""
     f = onset_functions(audio, sr)
+    if next(iter(f.values())).numel() == 0:
+        return next(iter(f.values()))
     return torch.stack([v / v.max() for v in f.values()]).mean(0)

@@ -382,6 +382,9 @@ def test_classic_onsets_madmom_chain(clip):
         # (frame 8 k + 4 is centred on a click; the ratio-based function fires when the click enters the window, a frame early)
         assert all(int(p) % 8 in (3, 4, 5) for p in peaks) and len({int(p) // 8 for p in peaks}) == 5, (name, sorted(peaks))
     assert ar.onsets(clip, sr, prepercussive=4).shape == (int(np.ceil(len(clip) / 512)),)   # default type = "mm"
+    assert all(v.numel() == 0 for v in MM.onset_functions(torch.zeros(0), sr).values())      # empty clip -> empty envelope
+    one = MM.onset_functions(torch.ones(1), sr)                                              # a single sample -> one frame
+    assert all(v.shape == (1,) and bool(torch.isfinite(v).all()) for v in one.values())
 
 
 def test_sinc_resample_and_load_audio(tmp_path):
