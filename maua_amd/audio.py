@@ -136,12 +136,14 @@ def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, dtype=torch.float
     return (weights * enorm[:, None]).to(dtype)
 
 
-def melspectrogram(y, sr, n_fft=2048, hop_length=1024, power=2.0, fmax=None, **_):
+def melspectrogram(y, sr, n_fft=2048, hop_length=1024, power=2.0, fmax=None, keep_last=False, **_):
+    """spectral.py:65-70 (drops the last STFT column like the in-tree spectrogram, :59-62); ``keep_last``: librosa's
+    own framing (1 + len // hop frames), what the classic mir.onsets(type="rosa") sees."""
     if power != 2.0:
         raise NotImplementedError("power must be 2 (the onset path)")
     D = stft(y, n_fft, hop_length)
     buf = _frame_major(D)
-    T = buf.shape[0] - 1
+    T = buf.shape[0] - (0 if keep_last else 1)
     basis = _f32(mel(sr, n_fft, fmax=fmax))
     out = torch.empty((basis.shape[0], T), dtype=torch.float32, device=buf.device)
     L.check(L.lib().maua_mel_power(L.ctx(buf.device), L.ptr(buf), T, L.ptr(basis), basis.shape[0], L.ptr(out)))
@@ -158,12 +160,12 @@ def power_to_db(magnitude, ref_value=1.0, amin=1e-10, top_db=80.0):
     return log_spec
 
 
-def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None, fmax=11025.0):
+def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None, fmax=11025.0, keep_last=False):
     """beat.py:10-23 -> [T] on device.  ``aggregate``: None / torch.mean, or "median" (what plp passes, beat.py:44).
     ``fmax``: the in-tree function fixes 11 025 Hz; librosa's own default (the classic mir.onsets) is sr / 2."""
     if n_fft != N_FFT:
         raise NotImplementedError("onset_strength: n_fft must be 2048 (the mel kernel's bin count)")
-    S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=fmax)
+    S = melspectrogram(y, sr, n_fft=n_fft, hop_length=hop_length, fmax=fmax, keep_last=keep_last)
     n_mels, T = S.shape
     env = torch.empty((T,), dtype=torch.float32, device=S.device)
     pad_width = 1 + n_fft // (2 * hop_length)

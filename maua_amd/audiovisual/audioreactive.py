@@ -23,10 +23,13 @@ def onsets(audio, sr, type="mm", prepercussive=4, hop_length=512):
     normalised onset detection functions (maua_amd/mmonsets.py);
     type="rosa": ``rosa.onset.onset_strength(y, sr)`` at librosa's own framing (n_fft 2048, hop 512, 128 mels up to
     sr / 2, lag 1, centre compensation).  Pass ``hop_length=1024`` for the hop-aligned framing of the selfsupervised
-    features (type="rosa" only).  Before either: ``percussive(audio, margin=prepercussive)``; after: percentile_clip(95)."""
+    features (type="rosa" only).  Before either: ``percussive(audio, sr)`` at its default margin of 8 whenever
+    ``prepercussive`` is truthy (the reference uses the argument only as a flag, mir.py:29-30, audio.py:91-93); after:
+    percentile_clip(95).  type="rosa" keeps librosa's frame count (1 + len // hop; the in-tree spectrogram's dropped
+    last column, spectral.py:59-62, is not on this path)."""
     a = torch.as_tensor(audio)
     if prepercussive:
-        a = percussive(a, margin=float(prepercussive), hop_length=hop_length)
+        a = percussive(a, margin=8.0, hop_length=hop_length)
     if type == "mm":
         if hop_length != 512:
             raise NotImplementedError('onsets(type="mm") runs at madmom\'s framing of the reference (hop 512)')
@@ -34,7 +37,7 @@ def onsets(audio, sr, type="mm", prepercussive=4, hop_length=512):
         return percentile_clip(mm_onset_envelope(a, sr), 95).squeeze()
     if type != "rosa":
         raise ValueError(f"unknown onset type {type!r}")
-    return percentile_clip(onset_strength(a, sr, hop_length=hop_length, fmax=sr / 2), 95).squeeze()
+    return percentile_clip(onset_strength(a, sr, hop_length=hop_length, fmax=sr / 2, keep_last=True), 95).squeeze()
 
 
 def rms(audio, sr):

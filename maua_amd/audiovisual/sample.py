@@ -51,12 +51,13 @@ def retrieve_music_information(audio, sr, ks=(2, 4, 6, 8, 12, 16), device="cuda"
     n_sync = len(beats) + 1
     ks = [k for k in ks if k <= n_sync] if n_sync > 7 else []
     segmentations = {}
-    for name, feature in raw.items():
-        for k, s in zip(ks, SG.laplacian_segmentation(feature, beats, ks=ks)):
-            segmentations[(name, k)] = s.argmax(1)
-    n_frames = raw[AFEATFNS[0].__name__].shape[0]
-    for k, seg in zip(ks, SG.laplacian_segmentation_rosa(audio, sr, n_frames, ks=ks, beats=beats).unbind(1)):
-        segmentations[("rosa", k)] = seg
+    if ks:  # (both calls raise on an empty k list / on <= 7 beat-synchronous frames)
+        for name, feature in raw.items():
+            for k, s in zip(ks, SG.laplacian_segmentation(feature, beats, ks=ks)):
+                segmentations[(name, k)] = s.argmax(1)
+        n_frames = raw[AFEATFNS[0].__name__].shape[0]
+        for k, seg in zip(ks, SG.laplacian_segmentation_rosa(audio, sr, n_frames, ks=ks, beats=beats).unbind(1)):
+            segmentations[("rosa", k)] = seg
     feats = {k: A.normalize(A.salience_weighted(A.gaussian_filter(v, sigma=2))) for k, v in raw.items()}
     return feats, segmentations, tempo
 

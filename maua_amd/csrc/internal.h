@@ -87,10 +87,6 @@ struct HiresArgs {
 };
 bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W);
 int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);
-// modconv_cwalk.hip: the 64 -> 64 channel conv1 (+ toRGB + skip) as a row walk (weights in registers, every input row staged
-// once, one LDS fragment per three MFMAs)
-bool cwalk_supported(int dtype, int Ci, int Co, int up, int H, int W);
-int launch_conv_walk(hipStream_t stream, const HiresArgs& a);
 // modconv_upwalk.hip: the 64 -> 32 channel up-layer in half-folded form (horizontal FIR in the weights, vertical FIR on
 // the accumulators of a row walk); a.w = weights from launch_prep_upwalk_weights ([3][2][3][Co][Ci] bf16)
 bool upwalk_supported(int dtype, int Ci, int Co, int up, int H, int W);

@@ -141,6 +141,11 @@ int maua_rrdb_create(maua_ctx* ctx, int num_feat, int num_block, int num_grow_ch
   MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_rrdb_create: dtype must be MAUA_F32 or MAUA_BF16");
   MAUA_REQUIRE(num_feat % 32 == 0 && num_grow_ch % 32 == 0 && num_feat > 0 && num_grow_ch > 0 && num_block > 0,
                "maua_rrdb_create: num_feat / num_grow_ch must be positive multiples of 32");
+  // a dense-block convolution reads whole 64-channel K chunks of the block's buffer (zero weights beyond its own Ci):
+  // every padded prefix must stay inside the num_feat + 4 * grow channels of a pixel
+  for (int k = 0; k < 5; k++)
+    MAUA_REQUIRE((num_feat + k * num_grow_ch + 63) / 64 * 64 <= num_feat + 4 * num_grow_ch || dtype != MAUA_BF16,
+                 "maua_rrdb_create: num_feat + k * num_grow_ch padded to 64 exceeds the dense-block width (use 64 / 32)");
   maua_rrdbnet* n = new maua_rrdbnet();
   n->ctx = ctx; n->num_feat = num_feat; n->num_block = num_block; n->grow = num_grow_ch; n->dtype = dtype;
   n->esize = dtype == MAUA_BF16 ? 2 : 4;

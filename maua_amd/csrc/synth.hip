@@ -67,8 +67,6 @@ struct maua_synth {
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
   int upwalk = 2;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
                        // 2: the last block as one fused walk when nothing else reads its features
-  int cwalk = 0;       // 1: the 64 -> 64 channel conv1 (512^2 block) as a row walk (modconv_cwalk.hip) instead of the tiled
-                       // kernel - measured equal (0.80 vs 0.79 ms at B = 32), kept as an option
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
@@ -433,10 +431,6 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->upwalk = value;
     return MAUA_OK;
   }
-  if (!strcmp(key, "cwalk")) {
-    n->cwalk = value;
-    return MAUA_OK;
-  }
   if (!strcmp(key, "tconv_up")) {
     n->tconv_up = value;
     return MAUA_OK;
@@ -713,8 +707,6 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           }
           if (!fused_walk)
             if (int rc = launch_upwalk(st, a)) return rc;
-        } else if (n->cwalk && !a.rgb8_out && cwalk_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
-          if (int rc = launch_conv_walk(st, a)) return rc;
         } else if (int rc = launch_modconv_hires(st, a)) {
           return rc;
         }

@@ -139,6 +139,15 @@ def latent_patch(rng, latents, palette, segmentations, features, tempo, fps, pat
     """selfsupervised/latent.py:16-80"""
     feature = seq_feat_weight * features[seq_feat]
     permutation = torch.randperm(len(palette), generator=rng, device=rng.device).to(palette.device)
+    if patch_type == "segmentation" and (seq_feat, segments) not in segmentations:
+        # a saved patch asks for a cut this clip has no segmentation for (short clips drop the k they cannot be cut
+        # into, sample.retrieve_music_information): the nearest available k of the same feature, else the
+        # segmentation-free "feature" form - the reference raises KeyError here
+        have = sorted(k for (name, k) in segmentations if name == seq_feat)
+        if have:
+            segments = min(have, key=lambda k: (abs(k - segments), k))
+        else:
+            patch_type = "feature"
     if patch_type == "segmentation":
         segmentation = segmentations[(seq_feat, segments)]
         selection = permutation[:segments]

@@ -90,7 +90,7 @@ class SynthesisNetwork(torch.nn.Module):
     or torch.float32 (exact-f32 MFMA, parity mode)."""
 
     def __init__(self, w_dim, img_resolution, img_channels=3, channel_base=32768, channel_max=512, num_fp16_res=0,
-                 dtype=torch.bfloat16, nv_compat=False, generator=None, **block_kwargs):
+                 dtype=torch.bfloat16, nv_compat=False, generator=None, _params=None, **block_kwargs):
         super().__init__()
         if img_channels != 3:
             raise NotImplementedError("img_channels must be 3")
@@ -103,7 +103,9 @@ class SynthesisNetwork(torch.nn.Module):
         self.num_ws = 2 * len(self.block_resolutions)
         self.num_layers = 2 * len(self.block_resolutions) - 1
         self.dtype, self.nv_compat = dtype, bool(nv_compat)
-        self._params = init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max, generator)
+        # (_params: clone() hands over an existing parameter dict - no random init, the RNG is not touched)
+        self._params = dict(_params) if _params is not None else \
+            init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max, generator)
         self._net = None  # device handle, created on first use
         self._net_device = None
         self._keep_features = False
@@ -156,7 +158,10 @@ class SynthesisNetwork(torch.nn.Module):
         except Exception:
             pass
 
-    def _handle(self):
+    def _handle(self, upload_noise=True):
+        """The device object (built on first use).  ``upload_noise=False``: set_resize builds the object and then does
+        the one noise upload itself with the caller's generator (a draw here would come from the global RNG and be
+        cached, so the caller's seed would never be used)."""
         L.require_device()
         dev = torch.cuda.current_device()
         if self._net is None or self._net_device != dev:
@@ -173,7 +178,8 @@ class SynthesisNetwork(torch.nn.Module):
             self._net, self._net_device = net, dev
             if self._resize is not None:
                 self._apply_resize()
-                self._upload_noise(None)
+                if upload_noise:
+                    self._upload_noise(None)  # (rebuilt object: the resized buffers already exist in _resized_noise)
         else:
             L.ctx(dev)  # re-bind torch's current stream
         return self._net
@@ -201,10 +207,10 @@ class SynthesisNetwork(torch.nn.Module):
                             value=float(pad_value), fill=fn)
         if self._net is not None or torch.cuda.is_available():
             if self._net is None:
-                self._handle()  # builds the object, applies the resize and uploads what noise there is
+                self._handle(upload_noise=False)  # builds the object and applies the resize
             else:
                 self._apply_resize()
-            self._upload_noise(noise_generator)
+            self._upload_noise(noise_generator)  # the single upload: fresh buffers come from the caller's generator
 
     def _upload_noise(self, noise_generator):
         """After every maua_synth_set_resize: (re-)upload the noise buffer of every layer - the network's own
@@ -227,10 +233,8 @@ class SynthesisNetwork(torch.nn.Module):
     def clone(self):
         """An independent network with the same parameters (own device object, own resize state): what every wrapper
         built from one cached checkpoint gets."""
-        other = SynthesisNetwork(self.w_dim, self.img_resolution, self.img_channels, self.channel_base, self.channel_max,
-                                 dtype=self.dtype, nv_compat=self.nv_compat)
-        other._params = dict(self._params)
-        return other
+        return SynthesisNetwork(self.w_dim, self.img_resolution, self.img_channels, self.channel_base, self.channel_max,
+                                dtype=self.dtype, nv_compat=self.nv_compat, _params=self._params)
 
     def _apply_resize(self):
         r = self._resize

@@ -61,9 +61,10 @@ def istft(spec, n_fft=N_FFT, hop=HOP, length=None):
     return y
 
 
-def spectrogram(y, power=1, hop=HOP):
-    """spectral.py:59-62 — drops the LAST stft column."""
-    return stft(y, hop=hop)[:, :-1].abs() ** power
+def spectrogram(y, power=1, hop=HOP, keep_last=False):
+    """spectral.py:59-62 — drops the LAST stft column (keep_last: librosa's own frame count, the classic onsets)."""
+    D = stft(y, hop=hop)
+    return (D if keep_last else D[:, :-1]).abs() ** power
 
 
 def hz_to_mel(f):
@@ -119,9 +120,9 @@ def mel_basis(sr, n_fft=N_FFT, n_mels=128, fmin=0.0, fmax=None):
     return w * enorm[:, None]
 
 
-def melspectrogram(y, sr, power=2.0, fmax=None, hop=HOP):
+def melspectrogram(y, sr, power=2.0, fmax=None, hop=HOP, keep_last=False):
     """spectral.py:65-70."""
-    return mel_basis(sr, fmax=fmax) @ spectrogram(y, power=power, hop=hop)
+    return mel_basis(sr, fmax=fmax) @ spectrogram(y, power=power, hop=hop, keep_last=keep_last)
 
 
 def power_to_db(S, amin=1e-10, top_db=80.0):
@@ -131,10 +132,10 @@ def power_to_db(S, amin=1e-10, top_db=80.0):
     return torch.maximum(log_spec, log_spec.max() - top_db)
 
 
-def onset_strength(y, sr, n_fft=N_FFT, hop=HOP, aggregate="mean", fmax=11025.0):
+def onset_strength(y, sr, n_fft=N_FFT, hop=HOP, aggregate="mean", fmax=11025.0, keep_last=False):
     """beat.py:10-23 — mean (or, for plp :44, torch.median = lower middle) over mels of the rectified lag-1 dB
     difference, left-padded by 1 + n_fft // (2*hop) zeros and cropped to the spectrogram length."""
-    S = power_to_db(melspectrogram(y, sr, fmax=fmax, hop=hop).abs())
+    S = power_to_db(melspectrogram(y, sr, fmax=fmax, hop=hop, keep_last=keep_last).abs())
     d = torch.clamp(S[:, 1:] - S[:, :-1], min=0)
     d = d.mean(0) if aggregate == "mean" else torch.median(d, dim=0).values
     pad_width = 1 + n_fft // (2 * hop)
@@ -186,8 +187,8 @@ def classic_onsets(audio, sr, prepercussive=4, hop=512):
     """audioreactive/mir.py:16-61 with type="rosa": librosa's percussive separation and onset_strength (un-vendored;
     published algorithm, librosa's default framing n_fft 2048 / hop 512 / fmax sr/2), then percentile_clip(95)."""
     from .signal import percentile_clip
-    a = percussive(audio, float(prepercussive), hop) if prepercussive else audio
-    return percentile_clip(onset_strength(a, sr, hop=hop, fmax=sr / 2), 95).squeeze()
+    a = percussive(audio, 8.0, hop) if prepercussive else audio  # mir.py:29-30: a flag; audio.py:91 margin=8
+    return percentile_clip(onset_strength(a, sr, hop=hop, fmax=sr / 2, keep_last=True), 95).squeeze()
 
 
 def normalize(x):

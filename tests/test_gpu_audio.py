@@ -341,9 +341,11 @@ def test_classic_onsets_at_librosa_framing(clip):
     for hop in (512, 1024):
         got = ar.onsets(clip, sr, type="rosa", prepercussive=4, hop_length=hop).cpu()
         want = OA.classic_onsets(clip, sr, 4, hop)
-        assert got.shape == want.shape == (len(clip) // hop,)
+        assert got.shape == want.shape == (1 + len(clip) // hop,)   # librosa's frame count (no dropped last column)
         assert float((got - want).abs().max()) <= 2e-3, hop   # values in [0, 1]; dB of near-silent bins amplifies 1e-6
-    assert ar.onsets(clip, sr, type="rosa", prepercussive=0).shape == (len(clip) // 512,)
+    assert ar.onsets(clip, sr, type="rosa", prepercussive=0).shape == (1 + len(clip) // 512,)
+    # prepercussive is a flag (mir.py:29-30): any truthy value separates at percussive()'s default margin of 8
+    assert torch.equal(ar.onsets(clip, sr, type="rosa", prepercussive=1).cpu(), ar.onsets(clip, sr, type="rosa", prepercussive=4).cpu())
     with pytest.raises(ValueError):
         ar.onsets(clip, sr, type="other")
 

@@ -180,6 +180,28 @@ def test_resize_state_survives_repeats_and_is_per_instance(tmp_path):
     assert rel(s1.forward(ws16).cpu(), OS.synthesis_network(s1.G_synth.state_dict(), ws16)) <= 2e-4
 
 
+def test_resized_render_is_reproducible_from_the_seed():
+    """(advisor, round 2) the resized layers' noise buffers come from the wrapper's own generator on the FIRST resize
+    of a fresh network too: two synthesizers built from the same seed at a non-native size render identical frames
+    whatever the global RNG holds, and the clone of a network does not draw from any RNG."""
+    from maua_amd.stylegan2 import StyleGAN2Synthesizer
+    frames, noises = [], []
+    for other_seed in (123, 456):
+        torch.manual_seed(other_seed)  # the global RNG differs between the two constructions
+        gen = torch.Generator().manual_seed(7)
+        syn = StyleGAN2Synthesizer(None, False, (96, 40), "stretch", 2, img_resolution=64, dtype=torch.float32, generator=gen)
+        ws = torch.randn(2, syn.num_ws, 512, generator=torch.Generator().manual_seed(9))
+        frames.append(syn.forward(ws).cpu())
+        noises.append({k: v.clone() for k, v in syn.G_synth._resized_noise.items()})
+    assert noises[0].keys() == noises[1].keys() and len(noises[0]) > 0
+    for k in noises[0]:
+        assert torch.equal(noises[0][k], noises[1][k]), k
+    assert torch.equal(frames[0], frames[1])
+    state = torch.get_rng_state()
+    c = syn.G_synth.clone()
+    assert torch.equal(torch.get_rng_state(), state) and c._params.keys() == syn.G_synth._params.keys()
+
+
 def test_resample_matches_reference(golden):
     """lanczos pre-filter + bicubic(align_corners=True) (maua/ops/image.py:214-240) vs the reference's outputs (g17)."""
     from maua_amd import ops

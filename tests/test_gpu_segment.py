@@ -105,3 +105,36 @@ def test_retrieve_music_information_returns_segmentations_and_patch_uses_them():
     palette = torch.randn(20, 18, 512, generator=torch.Generator().manual_seed(0)).cuda()
     lat, noise = patch.forward(palette, downscale_factor=16)
     assert tuple(lat.shape) == (n_frames, 18, 512) and bool(torch.isfinite(lat).all())
+
+
+def test_short_clips_skip_segmentations_and_saved_patches_fall_back(monkeypatch):
+    """(advisor, round 2) a clip with <= 7 beat-synchronous frames gets no segmentations (and does not call the
+    segmentation code, which raises on it); a clip with few beats drops the k it cannot be cut into, and a saved patch
+    that asks for a dropped k renders with the nearest available one (or the "feature" form when there is none)."""
+    from maua_amd import segment as SG
+    from maua_amd.audiovisual import sample as S
+    from maua_amd.pipeline import synthetic_audio
+    n_frames, fps = 352, 30
+    wav = synthetic_audio(n_frames * 1024, 1024 * fps, seed=5)
+    palette = torch.randn(20, 18, 512, generator=torch.Generator().manual_seed(0)).cuda()
+    sub = dict(patch_type="segmentation", segments=16, loop_bars=4, seq_feat="chromagram", seq_feat_weight=1,
+               mod_feat="rms", mod_feat_weight=1, merge_type="average", merge_depth="all")
+    # (a) three beats: nothing to segment
+    monkeypatch.setattr(SG, "beat_track", lambda env, tempo: [60, 150, 260])
+    feats, segs, tempo = S.retrieve_music_information(wav, 1024 * fps)
+    assert segs == {} and set(feats) == set(S.ALLFEATS)
+    patch = S.Patch(feats, segs, tempo, fps=fps, seed=3)
+    assert patch.ks == [] and all(p["patch_type"] in ("feature", "loop") for p in patch.latent_patches)
+    patch.latent_patches = [dict(sub)]  # what Patch.load of a JSON written for a longer clip installs
+    lat, _ = patch.forward(palette, downscale_factor=16)
+    assert tuple(lat.shape) == (n_frames, 18, 512) and bool(torch.isfinite(lat).all())
+    # (b) nine beats: k <= 10 only; segments=16 falls back to k=8 (the nearest; 12 was dropped too)
+    monkeypatch.setattr(SG, "beat_track", lambda env, tempo: list(range(30, 330, 34))[:9])
+    feats, segs, tempo = S.retrieve_music_information(wav, 1024 * fps)
+    assert {k for (_, k) in segs} == {2, 4, 6, 8}
+    patch = S.Patch(feats, segs, tempo, fps=fps, seed=3)
+    patch.latent_patches = [dict(sub)]
+    a, _ = patch.forward(palette, downscale_factor=16)
+    patch.latent_patches = [dict(sub, segments=8)]
+    b, _ = patch.forward(palette, downscale_factor=16)
+    assert torch.equal(a, b)

@@ -439,49 +439,3 @@ def test_upwalk_block_walks_on_a_resized_non_square_grid(target):
     for mode in (0, 1, 2):
         assert psnr(imgs[mode], ref) >= 50.0, (mode, psnr(imgs[mode], ref))
     net.set_resize(None)
-
-
-def test_conv_walk_kernel_matches_tiled_kernel_and_oracle():
-    """modconv_cwalk.hip (the 64 -> 64 channel conv1 as a row walk, + toRGB + skip) against the tiled register-stationary
-    kernel it replaces and against the oracle: every 64-channel conv1 from 8^2 (one partial strip) to 512^2 (four strips,
-    row segments), with noise, biases and the skip image; with the toRGB fused and unfused; features stored or not."""
-    from maua_amd import _lib as L
-    from maua_amd.stylegan2 import SynthesisNetwork
-    g = torch.Generator().manual_seed(14)
-    net = SynthesisNetwork(64, 512, 3, channel_base=32768, channel_max=64, dtype=torch.bfloat16, generator=g)
-    p = net.state_dict()
-    g2 = torch.Generator().manual_seed(15)
-    for k in p:
-        if k.endswith(".bias") and "affine" not in k:
-            p[k] = torch.randn(p[k].shape, generator=g2) * 0.1
-    net.load_state_dict(p)
-    B = 3
-    ws = torch.randn(B, net.num_ws, 64, generator=g)
-    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
-    h = net._handle()
-    net.keep_features(True)
-    L.check(L.lib().maua_synth_set_option(h, b"cwalk", 1))   # (an option: the tiled kernel is the default, DESIGN 4.3c)
-    img_w = net(ws, noise=noise).cpu()
-    feats_w = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
-    L.check(L.lib().maua_synth_set_option(h, b"cwalk", 0))
-    img_t = net(ws, noise=noise).cpu()
-    feats_t = [net.get_feature(l, B).cpu() for l in range(net.num_layers)]
-    rng = float(img_t.max() - img_t.min())
-    for l, (a, b) in enumerate(zip(feats_w, feats_t)):
-        err = float((a - b).abs().max()) / float(b.abs().max())
-        assert err <= 2e-2, f"layer {l}: walk vs tiled {err}"      # bf16 features, different summation order
-    assert psnr(img_w, img_t) >= 60.0 and float((img_w - img_t).abs().max()) <= 2e-3 * rng
-    ref = OS.synthesis_network(p, ws, noise=noise)
-    assert psnr(img_w, ref) >= 40.0 and psnr(img_w, ref) >= psnr(img_t, ref) - 1.0
-    # toRGB unfused (the walk stores only features), and features not kept (same images)
-    L.check(L.lib().maua_synth_set_option(h, b"cwalk", 1))
-    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 0))
-    img_nf = net(ws, noise=noise).cpu()
-    assert float((img_nf - img_w).abs().max()) <= 1e-4 * rng
-    L.check(L.lib().maua_synth_set_option(h, b"fuse_torgb", 1))
-    net.keep_features(False)
-    img_nk = net(ws, noise=noise).cpu()
-    assert torch.equal(img_nk, img_w)
-    # frames do not depend on their position in the batch (items are dealt across workgroups by sample)
-    one = net(ws[1:2], noise=[n[1:2] for n in noise]).cpu()
-    assert torch.equal(one[0], img_w[1])
