@@ -40,6 +40,7 @@ enum maua_pad_mode { MAUA_PAD_CIRCULAR = 0, MAUA_PAD_REFLECT = 1, MAUA_PAD_REPLI
 typedef struct maua_ctx maua_ctx;
 typedef struct maua_synth maua_synth;
 typedef struct maua_rrdbnet maua_rrdbnet;
+typedef struct maua_unet maua_unet;
 
 /* ---- context (library plumbing: no reference counterpart — the reference relies on torch's current device and
  * stream; a maua_ctx carries exactly that: device ordinal, HIP stream, a scratch arena) --------------------------- */
@@ -338,6 +339,60 @@ int maua_rrdb_load(maua_rrdbnet* net, const char* name, const float* host_data, 
 /* img: device f32 [B][3][H][W] in [0,1].  out_nchw: device f32 [B][3][4H][4W] clamped to [0,1] (or NULL);
  * out_rgb8: device u8 [B][4H][4W][3] = round(clamp * 255) (or NULL). */
 int maua_rrdb_forward(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, float* out_nchw, uint8_t* out_rgb8);
+
+/* ---- N4 (second half): guided-diffusion UNet + DDIM, BASELINE configs[3] "guided-diffusion 256x256, 100-step DDIM" ------
+ * replaces the network maua/diffusion/processors/guided.py:164-209 create_models builds (guided_diffusion.script_util.
+ * create_model_and_diffusion: UNetModel with num_channels 256, num_res_blocks 2, attention_resolutions "32, 16, 8",
+ * num_head_channels 64, learn_sigma, resblock_updown, use_scale_shift_norm) and, with maua_ddim_step, the
+ * diffusion.ddim_sample(model, x, t, cond_fn=...) call that guided.py:277-339 GuidedDiffusion.forward loops over.  The
+ * guided_diffusion submodule is EMPTY in the reference checkout: the published architecture / sampler are restated, parity
+ * unpinned.  channel_mult: n_mult multipliers of model_channels per level; attention_ds: the down-sampling rates
+ * (image_size // resolution) at which blocks carry attention; only the flag set of guided.py:171-190 is implemented
+ * (use_scale_shift_norm, resblock_updown, legacy attention order, no class conditioning). */
+int maua_unet_create(maua_ctx* ctx, int image_size, int in_channels, int model_channels, int out_channels, int num_res_blocks,
+                     const float* channel_mult, int n_mult, const int* attention_ds, int n_attn, int num_head_channels,
+                     int dtype, maua_unet** out);
+void maua_unet_destroy(maua_unet* net);
+/* number of named parameters the network expects (every key of UNetModel.state_dict() + "timestep_embedding.freqs") */
+int maua_unet_param_count(maua_unet* net, long* count);
+/* name: a key of guided_diffusion's UNetModel.state_dict() (input_blocks.4.0.in_layers.2.weight, middle_block.1.qkv.weight,
+ * out.2.bias, time_embed.0.weight, ...), f32 on the host: 3x3 weights [Co][Ci][3][3], 1x1 weights [N][K][1(,1)], linear
+ * weights [N][K], GroupNorm scale / shift [C].  Optional "timestep_embedding.freqs" [model_channels / 2]: the float32
+ * frequency table of nn.py timestep_embedding as the host computes it (otherwise computed on the device). */
+int maua_unet_load(maua_unet* net, const char* name, const float* host_data, size_t count);
+/* "route": 0 per-shape routing of the 3x3 convolutions (default), 1 generic kernel only, 2 no split-K gather GEMM */
+int maua_unet_set_option(maua_unet* net, const char* key, int value);
+/* UNetModel.forward(x, timesteps): x device f32 [B][in_channels][H][W], timesteps device f32 [B] (the value the wrapped
+ * model of respace.py passes: original timestep index, rescaled to 0..1000), out device f32 [B][out_channels][H][W].
+ * H, W: multiples of 2^(levels - 1). */
+int maua_unet_forward(maua_unet* net, const float* x, const float* timesteps, int B, int H, int W, float* out);
+/* gaussian_diffusion.py ddim_sample for an epsilon model, clip_denoised False (guided.py:303-306): x [B][C][HW], model_out
+ * [B][Cm][HW] (first C channels = eps), cond_grad = cond_fn(x, t) [B][C][HW] or NULL (condition_score), noise or NULL
+ * (eta 0), coef device f32 [B][8] = {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, sqrt(1 - alphas_cumprod),
+ * sqrt(alphas_cumprod_prev), sqrt(1 - alphas_cumprod_prev - sigma^2), sigma * (t != 0), 0, 0} at each sample's t.
+ * sample (may alias x) and pred_xstart (or NULL): [B][C][HW]. */
+int maua_ddim_step(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* noise,
+                   const float* coef, int B, int C, int Cm, long HW, float* sample, float* pred_xstart);
+/* out[b] = ab[b][0] * x[b] + ab[b][1] * y[b] over rows of `row` floats: q_sample (guided.py:331, gaussian_diffusion.py) */
+int maua_axpby_rows(maua_ctx* ctx, const float* x, const float* y, const float* ab, int B, long row, float* out);
+/* 1 when the last maua_ddim_sample_loop(use_graph = 1) replayed a captured hipGraph, 0 when it ran launch by launch */
+int maua_unet_graph_active(maua_unet* net, int* active);
+/* operator-level forms of the UNet's building blocks, NHWC tensors in `dtype` (guided_diffusion/unet.py, nn.py):
+ * QKVAttentionLegacy.forward - qkv [B][T][3 * heads * head_ch] with channel = head * 3 ch + {q | k | v} * ch + c (what
+ * `qkv.reshape(bs * n_heads, ch * 3, length).split(ch, dim=1)` sees) -> out [B][T][heads * head_ch]; head_ch 32 or 64 */
+int maua_attention_legacy(maua_ctx* ctx, const void* qkv, void* out, int B, int T, int heads, int head_ch, int dtype);
+/* conv_nd(1, K, N, 1) / a linear layer over rows (AttentionBlock.qkv / proj_out + residual, ResBlock.skip_connection):
+ * c[M][N] = a[M][K] x w[N][K]^T + bias[N] (+ res[M][N]); K % 32 (bf16) / 16 (f32) == 0, N % 32 == 0 */
+int maua_linear_nt(maua_ctx* ctx, const void* a, const void* w, const float* bias, const void* res, void* c, long M, int N,
+                   int K, int dtype);
+/* GroupNorm32(32, C)(x) [* (1 + scale) + shift with scale_shift [B][2C] (ResBlock use_scale_shift_norm)] [-> SiLU];
+ * statistics in float64, eps 1e-5.  x, y [B][H][W][C] */
+int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* scale_shift,
+                         int silu, int B, int H, int W, int C, int dtype, void* y);
+/* the unconditioned sampling loop of guided.py:333-337 inside the library: n_steps x (forward + DDIM update) on x in place;
+ * model_t host f32 [n_steps], coef host f32 [n_steps][8]; use_graph: capture the loop in one hipGraph and replay it. */
+int maua_ddim_sample_loop(maua_unet* net, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,
+                          int use_graph, float* pred_xstart);
 
 /* ---- multi-GPU: the one exchange step of the frame-sharded render ------------------------------------
  * One process per GPU; frames are sharded by contiguous range (no data-path collective).  maua_gather_frames moves every

@@ -61,6 +61,12 @@ bool lowres_supported(int dtype, int Ci, int Co, int up, int H, int W);
 void lowres_workspace(int dtype, int B, int H, int W, int Ci, int Co, int up, size_t* xm_bytes, size_t* ws_bytes);
 int launch_modconv_lowres(hipStream_t stream, int dtype, const ConvArgs& a, void* xm, float* ws);
 
+// ... the same gather GEMM for plain 3x3 convolutions (a.s == NULL, dense input) on grids of <= 1024 pixels; honours
+// bias / act / gain / res / y_pstride / y_coff.  ws: gather_conv_workspace() bytes.
+bool gather_conv_supported(int dtype, int Ci, int Co, int H, int W);
+size_t gather_conv_workspace(int dtype, int B, int H, int W, int Ci, int Co);
+int launch_conv_gather(hipStream_t stream, int dtype, const ConvArgs& a, float* ws);
+
 // high-resolution specialisation (modconv_hires.hip): weights stationary in registers, persistent tile walk,
 // optional fused toRGB + skip on conv1 layers
 struct HiresArgs {
@@ -179,5 +185,35 @@ struct RgbArgs {
   float fir[16];      // 4x4 filter incl. gain 4 (upsample2d, ops.py:117-133)
 };
 int launch_torgb(hipStream_t stream, int dtype, const RgbArgs& a);
+
+// ---- gemm.hip: C[M][N] = A[M][K] x W[N][K]^T (+ bias[N]) (+ res[M][N]); A's columns may come from two tensors (K0 from
+// a0, K1 from a1: a channel concatenation that is never materialised).  T = network dtype; K0, K1 multiples of 64 bytes,
+// N % 32 == 0.  The 1x1 convolutions of the diffusion UNet (NHWC rows = pixels).
+struct GemmArgs {
+  const void* a0; long lda0; int K0;
+  const void* a1; long lda1; int K1;
+  const void* w;        // T [N][K0 + K1]
+  const float* bias;    // [N] or NULL
+  const void* res;      // T [M][ldr] or NULL
+  long ldr;
+  void* c;              // T [M][ldc] (f32 when c_f32)
+  long ldc;
+  long M;
+  int N;
+  int c_f32;
+};
+int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g);
+
+// ---- attention.hip: softmax(Q K^T / sqrt(D)) V per (sample, head); qkv [B][T][ld_qkv] with head-major [q | k | v] channel
+// layout (guided-diffusion's QKVAttentionLegacy), out [B][T][ld_out] with channel = head * D + d
+struct AttnArgs {
+  const void* qkv;
+  void* out;
+  int B, T, heads, D;
+  long ld_qkv, ld_out;
+  float scale;          // 1 / sqrt(D)
+};
+bool attention_supported(int head_ch);
+int launch_attention(hipStream_t stream, int dtype, const AttnArgs& a);
 
 }  // namespace maua

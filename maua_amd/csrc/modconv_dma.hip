@@ -459,7 +459,7 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
     MAUA_REQUIRE(!a.rgb_out && !a.out_scale, "modconv_dma: the narrow tiles carry no toRGB / style scaling");
     return a.Co == 64 ? launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
   }
-  MAUA_REQUIRE(!a.x_pstride && !a.y_pstride && !a.y_coff && !a.res, "modconv_dma: channel-sliced operands are for the narrow tiles");
+  // (channel-sliced operands and the residual are honoured by every tile shape: the kernel's address arithmetic is shared)
   // 256-channel N tile: 128-byte K rows, one tap per stage, 149 KB of LDS, one workgroup per CU.
   // 128-channel N tile: 64-byte K rows, two taps per stage, 75 KB -> two workgroups per CU (measured on the 256^2 layer,
   // K = 1152: 0.90 -> 0.65 ms against the same tile with 128-byte rows and one workgroup per CU; for the 256-channel

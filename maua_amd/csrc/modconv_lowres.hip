@@ -203,14 +203,20 @@ __global__ __launch_bounds__(256) void lowres_epilogue_kernel(ConvArgs a, const 
       v[k] = t;
     }
   }
-  T* dst = reinterpret_cast<T*>(a.y) + ((long)b * Ho * Wo + opix) * a.Co + co;
+  if (a.res) {  // residual added after activation / gain / clamp (plain convolutions of the diffusion UNet, unet.hip)
+    const T* rp = reinterpret_cast<const T*>(a.res) + (long)b * a.res_bstride + opix * a.res_pstride + co;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] += Elem<T>::load(rp + k);
+  }
+  const int yps = a.y_pstride ? a.y_pstride : a.Co;
+  T* dst = reinterpret_cast<T*>(a.y) + (long)b * (a.y_bstride ? a.y_bstride : (long)Ho * Wo * yps) + opix * yps + a.y_coff + co;
   if constexpr (sizeof(T) == 2)
     *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
   else
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-LowresGeom lowres_geom(int esize, int B, int H, int W, int Ci, int Co, int up) {
+LowresGeom lowres_geom(int esize, int B, int H, int W, int Ci, int Co, int up, int want_override = 0) {
   LowresGeom g;
   g.M = B * H * W;
   g.CoV = Co * up * up;
@@ -220,7 +226,10 @@ LowresGeom lowres_geom(int esize, int B, int H, int W, int Ci, int Co, int up) {
   // 18 slice-tiles per sample (~600 workgroups at 32 frames, 4-18 stages each); more slices cost more in workspace
   // traffic than they save in chain length.
   const int per_sample = std::max(1, (H * W * (g.CoV / LBN) + LBM - 1) / LBM);  // 64 x 128 tiles one sample fills
-  const int want = std::max(2, 18 / per_sample);  // measured at B = 32: 18 / 4 / 4 / 2 slices for the four layers of the 1024^2 net
+  int want = std::max(2, 18 / per_sample);  // measured at B = 32: 18 / 4 / 4 / 2 slices for the four layers of the 1024^2 net
+  // plain convolutions of a few samples with long K (diffusion UNet at 16^2 / 8^2, 9 * 1024 ... 9 * 2048): aim at ~256
+  // slice-tiles per sample instead, again from the layer shape only
+  if (want_override) want = std::max(1, std::min(g.stages_total, want_override / per_sample));
   g.ksplit = g.stages_total;
   for (int k = want; k <= g.stages_total; k++)
     if (g.stages_total % k == 0) { g.ksplit = k; break; }
@@ -228,14 +237,15 @@ LowresGeom lowres_geom(int esize, int B, int H, int W, int Ci, int Co, int up) {
 }
 
 template <typename T>
-int launch_lowres_t(hipStream_t stream, const ConvArgs& a, void* xm, float* ws) {
-  const LowresGeom g = lowres_geom((int)sizeof(T), a.B, a.H, a.W, a.Ci, a.Co, a.up);
+int launch_lowres_t(hipStream_t stream, const ConvArgs& a, void* xm, float* ws, int want = 0) {
+  const LowresGeom g = lowres_geom((int)sizeof(T), a.B, a.H, a.W, a.Ci, a.Co, a.up, want);
   constexpr int EPC = 16 / (int)sizeof(T);
   const long pieces = (long)g.M * (a.Ci / EPC);
-  hipLaunchKernelGGL(lowres_premod_kernel<T>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const T*>(a.x), a.x_bstride, a.s, reinterpret_cast<T*>(xm), a.B, a.H * a.W, a.Ci);
+  if (a.s)  // (a plain convolution has no styles: the gather reads the dense input itself)
+    hipLaunchKernelGGL(lowres_premod_kernel<T>, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const T*>(a.x), a.x_bstride, a.s, reinterpret_cast<T*>(xm), a.B, a.H * a.W, a.Ci);
   hipLaunchKernelGGL(lowres_conv_kernel<T>, dim3(cdiv(g.M, LBM), g.CoV / LBN, g.ksplit), dim3(256), 0, stream,
-                     reinterpret_cast<const T*>(xm), reinterpret_cast<const T*>(a.w), ws, a.H, a.W, a.Ci, g);
+                     reinterpret_cast<const T*>(a.s ? xm : a.x), reinterpret_cast<const T*>(a.w), ws, a.H, a.W, a.Ci, g);
   const long total = (long)g.M * (g.CoV / 4);
   hipLaunchKernelGGL(lowres_epilogue_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, ws,
                      g.ksplit);
@@ -256,6 +266,28 @@ void lowres_workspace(int dtype, int B, int H, int W, int Ci, int Co, int up, si
   const LowresGeom g = lowres_geom(esize, B, H, W, Ci, Co, up);
   *xm_bytes = (size_t)g.M * Ci * esize;
   *ws_bytes = (size_t)g.ksplit * g.M * g.CoV * sizeof(float);
+}
+
+// The same gather GEMM for PLAIN 3x3 convolutions (no styles, a.s == NULL; dense batch-major input) of any small grid:
+// the 16^2 / 8^2 levels of the diffusion UNet (unet.hip), where a per-sample tiling leaves the chip empty.
+bool gather_conv_supported(int dtype, int Ci, int Co, int H, int W) {
+  if (dtype != MAUA_BF16 && dtype != MAUA_F32) return false;
+  const int esize = dtype == MAUA_BF16 ? 2 : 4;
+  return H * W <= 1024 && Ci % (LKCB / esize) == 0 && Co % LBN == 0;
+}
+constexpr int GATHER_TILES = 256;
+size_t gather_conv_workspace(int dtype, int B, int H, int W, int Ci, int Co) {
+  const LowresGeom g = lowres_geom(dtype == MAUA_BF16 ? 2 : 4, B, H, W, Ci, Co, 1, GATHER_TILES);
+  return (size_t)g.ksplit * g.M * g.CoV * sizeof(float);
+}
+int launch_conv_gather(hipStream_t stream, int dtype, const ConvArgs& a, float* ws) {
+  MAUA_REQUIRE(gather_conv_supported(dtype, a.Ci, a.Co, a.H, a.W) && a.up == 1 && !a.s && !a.d && !a.x_pstride,
+               "conv_gather: unsupported shape / arguments");
+  MAUA_REQUIRE(a.x_bstride == (long)a.H * a.W * a.Ci, "conv_gather: the input must be dense batch-major NHWC");
+  if (a.B == 0) return MAUA_OK;
+  MAUA_REQUIRE((long)a.B * a.H * a.W * std::max(a.Ci, a.Co) < (1L << 31), "conv_gather: 32-bit pixel indices");
+  if (dtype == MAUA_BF16) return launch_lowres_t<bf16_t>(stream, a, nullptr, ws, GATHER_TILES);
+  return launch_lowres_t<float>(stream, a, nullptr, ws, GATHER_TILES);
 }
 
 int launch_modconv_lowres(hipStream_t stream, int dtype, const ConvArgs& a, void* xm, float* ws) {

@@ -1,0 +1,1085 @@
+// Guided-diffusion UNet forward + DDIM step for BASELINE configs[3] ("guided-diffusion 256x256, 100-step DDIM").
+//
+// Replaces (reference): the model maua/diffusion/processors/guided.py:164-209 `create_models` builds (OpenAI
+// guided-diffusion `UNetModel`: num_channels 256, num_res_blocks 2, attention at 32 / 16 / 8 with 64-channel heads,
+// learn_sigma, resblock_updown, use_scale_shift_norm; fp16 there, bf16 operands / f32 accumulate here) and the sampler
+// step `diffusion.ddim_sample(..., cond_fn=...)` that guided.py:277-339 `GuidedDiffusion.forward` loops over.  The network
+// and sampler sources are the git submodule maua/submodules/guided_diffusion - EMPTY in the reference checkout, no pinned
+// revision: the published architecture is restated (oracle/diffusion.py says the same), PARITY UNPINNED.
+//
+//   ResBlock : h = conv(resample(silu(gn(x))));  h = gn(h) * (1 + scale) + shift  [scale | shift = linear(silu(emb))];
+//              out = skip(resample(x)) + conv(silu(h))          resample = avg_pool 2 / nearest x2 / identity
+//   Attention: x + proj(attn(qkv(gn(x))))                        QKVAttentionLegacy, softmax in f32
+//   UNet     : emb = linear(silu(linear(timestep_embedding(t)))); encoder blocks push their outputs, decoder blocks
+//              read cat([h, hs.pop()]); out = conv(silu(gn(h)))
+//
+// MI355X design: activations NHWC in the network dtype (a 1x1 convolution is a plain row-major GEMM, GroupNorm's 32 groups
+// are contiguous channel runs of a pixel); every 3x3 convolution runs on the MFMA implicit-GEMM kernels written for the
+// StyleGAN2 path (LDS-direct-load kernel at >= 32-wide grids, the batch-wide split-K gather GEMM on the 16^2 / 8^2 levels,
+// generic kernel elsewhere) with bias and the block's residual in the epilogue; GroupNorm + scale-shift + SiLU + the
+// block's up / down resampling are ONE pass that writes the convolution's input; the decoder's channel concatenation is
+// never materialised (GroupNorm and the 1x1 skip GEMM read both tensors); all ResBlocks' timestep projections are one
+// batched GEMV at the top of the forward.  A forward is a fixed sequence of launches on one stream over a
+// pre-planned arena (no allocation, no host sync), so maua_ddim_sample_loop can capture the whole sampler in a hipGraph.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "internal.h"
+
+using namespace maua;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ small f32 kernels
+// nn.py timestep_embedding: e[b] = [cos(t_b * f_i) | sin(t_b * f_i)], f_i = exp(-ln(10000) * i / half)
+// (freqs: the host's float32 table when it was uploaded - the frequencies multiply timesteps up to 1000, so one ulp of
+//  difference between two exp implementations would show up as 6e-5 in the embedding)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ e,
+                                          int B, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  const float freq = freqs ? freqs[i] : expf(-logf(10000.0f) * (float)i / (float)half);
+  const float arg = t[b] * freq;
+  e[(long)b * dim + i] = cosf(arg);
+  e[(long)b * dim + half + i] = sinf(arg);
+  if ((dim & 1) && i == 0) e[(long)b * dim + dim - 1] = 0.f;
+}
+
+// y[b][n] = act_out(W[n] . act_in(x[b]) + bias[n]); one wave per output row n (W streamed once, coalesced), all B
+// samples per row (B <= 16 per pass).  act: 0 none, 1 SiLU.  The timestep MLP and every ResBlock's emb_layers (all in
+// f32 like the reference, whose convert_to_fp16 leaves nn.Linear alone).
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int B, int K,
+                                                          int N, int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wr = W + (long)n * K;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float w = wr[k];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (b0 + j < B) {
+          float v = x[(long)(b0 + j) * K + k];
+          if (act_in) v = v / (1.f + expf(-v));
+          acc[j] = fmaf(w, v, acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      float v = acc[j];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && b0 + j < B) {
+        v += bias ? bias[n] : 0.f;
+        if (act_out) v = v / (1.f + expf(-v));
+        y[(long)(b0 + j) * N + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ GroupNorm
+// Statistics in float64 (sum and sum of squares of exactly representable f32 products): no cancellation whatever the
+// mean / spread ratio; fixed summation order (bit-reproducible).  Pass 1: per (sample, pixel chunk, row slot) per-channel
+// partial sums; pass 2: per (sample, group) mean and 1 / sqrt(var + eps).
+template <typename T>
+__global__ void gn_partial_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1, long HW, int ppc,
+                                  double* __restrict__ part) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int C = C0 + C1, PPP = C / EPC;
+  const int pc = threadIdx.x % PPP, ry = threadIdx.x / PPP, RY = blockDim.x / PPP;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  if (ry >= RY) return;
+  const int c = pc * EPC;
+  const T* src;
+  long stride;
+  if (c < C0) { src = x0 + (long)b * HW * C0 + c; stride = C0; }
+  else { src = x1 + (long)b * HW * C1 + (c - C0); stride = C1; }
+  const long p0 = (long)chunk * ppc, p1 = p0 + ppc < HW ? p0 + ppc : HW;
+  double s[EPC], ss[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) s[e] = ss[e] = 0.0;
+  for (long p = p0 + ry; p < p1; p += RY) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * stride);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      float f;
+      if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+      else f = __uint_as_float(v[e]);
+      const double d = (double)f;
+      s[e] += d;
+      ss[e] += d * d;
+    }
+  }
+  double* dst = part + ((((long)b * gridDim.x + chunk) * RY + ry) * C + c) * 2;
+#pragma unroll
+  for (int e = 0; e < EPC; e++) { dst[2 * e] = s[e]; dst[2 * e + 1] = ss[e]; }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int rows, int C, long HW, float eps,
+                                                          float* __restrict__ stats) {
+  __shared__ double red[2][256];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / 32;
+  const long n = (long)rows * cpg;
+  double s = 0.0, ss = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const long row = i / cpg;
+    const int c = g * cpg + (int)(i - row * cpg);
+    const double* p = part + (((long)b * rows + row) * C + c) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + o];
+      red[1][threadIdx.x] += red[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)HW * cpg;
+    const double mean = red[0][0] / cnt;
+    double var = red[1][0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)b * 32 + g) * 2] = (float)mean;
+    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// y = [silu]( gn(x) [* (1 + scale) + shift] ), optionally resampled (mode 1: 2x2 average of the activated values - the
+// ResBlock's Downsample sits BEHIND norm + SiLU; mode 2: nearest x2), written dense NHWC as the next convolution's input.
+// xr (optional, modes 1 / 2): the same resampling of the raw input (the block's x_upd, its residual branch).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ ss, long ss_ld,
+                                                       int silu, int mode, T* __restrict__ y, T* __restrict__ xr, int B, int H,
+                                                       int W) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int C = C0 + C1, PPP = C / EPC, cpg = C / 32;
+  const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * PPP) return;
+  const int pc = (int)(idx % PPP);
+  long p = idx / PPP;
+  const int ox = (int)(p % Wo); p /= Wo;
+  const int oy = (int)(p % Ho);
+  const int b = (int)(p / Ho);
+  const int c = pc * EPC;
+  const T* src;
+  long stride;
+  if (c < C0) { src = x0 + (long)b * H * W * C0 + c; stride = C0; }
+  else { src = x1 + (long)b * H * W * C1 + (c - C0); stride = C1; }
+  float ca[EPC], cb[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) {
+    const int g = (c + e) / cpg;
+    const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
+    ca[e] = rstd * gamma[c + e];
+    cb[e] = beta[c + e] - mean * ca[e];
+    sc[e] = ss ? 1.f + ss[(long)b * ss_ld + c + e] : 1.f;
+    sh[e] = ss ? ss[(long)b * ss_ld + C + c + e] : 0.f;
+  }
+  float acc[EPC], raw[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) acc[e] = raw[e] = 0.f;
+  const int taps = mode == 1 ? 4 : 1;
+  for (int t = 0; t < taps; t++) {
+    int iy, ix;
+    if (mode == 1) { iy = 2 * oy + (t >> 1); ix = 2 * ox + (t & 1); }
+    else if (mode == 2) { iy = oy >> 1; ix = ox >> 1; }
+    else { iy = oy; ix = ox; }
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + ((long)iy * W + ix) * stride);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      float f;
+      if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+      else f = __uint_as_float(v[e]);
+      raw[e] += f;
+      float u = fmaf(f, ca[e], cb[e]);
+      if (ss) u = fmaf(u, sc[e], sh[e]);
+      if (silu) u = u / (1.f + expf(-u));
+      acc[e] += u;
+    }
+  }
+  const float norm = mode == 1 ? 0.25f : 1.f;
+  u32x4 o, ro;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      o[k] = pack2bf(acc[2 * k] * norm, acc[2 * k + 1] * norm);
+      ro[k] = pack2bf(raw[2 * k] * norm, raw[2 * k + 1] * norm);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o[k] = __float_as_uint(acc[k] * norm); ro[k] = __float_as_uint(raw[k] * norm); }
+  }
+  const long opix = ((long)b * Ho + oy) * Wo + ox;
+  *reinterpret_cast<u32x4*>(y + opix * C + c) = o;
+  if (xr) *reinterpret_cast<u32x4*>(xr + opix * C + c) = ro;
+}
+
+// ------------------------------------------------------------------------------------------------------ DDIM step
+// gaussian_diffusion.py ddim_sample for an epsilon-predicting model (clip_denoised False), in the reference's float32
+// operation order; coefficients per sample: cf[b] = {sqrt_recip_ac, sqrt_recipm1_ac, sqrt(1 - ac), sqrt(ac_prev),
+// sqrt(1 - ac_prev - sigma^2), sigma * nonzero_mask, 0, 0}.  model_out [B][Cm][HW] (eps = first C channels), x [B][C][HW].
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ model_out,
+                                                        const float* __restrict__ grad, const float* __restrict__ noise,
+                                                        const float* __restrict__ cf, int C, int Cm, long HW, long total,
+                                                        float* __restrict__ sample, float* __restrict__ pred_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long chw = (long)C * HW;
+  const int b = (int)(idx / chw);
+  const long rem = idx - (long)b * chw;
+  const float* k = cf + b * 8;
+  const float xv = x[idx];
+  const float eps_m = model_out[(long)b * Cm * HW + rem];
+  float pred = k[0] * xv - k[1] * eps_m;           // _predict_xstart_from_eps
+  if (grad) {                                      // condition_score
+    float eps = (k[0] * xv - pred) / k[1];
+    eps = eps - k[2] * grad[idx];
+    pred = k[0] * xv - k[1] * eps;
+  }
+  const float eps = (k[0] * xv - pred) / k[1];     // _predict_eps_from_xstart
+  float s = pred * k[3] + k[4] * eps;
+  if (noise) s += k[5] * noise[idx];
+  sample[idx] = s;
+  if (pred_out) pred_out[idx] = pred;
+}
+
+// out = a[b] * x + c[b] * y (q_sample: sqrt(ac) * x_start + sqrt(1 - ac) * noise), per-sample coefficients
+__global__ __launch_bounds__(256) void axpby_rows_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ ab, long row, long total,
+                                                         float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / row);
+  out[idx] = ab[2 * b] * x[idx] + ab[2 * b + 1] * y[idx];
+}
+
+// ----------------------------------------------------------------------------------------------------- parameters
+struct UGN { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
+struct UConv { int Ci = 0, Co = 0, Cip = 0, Cop = 0; void* wt = nullptr; float* bias = nullptr; };
+struct ULin { int K = 0, N = 0; void* w = nullptr; float* bias = nullptr; };
+struct URes { int Cin, Cout, updown; UGN n1; UConv c1; int emb_off; UGN n2; UConv c2; bool skip; ULin sk; };
+struct UAttn { int C, heads; UGN n; ULin qkv, proj; };
+struct ULayer { int kind; int idx; };  // 0 conv_in, 1 res, 2 attn
+struct UBlock { std::vector<ULayer> layers; int out_ch = 0; };
+
+enum PKind { P_GN_G, P_GN_B, P_CONV_W, P_CONV_B, P_LIN_W, P_LIN_B, P_F32 };
+struct PRef { PKind kind; void* obj; float* f32 = nullptr; size_t count = 0; };
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, top = 0, peak = 0;
+  bool plan = true;
+  void* get(size_t bytes) {
+    const size_t o = (top + 255) & ~(size_t)255;
+    top = o + bytes;
+    if (top > peak) peak = top;
+    return plan ? (void*)(uintptr_t)(o + 256) : (void*)(base + o);  // (planning: a non-NULL token, never dereferenced)
+  }
+};
+
+}  // namespace
+
+struct maua_unet {
+  maua_ctx* ctx;
+  int image_size, in_ch, mc, out_ch, nrb, head_ch, dtype;
+  size_t esize;
+  std::vector<float> mult;
+  std::vector<int> attn_ds;
+  int emb_dim;
+  UConv conv_in, conv_out;
+  UGN out_norm;
+  std::vector<URes> res;
+  std::vector<UAttn> attn;
+  std::vector<UBlock> input, output;
+  UBlock middle;
+  int final_ch = 0;
+  // f32 timestep path: time_embed.{0,2}, all emb_layers stacked [emb_total][emb_dim]
+  float *te0_w = nullptr, *te0_b = nullptr, *te2_w = nullptr, *te2_b = nullptr, *embw = nullptr, *embb = nullptr;
+  float* freqs = nullptr;  // [mc / 2] timestep-embedding frequencies (optional upload: "timestep_embedding.freqs")
+  int freqs_loaded = 0;
+  int emb_total = 0;
+  std::unordered_map<std::string, PRef> params;
+  std::vector<void*> owned;
+  float* ones = nullptr;
+  int ones_b = 0, max_ch = 0;
+  Arena arena;
+  size_t planned_key = 0;  // B, H, W the arena was planned for
+  size_t gather_bytes = 0; // split-K workspace of the gather GEMM at that shape
+  size_t out_cap = 0;      // bytes behind g_out + g_pred
+  int route = 0;           // debugging / ablation: 1 = every 3x3 convolution on the generic kernel
+  // sampler graph (maua_ddim_sample_loop)
+  hipGraphExec_t graph_exec = nullptr;
+  size_t graph_key = 0;
+  hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy NULL stream)
+  int graph_failed = 0;              // capture / instantiation failed once: the loop runs eagerly from then on
+  float *g_x = nullptr, *g_out = nullptr, *g_pred = nullptr, *g_t = nullptr, *g_cf = nullptr;
+  int g_steps = 0;
+};
+
+namespace {
+
+template <typename P>
+int dev_alloc(maua_unet* n, P** p, size_t bytes, bool zero = true) {
+  MAUA_HIP_CHECK(hipMalloc((void**)p, bytes));
+  if (zero) MAUA_HIP_CHECK(hipMemset(*p, 0, bytes));
+  n->owned.push_back(*p);
+  return MAUA_OK;
+}
+
+int make_gn(maua_unet* n, UGN& g, int C, const std::string& name) {
+  g.C = C;
+  if (int rc = dev_alloc(n, &g.gamma, (size_t)C * 4)) return rc;
+  if (int rc = dev_alloc(n, &g.beta, (size_t)C * 4)) return rc;
+  n->params[name + ".weight"] = PRef{P_GN_G, &g};
+  n->params[name + ".bias"] = PRef{P_GN_B, &g};
+  return MAUA_OK;
+}
+int make_conv(maua_unet* n, UConv& c, int Ci, int Co, const std::string& name) {
+  c.Ci = Ci; c.Co = Co; c.Cip = (Ci + 31) / 32 * 32; c.Cop = (Co + 31) / 32 * 32;
+  if (int rc = dev_alloc(n, &c.wt, (size_t)9 * c.Cop * c.Cip * n->esize)) return rc;
+  if (int rc = dev_alloc(n, &c.bias, (size_t)c.Cop * 4)) return rc;
+  n->params[name + ".weight"] = PRef{P_CONV_W, &c};
+  n->params[name + ".bias"] = PRef{P_CONV_B, &c};
+  return MAUA_OK;
+}
+int make_lin(maua_unet* n, ULin& l, int K, int N, const std::string& name) {
+  l.K = K; l.N = N;
+  if (int rc = dev_alloc(n, &l.w, (size_t)N * K * n->esize)) return rc;
+  if (int rc = dev_alloc(n, &l.bias, (size_t)N * 4)) return rc;
+  n->params[name + ".weight"] = PRef{P_LIN_W, &l};
+  n->params[name + ".bias"] = PRef{P_LIN_B, &l};
+  return MAUA_OK;
+}
+
+// UNetModel.__init__: the module tree (same walk as oracle/diffusion.py unet_structure and maua_amd/diffusion.py)
+int build_structure(maua_unet* n) {
+  const int mc = n->mc;
+  int ch = (int)(n->mult[0] * mc);
+  int rc;
+  if ((rc = make_conv(n, n->conv_in, n->in_ch, ch, "input_blocks.0.0"))) return rc;
+  std::vector<int> chans{ch};
+  {
+    UBlock b;
+    b.layers.push_back({0, 0});
+    b.out_ch = ch;
+    n->input.push_back(b);
+  }
+  // (vectors of parameter structs are referenced by pointer from the name table: reserve so they never move)
+  const size_t nlev = n->mult.size();
+  n->res.reserve(nlev * (2 * n->nrb + 3) + 4);
+  n->attn.reserve(nlev * (2 * n->nrb + 1) + 2);
+  auto is_attn = [&](int ds) {
+    for (int a : n->attn_ds)
+      if (a == ds) return true;
+    return false;
+  };
+  auto add_res = [&](UBlock& b, const std::string& name, int cin, int cout, int updown) -> int {
+    n->res.emplace_back();
+    URes& r = n->res.back();
+    r.Cin = cin; r.Cout = cout; r.updown = updown; r.skip = cin != cout;
+    int rc2;
+    if ((rc2 = make_gn(n, r.n1, cin, name + ".in_layers.0"))) return rc2;
+    if ((rc2 = make_conv(n, r.c1, cin, cout, name + ".in_layers.2"))) return rc2;
+    r.emb_off = n->emb_total;
+    n->emb_total += 2 * cout;
+    n->params[name + ".emb_layers.1.weight"] = PRef{P_F32, &r, nullptr, (size_t)2 * cout * n->emb_dim};
+    n->params[name + ".emb_layers.1.bias"] = PRef{P_F32, &r, nullptr, (size_t)2 * cout};
+    if ((rc2 = make_gn(n, r.n2, cout, name + ".out_layers.0"))) return rc2;
+    if ((rc2 = make_conv(n, r.c2, cout, cout, name + ".out_layers.3"))) return rc2;
+    if (r.skip && (rc2 = make_lin(n, r.sk, cin, cout, name + ".skip_connection"))) return rc2;
+    b.layers.push_back({1, (int)n->res.size() - 1});
+    b.out_ch = cout;
+    return MAUA_OK;
+  };
+  auto add_attn = [&](UBlock& b, const std::string& name, int c) -> int {
+    n->attn.emplace_back();
+    UAttn& a = n->attn.back();
+    a.C = c; a.heads = c / n->head_ch;
+    int rc2;
+    if ((rc2 = make_gn(n, a.n, c, name + ".norm"))) return rc2;
+    if ((rc2 = make_lin(n, a.qkv, c, 3 * c, name + ".qkv"))) return rc2;
+    if ((rc2 = make_lin(n, a.proj, c, c, name + ".proj_out"))) return rc2;
+    b.layers.push_back({2, (int)n->attn.size() - 1});
+    return MAUA_OK;
+  };
+  int ds = 1, bi = 1;
+  for (size_t level = 0; level < nlev; level++) {
+    for (int i = 0; i < n->nrb; i++) {
+      UBlock b;
+      const std::string pfx = "input_blocks." + std::to_string(bi);
+      const int co = (int)(n->mult[level] * mc);
+      if ((rc = add_res(b, pfx + ".0", ch, co, 0))) return rc;
+      ch = co;
+      if (is_attn(ds) && (rc = add_attn(b, pfx + ".1", ch))) return rc;
+      n->input.push_back(b);
+      chans.push_back(ch);
+      bi++;
+    }
+    if (level != nlev - 1) {
+      UBlock b;
+      if ((rc = add_res(b, "input_blocks." + std::to_string(bi) + ".0", ch, ch, 1))) return rc;
+      n->input.push_back(b);
+      chans.push_back(ch);
+      ds *= 2;
+      bi++;
+    }
+  }
+  if ((rc = add_res(n->middle, "middle_block.0", ch, ch, 0))) return rc;
+  if ((rc = add_attn(n->middle, "middle_block.1", ch))) return rc;
+  if ((rc = add_res(n->middle, "middle_block.2", ch, ch, 0))) return rc;
+  bi = 0;
+  for (int level = (int)nlev - 1; level >= 0; level--) {
+    for (int i = 0; i <= n->nrb; i++) {
+      UBlock b;
+      const std::string pfx = "output_blocks." + std::to_string(bi);
+      const int ich = chans.back();
+      chans.pop_back();
+      const int co = (int)(mc * n->mult[level]);
+      int li = 0;
+      if ((rc = add_res(b, pfx + "." + std::to_string(li++), ch + ich, co, 0))) return rc;
+      ch = co;
+      if (is_attn(ds) && (rc = add_attn(b, pfx + "." + std::to_string(li++), ch))) return rc;
+      if (level && i == n->nrb) {
+        if ((rc = add_res(b, pfx + "." + std::to_string(li++), ch, ch, 2))) return rc;
+        ds /= 2;
+      }
+      n->output.push_back(b);
+      bi++;
+    }
+  }
+  n->final_ch = ch;
+  if ((rc = make_gn(n, n->out_norm, ch, "out.0"))) return rc;
+  if ((rc = make_conv(n, n->conv_out, ch, n->out_ch, "out.2"))) return rc;
+  // f32 timestep path
+  const int E = n->emb_dim;
+  if ((rc = dev_alloc(n, &n->te0_w, (size_t)E * mc * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->te0_b, (size_t)E * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->te2_w, (size_t)E * E * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->te2_b, (size_t)E * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->embw, (size_t)n->emb_total * E * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->embb, (size_t)n->emb_total * 4))) return rc;
+  if ((rc = dev_alloc(n, &n->freqs, (size_t)(mc / 2) * 4))) return rc;
+  n->params["timestep_embedding.freqs"] = PRef{P_F32, nullptr, n->freqs, (size_t)(mc / 2)};
+  n->params["time_embed.0.weight"] = PRef{P_F32, nullptr, n->te0_w, (size_t)E * mc};
+  n->params["time_embed.0.bias"] = PRef{P_F32, nullptr, n->te0_b, (size_t)E};
+  n->params["time_embed.2.weight"] = PRef{P_F32, nullptr, n->te2_w, (size_t)E * E};
+  n->params["time_embed.2.bias"] = PRef{P_F32, nullptr, n->te2_b, (size_t)E};
+  for (auto& kv : n->params) {
+    if (kv.second.kind != P_F32 || kv.second.f32) continue;
+    const URes* r = (const URes*)kv.second.obj;
+    const bool is_w = kv.first.size() > 7 && kv.first.compare(kv.first.size() - 7, 7, ".weight") == 0;
+    kv.second.f32 = is_w ? n->embw + (size_t)r->emb_off * E : n->embb + r->emb_off;
+  }
+  n->max_ch = 0;
+  for (auto& r : n->res) n->max_ch = std::max(n->max_ch, std::max(r.Cin, r.Cout));
+  n->max_ch = std::max(n->max_ch, 32);
+  return MAUA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------ forward
+template <typename T>
+struct Runner {
+  maua_unet* n;
+  hipStream_t st;
+  int B;
+  bool plan;
+  Arena& ar;
+  float* emb_all = nullptr;  // [B][emb_total]
+  float* gather_ws = nullptr;
+  size_t gather_ws_bytes = 0;
+
+  Runner(maua_unet* n_, hipStream_t s, int B_, bool plan_) : n(n_), st(s), B(B_), plan(plan_), ar(n_->arena) {}
+
+  T* alloc(long px, int C) { return (T*)ar.get((size_t)px * C * sizeof(T)); }
+
+  // y = conv3x3(x) + bias (+ res); x, y, res dense NHWC [B][H][W][.]
+  int conv(const UConv& c, const T* x, T* y, int H, int W, const T* res) {
+    const size_t ws_need = gather_conv_supported(n->dtype, c.Cip, c.Cop, H, W) ? gather_conv_workspace(n->dtype, B, H, W, c.Cip, c.Cop) : 0;
+    if (plan) {
+      if (ws_need > gather_ws_bytes) gather_ws_bytes = ws_need;
+      return MAUA_OK;
+    }
+    ConvArgs a{};
+    a.x = x; a.x_bstride = (long)H * W * c.Cip; a.w = c.wt; a.s = nullptr; a.d = nullptr; a.noise = nullptr; a.bias = c.bias;
+    a.y = y; a.B = B; a.H = H; a.W = W; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
+    a.act = MAUA_ACT_LINEAR; a.alpha = 1.f; a.gain = 1.f; a.clamp = -1.f;
+    a.res = res; a.res_pstride = c.Cop; a.res_bstride = (long)H * W * c.Cop;
+    const bool bf = n->dtype == MAUA_BF16;
+    if (n->route != 1) {
+      const bool dma_wide = bf && dma_conv_supported(n->dtype, c.Cip, c.Cop, 1, H, W);
+      const bool dma_narrow = bf && dma_conv_narrow_supported(n->dtype, c.Cip, c.Cop, H, W);
+      const bool gather = ws_need > 0;
+      // enough workgroups for the chip on the LDS-direct kernel (8 x 32 pixel tiles x N tiles of 256 / 128 / Co channels)?
+      const long tiles = (long)B * (H / 8) * (W / 32);
+      const long dma_wgs = dma_wide ? tiles * (c.Cop % 256 == 0 ? c.Cop / 256 : c.Cop / 128) : tiles;
+      if ((dma_wide || dma_narrow) && (dma_wgs >= 128 || !gather || n->route == 2)) return launch_modconv_dma(st, a);
+      if (gather && n->route != 2) return launch_conv_gather(st, n->dtype, a, gather_ws);
+      if (dma_wide || dma_narrow) return launch_modconv_dma(st, a);
+    }
+    a.s = n->ones;
+    return launch_modconv3x3(st, n->dtype, a);
+  }
+
+  int gn_stats(const T* x0, int C0, const T* x1, int C1, long HW, float* stats) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    const int C = C0 + C1, PPP = C / EPC;
+    MAUA_REQUIRE(PPP <= 1024, "unet: GroupNorm over more than 1024 16-byte pieces per pixel");
+    const int RY = std::max(1, 512 / PPP);
+    long nchunk = HW / ((long)RY * 4);
+    nchunk = std::max(1L, std::min(128L, nchunk));
+    const int ppc = (int)((HW + nchunk - 1) / nchunk);
+    nchunk = (HW + ppc - 1) / ppc;
+    double* part = (double*)ar.get((size_t)B * nchunk * RY * C * 16);
+    if (plan) return MAUA_OK;
+    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, x0, C0, x1, C1, HW, ppc, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
+    MAUA_HIP_CHECK(hipGetLastError());
+    return MAUA_OK;
+  }
+
+  // GroupNorm (+ scale-shift) (+ SiLU) (+ resample) of [x0 | x1] -> y (dense, C0 + C1 channels); xr: resampled raw x0
+  int gn(const UGN& g, const T* x0, int C0, const T* x1, int C1, int H, int W, const float* ss, int silu, int mode, T* y,
+         T* xr) {
+    const size_t mark = ar.top;
+    float* stats = (float*)ar.get((size_t)B * 32 * 2 * 4);
+    int rc = gn_stats(x0, C0, x1, C1, (long)H * W, stats);
+    if (!rc && !plan) {
+      constexpr int EPC = 16 / (int)sizeof(T);
+      const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+      const long total = (long)B * Ho * Wo * ((C0 + C1) / EPC);
+      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x0, C0, x1, C1, stats,
+                         g.gamma, g.beta, ss, (long)n->emb_total, silu, mode, y, xr, B, H, W);
+      MAUA_HIP_CHECK(hipGetLastError());
+    }
+    ar.top = mark;
+    return rc;
+  }
+
+  // ResBlock on [x0 | x1] (H x W) -> out (dense, Cout channels at the resampled size)
+  int resblock(const URes& r, const T* x0, int C0, const T* x1, int C1, int H, int W, T* out) {
+    const size_t mark = ar.top;
+    const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
+    const long opx = (long)B * Ho * Wo;
+    T* a1 = alloc(opx, r.Cin);
+    T* xr = r.updown ? alloc(opx, r.Cin) : nullptr;
+    int rc;
+    if ((rc = gn(r.n1, x0, C0, x1, C1, H, W, nullptr, 1, r.updown, a1, xr))) return rc;
+    T* h1 = alloc(opx, r.Cout);
+    if ((rc = conv(r.c1, a1, h1, Ho, Wo, nullptr))) return rc;
+    T* a2 = alloc(opx, r.Cout);
+    if ((rc = gn(r.n2, h1, r.Cout, nullptr, 0, Ho, Wo, emb_all + r.emb_off, 1, 0, a2, nullptr))) return rc;
+    const T* resid;
+    if (r.skip) {  // 1x1 skip_connection over the (virtually concatenated) input
+      T* sk = alloc(opx, r.Cout);
+      if (!plan) {
+        GemmArgs g{};
+        g.a0 = x0; g.lda0 = C0; g.K0 = C0; g.a1 = x1; g.lda1 = C1; g.K1 = C1; g.w = r.sk.w; g.bias = r.sk.bias;
+        g.c = sk; g.ldc = r.Cout; g.M = opx; g.N = r.Cout;
+        if ((rc = launch_gemm_nt(st, n->dtype, g))) return rc;
+      }
+      resid = sk;
+    } else {
+      resid = r.updown ? xr : x0;  // (Cin == Cout: never a concatenated input)
+    }
+    if ((rc = conv(r.c2, a2, out, Ho, Wo, resid))) return rc;
+    ar.top = mark;
+    return MAUA_OK;
+  }
+
+  // AttentionBlock, in place on x (dense [B][HW][C])
+  int attention(const UAttn& at, T* x, int H, int W, T* out) {
+    const size_t mark = ar.top;
+    const long px = (long)B * H * W;
+    T* a = alloc(px, at.C);
+    int rc;
+    if ((rc = gn(at.n, x, at.C, nullptr, 0, H, W, nullptr, 0, 0, a, nullptr))) return rc;
+    T* qkv = alloc(px, 3 * at.C);
+    T* ao = alloc(px, at.C);
+    if (!plan) {
+      GemmArgs g{};
+      g.a0 = a; g.lda0 = at.C; g.K0 = at.C; g.w = at.qkv.w; g.bias = at.qkv.bias; g.c = qkv; g.ldc = 3 * at.C; g.M = px;
+      g.N = 3 * at.C;
+      if ((rc = launch_gemm_nt(st, n->dtype, g))) return rc;
+      AttnArgs aa{};
+      aa.qkv = qkv; aa.out = ao; aa.B = B; aa.T = H * W; aa.heads = at.heads; aa.D = n->head_ch; aa.ld_qkv = 3 * at.C;
+      aa.ld_out = at.C; aa.scale = 1.f / sqrtf((float)n->head_ch);
+      if ((rc = launch_attention(st, n->dtype, aa))) return rc;
+      GemmArgs p{};
+      p.a0 = ao; p.lda0 = at.C; p.K0 = at.C; p.w = at.proj.w; p.bias = at.proj.bias; p.res = x; p.ldr = at.C; p.c = out;
+      p.ldc = at.C; p.M = px; p.N = at.C;
+      if ((rc = launch_gemm_nt(st, n->dtype, p))) return rc;
+    }
+    ar.top = mark;
+    return MAUA_OK;
+  }
+
+  // one TimestepEmbedSequential: layers applied to [x0 | x1]; returns the block's output tensor (allocated persistently)
+  int block(const UBlock& b, const T* x0, int C0, const T* x1, int C1, int& H, int& W, T** outp) {
+    const T* cur0 = x0; int c0 = C0; const T* cur1 = x1; int c1 = C1;
+    T* out = nullptr;
+    for (const ULayer& l : b.layers) {
+      if (l.kind == 1) {
+        const URes& r = n->res[l.idx];
+        const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
+        out = alloc((long)B * Ho * Wo, r.Cout);
+        if (int rc = resblock(r, cur0, c0, cur1, c1, H, W, out)) return rc;
+        H = Ho; W = Wo;
+        cur0 = out; c0 = r.Cout; cur1 = nullptr; c1 = 0;
+      } else {
+        const UAttn& at = n->attn[l.idx];
+        T* o2 = alloc((long)B * H * W, at.C);
+        if (int rc = attention(at, const_cast<T*>(cur0), H, W, o2)) return rc;
+        out = o2;
+        cur0 = out; c0 = at.C;
+      }
+    }
+    *outp = out;
+    return MAUA_OK;
+  }
+
+  int forward(const float* x_nchw, const float* t, int H, int W, float* out_nchw) {
+    int rc;
+    const int E = n->emb_dim, mc = n->mc;
+    const long px = (long)B * H * W;
+    // ---- timestep path (f32)
+    float* e0 = (float*)ar.get((size_t)B * mc * 4);
+    float* e1 = (float*)ar.get((size_t)B * E * 4);
+    float* e2 = (float*)ar.get((size_t)B * E * 4);
+    emb_all = (float*)ar.get((size_t)B * n->emb_total * 4);
+    if (!plan) {
+      const int half = mc / 2;
+      hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * half + 255) / 256), dim3(256), 0, st, t,
+                         n->freqs_loaded ? n->freqs : nullptr, e0, B, mc);
+      hipLaunchKernelGGL(linear_rows_kernel, dim3((E + 3) / 4), dim3(256), 0, st, e0, n->te0_w, n->te0_b, e1, B, mc, E, 0, 1);
+      hipLaunchKernelGGL(linear_rows_kernel, dim3((E + 3) / 4), dim3(256), 0, st, e1, n->te2_w, n->te2_b, e2, B, E, E, 0, 0);
+      hipLaunchKernelGGL(linear_rows_kernel, dim3((n->emb_total + 3) / 4), dim3(256), 0, st, e2, n->embw, n->embb, emb_all, B,
+                         E, n->emb_total, 1, 0);
+      MAUA_HIP_CHECK(hipGetLastError());
+    }
+    // split-K workspace of the gather GEMM: sized in the planning pass, placed here in the real one
+    gather_ws = (float*)ar.get(plan ? 0 : n_gather_bytes);
+    // ---- input: NCHW f32 -> NHWC T, channels padded to 32
+    T* xin = alloc(px, n->conv_in.Cip);
+    if (!plan && (rc = launch_nchw_to_nhwc<float, T>(st, x_nchw, xin, B, n->in_ch, H * W, n->conv_in.Cip))) return rc;
+    std::vector<T*> hs;
+    std::vector<int> hs_c;
+    T* h = alloc(px, n->conv_in.Cop);
+    if ((rc = conv(n->conv_in, xin, h, H, W, nullptr))) return rc;
+    int ch = n->conv_in.Co, hh = H, ww = W;
+    hs.push_back(h); hs_c.push_back(ch);
+    for (size_t i = 1; i < n->input.size(); i++) {
+      T* o;
+      if ((rc = block(n->input[i], h, ch, nullptr, 0, hh, ww, &o))) return rc;
+      h = o; ch = n->input[i].out_ch;
+      hs.push_back(h); hs_c.push_back(ch);
+    }
+    {
+      T* o;
+      if ((rc = block(n->middle, h, ch, nullptr, 0, hh, ww, &o))) return rc;
+      h = o;
+    }
+    for (size_t i = 0; i < n->output.size(); i++) {
+      T* skip = hs.back(); const int sc = hs_c.back();
+      hs.pop_back(); hs_c.pop_back();
+      T* o;
+      if ((rc = block(n->output[i], h, ch, skip, sc, hh, ww, &o))) return rc;
+      h = o; ch = n->output[i].out_ch;
+    }
+    // ---- out: GroupNorm -> SiLU -> conv -> NCHW f32
+    T* a = alloc(px, ch);
+    if ((rc = gn(n->out_norm, h, ch, nullptr, 0, hh, ww, nullptr, 1, 0, a, nullptr))) return rc;
+    T* y = alloc(px, n->conv_out.Cop);
+    if ((rc = conv(n->conv_out, a, y, hh, ww, nullptr))) return rc;
+    if (!plan && (rc = launch_nhwc_to_nchw<T, float>(st, y, out_nchw, B, n->out_ch, H * W, n->conv_out.Cop))) return rc;
+    return MAUA_OK;
+  }
+
+  size_t n_gather_bytes = 0;
+};
+
+size_t shape_key(int B, int H, int W) { return ((size_t)B << 40) ^ ((size_t)H << 20) ^ (size_t)W; }
+
+template <typename T>
+int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int W, float* out) {
+  hipStream_t st = n->ctx->stream;
+  const size_t key = shape_key(B, H, W);
+  if (key != n->planned_key) {
+    // planning pass: the same walk with a counting arena
+    n->arena.plan = true; n->arena.top = 0; n->arena.peak = 0;
+    Runner<T> pr(n, st, B, true);
+    if (int rc = pr.forward(x, t, H, W, out)) return rc;
+    const size_t need = n->arena.peak + pr.gather_ws_bytes + (1 << 20);
+    if (need > n->arena.cap) {
+      MAUA_HIP_CHECK(hipStreamSynchronize(st));
+      if (n->arena.base) hipFree(n->arena.base);
+      n->arena.base = nullptr; n->arena.cap = 0;
+      MAUA_HIP_CHECK(hipMalloc((void**)&n->arena.base, need));
+      n->arena.cap = need;
+    }
+    n->gather_bytes = pr.gather_ws_bytes;
+    n->planned_key = key;
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+  }
+  if (B > n->ones_b) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<float> h((size_t)B * n->max_ch, 1.f);
+    float* p;
+    MAUA_HIP_CHECK(hipMalloc((void**)&p, h.size() * 4));
+    MAUA_HIP_CHECK(hipMemcpy(p, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    if (n->ones) hipFree(n->ones);
+    n->ones = p; n->ones_b = B;
+  }
+  n->arena.plan = false; n->arena.top = 0;
+  Runner<T> r(n, st, B, false);
+  r.n_gather_bytes = n->gather_bytes;
+  return r.forward(x, t, H, W, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int maua_unet_create(maua_ctx* ctx, int image_size, int in_channels, int model_channels, int out_channels, int num_res_blocks,
+                     const float* channel_mult, int n_mult, const int* attention_ds, int n_attn, int num_head_channels,
+                     int dtype, maua_unet** out) {
+  MAUA_REQUIRE(ctx && out && channel_mult && n_mult > 0 && (attention_ds || n_attn == 0), "maua_unet_create: NULL argument");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_unet_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(in_channels > 0 && in_channels <= 32 && out_channels > 0 && out_channels <= 32,
+               "maua_unet_create: image channels must be 1..32");
+  MAUA_REQUIRE(model_channels > 0 && model_channels % 32 == 0 && num_res_blocks > 0, "maua_unet_create: model_channels % 32");
+  MAUA_REQUIRE(attention_supported(num_head_channels), "maua_unet_create: num_head_channels must be 32 or 64");
+  for (int i = 0; i < n_mult; i++) {
+    const int c = (int)(channel_mult[i] * model_channels);
+    MAUA_REQUIRE(c > 0 && c % 32 == 0, "maua_unet_create: every level's channel count must be a multiple of 32 (GroupNorm32)");
+    MAUA_REQUIRE(c % num_head_channels == 0, "maua_unet_create: channels must divide into heads");
+  }
+  maua_unet* n = new maua_unet();
+  n->ctx = ctx; n->image_size = image_size; n->in_ch = in_channels; n->mc = model_channels; n->out_ch = out_channels;
+  n->nrb = num_res_blocks; n->head_ch = num_head_channels; n->dtype = dtype; n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  n->mult.assign(channel_mult, channel_mult + n_mult);
+  n->attn_ds.assign(attention_ds, attention_ds + n_attn);
+  n->emb_dim = 4 * model_channels;
+  if (const char* e = getenv("MAUA_UNET_ROUTE")) n->route = atoi(e);
+  if (int rc = build_structure(n)) {
+    maua_unet_destroy(n);
+    return rc;
+  }
+  *out = n;
+  return MAUA_OK;
+}
+
+void maua_unet_destroy(maua_unet* n) {
+  if (!n) return;
+  hipStreamSynchronize(n->ctx->stream);
+  if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
+  if (n->cap_stream) hipStreamDestroy(n->cap_stream);
+  for (void* p : n->owned) hipFree(p);
+  if (n->arena.base) hipFree(n->arena.base);
+  if (n->ones) hipFree(n->ones);
+  for (float* p : {n->g_out, n->g_pred, n->g_t, n->g_cf})  // (g_x is the caller's tensor the graph was captured on)
+    if (p) hipFree(p);
+  delete n;
+}
+
+// "route": 0 = per-shape routing of the 3x3 convolutions (LDS-direct kernel / split-K gather GEMM / generic kernel),
+// 1 = every convolution on the generic kernel, 2 = never the gather GEMM (parity tests compare the routes)
+int maua_unet_set_option(maua_unet* n, const char* key, int value) {
+  MAUA_REQUIRE(n && key, "maua_unet_set_option: NULL argument");
+  if (!strcmp(key, "route")) {
+    n->route = value;
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    return MAUA_OK;
+  }
+  return fail(std::string("maua_unet_set_option: unknown option ") + key);
+}
+
+// 1 when the last maua_ddim_sample_loop(use_graph = 1) replayed a captured hipGraph, 0 when it ran eagerly
+int maua_unet_graph_active(maua_unet* n, int* active) {
+  MAUA_REQUIRE(n && active, "maua_unet_graph_active: NULL argument");
+  *active = n->graph_exec && !n->graph_failed ? 1 : 0;
+  return MAUA_OK;
+}
+
+int maua_unet_param_count(maua_unet* n, long* count) {
+  MAUA_REQUIRE(n && count, "maua_unet_param_count: NULL argument");
+  *count = (long)n->params.size();
+  return MAUA_OK;
+}
+
+// name: a key of guided-diffusion's UNetModel state dict; 3x3 conv weights [Co][Ci][3][3], 1x1 (conv1d / conv2d) weights
+// [N][K][1(,1)], linear weights [N][K], GroupNorm weight / bias [C]; f32 on the host.
+int maua_unet_load(maua_unet* n, const char* name, const float* host, size_t count) {
+  MAUA_REQUIRE(n && name && host, "maua_unet_load: NULL argument");
+  auto it = n->params.find(name);
+  if (it == n->params.end()) return fail(std::string("maua_unet_load: unknown parameter name: ") + name);
+  const PRef& p = it->second;
+  hipStream_t st = n->ctx->stream;
+  auto wrong = [&]() { return fail(std::string("maua_unet_load: ") + name + ": wrong size"); };
+  switch (p.kind) {
+    case P_GN_G: case P_GN_B: {
+      UGN* g = (UGN*)p.obj;
+      if (count != (size_t)g->C) return wrong();
+      MAUA_HIP_CHECK(hipMemcpy(p.kind == P_GN_G ? g->gamma : g->beta, host, count * 4, hipMemcpyHostToDevice));
+      return MAUA_OK;
+    }
+    case P_CONV_B: {
+      UConv* c = (UConv*)p.obj;
+      if (count != (size_t)c->Co) return wrong();
+      MAUA_HIP_CHECK(hipMemcpy(c->bias, host, count * 4, hipMemcpyHostToDevice));
+      return MAUA_OK;
+    }
+    case P_LIN_B: {
+      ULin* l = (ULin*)p.obj;
+      if (count != (size_t)l->N) return wrong();
+      MAUA_HIP_CHECK(hipMemcpy(l->bias, host, count * 4, hipMemcpyHostToDevice));
+      return MAUA_OK;
+    }
+    case P_F32: {
+      if (count != p.count) return wrong();
+      MAUA_HIP_CHECK(hipMemcpy(p.f32, host, count * 4, hipMemcpyHostToDevice));
+      if (p.f32 == n->freqs) n->freqs_loaded = 1;
+      return MAUA_OK;
+    }
+    case P_CONV_W: {
+      UConv* c = (UConv*)p.obj;
+      if (count != (size_t)c->Co * c->Ci * 9) return wrong();
+      float* tmp;
+      MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+      MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+      MAUA_HIP_CHECK(hipMemsetAsync(c->wt, 0, (size_t)9 * c->Cop * c->Cip * n->esize, st));
+      int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, nullptr, c->Co, c->Ci, 3, 1, 0, c->Cop, c->Cip);
+      hipStreamSynchronize(st);
+      hipFree(tmp);
+      return rc;
+    }
+    case P_LIN_W: {
+      ULin* l = (ULin*)p.obj;
+      if (count != (size_t)l->N * l->K) return wrong();
+      float* tmp;
+      MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+      MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+      // a k = 1 "convolution": [N][K] rows, converted to the network dtype
+      int rc = launch_prep_weights(st, n->dtype, tmp, l->w, nullptr, l->N, l->K, 1, 1, 0, l->N, l->K);
+      hipStreamSynchronize(st);
+      hipFree(tmp);
+      return rc;
+    }
+  }
+  return MAUA_ERR;
+}
+
+// x: device f32 [B][in_channels][H][W]; timesteps: device f32 [B] (what the wrapped model passes: the ORIGINAL timestep,
+// rescaled to 0..1000); out: device f32 [B][out_channels][H][W].  H, W: multiples of 2^(levels - 1).
+int maua_unet_forward(maua_unet* n, const float* x, const float* timesteps, int B, int H, int W, float* out) {
+  MAUA_REQUIRE(n && x && timesteps && out, "maua_unet_forward: NULL argument");
+  MAUA_REQUIRE(B >= 0 && H > 0 && W > 0, "maua_unet_forward: bad shape");
+  const int down = 1 << (n->mult.size() - 1);
+  MAUA_REQUIRE(H % down == 0 && W % down == 0, "maua_unet_forward: H and W must be multiples of 2^(levels - 1)");
+  if (B == 0) return MAUA_OK;
+  return n->dtype == MAUA_BF16 ? run_forward<bf16_t>(n, x, timesteps, B, H, W, out) : run_forward<float>(n, x, timesteps, B, H, W, out);
+}
+
+// One DDIM update (gaussian_diffusion.py ddim_sample, epsilon model, clip_denoised False).  x [B][C][H][W], model_out
+// [B][Cm][H][W] (Cm >= C: the learned-variance channels are not used by DDIM), cond_grad = cond_fn(x, t) or NULL, noise or
+// NULL (eta = 0), coef: device f32 [B][8] = {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+// sqrt(1 - alphas_cumprod), sqrt(alphas_cumprod_prev), sqrt(1 - alphas_cumprod_prev - sigma^2), sigma * (t != 0), 0, 0}.
+int maua_ddim_step(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* noise,
+                   const float* coef, int B, int C, int Cm, long HW, float* sample, float* pred_xstart) {
+  MAUA_REQUIRE(ctx, "maua_ddim_step: ctx is NULL");
+  if (B == 0 || HW == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && model_out && coef && sample && C > 0 && Cm >= C, "maua_ddim_step: NULL argument");
+  const long total = (long)B * C * HW;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, model_out,
+                     cond_grad, noise, coef, C, Cm, HW, total, sample, pred_xstart);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// out[b] = ab[b][0] * x[b] + ab[b][1] * y[b] over rows of `row` elements (q_sample, gaussian_diffusion.py)
+int maua_axpby_rows(maua_ctx* ctx, const float* x, const float* y, const float* ab, int B, long row, float* out) {
+  MAUA_REQUIRE(ctx, "maua_axpby_rows: ctx is NULL");
+  if (B == 0 || row == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y && ab && out, "maua_axpby_rows: NULL argument");
+  const long total = (long)B * row;
+  hipLaunchKernelGGL(axpby_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, y, ab, row,
+                     total, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// ---- operator-level entry points of the UNet's building blocks (NHWC tensors in the network dtype) --------------------
+// QKVAttentionLegacy.forward: qkv [B][T][3 * heads * head_ch] (channel = head * 3 ch + {q, k, v} * ch + c) -> out [B][T][heads * ch]
+int maua_attention_legacy(maua_ctx* ctx, const void* qkv, void* out, int B, int T, int heads, int head_ch, int dtype) {
+  MAUA_REQUIRE(ctx, "maua_attention_legacy: ctx is NULL");
+  AttnArgs a{};
+  a.qkv = qkv; a.out = out; a.B = B; a.T = T; a.heads = heads; a.D = head_ch; a.ld_qkv = 3L * heads * head_ch;
+  a.ld_out = (long)heads * head_ch; a.scale = 1.f / sqrtf((float)head_ch);
+  return launch_attention(ctx->stream, dtype, a);
+}
+
+// conv_nd(1, K, N, 1) / nn.Linear on rows: c[M][N] = a[M][K] x w[N][K]^T + bias (+ res[M][N]); a, w, res, c in dtype
+int maua_linear_nt(maua_ctx* ctx, const void* a, const void* w, const float* bias, const void* res, void* c, long M, int N,
+                   int K, int dtype) {
+  MAUA_REQUIRE(ctx, "maua_linear_nt: ctx is NULL");
+  GemmArgs g{};
+  g.a0 = a; g.lda0 = K; g.K0 = K; g.w = w; g.bias = bias; g.res = res; g.ldr = N; g.c = c; g.ldc = N; g.M = M; g.N = N;
+  return launch_gemm_nt(ctx->stream, dtype, g);
+}
+
+// GroupNorm32(32, C) (+ optional per-sample scale-shift [B][2C]: y * (1 + scale) + shift) (+ SiLU) on NHWC x -> y
+int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* scale_shift,
+                         int silu, int B, int H, int W, int C, int dtype, void* y) {
+  MAUA_REQUIRE(ctx && x && gamma && beta && y, "maua_group_norm_nhwc: NULL argument");
+  MAUA_REQUIRE(C % 32 == 0 && (dtype == MAUA_F32 || dtype == MAUA_BF16), "maua_group_norm_nhwc: C % 32, f32 / bf16");
+  if (B == 0) return MAUA_OK;
+  const int epc = dtype == MAUA_BF16 ? 8 : 4, PPP = C / epc;
+  MAUA_REQUIRE(PPP <= 1024, "maua_group_norm_nhwc: too many channels");
+  const long HW = (long)H * W;
+  const int RY = std::max(1, 512 / PPP);
+  long nchunk = std::max(1L, std::min(128L, HW / ((long)RY * 4)));
+  const int ppc = (int)((HW + nchunk - 1) / nchunk);
+  nchunk = (HW + ppc - 1) / ppc;
+  const size_t part_bytes = (size_t)B * nchunk * RY * C * 16;
+  if (int rc = scratch_reserve(ctx, part_bytes + (size_t)B * 64 * 4 + 256)) return rc;
+  double* part = (double*)ctx->scratch;
+  float* stats = (float*)((char*)ctx->scratch + ((part_bytes + 255) & ~(size_t)255));
+  hipStream_t st = ctx->stream;
+  const long total = (long)B * HW * PPP;
+  if (dtype == MAUA_BF16) {
+    hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, (const bf16_t*)x, C,
+                       (const bf16_t*)nullptr, 0, HW, ppc, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, C,
+                       (const bf16_t*)nullptr, 0, stats, gamma, beta, scale_shift, 2L * C, silu, 0, (bf16_t*)y,
+                       (bf16_t*)nullptr, B, H, W);
+  } else {
+    hipLaunchKernelGGL(gn_partial_kernel<float>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, (const float*)x, C,
+                       (const float*)nullptr, 0, HW, ppc, part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)x, C,
+                       (const float*)nullptr, 0, stats, gamma, beta, scale_shift, 2L * C, silu, 0, (float*)y,
+                       (float*)nullptr, B, H, W);
+  }
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// The unconditioned sampler loop inside the library: n_steps x (UNet forward + DDIM update), x updated in place.
+// model_t: host f32 [n_steps] (the timestep the network sees at each step, same for every sample); coef: host f32
+// [n_steps][8] (maua_ddim_step's coefficients).  use_graph: capture the whole loop in ONE hipGraph on first use for a
+// (B, H, W, n_steps) and replay it afterwards (a forward is ~400 short launches: the graph removes the launch gaps).
+// pred_xstart (optional) receives the last step's prediction.
+int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,
+                          int use_graph, float* pred_xstart) {
+  MAUA_REQUIRE(n && x && model_t && coef && n_steps > 0, "maua_ddim_sample_loop: NULL argument");
+  if (B == 0) return MAUA_OK;
+  hipStream_t st = n->ctx->stream;
+  const long chw = (long)n->in_ch * H * W;
+  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52);
+  // per-step constants on the device: timesteps [n_steps][B], coefficients [n_steps][B][8]
+  if (n->g_steps < n_steps * B || !n->g_t) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    for (float** p : {&n->g_t, &n->g_cf}) { if (*p) hipFree(*p); *p = nullptr; }
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->g_t, (size_t)n_steps * B * 4));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->g_cf, (size_t)n_steps * B * 8 * 4));
+    n->g_steps = n_steps * B;
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+  }
+  {
+    std::vector<float> ht((size_t)n_steps * B), hc((size_t)n_steps * B * 8);
+    for (int s = 0; s < n_steps; s++)
+      for (int b = 0; b < B; b++) {
+        ht[(size_t)s * B + b] = model_t[s];
+        memcpy(&hc[((size_t)s * B + b) * 8], coef + (size_t)s * 8, 32);
+      }
+    MAUA_HIP_CHECK(hipMemcpyAsync(n->g_t, ht.data(), ht.size() * 4, hipMemcpyHostToDevice, st));
+    MAUA_HIP_CHECK(hipMemcpyAsync(n->g_cf, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st));
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  const size_t out_bytes = (size_t)B * n->out_ch * H * W * 4, pred_bytes = (size_t)B * chw * 4;
+  if (!n->g_out || n->out_cap < out_bytes + pred_bytes) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    for (float** p : {&n->g_out, &n->g_pred}) { if (*p) hipFree(*p); *p = nullptr; }
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->g_out, out_bytes));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->g_pred, pred_bytes));
+    n->out_cap = out_bytes + pred_bytes;
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+  }
+  auto body = [&](int s) -> int {
+    if (int rc = maua_unet_forward(n, x, n->g_t + (size_t)s * B, B, H, W, n->g_out)) return rc;
+    return maua_ddim_step(n->ctx, x, n->g_out, nullptr, nullptr, n->g_cf + (size_t)s * B * 8, B, n->in_ch, n->out_ch,
+                          (long)H * W, x, n->g_pred);
+  };
+  if (use_graph && !n->graph_failed) {
+    if (!n->graph_exec || n->graph_key != key || n->g_x != x) {
+      // one eager forward first: plans the arena, sets the kernels' attributes (nothing of that is capturable)
+      // - on a scratch copy so that x is not advanced
+      if (n->planned_key != shape_key(B, H, W) || B > n->ones_b) {
+        float* tmp;
+        MAUA_HIP_CHECK(hipMalloc((void**)&tmp, pred_bytes));
+        MAUA_HIP_CHECK(hipMemcpyAsync(tmp, x, pred_bytes, hipMemcpyDeviceToDevice, st));
+        int rc = maua_unet_forward(n, tmp, n->g_t, B, H, W, n->g_out);
+        hipStreamSynchronize(st);
+        hipFree(tmp);
+        if (rc) return rc;
+      }
+      if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; }
+      if (!n->cap_stream) MAUA_HIP_CHECK(hipStreamCreateWithFlags(&n->cap_stream, hipStreamNonBlocking));
+      MAUA_HIP_CHECK(hipStreamSynchronize(st));
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(n->cap_stream, hipStreamCaptureModeThreadLocal);
+      int rc = MAUA_OK;
+      if (e == hipSuccess) {
+        n->ctx->stream = n->cap_stream;   // the launchers read the context's stream
+        for (int s = 0; s < n_steps && !rc; s++) rc = body(s);
+        n->ctx->stream = st;
+        e = hipStreamEndCapture(n->cap_stream, &graph);
+      }
+      if (!rc && e == hipSuccess) e = hipGraphInstantiate(&n->graph_exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc || e != hipSuccess) {
+        (void)hipGetLastError();  // clear the sticky error; run eagerly from now on
+        n->graph_exec = nullptr;
+        n->graph_failed = 1;
+        if (getenv("MAUA_VERBOSE"))
+          fprintf(stderr, "[maua] ddim_sample_loop: graph capture unavailable (%s), running eagerly\n",
+                  rc ? maua_last_error() : hipGetErrorString(e));
+      } else {
+        n->graph_key = key;
+        n->g_x = x;
+      }
+    }
+  }
+  if (use_graph && n->graph_exec && !n->graph_failed) {
+    MAUA_HIP_CHECK(hipGraphLaunch(n->graph_exec, st));
+  } else {
+    for (int s = 0; s < n_steps; s++)
+      if (int rc = body(s)) return rc;
+  }
+  if (pred_xstart) MAUA_HIP_CHECK(hipMemcpyAsync(pred_xstart, n->g_pred, pred_bytes, hipMemcpyDeviceToDevice, st));
+  return MAUA_OK;
+}
+
+}  // extern "C"

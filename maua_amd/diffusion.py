@@ -1,0 +1,580 @@
+"""Guided diffusion on the HIP device (BASELINE configs[3]: "guided-diffusion 256x256, 100-step DDIM,
+audio-onset-switched prompts").
+
+Drop-in surface (same names, arguments and defaults):
+  * ``create_models`` / ``GradientGuidedConditioning`` / ``GuidedDiffusion``  <- maua/diffusion/processors/guided.py:164-339
+  * ``UNetModel``, ``SpacedDiffusion``, ``create_model_and_diffusion``, ``model_and_diffusion_defaults`` <- the slice of
+    the un-vendored ``maua/submodules/guided_diffusion`` (unet.py, gaussian_diffusion.py, respace.py, script_util.py) that
+    guided.py calls.  The submodule is EMPTY in the reference checkout (no pinned revision): the published algorithm is
+    restated, **parity unpinned**; state-dict keys are upstream's, so a released checkpoint loads unchanged.
+The network runs behind the C ABI (``maua_unet_*``, csrc/unet.hip); the sampler's arithmetic is ``maua_ddim_step`` /
+``maua_axpby_rows``; schedules are float64 numpy on the host exactly like gaussian_diffusion.py builds them.
+
+What is NOT here, and why: CLIP / LPIPS prompts (un-vendored models, no network for weights) - ``grad_modules`` are
+caller-supplied objects with ``scale``, ``set_targets(prompts)`` and ``__call__(img, t) -> d loss / d img``; the
+conditioning speeds "fast" / "regular" differentiate THROUGH a network (secondary model / the UNet) with autograd, which
+an inference library does not have - ``speed="hyper"`` (guided.py:248-249: the x0 estimate from the known noise, whose
+Jacobian is 1 / alpha) is implemented exactly.  The "p" and "plms" samplers are not implemented (configs[3] names DDIM).
+"""
+import ctypes as C
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------------- network
+def _channel_mult_for(image_size):
+    """script_util.create_model"""
+    table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+    if image_size not in table:
+        raise ValueError(f"unsupported image size: {image_size}")
+    return table[image_size]
+
+
+class UNetModel(torch.nn.Module):
+    """guided_diffusion.unet.UNetModel (constructor arguments as upstream; ``attention_resolutions`` are down-sampling
+    rates).  Only the flag set guided.py:171-190 selects is implemented: use_scale_shift_norm, resblock_updown, legacy
+    attention order, num_head_channels heads, no class conditioning, dropout 0.
+    ``dtype``: torch.bfloat16 (default; the reference runs fp16) or torch.float32 (exact-f32 MFMA parity mode)."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, dtype=torch.bfloat16, generator=None):
+        super().__init__()
+        if not (use_scale_shift_norm and resblock_updown) or use_new_attention_order or num_classes is not None or dims != 2 \
+                or dropout != 0 or num_head_channels not in (32, 64):
+            raise NotImplementedError("only the configuration of maua's create_models is implemented: use_scale_shift_norm, "
+                                      "resblock_updown, legacy attention order, num_head_channels 32 / 64, unconditional")
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions = num_res_blocks, tuple(int(a) for a in attention_resolutions)
+        self.channel_mult, self.num_head_channels = tuple(channel_mult), num_head_channels
+        self.dtype = dtype
+        self._structure = self._build_structure()
+        self._params = self._init_params(generator)
+        self._net = None
+
+    # -- structure: UNetModel.__init__'s module tree as layer descriptions -------------------------------------
+    def _build_structure(self):
+        mc, cm, nrb = self.model_channels, self.channel_mult, self.num_res_blocks
+        ch = int(cm[0] * mc)
+        inp, chans, ds = [[("conv", self.in_channels, ch)]], [ch], 1
+        for level, mult in enumerate(cm):
+            for _ in range(nrb):
+                layers = [("res", ch, int(mult * mc))]
+                ch = int(mult * mc)
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch))
+                inp.append(layers)
+                chans.append(ch)
+            if level != len(cm) - 1:
+                inp.append([("res", ch, ch)])
+                chans.append(ch)
+                ds *= 2
+        mid = [("res", ch, ch), ("attn", ch), ("res", ch, ch)]
+        out = []
+        for level, mult in list(enumerate(cm))[::-1]:
+            for i in range(nrb + 1):
+                ich = chans.pop()
+                layers = [("res", ch + ich, int(mc * mult))]
+                ch = int(mc * mult)
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch))
+                if level and i == nrb:
+                    layers.append(("res", ch, ch))
+                    ds //= 2
+                out.append(layers)
+        return dict(input=inp, middle=mid, output=out, final_ch=ch)
+
+    def _param_shapes(self):
+        emb = self.model_channels * 4
+        shapes = {"time_embed.0.weight": (emb, self.model_channels), "time_embed.0.bias": (emb,),
+                  "time_embed.2.weight": (emb, emb), "time_embed.2.bias": (emb,)}
+
+        def layer(pfx, l):
+            if l[0] == "conv":
+                shapes[pfx + ".weight"], shapes[pfx + ".bias"] = (l[2], l[1], 3, 3), (l[2],)
+            elif l[0] == "res":
+                _, ci, co = l
+                shapes[pfx + ".in_layers.0.weight"] = shapes[pfx + ".in_layers.0.bias"] = (ci,)
+                shapes[pfx + ".in_layers.2.weight"], shapes[pfx + ".in_layers.2.bias"] = (co, ci, 3, 3), (co,)
+                shapes[pfx + ".emb_layers.1.weight"], shapes[pfx + ".emb_layers.1.bias"] = (2 * co, emb), (2 * co,)
+                shapes[pfx + ".out_layers.0.weight"] = shapes[pfx + ".out_layers.0.bias"] = (co,)
+                shapes[pfx + ".out_layers.3.weight"], shapes[pfx + ".out_layers.3.bias"] = (co, co, 3, 3), (co,)
+                if ci != co:
+                    shapes[pfx + ".skip_connection.weight"], shapes[pfx + ".skip_connection.bias"] = (co, ci, 1, 1), (co,)
+            else:
+                c = l[1]
+                shapes[pfx + ".norm.weight"] = shapes[pfx + ".norm.bias"] = (c,)
+                shapes[pfx + ".qkv.weight"], shapes[pfx + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
+                shapes[pfx + ".proj_out.weight"], shapes[pfx + ".proj_out.bias"] = (c, c, 1), (c,)
+        s = self._structure
+        for i, layers in enumerate(s["input"]):
+            for j, l in enumerate(layers):
+                layer(f"input_blocks.{i}.{j}", l)
+        for j, l in enumerate(s["middle"]):
+            layer(f"middle_block.{j}", l)
+        for i, layers in enumerate(s["output"]):
+            for j, l in enumerate(layers):
+                layer(f"output_blocks.{i}.{j}", l)
+        shapes["out.0.weight"] = shapes["out.0.bias"] = (s["final_ch"],)
+        shapes["out.2.weight"], shapes["out.2.bias"] = (self.out_channels, s["final_ch"], 3, 3), (self.out_channels,)
+        return shapes
+
+    @L.host_threads(8)
+    def _init_params(self, generator):
+        """Random initialisation (there is no network access for the released checkpoints): fan-in scaled normal weights,
+        GroupNorm scales around 1.  Upstream's ``zero_module`` layers (every ResBlock's last conv, every proj_out, the
+        output conv) are drawn like the others - a zero-initialised network would make every sample a no-op."""
+        g = generator or torch.Generator().manual_seed(0)
+        p = {}
+        for name, shape in self._param_shapes().items():
+            if ".in_layers.0." in name or ".out_layers.0." in name or ".norm." in name or name.startswith("out.0."):
+                p[name] = (1 + 0.1 * torch.randn(shape, generator=g)) if name.endswith("weight") else 0.1 * torch.randn(shape, generator=g)
+            elif name.endswith(".bias"):
+                p[name] = 0.1 * torch.randn(shape, generator=g)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+                p[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        return p
+
+    # -- parameters ------------------------------------------------------------------------------------------
+    def state_dict(self, *a, **k):
+        return dict(self._params)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        unexpected = [k for k in sd if k not in self._params]
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing {missing[:4]}..., unexpected {unexpected[:4]}...")
+        for k in self._params:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(self._params[k].shape):
+                    raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {tuple(self._params[k].shape)}")
+                self._params[k] = sd[k].detach().float().cpu().contiguous()
+        self._destroy()
+
+    def convert_to_fp16(self):
+        """guided.py:198-199 calls this; the compute type here is the constructor's ``dtype``."""
+        return self
+
+    def requires_grad_(self, flag=True):
+        return self
+
+    def _destroy(self):
+        if self._net is not None:
+            L.lib().maua_unet_destroy(self._net)
+            self._net = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _handle(self):
+        L.require_device()
+        if self._net is None:
+            lib = L.lib()
+            net = C.c_void_p()
+            cm = (C.c_float * len(self.channel_mult))(*[float(m) for m in self.channel_mult])
+            ads = (C.c_int * max(1, len(self.attention_resolutions)))(*self.attention_resolutions)
+            L.check(lib.maua_unet_create(L.ctx(), self.image_size, self.in_channels, self.model_channels, self.out_channels,
+                                         self.num_res_blocks, cm, len(self.channel_mult), ads,
+                                         len(self.attention_resolutions), self.num_head_channels, L.dtype_id(self.dtype),
+                                         C.byref(net)))
+            for k, v in self._params.items():
+                a = np.ascontiguousarray(v.numpy(), dtype=np.float32)
+                L.check(lib.maua_unet_load(net, k.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
+            # nn.py timestep_embedding's frequency table, computed on the host with the reference's own expression
+            half = self.model_channels // 2
+            freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).numpy()
+            L.check(lib.maua_unet_load(net, b"timestep_embedding.freqs", freqs.ctypes.data_as(C.c_void_p), C.c_size_t(half)))
+            self._net = net
+        else:
+            L.ctx()
+        return self._net
+
+    def graph_active(self):
+        """True when the in-library sampler loop replays a captured hipGraph (False: capture unavailable, eager launches)."""
+        a = C.c_int()
+        L.check(L.lib().maua_unet_graph_active(self._handle(), C.byref(a)))
+        return bool(a.value)
+
+    def set_route(self, route):
+        """0: per-shape kernel routing (default), 1: generic 3x3 kernel only, 2: no split-K gather GEMM."""
+        L.check(L.lib().maua_unet_set_option(self._handle(), b"route", int(route)))
+
+    def forward(self, x, timesteps, y=None, out=None):
+        """x [N, C, H, W], timesteps [N] -> [N, out_channels, H, W] (float32)."""
+        if y is not None:
+            raise NotImplementedError("class conditioning is not on this path")
+        x = L.dev_tensor(x, torch.float32)
+        t = L.dev_tensor(torch.as_tensor(timesteps), torch.float32).reshape(-1)
+        B, _, H, W = x.shape
+        if t.numel() != B:
+            raise ValueError("one timestep per sample")
+        if out is None:
+            out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        L.check(L.lib().maua_unet_forward(self._handle(), L.ptr(x), L.ptr(t), B, H, W, L.ptr(out)))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------ diffusion
+def space_timesteps(num_timesteps, section_counts):
+    """respace.space_timesteps"""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            desired = int(section_counts[len("ddim"):])
+            for i in range(1, num_timesteps):
+                if len(range(0, num_timesteps, i)) == desired:
+                    return set(range(0, num_timesteps, i))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = num_timesteps // len(section_counts), num_timesteps % len(section_counts)
+    start_idx, all_steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        frac_stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur = 0.0
+        for _ in range(count):
+            all_steps.append(start_idx + round(cur))
+            cur += frac_stride
+        start_idx += size
+    return set(all_steps)
+
+
+class SpacedDiffusion:
+    """respace.SpacedDiffusion over gaussian_diffusion.GaussianDiffusion (linear schedule, epsilon prediction, learned-range
+    variance): float64 tables of the respaced process, ``timestep_map``, ``q_sample`` and ``ddim_sample``."""
+
+    def __init__(self, use_timesteps, betas, rescale_timesteps=True):
+        base = np.array(betas, dtype=np.float64)
+        self.original_num_steps, self.rescale_timesteps = len(base), rescale_timesteps
+        self.use_timesteps = set(use_timesteps)
+        ac, last, new_betas, self.timestep_map = np.cumprod(1.0 - base, axis=0), 1.0, [], []
+        for i, a in enumerate(ac):
+            if i in self.use_timesteps:
+                new_betas.append(1 - a / last)
+                last = a
+                self.timestep_map.append(i)
+        self.betas = b = np.array(new_betas, dtype=np.float64)
+        self.num_timesteps = int(b.shape[0])
+        self.alphas_cumprod = np.cumprod(1.0 - b, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def model_timesteps(self, t):
+        """_WrappedModel.__call__: respaced index -> the timestep the network sees (float when rescaled)."""
+        ts = torch.tensor(self.timestep_map, device=t.device)[t.long()]
+        return ts.float() * (1000.0 / self.original_num_steps) if self.rescale_timesteps else ts.float()
+
+    def _f32(self, arr, t):
+        """_extract_into_tensor: the table values at t as float32 (host)."""
+        return torch.from_numpy(arr)[torch.as_tensor(t).long().cpu()].float()
+
+    def step_coefficients(self, t, eta=0.0):
+        """[len(t), 8] float32 coefficients of maua_ddim_step, evaluated like ddim_sample evaluates them (float32 tensors
+        extracted from the float64 tables, then float32 arithmetic)."""
+        t = torch.as_tensor(t).long().cpu().reshape(-1)
+        ab, abp = self._f32(self.alphas_cumprod, t), self._f32(self.alphas_cumprod_prev, t)
+        sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+        cf = torch.zeros((len(t), 8), dtype=torch.float32)
+        cf[:, 0] = self._f32(self.sqrt_recip_alphas_cumprod, t)
+        cf[:, 1] = self._f32(self.sqrt_recipm1_alphas_cumprod, t)
+        cf[:, 2] = (1 - ab).sqrt()
+        cf[:, 3] = torch.sqrt(abp)
+        cf[:, 4] = torch.sqrt(1 - abp - sigma ** 2)
+        cf[:, 5] = sigma * (t != 0).float()
+        return cf
+
+    # -- gaussian_diffusion.py ---------------------------------------------------------------------------------
+    def q_sample(self, x_start, t, noise=None):
+        x = L.dev_tensor(x_start, torch.float32)
+        noise = torch.randn_like(x) if noise is None else L.dev_tensor(noise, torch.float32)
+        ab = torch.stack([self._f32(self.sqrt_alphas_cumprod, t), self._f32(self.sqrt_one_minus_alphas_cumprod, t)], 1)
+        ab = L.dev_tensor(ab.contiguous(), torch.float32)
+        out = torch.empty_like(x)
+        L.check(L.lib().maua_axpby_rows(L.ctx(x.device), L.ptr(x), L.ptr(noise), L.ptr(ab), x.shape[0],
+                                        C.c_long(x[0].numel()), L.ptr(out)))
+        return out
+
+    def ddim_sample(self, model, x, t, clip_denoised=False, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0,
+                    noise=None):
+        """One DDIM step -> {"sample", "pred_xstart"}; ``cond_fn(x, model_timesteps)`` -> gradient (condition_score)."""
+        if clip_denoised or denoised_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn (the reference passes clip_denoised=False)")
+        x = L.dev_tensor(x, torch.float32)
+        mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
+        out = model(x, mt)
+        grad = None
+        if cond_fn is not None:
+            grad = L.dev_tensor(cond_fn(x, mt), torch.float32)
+        if eta != 0.0 and noise is None:
+            noise = torch.randn_like(x)
+        cf = L.dev_tensor(self.step_coefficients(t, eta), torch.float32)
+        sample, pred = torch.empty_like(x), torch.empty_like(x)
+        B, Cc = x.shape[0], x.shape[1]
+        L.check(L.lib().maua_ddim_step(L.ctx(x.device), L.ptr(x), L.ptr(out), L.ptr(grad),
+                                       L.ptr(noise if eta != 0.0 else None), L.ptr(cf), B, Cc, out.shape[1],
+                                       C.c_long(x[0, 0].numel()), L.ptr(sample), L.ptr(pred)))
+        return {"sample": sample, "pred_xstart": pred}
+
+    def ddim_sample_loop(self, model, x, start_step=None, n_steps=None, use_graph=True):
+        """The unconditioned loop inside the library (one hipGraph per shape): t = start_step, start_step - 1, ...
+        -> (x after the last step, its pred_xstart).  x is updated in place."""
+        start = self.num_timesteps - 1 if start_step is None else int(start_step)
+        n_steps = start + 1 if n_steps is None else int(n_steps)
+        ts = torch.arange(start, start - n_steps, -1)
+        ts = torch.where(ts < 0, ts + self.num_timesteps, ts)  # (negative t index the tables from the end, like numpy)
+        mt = np.ascontiguousarray(self.model_timesteps(ts).numpy(), dtype=np.float32)
+        cf = np.ascontiguousarray(self.step_coefficients(ts).numpy(), dtype=np.float32)
+        x = L.dev_tensor(x, torch.float32)
+        pred = torch.empty_like(x)
+        B, _, H, W = x.shape
+        L.check(L.lib().maua_ddim_sample_loop(model._handle(), L.ptr(x), B, H, W, mt.ctypes.data_as(C.c_void_p),
+                                              cf.ctypes.data_as(C.c_void_p), n_steps, int(bool(use_graph)), L.ptr(pred)))
+        return x, pred
+
+
+def model_and_diffusion_defaults():
+    """script_util.model_and_diffusion_defaults (the keys guided.py:171-190 reads or overrides)."""
+    return dict(image_size=64, num_channels=128, num_res_blocks=2, num_heads=4, num_heads_upsample=-1, num_head_channels=-1,
+                attention_resolutions="16,8", channel_mult="", dropout=0.0, class_cond=False, use_checkpoint=False,
+                use_scale_shift_norm=True, resblock_updown=False, use_fp16=False, use_new_attention_order=False,
+                learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing="", use_kl=False,
+                predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+
+
+def create_model_and_diffusion(image_size, class_cond, learn_sigma, num_channels, num_res_blocks, channel_mult, num_heads,
+                               num_head_channels, num_heads_upsample, attention_resolutions, dropout, diffusion_steps,
+                               noise_schedule, timestep_respacing, use_kl, predict_xstart, rescale_timesteps,
+                               rescale_learned_sigmas, use_checkpoint, use_scale_shift_norm, resblock_updown, use_fp16,
+                               use_new_attention_order, dtype=torch.bfloat16, generator=None):
+    """script_util.create_model_and_diffusion"""
+    if class_cond or predict_xstart or use_kl or noise_schedule != "linear":
+        raise NotImplementedError("unconditional epsilon model on the linear schedule (what create_models configures)")
+    cm = _channel_mult_for(image_size) if channel_mult == "" else tuple(float(m) for m in str(channel_mult).split(","))
+    ads = tuple(image_size // int(r) for r in str(attention_resolutions).split(","))
+    model = UNetModel(image_size=image_size, in_channels=3, model_channels=num_channels,
+                      out_channels=6 if learn_sigma else 3, num_res_blocks=num_res_blocks, attention_resolutions=ads,
+                      dropout=dropout, channel_mult=cm, num_heads=num_heads, num_head_channels=num_head_channels,
+                      num_heads_upsample=num_heads_upsample, use_scale_shift_norm=use_scale_shift_norm,
+                      resblock_updown=resblock_updown, use_fp16=use_fp16, use_new_attention_order=use_new_attention_order,
+                      dtype=dtype, generator=generator)
+    scale = 1000 / diffusion_steps
+    betas = np.linspace(scale * 0.0001, scale * 0.02, diffusion_steps, dtype=np.float64)
+    diffusion = SpacedDiffusion(space_timesteps(diffusion_steps, timestep_respacing or [diffusion_steps]), betas,
+                                rescale_timesteps=rescale_timesteps)
+    return model, diffusion
+
+
+CHECKPOINTS = {"uncondImageNet512": ("modelzoo/512x512_diffusion_uncond_finetune_008100.pt", 512),
+               "uncondImageNet256": ("modelzoo/256x256_diffusion_uncond.pt", 256)}
+
+
+def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diffusion_steps=1000, use_secondary=False,
+                  allow_random_init=False, dtype=torch.bfloat16, generator=None, **overrides):
+    """guided.py:164-209.  The checkpoint file is loaded when it exists (upstream state-dict keys); there is no network
+    access to download it: without the file this raises unless ``allow_random_init`` (seeded random weights of the same
+    architecture - what the bench and the tests run).  ``overrides``: model_config entries (tests build small networks)."""
+    import os
+    path, size = CHECKPOINTS[checkpoint]
+    cfg = model_and_diffusion_defaults()
+    cfg.update({"attention_resolutions": "32, 16, 8", "class_cond": False, "diffusion_steps": diffusion_steps,
+                "rescale_timesteps": True, "timestep_respacing": timestep_respacing, "learn_sigma": True,
+                "noise_schedule": "linear", "num_channels": 256, "num_head_channels": 64, "num_res_blocks": 2,
+                "resblock_updown": True, "use_fp16": True, "use_scale_shift_norm": True, "image_size": size})
+    cfg.update(overrides)
+    model, diffusion = create_model_and_diffusion(**cfg, dtype=dtype, generator=generator)
+    if os.path.exists(path):
+        model.load_state_dict(torch.load(path, map_location="cpu"))
+    elif not allow_random_init:
+        raise FileNotFoundError(f"{path} not found (the reference downloads it; this box has no network): place the file "
+                                "there or pass allow_random_init=True")
+    if use_secondary:
+        raise NotImplementedError("the secondary model serves the autograd-based 'fast' conditioning (see the module "
+                                  "docstring); use speed='hyper'")
+    return model, diffusion, None
+
+
+class GradientGuidedConditioning(torch.nn.Module):
+    """guided.py:212-274 with speed="hyper": img = (x - sigma * noise) / alpha is the clean-image estimate from the KNOWN
+    noise; the grad modules return d loss / d img, and d img / d x = 1 / alpha, so cond_fn = -sum(grads) / alpha."""
+
+    def __init__(self, diffusion, model, grad_modules, speed="hyper"):
+        super().__init__()
+        if speed != "hyper":
+            raise NotImplementedError('speed "fast" / "regular" back-propagate through a network; use speed="hyper"')
+        self.speed, self.grad_modules = speed, list(grad_modules)
+        self.timestep_map = list(diffusion.timestep_map)
+        self.sqrt_alphas_cumprod = torch.from_numpy(diffusion.sqrt_alphas_cumprod).float()
+        self.sqrt_one_minus_alphas_cumprod = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod).float()
+        self.noise = None
+
+    def set_targets(self, prompts, noise):
+        self.noise = noise
+        for gm in self.grad_modules:
+            gm.set_targets(prompts)
+
+    def forward(self, x, t, kw={}):
+        ot = t.clone()
+        idx = torch.tensor([self.timestep_map.index(int(v)) for v in t.long().cpu()])
+        alpha, sigma = self.sqrt_alphas_cumprod[idx], self.sqrt_one_minus_alphas_cumprod[idx]
+        x = L.dev_tensor(x, torch.float32)
+        ab = L.dev_tensor(torch.stack([1 / alpha, -sigma / alpha], 1).contiguous(), torch.float32)
+        img = torch.empty_like(x)
+        L.check(L.lib().maua_axpby_rows(L.ctx(x.device), L.ptr(x), L.ptr(self.noise), L.ptr(ab), x.shape[0],
+                                        C.c_long(x[0].numel()), L.ptr(img)))
+        img_grad = torch.zeros_like(img)
+        for gm in self.grad_modules:
+            sub = gm(img, ot)
+            if torch.isnan(sub).any():
+                sub = torch.zeros_like(img)
+            img_grad += sub
+        return -img_grad / alpha.to(x.device).reshape(-1, 1, 1, 1)
+
+
+class MSEGuide:
+    """A grad module that needs no un-vendored perceptor: loss = scale * mean((img - target)^2) per sample, so
+    d loss / d img = 2 * scale * (img - target) / numel.  ``set_targets`` takes the prompts' ``target`` images (the
+    audio-switched prompt schedule hands over one prompt per frame)."""
+
+    def __init__(self, scale=1000.0):
+        self.scale, self.target = scale, None
+
+    def set_targets(self, prompts):
+        ts = [p.target if hasattr(p, "target") else p for p in prompts]
+        self.target = None if not ts else torch.stack([torch.as_tensor(t).float() for t in ts]).mean(0).cuda()
+
+    def __call__(self, img, t):
+        if self.target is None:
+            return torch.zeros_like(img)
+        return (2.0 * self.scale / img[0].numel()) * (img - self.target.to(img.device))
+
+
+class ImageTarget:
+    """The prompt type MSEGuide consumes: a target image [C, H, W] in [-1, 1]."""
+
+    def __init__(self, target):
+        self.target = target
+
+    def to(self, *_a, **_k):
+        return self
+
+
+class GuidedDiffusion(torch.nn.Module):
+    """guided.py:277-339 (sampler "ddim").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
+    checkpoint name (file must exist, see create_models) or ready objects (tests, bench)."""
+
+    def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
+                 ddim_eta=0, plms_order=2, speed="hyper", model=None, diffusion=None, allow_random_init=False,
+                 dtype=torch.bfloat16):
+        super().__init__()
+        if sampler != "ddim":
+            raise NotImplementedError('only sampler="ddim" (BASELINE configs[3]) is implemented')
+        if model is None:
+            model, diffusion, _ = create_models(checkpoint=model_checkpoint, timestep_respacing=f"ddim{timesteps}",
+                                                use_secondary=False, allow_random_init=allow_random_init, dtype=dtype)
+        self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
+        mods = [gm for gm in grad_modules if gm.scale != 0]
+        self.conditioning = GradientGuidedConditioning(diffusion, None, mods, speed=speed) if mods else None
+        self.device = device
+        self.original_num_steps = diffusion.original_num_steps
+        self.timestep_map = diffusion.timestep_map
+        self.image_size = model.image_size
+
+    @torch.no_grad()
+    def run(self, img, prompts, start_step, n_steps, noise=None):
+        """q_sample(img, start_step, noise), then n_steps DDIM updates with t = start_step, start_step - 1, ...
+        -> the last step's pred_xstart.  Without grad modules the loop runs inside the library as one hipGraph."""
+        img = L.dev_tensor(img, torch.float32)
+        t = torch.tensor([start_step] * img.shape[0], dtype=torch.long)
+        noise = torch.randn_like(img) if noise is None else L.dev_tensor(noise, torch.float32)
+        x = self.diffusion.q_sample(img, t, noise)
+        if n_steps <= 0:
+            return None  # (the reference returns out["pred_xstart"] of out = None here, i.e. raises)
+        if self.conditioning is None and self.ddim_eta == 0:
+            return self.diffusion.ddim_sample_loop(self.model, x, start_step, n_steps)[1]
+        if self.conditioning is not None:
+            self.conditioning.set_targets([p.to(img) for p in prompts], noise)
+        out = None
+        for _ in range(n_steps):
+            out = self.diffusion.ddim_sample(self.model, x, t, clip_denoised=False, cond_fn=self.conditioning,
+                                             model_kwargs={}, eta=self.ddim_eta)
+            x = out["sample"]
+            t = t - 1
+        return out["pred_xstart"]
+
+    def forward(self, img, prompts, t_start, t_end=1, verbose=True, noise=None):
+        """:322-339, arithmetic kept as written there (start_step counts from the NOISY end: t_start = 0.5 runs the last
+        half of the schedule; t never reaches 0)."""
+        n = len(self.timestep_map)
+        return self.run(img, prompts, round(t_start * (n - 1)), round((t_end - t_start) * (n - 1)), noise)
+
+
+# ------------------------------------------------------------------- audio-onset-switched prompts (configs[3])
+def onset_prompt_schedule(audio, sr, fps, n_prompts, percentile=90):
+    """Per video frame, which prompt is active: the prompt index advances at every onset PEAK of the clip (frames where
+    the hop-aligned onset envelope - the same bit-exact path the StyleGAN2 render uses, audio.onsets - is a local maximum
+    above its ``percentile``), cyclically.  -> int64 [n_frames] on the host.  The reference has no audio coupling in
+    maua.diffusion; this is the coupling BASELINE configs[3] names, built from the path's own onset bins."""
+    from . import audio as A
+    from . import signal as SG
+    if sr != 1024 * fps:
+        raise ValueError("resample the clip to 1024 * fps first (audio_io.load_audio does): one STFT hop = one frame")
+    env = A.onsets(torch.as_tensor(audio), sr).squeeze(-1)
+    thr = SG.percentile(env, percentile)
+    e = env.cpu()
+    peak = torch.zeros_like(e, dtype=torch.bool)
+    if len(e) > 2:
+        peak[1:-1] = (e[1:-1] > e[:-2]) & (e[1:-1] >= e[2:]) & (e[1:-1] > float(thr))
+    return (torch.cumsum(peak.long(), 0) % max(1, n_prompts)).long()
+
+
+@torch.no_grad()
+def sample(prompts: List, audio=None, sr=None, fps=30, n_frames=None, size=(256, 256), timesteps=100,
+           t_start: Optional[float] = None, model=None, diffusion=None, grad_modules=None, seed=0, batch=4, init=None,
+           verbose=False):
+    """configs[3]: one 100-step DDIM sample per video frame, the active prompt switched on the clip's onset bins.
+    ``prompts``: list of prompt objects (what the grad modules' set_targets understands).  -> ([n_frames, 3, H, W] in
+    [-1, 1], prompt index per frame)."""
+    if model is None:
+        model, diffusion, _ = create_models("uncondImageNet256", f"ddim{timesteps}")
+    gd = GuidedDiffusion(grad_modules or [], timesteps=timesteps, model=model, diffusion=diffusion)
+    if audio is not None:
+        idx = onset_prompt_schedule(audio, sr, fps, len(prompts))
+        n_frames = len(idx) if n_frames is None else min(n_frames, len(idx))
+        idx = idx[:n_frames]
+    else:
+        idx = torch.zeros(n_frames or 1, dtype=torch.long)
+        n_frames = len(idx)
+    g = torch.Generator().manual_seed(seed)
+    H, W = size
+    frames = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device="cuda")
+    n = len(gd.timestep_map)
+    f = 0
+    while f < n_frames:
+        # frames that share a prompt go through the sampler together (up to `batch`)
+        e = f + 1
+        while e < n_frames and e - f < batch and idx[e] == idx[f]:
+            e += 1
+        x0 = torch.randn((e - f, 3, H, W), generator=g) if init is None else torch.as_tensor(init).expand(e - f, 3, H, W)
+        nz = torch.randn((e - f, 3, H, W), generator=g)
+        active = [prompts[int(idx[f])]] if prompts else []
+        if t_start is None:   # the whole respaced schedule: t = n - 1 ... 0 (`timesteps` DDIM steps)
+            frames[f:e] = gd.run(x0, active, n - 1, n, noise=nz)
+        else:                 # the reference's GuidedDiffusion.forward arithmetic
+            frames[f:e] = gd.forward(x0, active, t_start, verbose=verbose, noise=nz)
+        f = e
+    return frames, idx

@@ -1,0 +1,344 @@
+"""Oracle restatement of the guided-diffusion slice of BASELINE configs[3] (TEST INFRASTRUCTURE ONLY: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product).
+
+What it restates (reference call sites): maua/diffusion/processors/guided.py:164-209 ``create_models`` (the OpenAI
+guided-diffusion UNet: num_channels 256, num_res_blocks 2, attention at 32 / 16 / 8, 64-channel heads, learn_sigma,
+resblock_updown, use_scale_shift_norm, linear noise schedule, "ddim100" respacing, rescale_timesteps) and :277-339
+``GuidedDiffusion.forward`` (q_sample -> ddim_sample loop with a cond_fn).
+
+The network and the sampler themselves live in the git submodule ``maua/submodules/guided_diffusion``
+(github.com/crowsonkb/guided-diffusion, no pinned SHA, EMPTY in /root/reference): **PARITY UNPINNED**.  The code below
+restates the published algorithm of guided_diffusion/unet.py (UNetModel, ResBlock, AttentionBlock, QKVAttentionLegacy,
+timestep_embedding, GroupNorm32), gaussian_diffusion.py (linear betas, q_sample, p_mean_variance for epsilon /
+learned-range models, condition_score, ddim_sample) and respace.py (space_timesteps, SpacedDiffusion, the wrapped
+model's timestep map) in plain PyTorch-CPU fp32 (network) and numpy float64 (schedules), with the upstream state-dict
+key names so that a released checkpoint would load unchanged.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ configuration
+def default_channel_mult(image_size):
+    """script_util.create_model: the channel multipliers chosen from the image size."""
+    return {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}[image_size]
+
+
+def unet_config(image_size=256, model_channels=256, num_res_blocks=2, attention_resolutions=(32, 16, 8),
+                channel_mult=None, num_head_channels=64, in_channels=3, learn_sigma=True):
+    """guided.py:171-190's model_config as the structural numbers the UNet needs.  ``attention_resolutions`` are
+    feature-map sizes like the reference's string "32, 16, 8"; upstream turns them into down-sampling rates
+    image_size // res."""
+    cm = tuple(channel_mult) if channel_mult is not None else default_channel_mult(image_size)
+    return dict(image_size=image_size, in_channels=in_channels, model_channels=model_channels,
+                out_channels=(2 if learn_sigma else 1) * in_channels, num_res_blocks=num_res_blocks,
+                attention_ds=tuple(image_size // int(r) for r in attention_resolutions), channel_mult=cm,
+                num_head_channels=num_head_channels)
+
+
+def unet_structure(cfg):
+    """UNetModel.__init__ (unet.py): the module tree as lists of layer descriptions.
+    -> dict(input=[[layer, ...], ...], middle=[...], output=[[...], ...]); a layer is ("conv", cin, cout),
+    ("res", cin, cout, updown) with updown in (None, "down", "up"), or ("attn", ch)."""
+    mc, cm, nrb = cfg["model_channels"], cfg["channel_mult"], cfg["num_res_blocks"]
+    ch = int(cm[0] * mc)
+    inp = [[("conv", cfg["in_channels"], ch)]]
+    chans = [ch]
+    ds = 1
+    for level, mult in enumerate(cm):
+        for _ in range(nrb):
+            layers = [("res", ch, int(mult * mc), None)]
+            ch = int(mult * mc)
+            if ds in cfg["attention_ds"]:
+                layers.append(("attn", ch))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(cm) - 1:
+            inp.append([("res", ch, ch, "down")])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", ch, ch, None), ("attn", ch), ("res", ch, ch, None)]
+    out = []
+    for level, mult in list(enumerate(cm))[::-1]:
+        for i in range(nrb + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, int(mc * mult), None)]
+            ch = int(mc * mult)
+            if ds in cfg["attention_ds"]:
+                layers.append(("attn", ch))
+            if level and i == nrb:
+                layers.append(("res", ch, ch, "up"))
+                ds //= 2
+            out.append(layers)
+    return dict(input=inp, middle=mid, output=out, final_ch=ch)
+
+
+def init_unet_params(cfg, generator=None, zero_out=False):
+    """A state dict with guided-diffusion's key names.  Upstream zero-initialises the last conv of every ResBlock, every
+    attention proj_out and the output conv (``zero_module``), which would make a random-init forward vacuous as a test;
+    ``zero_out=False`` draws them like the other layers (fan-in scaled normal)."""
+    g = generator or torch.Generator().manual_seed(0)
+    p = {}
+    emb = cfg["model_channels"] * 4
+
+    def rn(*shape, fan_in, scale=1.0):
+        return torch.randn(*shape, generator=g) * (scale / math.sqrt(fan_in))
+
+    def lin(name, k, n):
+        p[name + ".weight"], p[name + ".bias"] = rn(n, k, fan_in=k), rn(n, fan_in=1, scale=0.1)
+
+    def conv3(name, ci, co, zero=False):
+        p[name + ".weight"] = torch.zeros(co, ci, 3, 3) if zero else rn(co, ci, 3, 3, fan_in=ci * 9)
+        p[name + ".bias"] = torch.zeros(co) if zero else rn(co, fan_in=1, scale=0.1)
+
+    def gn(name, c):
+        p[name + ".weight"] = 1 + 0.1 * torch.randn(c, generator=g)
+        p[name + ".bias"] = 0.1 * torch.randn(c, generator=g)
+
+    def layer(pfx, l):
+        if l[0] == "conv":
+            conv3(pfx, l[1], l[2])
+        elif l[0] == "res":
+            _, ci, co, _ud = l
+            gn(pfx + ".in_layers.0", ci)
+            conv3(pfx + ".in_layers.2", ci, co)
+            lin(pfx + ".emb_layers.1", emb, 2 * co)
+            gn(pfx + ".out_layers.0", co)
+            conv3(pfx + ".out_layers.3", co, co, zero=zero_out)
+            if ci != co:
+                p[pfx + ".skip_connection.weight"] = rn(co, ci, 1, 1, fan_in=ci)
+                p[pfx + ".skip_connection.bias"] = rn(co, fan_in=1, scale=0.1)
+        else:
+            c = l[1]
+            gn(pfx + ".norm", c)
+            p[pfx + ".qkv.weight"], p[pfx + ".qkv.bias"] = rn(3 * c, c, 1, fan_in=c), rn(3 * c, fan_in=1, scale=0.1)
+            p[pfx + ".proj_out.weight"] = torch.zeros(c, c, 1) if zero_out else rn(c, c, 1, fan_in=c)
+            p[pfx + ".proj_out.bias"] = torch.zeros(c) if zero_out else rn(c, fan_in=1, scale=0.1)
+
+    s = unet_structure(cfg)
+    lin("time_embed.0", cfg["model_channels"], emb)
+    lin("time_embed.2", emb, emb)
+    for i, layers in enumerate(s["input"]):
+        for j, l in enumerate(layers):
+            layer(f"input_blocks.{i}.{j}", l)
+    for j, l in enumerate(s["middle"]):
+        layer(f"middle_block.{j}", l)
+    for i, layers in enumerate(s["output"]):
+        for j, l in enumerate(layers):
+            layer(f"output_blocks.{i}.{j}", l)
+    gn("out.0", s["final_ch"])
+    conv3("out.2", s["final_ch"], cfg["out_channels"], zero=zero_out)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------------- network
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """nn.py timestep_embedding: [N] -> [N, dim] (cos | sin)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def _gn(p, name, x):
+    """GroupNorm32(32, C): computed in float32, eps 1e-5."""
+    return F.group_norm(x.float(), 32, p[name + ".weight"], p[name + ".bias"], eps=1e-5)
+
+
+def _resblock(p, pfx, x, emb, updown):
+    """unet.py ResBlock._forward with use_scale_shift_norm and (for updown) Upsample / Downsample without conv:
+    nearest x2 / avg_pool 2."""
+    resample = {None: (lambda t: t), "down": (lambda t: F.avg_pool2d(t, 2, 2)),
+                "up": (lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))}[updown]
+    h = F.silu(_gn(p, pfx + ".in_layers.0", x))
+    h = resample(h)
+    x = resample(x)
+    h = F.conv2d(h, p[pfx + ".in_layers.2.weight"], p[pfx + ".in_layers.2.bias"], padding=1)
+    emb_out = F.linear(F.silu(emb), p[pfx + ".emb_layers.1.weight"], p[pfx + ".emb_layers.1.bias"])[..., None, None]
+    scale, shift = torch.chunk(emb_out, 2, dim=1)
+    h = _gn(p, pfx + ".out_layers.0", h) * (1 + scale) + shift
+    h = F.conv2d(F.silu(h), p[pfx + ".out_layers.3.weight"], p[pfx + ".out_layers.3.bias"], padding=1)
+    if pfx + ".skip_connection.weight" in p:
+        x = F.conv2d(x, p[pfx + ".skip_connection.weight"], p[pfx + ".skip_connection.bias"])
+    return x + h
+
+
+def _attention(p, pfx, x, head_ch):
+    """unet.py AttentionBlock._forward with QKVAttentionLegacy (use_new_attention_order False): the qkv channels are
+    laid out [head][q | k | v][ch]; scale 1 / sqrt(sqrt(ch)) on both q and k; softmax in float32."""
+    b, c, hh, ww = x.shape
+    xf = x.reshape(b, c, -1)
+    n_heads = c // head_ch
+    qkv = F.conv1d(_gn(p, pfx + ".norm", xf), p[pfx + ".qkv.weight"], p[pfx + ".qkv.bias"])
+    length = qkv.shape[-1]
+    q, k, v = qkv.reshape(b * n_heads, head_ch * 3, length).split(head_ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(head_ch))
+    w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    w = torch.softmax(w.float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, length)
+    h = F.conv1d(a, p[pfx + ".proj_out.weight"], p[pfx + ".proj_out.bias"])
+    return (xf + h).reshape(b, c, hh, ww)
+
+
+def _run(p, pfx, layers, h, emb, cfg):
+    for j, l in enumerate(layers):
+        name = f"{pfx}.{j}"
+        if l[0] == "conv":
+            h = F.conv2d(h, p[name + ".weight"], p[name + ".bias"], padding=1)
+        elif l[0] == "res":
+            h = _resblock(p, name, h, emb, l[3])
+        else:
+            h = _attention(p, name, h, cfg["num_head_channels"])
+    return h
+
+
+@torch.no_grad()
+def unet_forward(p, cfg, x, timesteps, capture=None):
+    """UNetModel.forward: x [N, C, H, W], timesteps [N] (already scaled) -> [N, out_channels, H, W].
+    ``capture``: optional dict that receives every block's output (for layer-by-layer parity)."""
+    s = unet_structure(cfg)
+    emb = timestep_embedding(timesteps, cfg["model_channels"])
+    emb = F.linear(F.silu(F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])),
+                   p["time_embed.2.weight"], p["time_embed.2.bias"])
+    hs = []
+    h = x.float()
+    for i, layers in enumerate(s["input"]):
+        h = _run(p, f"input_blocks.{i}", layers, h, emb, cfg)
+        hs.append(h)
+        if capture is not None:
+            capture[f"input_blocks.{i}"] = h
+    h = _run(p, "middle_block", s["middle"], h, emb, cfg)
+    if capture is not None:
+        capture["middle_block"] = h
+    for i, layers in enumerate(s["output"]):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = _run(p, f"output_blocks.{i}", layers, h, emb, cfg)
+        if capture is not None:
+            capture[f"output_blocks.{i}"] = h
+    h = F.silu(_gn(p, "out.0", h))
+    return F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
+
+
+# ------------------------------------------------------------------------------------------------------ diffusion
+def linear_betas(num_diffusion_timesteps=1000):
+    """gaussian_diffusion.get_named_beta_schedule("linear")."""
+    scale = 1000 / num_diffusion_timesteps
+    return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """respace.space_timesteps for "ddimN" and plain "N" / "a,b,c" strings."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            desired = int(section_counts[len("ddim"):])
+            for i in range(1, num_timesteps):
+                if len(range(0, num_timesteps, i)) == desired:
+                    return set(range(0, num_timesteps, i))
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    size_per = num_timesteps // len(section_counts)
+    extra = num_timesteps % len(section_counts)
+    start_idx, all_steps = 0, []
+    for i, count in enumerate(section_counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        frac_stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        cur, taken = 0.0, []
+        for _ in range(count):
+            taken.append(start_idx + round(cur))
+            cur += frac_stride
+        all_steps += taken
+        start_idx += size
+    return set(all_steps)
+
+
+class Schedule:
+    """SpacedDiffusion(GaussianDiffusion): the float64 tables of the respaced process + the timestep map."""
+
+    def __init__(self, diffusion_steps=1000, timestep_respacing="ddim100", rescale_timesteps=True):
+        base = linear_betas(diffusion_steps)
+        use = space_timesteps(diffusion_steps, timestep_respacing)
+        ac = np.cumprod(1.0 - base, axis=0)
+        last, betas, self.timestep_map = 1.0, [], []
+        for i, a in enumerate(ac):
+            if i in use:
+                betas.append(1 - a / last)
+                last = a
+                self.timestep_map.append(i)
+        self.original_num_steps, self.rescale_timesteps = diffusion_steps, rescale_timesteps
+        self.betas = b = np.array(betas, dtype=np.float64)
+        self.num_timesteps = len(b)
+        self.alphas_cumprod = np.cumprod(1.0 - b, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+
+    def model_timesteps(self, t):
+        """_WrappedModel.__call__: spaced index -> the timestep the network sees."""
+        ts = torch.tensor(self.timestep_map)[t]
+        return ts.float() * (1000.0 / self.original_num_steps) if self.rescale_timesteps else ts
+
+
+def _ex(arr, t, shape):
+    """_extract_into_tensor: float64 table -> float32 values broadcast to ``shape``."""
+    v = torch.from_numpy(arr)[t].float()
+    while v.dim() < len(shape):
+        v = v[..., None]
+    return v.expand(shape)
+
+
+def q_sample(sch, x_start, t, noise):
+    return _ex(sch.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
+        _ex(sch.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+
+
+def ddim_step(sch, model_output, x, t, cond_grad=None, eta=0.0, noise=None):
+    """ddim_sample for an epsilon-predicting, learned-range model, clip_denoised False: ``model_output`` [N, 2C, H, W] is
+    the network's output at (x, model_timesteps(t)); ``cond_grad`` = cond_fn(x, t) or None.
+    -> (sample, pred_xstart)."""
+    C = x.shape[1]
+    eps_model = model_output[:, :C]
+    c1, c2 = _ex(sch.sqrt_recip_alphas_cumprod, t, x.shape), _ex(sch.sqrt_recipm1_alphas_cumprod, t, x.shape)
+    pred = c1 * x - c2 * eps_model                                  # _predict_xstart_from_eps
+    alpha_bar = _ex(sch.alphas_cumprod, t, x.shape)
+    if cond_grad is not None:                                       # condition_score
+        eps = (c1 * x - pred) / c2
+        eps = eps - (1 - alpha_bar).sqrt() * cond_grad
+        pred = c1 * x - c2 * eps
+    eps = (c1 * x - pred) / c2                                      # _predict_eps_from_xstart
+    alpha_bar_prev = _ex(sch.alphas_cumprod_prev, t, x.shape)
+    sigma = eta * torch.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar)) * torch.sqrt(1 - alpha_bar / alpha_bar_prev)
+    mean_pred = pred * torch.sqrt(alpha_bar_prev) + torch.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
+    nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+    if noise is None:
+        noise = torch.zeros_like(x)
+    return mean_pred + nonzero * sigma * noise, pred
+
+
+@torch.no_grad()
+def guided_diffusion_forward(p, cfg, sch, img, t_start, t_end=1, noise=None, cond_fn=None):
+    """guided.py:322-339 GuidedDiffusion.forward with the "ddim" sampler (eta 0): q_sample to start_step, then n_steps
+    ddim steps with t counting down; returns the last pred_xstart."""
+    n = len(sch.timestep_map)
+    start_step = round(t_start * (n - 1))
+    n_steps = round((t_end - t_start) * (n - 1))
+    t = torch.tensor([start_step] * img.shape[0], dtype=torch.long)
+    if noise is None:
+        noise = torch.randn_like(img)
+    x = q_sample(sch, img, t, noise)
+    pred = None
+    for _ in range(n_steps):
+        out = unet_forward(p, cfg, x, sch.model_timesteps(t))
+        grad = None if cond_fn is None else cond_fn(x, sch.model_timesteps(t))
+        x, pred = ddim_step(sch, out, x, t, grad)
+        t = t - 1
+    return pred

@@ -1,0 +1,231 @@
+"""BASELINE configs[3] (second half): guided-diffusion UNet forward + DDIM sampler on the HIP device against
+the CPU oracle's restatement of the published algorithm (oracle/diffusion.py; the guided_diffusion submodule is empty in the
+reference checkout: PARITY UNPINNED - the oracle and the device agree with each other and with torch's own ops, nothing
+here was produced by the reference).  Tolerances: exact-f32 mode <= 2e-5 of the reference's maximum per operator, <= 1e-4
+end to end on a small UNet (40+ chained layers); bf16 PSNR >= 40 dB."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import diffusion as OD
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max()) / max(1e-20, float(b.abs().max()))
+
+
+def psnr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    mse = float(((a - b) ** 2).mean())
+    rng = float(b.max() - b.min())
+    return 10 * math.log10(rng * rng / max(mse, 1e-30))
+
+
+def _nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(device="cuda", dtype=dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 2, 32), (1, 256, 4, 64), (2, 48, 1, 64), (1, 1024, 2, 64), (3, 16, 2, 32)])
+def test_attention_matches_legacy_qkv_attention(dt, B, T, heads, ch):
+    """QKVAttentionLegacy.forward on [N, 3 * H * C, T] vs maua_attention_legacy on the NHWC form (T not a multiple of 32,
+    several key blocks, one and several query tiles)."""
+    from maua_amd import _lib as L
+    g = torch.Generator().manual_seed(T + heads)
+    qkv = torch.randn(B, 3 * heads * ch, T, generator=g)
+    if dt == torch.bfloat16:
+        qkv = qkv.bfloat16().float()
+    q, k, v = qkv.reshape(B * heads, ch * 3, T).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1)
+    want = torch.einsum("bts,bcs->bct", w, v).reshape(B, -1, T)          # [B, heads * ch, T]
+    x = qkv.permute(0, 2, 1).contiguous().to(device="cuda", dtype=dt)        # [B, T, 3 * heads * ch]
+    out = torch.empty((B, T, heads * ch), dtype=dt, device="cuda")
+    L.check(L.lib().maua_attention_legacy(L.ctx(), L.ptr(x), L.ptr(out), B, T, heads, ch, L.dtype_id(dt)))
+    got = out.float().cpu().permute(0, 2, 1)
+    assert rel(got, want) <= (2e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(70, 96, 64), (1024, 256, 512), (5, 32, 32), (300, 1536, 512)])
+def test_linear_nt_matches_torch(dt, M, N, K):
+    from maua_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g), \
+        torch.randn(M, N, generator=g)
+    if dt == torch.bfloat16:
+        a, w, r = a.bfloat16().float(), w.bfloat16().float(), r.bfloat16().float()
+    want = F.linear(a, w, b) + r
+    ad, wd, rd = (t.to(device="cuda", dtype=dt).contiguous() for t in (a, w, r))
+    c = torch.empty((M, N), dtype=dt, device="cuda")
+    bd = b.cuda()
+    L.check(L.lib().maua_linear_nt(L.ctx(), L.ptr(ad), L.ptr(wd), L.ptr(bd), L.ptr(rd), L.ptr(c), C.c_long(M), N, K,
+                                   L.dtype_id(dt)))
+    assert rel(c, want) <= (1e-5 if dt == torch.float32 else 1e-2)
+    L.check(L.lib().maua_linear_nt(L.ctx(), L.ptr(ad), L.ptr(wd), None, None, L.ptr(c), C.c_long(M), N, K, L.dtype_id(dt)))
+    assert rel(c, F.linear(a, w)) <= (1e-5 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C_,H,W", [(2, 32, 8, 8), (1, 256, 32, 32), (2, 96, 5, 7), (1, 768, 16, 16), (1, 2048, 8, 8)])
+def test_group_norm_matches_torch(dt, B, C_, H, W):
+    """GroupNorm32 (+ scale-shift, + SiLU) incl. a large mean / small spread input (float64 statistics)."""
+    from maua_amd import _lib as L
+    g = torch.Generator().manual_seed(C_ + H)
+    x = torch.randn(B, C_, H, W, generator=g) * 0.5 + 30.0 * torch.randn(1, C_, 1, 1, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    ss = 0.3 * torch.randn(B, 2 * C_, generator=g)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = _nhwc(x, dt)
+    y = torch.empty_like(xd)
+    gd, bd, ssd = gamma.cuda(), beta.cuda(), ss.cuda()   # (kept alive: the library gets raw pointers)
+    for use_ss, silu in ((False, False), (True, True), (False, True)):
+        want = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+        if use_ss:
+            want = want * (1 + ss[:, :C_, None, None]) + ss[:, C_:, None, None]
+        if silu:
+            want = F.silu(want)
+        L.check(L.lib().maua_group_norm_nhwc(L.ctx(), L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(ssd) if use_ss else None,
+                                             int(silu), B, H, W, C_, L.dtype_id(dt), L.ptr(y)))
+        got = y.float().cpu().permute(0, 3, 1, 2)
+        assert rel(got, want) <= (2e-5 if dt == torch.float32 else 1e-2), (use_ss, silu)
+
+
+SMALL = dict(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions=(16, 8), channel_mult=(1, 2, 2),
+             num_head_channels=32)
+WIDE = dict(image_size=64, model_channels=128, num_res_blocks=1, attention_resolutions=(32,), channel_mult=(1, 2),
+            num_head_channels=64)
+
+
+def _build(cfgkw, dt, seed=0):
+    from maua_amd.diffusion import UNetModel
+    cfg = OD.unet_config(**cfgkw)
+    p = OD.init_unet_params(cfg, torch.Generator().manual_seed(seed))
+    net = UNetModel(image_size=cfg["image_size"], in_channels=3, model_channels=cfg["model_channels"],
+                    out_channels=cfg["out_channels"], num_res_blocks=cfg["num_res_blocks"],
+                    attention_resolutions=cfg["attention_ds"], channel_mult=cfg["channel_mult"],
+                    num_head_channels=cfg["num_head_channels"], use_scale_shift_norm=True, resblock_updown=True, dtype=dt)
+    net.load_state_dict(p)
+    return cfg, p, net
+
+
+@pytest.mark.parametrize("cfgkw,hw", [(SMALL, (64, 64)), (SMALL, (32, 96)), (WIDE, (64, 64))], ids=["small", "small-32x96", "wide"])
+def test_unet_forward_matches_oracle(cfgkw, hw):
+    """UNetModel.forward (ResBlocks with scale-shift norm and up / down resampling, legacy attention, virtual skip
+    concatenation, timestep MLP) against the oracle: f32 <= 1e-4 of the output's maximum, bf16 PSNR >= 40 dB; every
+    convolution route (LDS-direct kernel / split-K gather GEMM / generic kernel) gives the same f32 answer."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, *hw, generator=g)
+    t = torch.tensor([990.0, 120.0])
+    cfg, p, net = _build(cfgkw, torch.float32)
+    want = OD.unet_forward(p, cfg, x, t)
+    got = net(x, t)
+    assert rel(got, want) <= 1e-4
+    net.set_route(1)
+    assert rel(net(x, t), want) <= 1e-4
+    net.set_route(0)
+    one = net(x[1:], t[1:])                       # a sample does not depend on its batch neighbours
+    assert rel(one, want[1:]) <= 1e-4
+    _, _, net16 = _build(cfgkw, torch.bfloat16)
+    got16 = net16(x, t)
+    assert psnr(got16, want) >= 40.0, psnr(got16, want)
+    net16.set_route(1)
+    assert psnr(net16(x, t), want) >= 40.0
+
+
+def test_schedule_and_ddim_step_match_oracle():
+    """SpacedDiffusion("ddim100") tables, model timesteps, q_sample and one ddim step (with and without a conditioning
+    gradient) vs the oracle's float64 / float32 restatement."""
+    from maua_amd.diffusion import SpacedDiffusion, space_timesteps
+    sch = OD.Schedule(1000, "ddim100", True)
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim100"), OD.linear_betas(1000), rescale_timesteps=True)
+    assert sd.timestep_map == sch.timestep_map and sd.num_timesteps == 100
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod"):
+        assert np.array_equal(getattr(sd, name), getattr(sch, name)), name
+    t = torch.tensor([99, 37, 0])
+    assert torch.equal(sd.model_timesteps(t), sch.model_timesteps(t))
+    assert space_timesteps(1000, "100") == OD.space_timesteps(1000, "100") and len(space_timesteps(1000, "10,15,20")) == 45
+    g = torch.Generator().manual_seed(5)
+    x0, nz = torch.randn(3, 3, 16, 16, generator=g), torch.randn(3, 3, 16, 16, generator=g)
+    assert rel(sd.q_sample(x0, t, nz), OD.q_sample(sch, x0, t, nz)) <= 1e-6
+    mo, grad = torch.randn(3, 6, 16, 16, generator=g), 0.1 * torch.randn(3, 3, 16, 16, generator=g)
+
+    class Fixed:
+        def __call__(self, x, ts):
+            return mo.cuda()
+    for gr in (None, grad):
+        out = sd.ddim_sample(Fixed(), x0, t, cond_fn=None if gr is None else (lambda x, ts: gr.cuda()))
+        ws, wp = OD.ddim_step(sch, mo, x0, t, gr)
+        assert rel(out["sample"], ws) <= 2e-6 and rel(out["pred_xstart"], wp) <= 2e-6
+
+
+def test_guided_diffusion_forward_and_sampler_loop():
+    """GuidedDiffusion.forward with the reference's start / step arithmetic on a small UNet: the in-library loop (one
+    hipGraph), the eager step-by-step path and the oracle agree; a conditioning gradient (speed="hyper") changes the
+    result the way the oracle says."""
+    from maua_amd.diffusion import GuidedDiffusion, ImageTarget, MSEGuide, SpacedDiffusion, space_timesteps
+    cfg, p, net = _build(SMALL, torch.float32)
+    sch = OD.Schedule(1000, "ddim20", True)
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim20"), OD.linear_betas(1000), rescale_timesteps=True)
+    g = torch.Generator().manual_seed(9)
+    img, nz = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 3, 64, 64, generator=g)
+    gd = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd)
+    want = OD.guided_diffusion_forward(p, cfg, sch, img, 0.3, noise=nz)          # start_step 6, 13 steps: t = 6 .. -6
+    got = gd.forward(img, [], 0.3, noise=nz)
+    assert rel(got, want) <= 5e-4          # 13 chained network evaluations
+    again = gd.forward(img, [], 0.3, noise=nz)                                    # graph replay
+    assert torch.equal(got, again)
+    assert net.graph_active(), "the sampler loop did not capture into a hipGraph"
+    x = sd.q_sample(img, torch.tensor([6, 6]), nz)
+    eager = sd.ddim_sample_loop(net, x.clone(), 6, 13, use_graph=False)[1]
+    assert torch.equal(eager, got)
+    # conditioning
+    target = torch.randn(3, 64, 64, generator=g).clamp(-1, 1)
+    guide = MSEGuide(scale=500.0)
+    gdc = GuidedDiffusion([guide], timesteps=20, model=net, diffusion=sd, speed="hyper")
+
+    def cond_fn(x, ts):   # the oracle's restatement of guided.py:238-274 with speed "hyper"
+        idx = torch.tensor([sch.timestep_map.index(int(v)) for v in ts.long()])
+        a = torch.from_numpy(sch.sqrt_alphas_cumprod).float()[idx].reshape(-1, 1, 1, 1)
+        s = torch.from_numpy(sch.sqrt_one_minus_alphas_cumprod).float()[idx].reshape(-1, 1, 1, 1)
+        est = (x - s * nz) / a
+        return -(2.0 * 500.0 / est[0].numel()) * (est - target) / a
+    want_c = OD.guided_diffusion_forward(p, cfg, sch, img, 0.3, t_end=0.6, noise=nz, cond_fn=cond_fn)
+    got_c = gdc.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz)
+    assert rel(got_c, want_c) <= 5e-4
+    assert rel(got_c, OD.guided_diffusion_forward(p, cfg, sch, img, 0.3, t_end=0.6, noise=nz)) > 1e-3   # the gradient matters
+
+
+def test_onset_prompt_schedule_and_sample():
+    """configs[3]'s audio coupling: the active prompt advances at the onset peaks of the clip (bit-exact onset bins of the
+    render path), frames with the same prompt share a sampler batch; frames are reproducible from the seed."""
+    from maua_amd import audio as A
+    from maua_amd.diffusion import ImageTarget, MSEGuide, SpacedDiffusion, onset_prompt_schedule, sample, space_timesteps
+    from maua_amd.pipeline import synthetic_audio
+    from oracle import audio as OA, signal as OSG
+    fps, n = 30, 48
+    wav = synthetic_audio(n * 1024, 1024 * fps, seed=2)
+    idx = onset_prompt_schedule(wav, 1024 * fps, fps, 3)
+    env = OA.onsets(wav, 1024 * fps).squeeze(-1)
+    thr = OSG.percentile(env, 90)
+    peak = torch.zeros(n, dtype=torch.bool)
+    peak[1:-1] = (env[1:-1] > env[:-2]) & (env[1:-1] >= env[2:]) & (env[1:-1] > thr)
+    assert idx.dtype == torch.int64 and torch.equal(idx, torch.cumsum(peak.long(), 0) % 3) and int(idx.max()) >= 1
+    cfg, p, net = _build(SMALL, torch.bfloat16)
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim5"), OD.linear_betas(1000), rescale_timesteps=True)
+    g = torch.Generator().manual_seed(1)
+    prompts = [ImageTarget(torch.randn(3, 64, 64, generator=g).clamp(-1, 1)) for _ in range(3)]
+    a, ia = sample(prompts, wav, 1024 * fps, fps, n_frames=6, size=(64, 64), timesteps=5, model=net, diffusion=sd,
+                   grad_modules=[MSEGuide(100.0)], seed=4)
+    b, _ = sample(prompts, wav, 1024 * fps, fps, n_frames=6, size=(64, 64), timesteps=5, model=net, diffusion=sd,
+                  grad_modules=[MSEGuide(100.0)], seed=4)
+    assert tuple(a.shape) == (6, 3, 64, 64) and torch.equal(ia, idx[:6]) and torch.equal(a, b) and bool(torch.isfinite(a).all())
