@@ -464,7 +464,9 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   // 128-channel N tile: 64-byte K rows, two taps per stage, 75 KB -> two workgroups per CU (measured on the 256^2 layer,
   // K = 1152: 0.90 -> 0.65 ms against the same tile with 128-byte rows and one workgroup per CU; for the 256-channel
   // layers the two-workgroup shape measured the same as the big tile, which also keeps their toRGB fused)
-  if (a.Co % 256 == 0) return launch_dma_variant<2, 4, 4, 2, 1, 128>(stream, a);
+  // (a.variant == 128: the caller asks for the 128-channel tile although 256 would divide - twice the workgroups for
+  //  launches that would otherwise leave CUs idle, e.g. the diffusion UNet's 64^2 level at small batch)
+  if (a.Co % 256 == 0 && a.variant != 128) return launch_dma_variant<2, 4, 4, 2, 1, 128>(stream, a);
   return launch_dma_variant<4, 2, 2, 2, 2, 64>(stream, a);
 }
 

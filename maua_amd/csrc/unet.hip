@@ -236,6 +236,216 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
   if (xr) *reinterpret_cast<u32x4*>(xr + opix * C + c) = ro;
 }
 
+// ---- fast path (C / 32 channels per group a multiple of the 16-byte piece: every real layer of the network; the
+// per-channel kernels above serve narrow test networks).  Same arithmetic, organised for the memory system:
+//   * partial sums per GROUP, reduced inside the workgroup (LDS, fixed order) -> one row of 32 (sum, sumsq) pairs per
+//     pixel chunk; a finalize launch of B x 32 threads adds the <= 128 chunk rows;
+//   * the apply pass indexes (sample, row) by blockIdx.y and (pixel, piece) by 32-bit arithmetic, loads its piece's
+//     coefficients as float4s, and in bf16 mode uses the hardware exp / reciprocal for SiLU (exact in f32 mode).
+template <typename T>
+__global__ void gn_partial_group_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1, long HW, int ppc,
+                                        double* __restrict__ part) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ double red[2][1024];
+  const int C = C0 + C1, PPP = C / EPC;
+  const int pc = threadIdx.x % PPP, ry = threadIdx.x / PPP, RY = blockDim.x / PPP;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int c = pc * EPC;
+  const T* src;
+  long stride;
+  if (c < C0) { src = x0 + (long)b * HW * C0 + c; stride = C0; }
+  else { src = x1 + (long)b * HW * C1 + (c - C0); stride = C1; }
+  const long p0 = (long)chunk * ppc, p1 = p0 + ppc < HW ? p0 + ppc : HW;
+  double s = 0.0, ss = 0.0;
+  for (long p = p0 + ry; p < p1; p += RY) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + p * stride);
+    float fs = 0.f, fq = 0.f;   // 8 (4) values: exact enough in f32 before they join the f64 sums
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      float f;
+      if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+      else f = __uint_as_float(v[e]);
+      if constexpr (sizeof(T) == 2) { fs += f; fq = fmaf(f, f, fq); }
+      else { s += (double)f; ss += (double)f * (double)f; }
+    }
+    if constexpr (sizeof(T) == 2) { s += (double)fs; ss += (double)fq; }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int g = threadIdx.x, ppg = PPP / 32;
+    double ts = 0.0, tq = 0.0;
+    for (int r = 0; r < RY; r++)
+      for (int j = 0; j < ppg; j++) {
+        ts += red[0][r * PPP + g * ppg + j];
+        tq += red[1][r * PPP + g * ppg + j];
+      }
+    double* dst = part + (((long)b * gridDim.x + chunk) * 32 + g) * 2;
+    dst[0] = ts;
+    dst[1] = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_group_kernel(const double* __restrict__ part, int nchunk, double cnt,
+                                                                float eps, float* __restrict__ stats) {
+  // 32 groups x 8 lanes: lane j adds chunks j, j + 8, ... (independent loads in flight), then a fixed-order LDS tree
+  __shared__ double red[2][256];
+  const int g = threadIdx.x & 31, j = threadIdx.x >> 5, b = blockIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int k = j; k < nchunk; k += 8) {
+    const double* p = part + (((long)b * nchunk + k) * 32 + g) * 2;
+    s += p[0];
+    ss += p[1];
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (j == 0) {
+#pragma unroll
+    for (int q = 1; q < 8; q++) { s += red[0][q * 32 + g]; ss += red[1][q * 32 + g]; }
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)b * 32 + g) * 2] = (float)mean;
+    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_group_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ ss,
+                                                             long ss_ld, int silu, int mode, T* __restrict__ y,
+                                                             T* __restrict__ xr, int H, int W, int Ho, int Wo) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const unsigned C = C0 + C1, PPP = C / EPC, cpg = C / 32;
+  const unsigned li = blockIdx.x * 256u + threadIdx.x;
+  if (li >= (unsigned)Wo * PPP) return;
+  const unsigned ox = li / PPP, pc = li - ox * PPP;
+  const unsigned b = blockIdx.y / (unsigned)Ho, oy = blockIdx.y - b * (unsigned)Ho;
+  const unsigned c = pc * EPC;
+  const T* src;
+  unsigned stride;
+  if (c < (unsigned)C0) { src = x0 + (long)b * H * W * C0 + c; stride = C0; }
+  else { src = x1 + (long)b * H * W * C1 + (c - C0); stride = C1; }
+  const unsigned g = c / cpg;
+  const float2 mr = *reinterpret_cast<const float2*>(stats + ((long)b * 32 + g) * 2);
+  float ca[EPC], cb[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+  for (int q4 = 0; q4 < EPC / 4; q4++) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c + 4 * q4);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c + 4 * q4);
+    const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float sv[4] = {1.f, 1.f, 1.f, 1.f}, hv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ss) {
+      const float4 s4 = *reinterpret_cast<const float4*>(ss + (long)b * ss_ld + c + 4 * q4);
+      const float4 h4 = *reinterpret_cast<const float4*>(ss + (long)b * ss_ld + C + c + 4 * q4);
+      sv[0] = 1.f + s4.x; sv[1] = 1.f + s4.y; sv[2] = 1.f + s4.z; sv[3] = 1.f + s4.w;
+      hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = 4 * q4 + k;
+      ca[e] = mr.y * gv[k];
+      cb[e] = bv[k] - mr.x * ca[e];
+      sc[e] = sv[k];
+      sh[e] = hv[k];
+    }
+  }
+  float acc[EPC], raw[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e++) acc[e] = raw[e] = 0.f;
+  const int taps = mode == 1 ? 4 : 1;
+  for (int t = 0; t < taps; t++) {
+    unsigned iy, ix;
+    if (mode == 1) { iy = 2 * oy + (t >> 1); ix = 2 * ox + (t & 1); }
+    else if (mode == 2) { iy = oy >> 1; ix = ox >> 1; }
+    else { iy = oy; ix = ox; }
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(iy * (unsigned)W + ix) * stride);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      float f;
+      if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+      else f = __uint_as_float(v[e]);
+      raw[e] += f;
+      float u = fmaf(f, ca[e], cb[e]);
+      if (ss) u = fmaf(u, sc[e], sh[e]);
+      if (silu) {
+        if constexpr (sizeof(T) == 2) u = __fdividef(u, 1.f + __expf(-u));
+        else u = u / (1.f + expf(-u));
+      }
+      acc[e] += u;
+    }
+  }
+  const float norm = mode == 1 ? 0.25f : 1.f;
+  u32x4 o, ro;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      o[k] = pack2bf(acc[2 * k] * norm, acc[2 * k + 1] * norm);
+      ro[k] = pack2bf(raw[2 * k] * norm, raw[2 * k + 1] * norm);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { o[k] = __float_as_uint(acc[k] * norm); ro[k] = __float_as_uint(raw[k] * norm); }
+  }
+  const long opix = ((long)b * Ho + oy) * Wo + ox;
+  *reinterpret_cast<u32x4*>(y + opix * C + c) = o;
+  if (xr) *reinterpret_cast<u32x4*>(xr + opix * C + c) = ro;
+}
+
+// workspace (bytes) of one GroupNorm over [B][HW][C]: partial sums + the [B][32][2] statistics
+struct GnPlan { int fast, RY, ppc; long nchunk; size_t part_bytes; };
+static GnPlan gn_plan(int B, int C, long HW, int esize) {
+  GnPlan p;
+  const int EPC = 16 / esize, PPP = C / EPC, cpg = C / 32;
+  p.fast = cpg % EPC == 0 && PPP <= 1024;
+  p.RY = std::max(1, 512 / PPP);
+  long nchunk = HW / ((long)p.RY * 4);
+  nchunk = std::max(1L, std::min(128L, nchunk));
+  p.ppc = (int)((HW + nchunk - 1) / nchunk);
+  p.nchunk = (HW + p.ppc - 1) / p.ppc;
+  p.part_bytes = p.fast ? (size_t)B * p.nchunk * 32 * 16 : (size_t)B * p.nchunk * p.RY * C * 16;
+  return p;
+}
+
+// GroupNorm32 (+ scale-shift) (+ SiLU) (+ resample) of the virtually concatenated [x0 | x1]; part / stats: workspaces
+template <typename T>
+static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, int C1, int B, int H, int W,
+                             const float* gamma, const float* beta, const float* ss, long ss_ld, int silu, int mode, T* y, T* xr,
+                             double* part, float* stats) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int C = C0 + C1, PPP = C / EPC;
+  const long HW = (long)H * W;
+  MAUA_REQUIRE(C % 32 == 0 && PPP <= 1024 && C0 % EPC == 0, "group_norm: C % 32 == 0, at most 1024 16-byte pieces per pixel");
+  const GnPlan p = gn_plan(B, C, HW, (int)sizeof(T));
+  const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+  if (p.fast && (long)B * Ho <= 65535) {
+    hipLaunchKernelGGL(gn_partial_group_kernel<T>, dim3((unsigned)p.nchunk, B), dim3(PPP * p.RY), 0, st, x0, C0, x1, C1, HW,
+                       p.ppc, part);
+    hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
+                       stats);
+    hipLaunchKernelGGL(gn_apply_group_kernel<T>, dim3((unsigned)(((long)Wo * PPP + 255) / 256), (unsigned)(B * Ho)), dim3(256),
+                       0, st, x0, C0, x1, C1, stats, gamma, beta, ss, ss_ld, silu, mode, y, xr, H, W, Ho, Wo);
+  } else {
+    const GnPlan q = p.fast ? GnPlan{0, p.RY, p.ppc, p.nchunk, 0} : p;
+    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)q.nchunk, B), dim3(PPP * q.RY), 0, st, x0, C0, x1, C1, HW, q.ppc,
+                       part);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(q.nchunk * q.RY), C, HW, 1e-5f, stats);
+    const long total = (long)B * Ho * Wo * PPP;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x0, C0, x1, C1, stats, gamma,
+                       beta, ss, ss_ld, silu, mode, y, xr, B, H, W);
+  }
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+static size_t gn_part_bytes(int B, int C, long HW, int esize) {
+  // (the per-channel layout is the larger one and also serves the fall-back of a fast-path shape with too many rows)
+  const GnPlan p = gn_plan(B, C, HW, esize);
+  return std::max(p.part_bytes, (size_t)B * p.nchunk * p.RY * C * 16);
+}
+
 // ------------------------------------------------------------------------------------------------------ DDIM step
 // gaussian_diffusion.py ddim_sample for an epsilon-predicting model (clip_denoised False), in the reference's float32
 // operation order; coefficients per sample: cf[b] = {sqrt_recip_ac, sqrt_recipm1_ac, sqrt(1 - ac), sqrt(ac_prev),
@@ -533,7 +743,11 @@ struct Runner {
       const bool gather = ws_need > 0;
       // enough workgroups for the chip on the LDS-direct kernel (8 x 32 pixel tiles x N tiles of 256 / 128 / Co channels)?
       const long tiles = (long)B * (H / 8) * (W / 32);
-      const long dma_wgs = dma_wide ? tiles * (c.Cop % 256 == 0 ? c.Cop / 256 : c.Cop / 128) : tiles;
+      long dma_wgs = dma_wide ? tiles * (c.Cop % 256 == 0 ? c.Cop / 256 : c.Cop / 128) : tiles;
+      if (dma_wide && c.Cop % 256 == 0 && dma_wgs < 512) {  // fewer than two rounds of big tiles: 128-channel tiles, 2 per CU
+        a.variant = 128;
+        dma_wgs *= 2;
+      }
       if ((dma_wide || dma_narrow) && (dma_wgs >= 128 || !gather || n->route == 2)) return launch_modconv_dma(st, a);
       if (gather && n->route != 2) return launch_conv_gather(st, n->dtype, a, gather_ws);
       if (dma_wide || dma_narrow) return launch_modconv_dma(st, a);
@@ -542,37 +756,16 @@ struct Runner {
     return launch_modconv3x3(st, n->dtype, a);
   }
 
-  int gn_stats(const T* x0, int C0, const T* x1, int C1, long HW, float* stats) {
-    constexpr int EPC = 16 / (int)sizeof(T);
-    const int C = C0 + C1, PPP = C / EPC;
-    MAUA_REQUIRE(PPP <= 1024, "unet: GroupNorm over more than 1024 16-byte pieces per pixel");
-    const int RY = std::max(1, 512 / PPP);
-    long nchunk = HW / ((long)RY * 4);
-    nchunk = std::max(1L, std::min(128L, nchunk));
-    const int ppc = (int)((HW + nchunk - 1) / nchunk);
-    nchunk = (HW + ppc - 1) / ppc;
-    double* part = (double*)ar.get((size_t)B * nchunk * RY * C * 16);
-    if (plan) return MAUA_OK;
-    hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, x0, C0, x1, C1, HW, ppc, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
-    MAUA_HIP_CHECK(hipGetLastError());
-    return MAUA_OK;
-  }
-
   // GroupNorm (+ scale-shift) (+ SiLU) (+ resample) of [x0 | x1] -> y (dense, C0 + C1 channels); xr: resampled raw x0
   int gn(const UGN& g, const T* x0, int C0, const T* x1, int C1, int H, int W, const float* ss, int silu, int mode, T* y,
          T* xr) {
     const size_t mark = ar.top;
     float* stats = (float*)ar.get((size_t)B * 32 * 2 * 4);
-    int rc = gn_stats(x0, C0, x1, C1, (long)H * W, stats);
-    if (!rc && !plan) {
-      constexpr int EPC = 16 / (int)sizeof(T);
-      const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
-      const long total = (long)B * Ho * Wo * ((C0 + C1) / EPC);
-      hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x0, C0, x1, C1, stats,
-                         g.gamma, g.beta, ss, (long)n->emb_total, silu, mode, y, xr, B, H, W);
-      MAUA_HIP_CHECK(hipGetLastError());
-    }
+    double* part = (double*)ar.get(gn_part_bytes(B, C0 + C1, (long)H * W, (int)sizeof(T)));
+    int rc = MAUA_OK;
+    if (!plan)
+      rc = launch_group_norm<T>(st, x0, C0, x1, C1, B, H, W, g.gamma, g.beta, ss, (long)n->emb_total, silu, mode, y, xr, part,
+                                stats);
     ar.top = mark;
     return rc;
   }
@@ -954,36 +1147,15 @@ int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const
   MAUA_REQUIRE(ctx && x && gamma && beta && y, "maua_group_norm_nhwc: NULL argument");
   MAUA_REQUIRE(C % 32 == 0 && (dtype == MAUA_F32 || dtype == MAUA_BF16), "maua_group_norm_nhwc: C % 32, f32 / bf16");
   if (B == 0) return MAUA_OK;
-  const int epc = dtype == MAUA_BF16 ? 8 : 4, PPP = C / epc;
-  MAUA_REQUIRE(PPP <= 1024, "maua_group_norm_nhwc: too many channels");
-  const long HW = (long)H * W;
-  const int RY = std::max(1, 512 / PPP);
-  long nchunk = std::max(1L, std::min(128L, HW / ((long)RY * 4)));
-  const int ppc = (int)((HW + nchunk - 1) / nchunk);
-  nchunk = (HW + ppc - 1) / ppc;
-  const size_t part_bytes = (size_t)B * nchunk * RY * C * 16;
-  if (int rc = scratch_reserve(ctx, part_bytes + (size_t)B * 64 * 4 + 256)) return rc;
+  const size_t part_bytes = gn_part_bytes(B, C, (long)H * W, dtype == MAUA_BF16 ? 2 : 4);
+  if (int rc = scratch_reserve(ctx, part_bytes + (size_t)B * 64 * 4 + 512)) return rc;
   double* part = (double*)ctx->scratch;
   float* stats = (float*)((char*)ctx->scratch + ((part_bytes + 255) & ~(size_t)255));
-  hipStream_t st = ctx->stream;
-  const long total = (long)B * HW * PPP;
-  if (dtype == MAUA_BF16) {
-    hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, (const bf16_t*)x, C,
-                       (const bf16_t*)nullptr, 0, HW, ppc, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, C,
-                       (const bf16_t*)nullptr, 0, stats, gamma, beta, scale_shift, 2L * C, silu, 0, (bf16_t*)y,
-                       (bf16_t*)nullptr, B, H, W);
-  } else {
-    hipLaunchKernelGGL(gn_partial_kernel<float>, dim3((unsigned)nchunk, B), dim3(PPP * RY), 0, st, (const float*)x, C,
-                       (const float*)nullptr, 0, HW, ppc, part);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(nchunk * RY), C, HW, 1e-5f, stats);
-    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)x, C,
-                       (const float*)nullptr, 0, stats, gamma, beta, scale_shift, 2L * C, silu, 0, (float*)y,
-                       (float*)nullptr, B, H, W);
-  }
-  MAUA_HIP_CHECK(hipGetLastError());
-  return MAUA_OK;
+  if (dtype == MAUA_BF16)
+    return launch_group_norm<bf16_t>(ctx->stream, (const bf16_t*)x, C, nullptr, 0, B, H, W, gamma, beta, scale_shift, 2L * C,
+                                     silu, 0, (bf16_t*)y, nullptr, part, stats);
+  return launch_group_norm<float>(ctx->stream, (const float*)x, C, nullptr, 0, B, H, W, gamma, beta, scale_shift, 2L * C, silu,
+                                  0, (float*)y, nullptr, part, stats);
 }
 
 // The unconditioned sampler loop inside the library: n_steps x (UNet forward + DDIM update), x updated in place.
