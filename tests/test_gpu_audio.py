@@ -64,6 +64,76 @@ def test_stft_full_clip_properties():
     assert env.shape == (3600,) and float(env[0]) == 0.0 and float(env[1]) == 0.0
 
 
+def test_full_clip_onset_chain_and_bin_assignments_match_oracle():
+    """BASELINE configs[1], the WHOLE 120 s clip (3 686 400 samples, 3600 frames): HPSS -> onset envelope vs the oracle
+    (<= 2e-4 of a [0, 1] envelope), and every integer decision taken on it - peak masks, percentile_clip, the
+    select_modulo onset-bin assignment, the diffusion leg's prompt schedule - bit for bit against the oracle on the same
+    envelope.  (north_star: "bit-exact for frame indices and onset-bin assignments".)"""
+    import maua_amd.audio as A
+    import maua_amd.latent as LT
+    import maua_amd.signal as S
+    from maua_amd import _lib as L
+    from maua_amd.pipeline import synthetic_audio
+    sr, T = 30720, 3600
+    y = synthetic_audio(T * 1024, sr)
+    env_d = A.onsets(y, sr).squeeze(-1)
+    env_o = OA.onsets(y, sr).squeeze(-1)
+    assert env_d.shape == env_o.shape == (T,)
+    assert float((env_d.cpu() - env_o).abs().max()) <= 2e-4
+    assert float(env_d.min()) == 0.0 and float(env_d[0]) == 0.0 and float(env_d[1]) == 0.0   # left pad exact
+    e = env_d.cpu()
+    # onset-bin assignment of select_modulo for several palette sizes
+    for n_lat in (7, 30, 180):
+        assert torch.equal(LT.select_modulo_indices(n_lat, env_d).cpu(), OL.select_modulo_indices(n_lat, e)), n_lat
+    # peak mask + percentile_clip (k-th order statistic of the peaks, then clamp / max-normalise)
+    mask = torch.empty((T,), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().maua_peak_mask(L.ctx(), L.ptr(env_d.contiguous()), T, L.ptr(mask)))
+    assert torch.equal(mask.cpu().bool(), OS.peak_mask(e)) and 100 < int(mask.sum()) < T // 2
+    for pct in (95, 80, 50):
+        assert torch.equal(S.percentile_clip(env_d.clone(), pct).cpu(), OS.percentile_clip(e, pct)), pct
+        assert S.percentile(env_d, pct) == float(OS.percentile(e, pct))
+    # the same decisions taken by each side on its OWN envelope agree except at rounding boundaries of the 1e-6 envelope
+    # difference (reported, bounded)
+    own = (LT.select_modulo_indices(30, env_d).cpu() != OL.select_modulo_indices(30, env_o)).float().mean()
+    assert float(own) <= 0.01, float(own)
+    # rms of the whole clip (no HPSS): frame count exact, values <= 2e-6
+    r = A.rms(y, sr)
+    ro = OA.rms(y)
+    assert r.shape == ro.shape == (T, 1) and rel(r, ro) <= 2e-6
+    # percussive() itself, whole clip
+    assert rel(A.percussive(y), OA.percussive(y)) <= 2e-5
+
+
+def test_bench_latent_schedule_matches_oracle_on_a_frame_subset():
+    """bench.py's own latent schedule at T = 3600 (pipeline.synthetic_clip_latents: mapper -> two spline-loop schedules
+    blended by the full clip's onset envelope -> gaussian sigma 2) against the oracle composition, on a strided subset of
+    frames and layers."""
+    from maua_amd import pipeline
+    from maua_amd.stylegan2 import MappingNetwork, get_z_latents
+    from oracle import stylegan2 as OSG
+    T, fps, num_ws, w_dim = 3600, 30, 18, 512
+    lat, _ = pipeline.synthetic_clip_latents(T, fps, num_ws, w_dim)
+    assert tuple(lat.shape) == (T, num_ws, w_dim)
+    wav = pipeline.synthetic_audio(T * 1024, 1024 * fps)
+    env = OA.onsets(wav, 1024 * fps).squeeze(-1)
+    mp = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0)).state_dict()
+    pal = OSG.mapping_network(mp, get_z_latents("0-60", w_dim).float(), num_ws_=num_ws)
+    half = pal.shape[0] // 2
+    sub = (slice(None), slice(0, num_ws, 6), slice(0, w_dim, 64))              # layers 0 / 6 / 12, every 64th channel
+    low = OL.spline_loops(pal[:half][sub], T, 4)
+    high = OL.spline_loops(pal[half:2 * half][sub], T, 4)
+    blend = lambda e: low * (1 - e[:, None, None]) + high * e[:, None, None]   # latent.py:12-18 per frame
+    want = OA.gaussian_filter(blend(env), 2)
+    got = lat.cpu()[sub]
+    frames = torch.arange(0, T, 37)
+    assert rel(got[frames], want[frames]) <= 2e-4      # (the envelope itself is a 2e-4 comparison)
+    # with the DEVICE envelope in the oracle composition the schedule agrees to rounding
+    import maua_amd.audio as A
+    env_d = A.onsets(wav, 1024 * fps).squeeze(-1).cpu()
+    want_d = OA.gaussian_filter(blend(env_d), 2)
+    assert rel(got[frames], want_d[frames]) <= 5e-6
+
+
 def test_mel_onset(clip, golden):
     import maua_amd.audio as A
     sr = 30720
