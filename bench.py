@@ -47,6 +47,8 @@ def parse():
                          "activations are ~10 GB of the MI355X's 288 GB and amortise the low-resolution layers: +8 %% frames/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-oracle baseline leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the configs[3] (guided-diffusion DDIM) and configs[4] (render -> RealESRGAN x4) legs (extra keys)")
     return ap.parse_args()
 
 
@@ -138,25 +140,51 @@ def layer_table(net):
 
 
 def build_inputs(device, rank, world, seed=0):
-    """Everything that is resident in HBM before the render loop."""
+    """Everything that is resident in HBM before the render loop.  The two host-bound halves of the set-up - the network's
+    random init (one CPU generator, 23.6 M draws) + upload, and the clip's chain (synthetic waveform -> onset pre-pass ->
+    mapper -> latent schedule -> noise planes) - are independent and run side by side (torch's CPU kernels release the
+    GIL); the results do not depend on the interleaving (separate generators)."""
+    import threading
     from maua_amd.noise import Loop
     from maua_amd.stylegan2 import SynthesisNetwork
     from maua_amd import pipeline
 
-    net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(seed))
-    latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, net.num_ws, W_DIM)
+    from maua_amd import _lib as L
+    L.ctx(device)   # the per-device library context exists before the two threads use it
+    box = {}
+
+    def make_net():
+        torch.cuda.set_device(device)
+        net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(seed))
+        net._handle()
+        box["net"] = net
+    th = threading.Thread(target=make_net)
+    th.start()
+    latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)
     rng = torch.Generator().manual_seed(42)
     noise = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
+    th.join()
+    net = box["net"]
+    assert net.num_ws == 18
     return net, latents.to(device), noise, info
 
 
 def cpu_baseline(seconds):
     """The oracle (CPU restatement of the reference, fp32, PyTorch-CPU convs composed like ops.py) on the same
     workload, bounded: whole 1024^2 frames (B=1) until `seconds` of CPU time are spent (at least 1)."""
+    from oracle import audio as OA
     from oracle import noise as ON
     from oracle import stylegan2 as OS
+    from maua_amd.pipeline import synthetic_audio
     # oneDNN convolutions stop scaling (and regress) far below the 256 hardware threads of the GPU box's host
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    # the clip's audio pre-pass (SURVEY 8(d): once per clip - STFT, HPSS medians, iSTFT, mel, onset envelope of all
+    # 3 686 400 samples), timed on its own: it belongs to the CPU path's whole-clip time, not to its per-frame rate
+    ta = time.time()
+    wav = synthetic_audio(T_FRAMES * 1024, 1024 * FPS)
+    env = OA.onsets(wav, 1024 * FPS)
+    audio_s = time.time() - ta
+    assert env.shape[0] == T_FRAMES
     p = OS.init_synthesis_params(RES, generator=torch.Generator().manual_seed(0))
     g = torch.Generator().manual_seed(1)
     ws = torch.randn(1, OS.num_ws(RES), W_DIM, generator=g)
@@ -173,17 +201,21 @@ def cpu_baseline(seconds):
                 break
     dt = time.time() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpu_count": os.cpu_count(), "audio_prepass_s": audio_s,
+            "clip_seconds_extrapolated": audio_s + T_FRAMES / (n / dt),
             "threads_capped": torch.get_num_threads() < (os.cpu_count() or 1),
             "threads_note": "oneDNN convolutions stop scaling (and regress) well below the host's hardware threads; "
                             "32 threads measured fastest on the 256-thread host",
-            "sample": f"{n} frame(s) of the same 1024x1024 workload (B=1, fp32 oracle: noise + synthesis + u8), {dt:.1f} s"}
+            "sample": f"the whole clip's audio pre-pass once ({audio_s:.1f} s) + {n} frame(s) of the same 1024x1024 workload "
+                      f"(B=1, fp32 oracle: noise + synthesis + u8), {dt:.1f} s"}
 
 
 def measured_traffic(kernel_name, batch=None):
     """HBM bytes per launch measured with rocprofv3 --pmc in an EARLIER run of this same command: profiles/traffic.json,
     written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the corrections of
     MI355X_MICROARCH.md section HBM (FETCH_SIZE x2 on gfx950, KiB -> B).  The file records the frames per step it was
-    collected at; activations scale with the batch, so another `batch` is scaled linearly.  (None, reason) if absent."""
+    collected at; weights and halos do not scale with the batch, so a file collected at another batch is NOT used.
+    (None, reason) if absent."""
     p = Path(__file__).resolve().parent / "profiles" / "traffic.json"
     if not p.exists():
         return None, "profiles/traffic.json absent"
@@ -191,11 +223,74 @@ def measured_traffic(kernel_name, batch=None):
         v = json.loads(p.read_text()).get(kernel_name)
         if v is None:
             return None, "kernel not in profiles/traffic.json"
-        scale = (batch / v["batch"]) if (batch and v.get("batch")) else 1.0
-        return float(v["bytes_per_launch"]) * scale, \
-            "replayed from profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command)"
+        if batch and v.get("batch") and int(v["batch"]) != int(batch):
+            return None, f"profiles/traffic.json was collected at {v['batch']} frames per step, this run uses {batch}"
+        return float(v["bytes_per_launch"]), \
+            "replayed from profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command at " \
+            f"{v.get('batch', '?')} frames per step)"
     except Exception as e:
         return None, f"profiles/traffic.json unreadable: {e}"
+
+
+def extra_diffusion(batch=8, steps=100, size=256):
+    """configs[3]: guided-diffusion UNet (guided.py:171-190's architecture, random init), `steps`-step DDIM at `size`^2 -
+    one hipGraph per sampler loop; timed after one untimed loop.  Own roofline: algorithmic FLOPs of the UNet."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+    from bench_diffusion import unet_gflop
+    from maua_amd.diffusion import create_models
+    model, diffusion, _ = create_models("uncondImageNet256", f"ddim{steps}", allow_random_init=True,
+                                        generator=torch.Generator().manual_seed(0))
+    x = torch.randn(batch, 3, size, size, generator=torch.Generator().manual_seed(1)).cuda()
+    xs = x.clone()
+    diffusion.ddim_sample_loop(model, xs)          # capture + first replay (untimed)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):
+        xs.copy_(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, pred = diffusion.ddim_sample_loop(model, xs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    gf = unet_gflop(model, size, size)
+    tf = gf * batch * steps / best / 1e3
+    return {"metric": "samples/sec, guided-diffusion 256x256, 100-step DDIM (configs[3])", "value": batch / best, "unit": "samples/s",
+            "batch": batch, "steps": steps, "seconds_per_batch": best, "ms_per_step": best / steps * 1e3, "dtype": "bf16",
+            "data": "synthetic (random-init UNet of the reference's configuration, 552.8 M parameters)",
+            "hipgraph": model.graph_active(), "finite": bool(torch.isfinite(pred).all()),
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                         "gflop_per_forward_per_sample": gf, "traffic": None}}
+
+
+def extra_upscale(steps=3):
+    """configs[4], one GPU's slice: 1024^2 StyleGAN2 frame -> RealESRGAN x4 (23 RRDB blocks, random init) -> 4096^2 u8."""
+    from maua_amd.stylegan2 import SynthesisNetwork
+    from maua_amd.super import RRDBNet
+    G = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(0))
+    S = RRDBNet(num_block=23, dtype=torch.bfloat16)
+    ws = torch.randn(1, G.num_ws, W_DIM, generator=torch.Generator().manual_seed(1)).cuda()
+    img = torch.empty((1, 3, RES, RES), device="cuda")
+    u8 = torch.empty((1, 4 * RES, 4 * RES, 3), dtype=torch.uint8, device="cuda")
+
+    def step():
+        G(ws, out=img)
+        S(img.add(1).div(2).clamp_(0, 1), rgb8_out=u8)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    f, g = 64, 32
+    rdb = 9 * sum((f + k * g) * (f if k == 4 else g) for k in range(5))
+    macs_px = 23 * 3 * rdb + 9 * (3 * f + f * f) + 9 * f * f * 4 + 9 * f * f * 16 + 9 * f * f * 16 + 9 * f * 3 * 16
+    tf = 2 * macs_px * RES * RES / 1e12 / dt
+    return {"metric": "frames/sec per GPU, 1024^2 StyleGAN2 render -> RealESRGAN x4 -> 4096^2 u8 (configs[4], one GPU's slice)",
+            "value": 1.0 / dt, "unit": "frames/s", "ms_per_frame": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                         "traffic": None}}
 
 
 def main():
@@ -273,32 +368,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- clip leg: this rank's whole frame range once (3600 / N frames, ceil((hi - lo) / B) steps), frames kept
-    # resident; then the ONE gather of the u8 shards to rank 0 (RCCL over xGMI) - the real end of a sharded render
+    # ---- clip leg: this rank's whole frame range once (3600 / N frames, ceil((hi - lo) / B) steps) into a resident
+    # buffer, the u8 shards travelling to rank 0 CHUNK BY CHUNK on a side stream while the next batch renders (RCCL
+    # point-to-point over xGMI, distributed.StreamingGather) - the real end of a sharded render.  `sustained` = until
+    # every rank has rendered its range; `gather_ms` = what is left of the exchange after that (the non-overlapped rest)
     del out_u8
+    from maua_amd.distributed import StreamingGather
     n_local = hi - lo
-    shard = torch.empty((n_local, RES, RES, 3), dtype=torch.uint8, device=device)
+    fence()
+    sg = StreamingGather(T_FRAMES, (RES, RES, 3), B, dtype=torch.uint8, device=device, rank=rank, world=world)
     fence()
     tc = time.perf_counter()
-    for i in range(lo, hi, B):
-        b = min(B, hi - i)
-        net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=shard[i - lo:i - lo + b])
-    fence()
+    for off, b in sg.chunks():
+        i = lo + off
+        net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=sg.local[off:off + b])
+        sg.chunk_done()
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(device))
+    done.synchronize()                      # the render stream only: the side stream may still be sending
     clip_s = time.perf_counter() - tc
+    full = sg.finish()
+    fence()
+    total_s = time.perf_counter() - tc
     gather_ms = None
     if dist is not None:
-        from maua_amd.distributed import gather_frames
-        t = torch.tensor([clip_s], device=device, dtype=torch.float64)
+        t = torch.tensor([clip_s, total_s], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        clip_s = float(t.item())
-        fence()
-        tg = time.perf_counter()
-        full = gather_frames(shard, T_FRAMES, rank, world)
-        fence()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        if rank == 0:
-            assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
-        del full
+        clip_s, total_s = float(t[0].item()), float(t[1].item())
+        gather_ms = max(0.0, total_s - clip_s) * 1e3
+    if rank == 0:
+        assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
+    del full, sg
 
     if rank == 0:
         frames = world * B * a.steps
@@ -335,6 +435,14 @@ def main():
         traffic, traffic_source = measured_traffic(dom, B)
         roof.update({"kernel": dom, "avg_launch_ms": gd["ms"] / gd["launches"], "launches_timed": gd["launches"],
                      "traffic": traffic, "traffic_source": traffic_source})
+        # the whole step against both roofs: algorithmic FLOPs / bytes of every launch of the forward (+ the noise maps the
+        # step writes and the synthesis reads: 2 x 4 B x sum of the 17 map sizes per frame) over the step's wall time
+        step_gflop = sum(r[2] for r in rows) * B
+        step_bytes = (sum(r[3] for r in rows) + 8 * sum(sz * sz for sz in NOISE_SIZES)) * B
+        step_ms = elapsed / a.steps * 1e3
+        roof["whole_step"] = {"tflops": step_gflop / step_ms, "frac_mfma": step_gflop / step_ms / MFMA_BF16_PEAK_TF,
+                              "gbs": step_bytes / step_ms / 1e6, "frac_hbm": step_bytes / step_ms / 1e6 / HBM_PEAK_GBS,
+                              "gflop_per_frame": step_gflop / B, "bytes_per_frame": step_bytes / B}
         res = {
             "metric": "frames/sec (whole node), 1024x1024 StyleGAN2 audio-reactive render",
             "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -357,6 +465,17 @@ def main():
                                 "noise planes, render + u8 pack of every frame, gather (N > 1); excludes the HIP "
                                 "context / first import"},
         }
+        res["config"]["gather"] = "streamed: finished chunks of frames_per_step frames travel to rank 0 on a side stream during the render"
+        if world == 1 and not a.no_extras:
+            # the other single-GPU BASELINE configs, as extra keys (each with its own metric / roofline; never part of `value`)
+            del latents, noise
+            net._destroy()
+            torch.cuda.empty_cache()
+            for key, fn in (("diffusion", extra_diffusion), ("upscale", extra_upscale)):
+                try:
+                    res[key] = fn()
+                except Exception as e:   # an extra leg must not take the headline line down with it
+                    res[key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(res))

@@ -41,6 +41,7 @@ typedef struct maua_ctx maua_ctx;
 typedef struct maua_synth maua_synth;
 typedef struct maua_rrdbnet maua_rrdbnet;
 typedef struct maua_unet maua_unet;
+typedef struct maua_srvgg maua_srvgg;
 
 /* ---- context (library plumbing: no reference counterpart — the reference relies on torch's current device and
  * stream; a maua_ctx carries exactly that: device ordinal, HIP stream, a scratch arena) --------------------------- */
@@ -339,6 +340,21 @@ int maua_rrdb_load(maua_rrdbnet* net, const char* name, const float* host_data, 
 /* img: device f32 [B][3][H][W] in [0,1].  out_nchw: device f32 [B][3][4H][4W] clamped to [0,1] (or NULL);
  * out_rgb8: device u8 [B][4H][4W][3] = round(clamp * 255) (or NULL). */
 int maua_rrdb_forward(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, float* out_nchw, uint8_t* out_rgb8);
+/* the RRDB forward without the [0,1] clamp on out_nchw (RealESRGANer clamps AFTER its tile stitching / pre-pad crop; the
+ * u8 output is always clamped).  clamp01 = 1 is maua_rrdb_forward. */
+int maua_rrdb_forward_ex(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
+                         uint8_t* out_rgb8);
+
+/* ---- N4: the "xsx4-animevideo" model of realesrgan.py:34-35: realesrgan's SRVGGNetCompact(3, 3, num_feat, num_conv,
+ * upscale, act_type) - convolutions + PReLU, PixelShuffle, + nearest-upsampled input (un-vendored: published architecture).
+ * act_type: 0 prelu, 1 relu, 2 leakyrelu(0.1).  Parameter names: body.<2k>.weight / .bias, body.<2k+1>.weight (PReLU). */
+int maua_srvgg_create(maua_ctx* ctx, int num_feat, int num_conv, int upscale, int act_type, int dtype, maua_srvgg** out);
+void maua_srvgg_destroy(maua_srvgg* net);
+int maua_srvgg_load(maua_srvgg* net, const char* name, const float* host_data, size_t count);
+/* img device f32 [B][3][H][W]; out_nchw device f32 [B][3][sH][sW] (clamped to [0,1] when clamp01) or NULL; out_rgb8 device u8
+ * [B][sH][sW][3] = round(clamp * 255) or NULL */
+int maua_srvgg_forward(maua_srvgg* net, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
+                       uint8_t* out_rgb8);
 
 /* ---- N4 (second half): guided-diffusion UNet + DDIM, BASELINE configs[3] "guided-diffusion 256x256, 100-step DDIM" ------
  * replaces the network maua/diffusion/processors/guided.py:164-209 create_models builds (guided_diffusion.script_util.
@@ -407,6 +423,11 @@ int maua_comm_unique_id(maua_comm_id* id);
 int maua_comm_init(maua_ctx* ctx, const maua_comm_id* id, int rank, int world, maua_comm** out);
 /* bytes_per_rank [world]: shard sizes (host array); send: this rank's shard (device); recv: root only, sum of the sizes. */
 int maua_gather_frames(maua_comm* comm, const uint8_t* send, const long* bytes_per_rank, uint8_t* recv, int root);
+/* one round of the STREAMED gather: rank r's piece (bytes_per_rank[r] bytes; 0 = not in this round) lands at byte
+ * offsets_per_rank[r] of the root's clip buffer recv_base - the k-th finished chunk of every rank, sent on a side stream
+ * while chunk k + 1 renders, so the root's ingress hides behind the render.  The root's own piece is not moved. */
+int maua_gather_frames_at(maua_comm* comm, const uint8_t* send, const long* bytes_per_rank, uint8_t* recv_base,
+                          const long* offsets_per_rank, int root);
 int maua_comm_destroy(maua_comm* comm);
 
 #ifdef __cplusplus

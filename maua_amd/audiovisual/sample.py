@@ -5,7 +5,7 @@ Audio is resampled to sr = 1024*fps so that one STFT hop == one video frame.  Fe
 spectral_contrast, spectral_flatness, rms, drop_strength, onsets).  The tempo is estimated from the onset envelope (the autocorrelation-tempogram estimate the
 reference takes from librosa), beats by librosa's published dynamic program and the beat-synchronous Laplacian segmentations
 by maua_amd.segment (device kernels; librosa / torch_geometric / sklearn are un-vendored).  Frames are sharded by contiguous range over the ranks of the current process group and gathered to
-rank 0 with one RCCL gather at the end.
+rank 0 chunk by chunk while the next batch renders (distributed.StreamingGather: RCCL point-to-point over xGMI).
 
     python -m maua_amd.audiovisual.sample --audio_file clip.wav --stylegan2_checkpoint None --downscale_factor 4
 """
@@ -22,7 +22,7 @@ from .. import latent as LT
 from .. import noise as N
 from .. import segment as SG
 from ..audio_io import load_audio
-from ..distributed import gather_frames, world_info
+from ..distributed import StreamingGather, world_info
 from ..pipeline import frame_range
 from ..stylegan2 import StyleGAN2
 from ..video import VideoWriter
@@ -182,12 +182,16 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     # the network renders output_size rounded to the resize layer's multiple (wrappers/stylegan2.py:115-120); the
     # reference writes those frames into a writer opened at out_size — here they are resampled to out_size first
     rh, rw = G.synthesizer.G_synth.output_hw
-    local = torch.empty((hi - lo, rh, rw, 3), dtype=torch.uint8, device="cuda")
-    for i in range(lo, hi, batch_size):
-        b = min(batch_size, hi - i)
+    # frames travel to rank 0 chunk by chunk while the next batch renders (RCCL point-to-point over xGMI; rank 0 renders
+    # straight into the clip buffer)
+    sg = StreamingGather(T, (rh, rw, 3), batch_size, dtype=torch.uint8, device="cuda", rank=rank, world=world)
+    assert (sg.lo, sg.hi) == (lo, hi)
+    for off, b in sg.chunks():
+        i = lo + off
         nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
-        G.synthesizer(latents=latents[i:i + b], rgb8_out=local[i - lo:i - lo + b], **nz)
-    frames = gather_frames(local, T, rank, world)  # one RCCL gather at the end (rank 0 receives)
+        G.synthesizer(latents=latents[i:i + b], rgb8_out=sg.local[off:off + b], **nz)
+        sg.chunk_done()
+    frames = sg.finish()
     if rank == 0:
         wav = audio_file if str(audio_file).lower().endswith(".wav") else None
         with VideoWriter(out_file, out_size, fps, wav, audio_offset, audio_duration) as video:

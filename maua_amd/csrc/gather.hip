@@ -130,4 +130,38 @@ int maua_gather_frames(maua_comm* comm, const uint8_t* send, const long* bytes_p
   return MAUA_OK;
 }
 
+// One ROUND of the streamed gather: like maua_gather_frames, but every rank's piece lands at its own byte offset of the
+// root's clip buffer (offsets_per_rank) - the pieces of a round are the k-th finished chunk of every rank, which are not
+// adjacent in the clip.  Ranks with bytes_per_rank[r] == 0 take no part in the round.  The root's own piece is not moved
+// (the root renders straight into the clip buffer).  Called on a side stream while the next chunk renders.
+int maua_gather_frames_at(maua_comm* comm, const uint8_t* send, const long* bytes_per_rank, uint8_t* recv_base,
+                          const long* offsets_per_rank, int root) {
+  MAUA_REQUIRE(comm && bytes_per_rank && offsets_per_rank, "maua_gather_frames_at: NULL argument");
+  MAUA_REQUIRE(root >= 0 && root < comm->world, "maua_gather_frames_at: root outside [0, world)");
+  const long mine = bytes_per_rank[comm->rank];
+  hipStream_t st = comm->ctx->stream;
+  if (comm->rank != root) {
+    if (mine <= 0) return MAUA_OK;
+    MAUA_REQUIRE(send, "maua_gather_frames_at: this rank's piece is missing");
+    if (int rc = g_rccl.send(send, (size_t)mine, /*ncclUint8*/ 1, root, comm->comm, st)) return rccl_fail("ncclSend", rc);
+    return MAUA_OK;
+  }
+  MAUA_REQUIRE(recv_base, "maua_gather_frames_at: the root needs the clip buffer");
+  bool any = false;
+  for (int r = 0; r < comm->world; r++) any = any || (r != root && bytes_per_rank[r] > 0);
+  if (!any) return MAUA_OK;
+  if (int rc = g_rccl.group_start()) return rccl_fail("ncclGroupStart", rc);
+  for (int r = 0; r < comm->world; r++) {
+    const long n = bytes_per_rank[r];
+    if (n <= 0 || r == root) continue;
+    if (offsets_per_rank[r] < 0) { g_rccl.group_end(); return maua::fail("maua_gather_frames_at: negative offset"); }
+    if (int rc = g_rccl.recv(recv_base + offsets_per_rank[r], (size_t)n, 1, r, comm->comm, st)) {
+      g_rccl.group_end();
+      return rccl_fail("ncclRecv", rc);
+    }
+  }
+  if (int rc = g_rccl.group_end()) return rccl_fail("ncclGroupEnd", rc);
+  return MAUA_OK;
+}
+
 }  // extern "C"

@@ -44,6 +44,7 @@ struct ConvArgs {
   const void* res;        // optional residual added after activation / gain / clamp: NHWC, res_pstride elements per pixel
   int res_pstride;
   long res_bstride;
+  const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);

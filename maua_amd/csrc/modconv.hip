@@ -275,7 +275,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   // lrelu / linear (every synthesis layer): positively homogeneous, so the gain is folded into the coefficients,
   // act(acc*d + nz + b)*g == act(acc*(d*g) + (nz + b)*g); other activations keep the reference order of operations
   const float alpha = a.act == MAUA_ACT_LINEAR ? 1.f : a.alpha;
-  const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f;
+  const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f && !a.prelu;
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
 #pragma unroll
   for (int i = 0; i < WM; i++) {
@@ -307,6 +307,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
             float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
             t = fmaxf(t, t * alpha);
             v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+          }
+        } else if (a.prelu) {  // PReLU: per-channel slope on the negative side
+          const float4 pv = *reinterpret_cast<const float4*>(a.prelu + co);
+          const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            float t = acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k];
+            t = (t >= 0.f ? t : t * pp[k]) * a.gain;
+            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+            v[k] = t;
           }
         } else {
 #pragma unroll

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void upsample2_nearest_nhwc_kernel(const T* __
 // final image: NHWC network dtype (first 3 of Cp channels) -> planar f32 [B][3][H][W] and / or u8 HWC, clamped to [0,1]
 // (RealESRGANer.enhance: output.clamp_(0, 1), then (x * 255).round() for 8-bit images)
 template <typename T>
-__global__ __launch_bounds__(256) void rrdb_output_kernel(const T* __restrict__ x, int Cp, long HW, int B,
+__global__ __launch_bounds__(256) void rrdb_output_kernel(const T* __restrict__ x, int Cp, long HW, int B, int do_clamp,
                                                           float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * HW) return;
@@ -89,9 +89,8 @@ __global__ __launch_bounds__(256) void rrdb_output_kernel(const T* __restrict__ 
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     float v = Elem<T>::load(x + idx * Cp + c);
-    v = fminf(fmaxf(v, 0.f), 1.f);
-    if (out_f32) out_f32[(b * 3 + c) * HW + p] = v;
-    if (out_u8) out_u8[idx * 3 + c] = (uint8_t)__float2int_rn(v * 255.0f);
+    if (out_f32) out_f32[(b * 3 + c) * HW + p] = do_clamp ? fminf(fmaxf(v, 0.f), 1.f) : v;
+    if (out_u8) out_u8[idx * 3 + c] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
   }
 }
 
@@ -225,7 +224,7 @@ int maua_rrdb_load(maua_rrdbnet* n, const char* name, const float* host, size_t 
 namespace {
 
 template <typename T>
-int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, float* out_f32, uint8_t* out_u8) {
+int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_clamp, float* out_f32, uint8_t* out_u8) {
   hipStream_t st = n->ctx->stream;
   const int F = n->num_feat, G = n->grow, D = F + 4 * G;
   const size_t es = n->esize;
@@ -317,19 +316,210 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, float* out
   if ((rc = conv(n->conv_last, n->f4, F, n->f5, 32, 0, 4 * H, 4 * W, false, 1.f, nullptr, 0))) return rc;
   const long opx = (long)B * 16 * H * W;
   hipLaunchKernelGGL(rrdb_output_kernel<T>, dim3((unsigned)((opx + 255) / 256)), dim3(256), 0, st, (const T*)n->f5, 32,
-                     (long)16 * H * W, B, out_f32, out_u8);
+                     (long)16 * H * W, B, do_clamp, out_f32, out_u8);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 
 }  // namespace
 
-extern "C" int maua_rrdb_forward(maua_rrdbnet* n, const float* img_nchw, int B, int H, int W, float* out_nchw,
-                                 uint8_t* out_rgb8) {
+extern "C" int maua_rrdb_forward_ex(maua_rrdbnet* n, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
+                                    uint8_t* out_rgb8) {
   MAUA_REQUIRE(n && img_nchw, "maua_rrdb_forward: NULL argument");
   MAUA_REQUIRE(out_nchw || out_rgb8, "maua_rrdb_forward: no output buffer");
   MAUA_REQUIRE(B >= 0 && H > 0 && W > 0, "maua_rrdb_forward: bad shape");
   if (B == 0) return MAUA_OK;
-  return n->dtype == MAUA_BF16 ? forward_t<bf16_t>(n, img_nchw, B, H, W, out_nchw, out_rgb8)
-                               : forward_t<float>(n, img_nchw, B, H, W, out_nchw, out_rgb8);
+  return n->dtype == MAUA_BF16 ? forward_t<bf16_t>(n, img_nchw, B, H, W, clamp01, out_nchw, out_rgb8)
+                               : forward_t<float>(n, img_nchw, B, H, W, clamp01, out_nchw, out_rgb8);
+}
+extern "C" int maua_rrdb_forward(maua_rrdbnet* n, const float* img_nchw, int B, int H, int W, float* out_nchw,
+                                 uint8_t* out_rgb8) {
+  return maua_rrdb_forward_ex(n, img_nchw, B, H, W, 1, out_nchw, out_rgb8);
+}
+
+// ================================================================================================ SRVGGNetCompact
+// Replaces (reference): maua/super/image/models/realesrgan.py:34-35 - the "xsx4-animevideo" model,
+// realesrgan.archs.srvgg_arch.SRVGGNetCompact(3, 3, num_feat 64, num_conv 16, upscale 4, act_type "prelu") (un-vendored:
+// published architecture, oracle/super.py restates it; parity unpinned):
+//     out = conv_last(act(conv_k(... act(conv_0(x))))) -> PixelShuffle(upscale) -> + nearest_upsample(x, upscale)
+// Every convolution runs on the MFMA conv kernels with the PReLU slopes in the epilogue (ConvArgs.prelu); the pixel shuffle,
+// the nearest-neighbour base image, the clamp and the u8 pack are ONE output pass over the last convolution's NHWC tile.
+namespace {
+
+// y[c][s y + dy][s x + dx] = feat[y][x][c s^2 + dy s + dx] + img[c][y][x]   (PixelShuffle + F.interpolate(nearest))
+template <typename T>
+__global__ __launch_bounds__(256) void srvgg_output_kernel(const T* __restrict__ feat, int Cp, const float* __restrict__ img,
+                                                           int B, int H, int W, int S, int do_clamp,
+                                                           float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+  const long Ho = (long)H * S, Wo = (long)W * S;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo) return;
+  const int ox = (int)(idx % Wo);
+  const long t = idx / Wo;
+  const int oy = (int)(t % Ho), b = (int)(t / Ho);
+  const int x = ox / S, dx = ox - x * S, y = oy / S, dy = oy - y * S;
+  const T* fp = feat + (((long)b * H + y) * W + x) * Cp;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float v = Elem<T>::load(fp + c * S * S + dy * S + dx) + img[(((long)b * 3 + c) * H + y) * W + x];
+    if (do_clamp) v = fminf(fmaxf(v, 0.f), 1.f);
+    if (out_f32) out_f32[(((long)b * 3 + c) * Ho + oy) * Wo + ox] = v;
+    if (out_u8) out_u8[idx * 3 + c] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
+  }
+}
+
+}  // namespace
+
+struct maua_srvgg {
+  maua_ctx* ctx;
+  int num_feat, num_conv, upscale, dtype, act;  // act: 0 prelu, 1 relu, 2 leakyrelu(0.1)
+  size_t esize;
+  std::vector<PlainConv> convs;   // num_conv + 2
+  std::vector<float*> slopes;     // num_conv + 1 PReLU vectors [num_feat]
+  float* ones = nullptr;
+  int ones_b = 0;
+  size_t cap_px = 0;
+  void *in32 = nullptr, *fa = nullptr, *fb = nullptr, *flast = nullptr;
+};
+
+extern "C" {
+
+int maua_srvgg_create(maua_ctx* ctx, int num_feat, int num_conv, int upscale, int act_type, int dtype, maua_srvgg** out) {
+  MAUA_REQUIRE(ctx && out, "maua_srvgg_create: NULL argument");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_srvgg_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(num_feat > 0 && num_feat % 32 == 0 && num_conv >= 0 && upscale >= 1 && 3 * upscale * upscale <= 64,
+               "maua_srvgg_create: num_feat % 32 == 0, upscale <= 4");
+  MAUA_REQUIRE(act_type >= 0 && act_type <= 2, "maua_srvgg_create: act_type 0 prelu / 1 relu / 2 leakyrelu");
+  maua_srvgg* n = new maua_srvgg();
+  n->ctx = ctx; n->num_feat = num_feat; n->num_conv = num_conv; n->upscale = upscale; n->dtype = dtype; n->act = act_type;
+  n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  n->convs.resize((size_t)num_conv + 2);
+  int rc = alloc_conv(n->convs[0], 3, num_feat, n->esize);
+  for (int i = 1; i <= num_conv && !rc; i++) rc = alloc_conv(n->convs[i], num_feat, num_feat, n->esize);
+  if (!rc) rc = alloc_conv(n->convs[num_conv + 1], num_feat, 3 * upscale * upscale, n->esize);
+  n->slopes.assign((size_t)num_conv + 1, nullptr);
+  for (auto& p : n->slopes) {
+    if (rc) break;
+    if (hipMalloc((void**)&p, (size_t)num_feat * 4) != hipSuccess) { rc = fail("maua_srvgg_create: out of memory"); break; }
+    std::vector<float> init((size_t)num_feat, 0.25f);   // nn.PReLU's default slope
+    hipMemcpy(p, init.data(), init.size() * 4, hipMemcpyHostToDevice);
+  }
+  if (rc) {
+    maua_srvgg_destroy(n);
+    return rc;
+  }
+  *out = n;
+  return MAUA_OK;
+}
+
+void maua_srvgg_destroy(maua_srvgg* n) {
+  if (!n) return;
+  hipStreamSynchronize(n->ctx->stream);
+  for (auto& c : n->convs) {
+    if (c.wt) hipFree(c.wt);
+    if (c.bias) hipFree(c.bias);
+  }
+  for (float* p : n->slopes)
+    if (p) hipFree(p);
+  for (void* p : {n->in32, n->fa, n->fb, n->flast, (void*)n->ones})
+    if (p) hipFree(p);
+  delete n;
+}
+
+// name: a key of SRVGGNetCompact's state dict: body.<2k>.weight / .bias (convolutions), body.<2k+1>.weight (PReLU slopes)
+int maua_srvgg_load(maua_srvgg* n, const char* name, const float* host, size_t count) {
+  MAUA_REQUIRE(n && name && host, "maua_srvgg_load: NULL argument");
+  int idx = -1;
+  char par[16] = {0};
+  if (sscanf(name, "body.%d.%15s", &idx, par) != 2 || idx < 0 || idx > 2 * (n->num_conv + 1))
+    return fail(std::string("maua_srvgg_load: unknown parameter name: ") + name);
+  hipStream_t st = n->ctx->stream;
+  if (idx & 1) {  // activation module
+    if (strcmp(par, "weight") || n->act != 0) return fail(std::string("maua_srvgg_load: unknown parameter name: ") + name);
+    if (count != (size_t)n->num_feat) return fail(std::string("maua_srvgg_load: ") + name + ": wrong size");
+    MAUA_HIP_CHECK(hipMemcpy(n->slopes[idx / 2], host, count * 4, hipMemcpyHostToDevice));
+    return MAUA_OK;
+  }
+  PlainConv& c = n->convs[idx / 2];
+  if (!strcmp(par, "bias")) {
+    if (count != (size_t)c.Co) return fail(std::string("maua_srvgg_load: ") + name + ": wrong size");
+    MAUA_HIP_CHECK(hipMemcpy(c.bias, host, count * 4, hipMemcpyHostToDevice));
+    return MAUA_OK;
+  }
+  if (strcmp(par, "weight")) return fail(std::string("maua_srvgg_load: unknown parameter name: ") + name);
+  if (count != (size_t)c.Co * c.Ci * 9) return fail(std::string("maua_srvgg_load: ") + name + ": wrong size");
+  float* tmp;
+  MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+  MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+  MAUA_HIP_CHECK(hipMemsetAsync(c.wt, 0, (size_t)9 * c.Cop * c.Cip * n->esize, st));
+  int rc = launch_prep_weights(st, n->dtype, tmp, c.wt, nullptr, c.Co, c.Ci, 3, 1, 0, c.Cop, c.Cip);
+  hipStreamSynchronize(st);
+  hipFree(tmp);
+  return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+template <typename T>
+int srvgg_forward_t(maua_srvgg* n, const float* img, int B, int H, int W, int do_clamp, float* out_f32, uint8_t* out_u8) {
+  hipStream_t st = n->ctx->stream;
+  const int F = n->num_feat;
+  const size_t es = n->esize, px = (size_t)B * H * W;
+  const int CL = n->convs.back().Cop;
+  if (px > n->cap_px) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    for (void** p : {&n->in32, &n->fa, &n->fb, &n->flast}) { if (*p) hipFree(*p); *p = nullptr; }
+    MAUA_HIP_CHECK(hipMalloc(&n->in32, px * 32 * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->fa, px * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->fb, px * F * es));
+    MAUA_HIP_CHECK(hipMalloc(&n->flast, px * CL * es));
+    n->cap_px = px;
+  }
+  if (B > n->ones_b) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    if (n->ones) hipFree(n->ones);
+    std::vector<float> h((size_t)B * std::max(F, 32), 1.f);
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->ones, h.size() * 4));
+    MAUA_HIP_CHECK(hipMemcpy(n->ones, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    n->ones_b = B;
+  }
+  auto conv = [&](const PlainConv& c, const void* x, void* y, const float* slopes, bool activated) -> int {
+    ConvArgs a{};
+    a.x = x; a.x_bstride = (long)H * W * c.Cip; a.w = c.wt; a.s = n->ones; a.bias = c.bias; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1; a.gain = 1.f; a.clamp = -1.f; a.alpha = 0.1f;
+    a.act = !activated ? MAUA_ACT_LINEAR : (n->act == 1 ? MAUA_ACT_RELU : MAUA_ACT_LRELU);
+    a.prelu = activated && n->act == 0 ? slopes : nullptr;
+    if (dma_conv_narrow_supported(n->dtype, c.Cip, c.Cop, H, W)) return launch_modconv_dma(st, a);
+    return launch_modconv3x3(st, n->dtype, a);
+  };
+  int rc = launch_nchw_to_nhwc<float, T>(st, img, n->in32, B, 3, H * W, 32);
+  if (rc) return rc;
+  if ((rc = conv(n->convs[0], n->in32, n->fa, n->slopes[0], true))) return rc;
+  void *cur = n->fa, *nxt = n->fb;
+  for (int i = 1; i <= n->num_conv; i++) {
+    if ((rc = conv(n->convs[i], cur, nxt, n->slopes[i], true))) return rc;
+    std::swap(cur, nxt);
+  }
+  if ((rc = conv(n->convs[n->num_conv + 1], cur, n->flast, nullptr, false))) return rc;
+  const long total = (long)B * H * W * n->upscale * n->upscale;
+  hipLaunchKernelGGL(srvgg_output_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const T*)n->flast, CL, img,
+                     B, H, W, n->upscale, do_clamp, out_f32, out_u8);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+}  // namespace
+
+// img: device f32 [B][3][H][W]; out_nchw: device f32 [B][3][sH][sW] (the network's raw output; clamped to [0,1] when clamp01) or
+// NULL; out_rgb8: device u8 [B][sH][sW][3] = round(clamp(y, 0, 1) * 255) or NULL
+extern "C" int maua_srvgg_forward(maua_srvgg* n, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
+                                  uint8_t* out_rgb8) {
+  MAUA_REQUIRE(n && img_nchw, "maua_srvgg_forward: NULL argument");
+  MAUA_REQUIRE(out_nchw || out_rgb8, "maua_srvgg_forward: no output buffer");
+  MAUA_REQUIRE(B >= 0 && H > 0 && W > 0, "maua_srvgg_forward: bad shape");
+  if (B == 0) return MAUA_OK;
+  return n->dtype == MAUA_BF16 ? srvgg_forward_t<bf16_t>(n, img_nchw, B, H, W, clamp01, out_nchw, out_rgb8)
+                               : srvgg_forward_t<float>(n, img_nchw, B, H, W, clamp01, out_nchw, out_rgb8);
 }

@@ -83,24 +83,146 @@ def gather_frames_cabi(local, n_frames, rank=None, world=None, dst=0):
     return out
 
 
+def _gather_p2p(local, n_frames, rank, world, dst):
+    """Exact-size point-to-point gather through torch.distributed (any backend; the CPU / gloo form of
+    maua_gather_frames): every rank sends its shard once, the root receives each straight into its slice of the clip."""
+    sizes = [frame_range(n_frames, r, world) for r in range(world)]
+    local = local.contiguous()
+    if rank != dst:
+        if local.shape[0]:
+            dist.send(local, dst=dst)
+        return None
+    shape = list(local.shape[1:])
+    if not local.shape[0]:   # (the root always owns frames under frame_range; kept for dst != 0)
+        raise ValueError("the gather root must own at least one frame")
+    out = torch.empty((n_frames, *shape), dtype=local.dtype, device=local.device)
+    reqs = []
+    for r, (lo, hi) in enumerate(sizes):
+        if r == rank:
+            out[lo:hi] = local
+        elif hi > lo:
+            reqs.append(dist.irecv(out[lo:hi], src=r))
+    for q in reqs:
+        q.wait()
+    return out
+
+
 def gather_frames(local, n_frames, rank=None, world=None, dst=0):
-    """Gather per-rank frame shards [n_r, ...] (contiguous ranges from ``frame_range``) into [n_frames, ...] on
-    ``dst``; other ranks get None.  Shards may differ by one frame: they are padded to the largest shard so that a
-    single gather call moves them, then trimmed."""
+    """Gather per-rank frame shards [n_r, ...] (contiguous ranges from ``frame_range``) into [n_frames, ...] on ``dst``;
+    other ranks get None.  Exact shard sizes, one transfer per rank, received in place (no padding, no concatenation):
+    on the device through the library's own ``maua_gather_frames`` (grouped RCCL send / recv over xGMI), on the CPU
+    (gloo: the tests) through torch.distributed point-to-point calls."""
     if rank is None or world is None:
         rank, world = world_info()
     if world == 1:
         return local
-    if os.environ.get("MAUA_GATHER") == "cabi" and local.is_cuda:
+    if local.is_cuda:
         return gather_frames_cabi(local, n_frames, rank, world, dst)
-    sizes = [frame_range(n_frames, r, world) for r in range(world)]
-    maxn = max(hi - lo for lo, hi in sizes)
-    pad = local
-    if local.shape[0] < maxn:
-        pad = torch.zeros((maxn, *local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad.contiguous(), bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)])
+    return _gather_p2p(local, n_frames, rank, world, dst)
+
+
+class StreamingGather:
+    """The gather of a frame-sharded render, STREAMED: every rank renders its contiguous frame range in chunks; as soon as
+    a chunk is finished it travels to the root (side stream, RCCL point-to-point over xGMI) while the next chunk renders,
+    so the root's ingress (8 x 1.4 GB at 8 GPUs) hides behind the render instead of following it.
+
+        g = StreamingGather(n_frames, frame_shape, chunk, dtype=torch.uint8)     # collective: all ranks
+        for off, n in g.chunks():                # this rank's chunks: (offset inside the shard, frames)
+            render into g.local[off:off + n]
+            g.chunk_done()
+        clip = g.finish()                        # root: [n_frames, *frame_shape]; other ranks: None
+
+    The root renders straight into its slice of the clip buffer (``g.local`` is a view of it).  Round k = the k-th chunk
+    of every rank; the root posts the round's receives (one group) when its own k-th chunk is done, the other ranks
+    send theirs - rank 0 owns the longest range (``frame_range``), so it has a chunk in every round.  CPU tensors
+    (gloo) follow the same protocol with torch.distributed isend / irecv (the tests)."""
+
+    def __init__(self, n_frames, frame_shape, chunk, dtype=torch.uint8, device=None, rank=None, world=None, dst=0):
+        if rank is None or world is None:
+            rank, world = world_info()
+        if dst != 0:
+            raise NotImplementedError("the streamed gather collects on rank 0 (the rank with the longest frame range)")
+        self.rank, self.world, self.dst, self.n_frames, self.chunk = rank, world, dst, n_frames, int(chunk)
+        self.ranges = [frame_range(n_frames, r, world) for r in range(world)]
+        lo, hi = self.ranges[rank]
+        self.lo, self.hi = lo, hi
+        if device is None:
+            device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device)
+        if rank == dst:
+            self.clip = torch.empty((n_frames, *frame_shape), dtype=dtype, device=self.device)
+            self.local = self.clip[lo:hi]
+        else:
+            self.clip = None
+            self.local = torch.empty((hi - lo, *frame_shape), dtype=dtype, device=self.device)
+        self.frame_bytes = int(torch.empty((1, *frame_shape), dtype=dtype).numel()) * torch.empty((), dtype=dtype).element_size()
+        self.round = 0
+        self._reqs = []
+        self._side = None
+        if self.device.type == "cuda" and world > 1:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._comm = _cabi_comm(rank, world, self.device)
+
+    def n_rounds(self, r=None):
+        lo, hi = self.ranges[self.rank if r is None else r]
+        return -(-(hi - lo) // self.chunk)
+
+    def chunks(self):
+        for off in range(0, self.hi - self.lo, self.chunk):
+            yield off, min(self.chunk, self.hi - self.lo - off)
+
+    def _round_pieces(self, k):
+        """(frames, clip frame offset) of every rank's k-th chunk (0 frames: the rank has no such chunk)."""
+        out = []
+        for lo, hi in self.ranges:
+            off = k * self.chunk
+            n = max(0, min(self.chunk, hi - lo - off))
+            out.append((n, lo + off))
+        return out
+
+    def chunk_done(self):
+        """This rank's next chunk (in ``chunks()`` order) is rendered (its kernels are queued on the current stream)."""
+        k = self.round
+        self.round += 1
+        if self.world == 1:
+            return
+        pieces = self._round_pieces(k)
+        if self._side is not None:
+            import ctypes as C
+            from . import _lib as L
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            nbytes = (C.c_long * self.world)(*[n * self.frame_bytes for n, _ in pieces])
+            offs = (C.c_long * self.world)(*[o * self.frame_bytes for _, o in pieces])
+            n_mine, _ = pieces[self.rank]
+            off = k * self.chunk
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                send = self.local[off:off + n_mine].view(torch.uint8).reshape(-1) if self.rank != self.dst and n_mine else None
+                recv = self.clip.view(torch.uint8).reshape(-1) if self.rank == self.dst else None
+                L.check(L.lib().maua_gather_frames_at(self._comm, L.ptr(send), nbytes, L.ptr(recv), offs, self.dst))
+            return
+        # CPU / gloo
+        if self.rank == self.dst:
+            for r, (n, o) in enumerate(pieces):
+                if r != self.rank and n:
+                    self._reqs.append(dist.irecv(self.clip[o:o + n], src=r))
+        else:
+            n, _ = pieces[self.rank]
+            if n:
+                off = k * self.chunk
+                self._reqs.append(dist.isend(self.local[off:off + n].contiguous(), dst=self.dst))
+
+    def finish(self):
+        """Every chunk announced: wait for the transfers; the root returns the clip."""
+        if self.round != self.n_rounds():
+            raise RuntimeError(f"{self.round} of {self.n_rounds()} chunks were announced")
+        if self.world > 1 and self.rank == self.dst:
+            # rounds this rank has no chunk in cannot exist (rank 0 owns the longest range)
+            assert all(self.n_rounds(r) <= self.n_rounds() for r in range(self.world))
+        for q in self._reqs:
+            q.wait()
+        self._reqs = []
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+        return self.clip if self.rank == self.dst else None

@@ -43,12 +43,18 @@ def _worker(rank, world, port, T, q):
     assert maybe_init_process_group("nccl") == (rank, world)
     lo, hi = frame_range(T, rank, world)
     shard = _render(lo, hi, T)
-    full = gather_frames(shard, T, rank, world)
-    from maua_amd.distributed import gather_frames_cabi
-    full2 = gather_frames_cabi(shard, T, rank, world)     # the library's own entry point (maua_gather_frames)
+    full = gather_frames(shard, T, rank, world)           # default on the device: the library's maua_gather_frames
+    from maua_amd.distributed import StreamingGather, _gather_p2p
+    full2 = _gather_p2p(shard, T, rank, world, 0)         # the same exchange through torch.distributed's RCCL send / recv
+    # streamed: chunks of 3 frames travel on a side stream while the next ones render
+    g = StreamingGather(T, (64, 64, 3), 3)
+    for off, n in g.chunks():
+        g.local[off:off + n] = shard[off:off + n]
+        g.chunk_done()
+    full3 = g.finish()
     torch.cuda.synchronize()
     if rank == 0:
-        assert torch.equal(full, full2)
+        assert torch.equal(full, full2) and torch.equal(full, full3)
         q.put(full.cpu())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -76,8 +82,17 @@ def test_two_rank_render_equals_single_gpu():
 def test_cabi_gather_single_rank():
     """maua_comm_* / maua_gather_frames on one GPU (world 1: RCCL is bound and a communicator created, the root's own shard
     is copied into place); the two-rank exchange is the test above wherever two GPUs exist."""
-    from maua_amd.distributed import gather_frames_cabi
+    from maua_amd.distributed import StreamingGather, gather_frames_cabi
     x = torch.randint(0, 255, (5, 8, 8, 3), dtype=torch.uint8, device="cuda")
     out = gather_frames_cabi(x, 5, rank=0, world=1)
     torch.cuda.synchronize()
     assert out.data_ptr() != x.data_ptr() and torch.equal(out, x)
+    # the streamed form at world 1: the clip buffer IS the shard, chunks are only counted
+    g = StreamingGather(5, (8, 8, 3), 2, rank=0, world=1)
+    for off, n in g.chunks():
+        g.local[off:off + n] = x[off:off + n]
+        g.chunk_done()
+    clip = g.finish()
+    assert torch.equal(clip, x) and clip.data_ptr() == g.local.data_ptr()
+    with pytest.raises(RuntimeError):
+        StreamingGather(5, (8, 8, 3), 2, rank=0, world=1).finish()   # chunks not announced
