@@ -18,14 +18,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out", "traffic")
-BATCH = int(os.environ.get("BATCH", "32"))  # frames per step (bench.py's default)
+BATCH = int(os.environ.get("BATCH", "128"))  # frames per step (bench.py default)
 
 
 def run(counter):
     os.makedirs(OUT, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", OUT, "-o", counter, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
            "--batch", str(BATCH)]
     subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
     f = glob.glob(os.path.join(OUT, f"{counter}_counter_collection.csv"))[0]

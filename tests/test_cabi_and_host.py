@@ -210,6 +210,12 @@ def test_maua_namespace_resolves_to_the_native_package():
     assert StyleGAN2 is native_sg.StyleGAN2 and StyleGAN2Synthesizer is native_sg.StyleGAN2Synthesizer
     assert callable(ar.onsets) and callable(ar.spline_loops) and callable(FA.mfcc) and callable(FP.gaussian_filter)
     assert callable(generate) and callable(generate_audiovisal_from_patch)
+    import maua_amd.diffusion as native_df
+    from maua.diffusion.processors.guided import GuidedDiffusion, create_models
+    from maua.diffusion.sample import sample
+    from maua.super.image.models.realesrgan import SRVGGNetCompact, load_model
+    assert GuidedDiffusion is native_df.GuidedDiffusion and create_models is native_df.create_models and callable(sample)
+    assert callable(load_model) and SRVGGNetCompact.__module__ == "maua_amd.super"
     # the reference's default patch file resolves through the namespace to a class defined in that module
     cls = get_patch_from_file("maua/audiovisual/patches/examples/stylegan2.py")
     assert issubclass(cls, StyleGAN2Patch) and issubclass(cls, MauaPatch)
