@@ -62,6 +62,9 @@ def kernel_of(ci, co, res, up):
         return "upwalk_fused_kernel<64,32>"
     if (ci, co, up) in ((32, 32, 1), (64, 64, 1), (64, 32, 2)) and hin % 32 == 0:
         return f"modconv_hires_kernel<{ci},{co},{up}>"
+    if up == 2 and 256 <= hin <= 512:
+        # transposed conv + FIR + epilogue in one kernel, t in LDS (modconv_tconv_fir.hip; synth option tconv_fir = 256)
+        return "tconv_fir_kernel"
     if up == 2 and 32 <= hin <= 512:
         # main position block on LDS-direct loads; the profile slot also holds the thin last row / column
         # (tconv2_kernel) and, where the producing conv1 could not pre-scale its output, the premod pass;
@@ -124,7 +127,10 @@ def layer_table(net):
                 byts += r * r * 12 + (r // 2) ** 2 * 12
                 if i == len(net.block_resolutions) - 1:  # last block: the features are not stored and the image
                     byts += r * r * 3 - res * res * co * 2 - r * r * 12  # leaves as u8 (no f32 image, no pack pass)
-            if kern.startswith("tconv_dma"):  # two profile slots: MACs on the first, the output write on the second
+            if kern.startswith("tconv_fir"):  # two profile slots like the two-launch path; everything happens in the first
+                rows.append((pfx + ".tconv", kern, gflop, byts))
+                rows.append((pfx + ".upfir", "(in tconv_fir)", 0.0, 0.0))
+            elif kern.startswith("tconv_dma"):  # two profile slots: MACs on the first, the output write on the second
                 t_bytes = (res + 1) * (res + 1) * co * 2
                 rows.append((pfx + ".tconv", kern, gflop, hin * hin * ci * 2 + t_bytes))
                 rows.append((pfx + ".upfir", "upfir_epilogue_kernel<bf16>", 0.0, t_bytes + res * res * co * 2 + res * res * 4))

@@ -136,6 +136,10 @@ struct UpfirArgs {
   float alpha, gain, clamp;
 };
 int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a);
+// modconv_tconv_fir.hip: both halves in one kernel, t stays in LDS (bf16; x already multiplied by the styles); the output is
+// bit-identical to launch_tconv_dma (+ edges) followed by launch_upfir_epilogue
+bool tconv_fir_supported(int dtype, int Ci, int Co, int H, int W);
+int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u);
 size_t prepped_weight_elems(int k, int up, int Cop, int Cip);
 
 // resize.hip: bicubic / pad / crop of NHWC features (network dtype) or planar images; optional per-channel noise

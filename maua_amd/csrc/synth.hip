@@ -69,6 +69,10 @@ struct maua_synth {
                        // 2: the last block as one fused walk when nothing else reads its features
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
+  int tconv_fir = 256; // up-layers with inputs of at least this size: transposed conv + FIR + epilogue in ONE kernel, t stays in
+                       // LDS (modconv_tconv_fir.hip); 0 = never.  Measured at B = 128 (pair -> fused): 256^2 inputs 3.61 -> 3.48 ms,
+                       // 128^2 2.33 -> 2.62, 64^2 1.89 -> 2.65: the 1.42x MACs pay only where the t round trip was HBM-bound.
+  int tconv_min = 32;  // ... from this input size up (below: the phase kernels / the batch-wide low-resolution GEMM)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
   int tconv_dma = 2;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
   float* ones = nullptr;   // [Bcap][max channels] unit styles (kernels that take already-modulated input)
@@ -431,6 +435,14 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->upwalk = value;
     return MAUA_OK;
   }
+  if (!strcmp(key, "tconv_min")) {
+    n->tconv_min = value;
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "tconv_fir")) {
+    n->tconv_fir = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "tconv_up")) {
     n->tconv_up = value;
     return MAUA_OK;
@@ -545,7 +557,7 @@ static bool up_uses_tconv_dma(const maua_synth* n, const ConvLayer& c) {
   if (!n->tconv_dma || n->tconv_up != 1 || c.up != 2) return false;
   const bool hires_up = n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw);
   const int hin = std::min(c.ih, c.iw), hmax = std::max(c.ih, c.iw);
-  return !hires_up && hin >= 32 && hmax <= 512 && tconv_dma_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw);
+  return !hires_up && hin >= n->tconv_min && hmax <= 512 && tconv_dma_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw);
 }
 
 int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* noise, const long* noise_bstride, int B,
@@ -605,7 +617,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       //  FIR-folded phase form beats tconv + upfir, whose t round trip is HBM-bound there: 1.33 vs 1.56 ms at B = 32)
       const bool hires_up = c.up == 2 && n->tconv_up == 1 && n->use_hires &&
                             hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw);
-      const bool via_tconv = c.up == 2 && n->tconv_up && !hires_up && hin >= (n->tconv_up == 1 ? 32 : 1) &&
+      const bool via_tconv = c.up == 2 && n->tconv_up && !hires_up && hin >= (n->tconv_up == 1 ? n->tconv_min : 1) &&
                              hin_max <= tconv_max;
       const bool rs_block = n->rs_layer >= 1 && n->convs[n->rs_layer - 1].block == blk;  // toRGB needs the hook path
       // a translate / zoom / rotate hook on this layer replaces its output before toRGB reads it: no fused toRGB then
@@ -717,6 +729,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt_t; a.s = c.s; a.d = nullptr; a.noise = nullptr; a.bias = nullptr;
         a.y = n->tbuf; a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 2;
+        bool up_fused = false;
         if (up_uses_tconv_dma(n, c)) {
           // main block on the LDS-direct kernel (input already multiplied by the styles: by the producing conv1, or by
           // a pass over the - small - input here), last row / column of positions on the register-staged kernel
@@ -726,9 +739,24 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             a.x_bstride = (long)c.ih * c.iw * c.Ci;
           }
           a.s = n->ones;
+          if (n->tconv_fir > 0 && hin >= n->tconv_fir && tconv_fir_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw)) {
+            // the whole layer in one kernel: t never leaves LDS (bit-identical output)
+            UpfirArgs u{};
+            u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
+            u.bias = c.bias; u.B = B; u.H = c.ih; u.W = c.iw; u.Co = c.Co;
+            if (premod_out) {
+              u.out_scale = n->convs[li + 1].s;
+              x_premod = true;
+            }
+            u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
+            if (int rc = launch_tconv_fir(st, a, u)) return rc;
+            prof_mark(n, "conv0_tconv");   // (two profile slots like the two-launch path: the second measures ~0)
+            up_fused = true;
+          }
           // (the thin edges first, the main block behind them; running the edges on a side stream beside the main block
           //  measured no different: 8.06 vs 8.08 ms per forward)
-          if (n->tconv_dma >= 2) {          // dedicated edge kernel (3 of 9 weight blocks, no tile waste)
+          if (up_fused) {
+          } else if (n->tconv_dma >= 2) {          // dedicated edge kernel (3 of 9 weight blocks, no tile waste)
             if (int rc = launch_tconv_edges(st, a)) return rc;
           } else {
             ConvArgs e = a;
@@ -736,10 +764,12 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             if (int rc = launch_tconv2(st, n->dtype, e)) return rc;
           }
           a.variant = 0;
-          if (int rc = launch_tconv_dma(st, a)) return rc;
+          if (!up_fused)
+            if (int rc = launch_tconv_dma(st, a)) return rc;
         } else if (int rc = launch_tconv2(st, n->dtype, a)) {
           return rc;
         }
+        if (!up_fused) {
         prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
         UpfirArgs u{};
         u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
@@ -750,6 +780,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         }
         u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
         if (int rc = launch_upfir_epilogue(st, n->dtype, u)) return rc;
+        }
       } else {
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;

@@ -40,6 +40,8 @@ def bench_name(k):
     m = re.search(r"modconv3x3_kernel<unsigned short, (\d), (\d), (\d), (\d), (\d), (\d+)>", k)
     if m:
         return "modconv3x3_kernel<bf16,%s,%s,%s,%s,%s,%s>" % m.groups()
+    if "tconv_fir_kernel" in k:
+        return "tconv_fir_kernel"
     if "tconv_dma_kernel" in k:
         return "tconv_dma_kernel (+edges, +premod)"
     if "tconv_edges_kernel" in k:

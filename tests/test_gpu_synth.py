@@ -488,3 +488,38 @@ def test_upwalk_block_walks_on_a_resized_non_square_grid(target):
     for mode in (0, 1, 2):
         assert psnr(imgs[mode], ref) >= 50.0, (mode, psnr(imgs[mode], ref))
     net.set_resize(None)
+
+
+def test_fused_up_layer_is_bit_identical_to_the_two_launch_path():
+    """modconv_tconv_fir.hip (transposed conv + 4x4 FIR + epilogue in one kernel, t in LDS) against the two-launch path
+    (tconv_dma + edges, then upfir_epilogue: t through HBM): the whole image bit for bit, on a 256^2 network whose 32^2 ...
+    128^2 up-layers (tiles that overhang the image on every side, several channel blocks, noise, biases) all take the fused
+    kernel, on a resized non-square grid, and against the oracle."""
+    from maua_amd import _lib as L
+    net, p = build(256, 8192, 128, torch.bfloat16)
+    g = torch.Generator().manual_seed(21)
+    B = 3
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    h = net._handle()
+    imgs = {}
+    for v in (0, 32):
+        L.check(L.lib().maua_synth_set_option(h, b"tconv_fir", v))
+        imgs[v] = net(ws, noise=noise).cpu()
+        u8 = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
+        net(ws, noise=noise, rgb8_out=u8)
+        imgs[(v, "u8")] = u8.cpu()
+    assert torch.equal(imgs[0], imgs[32]) and torch.equal(imgs[(0, "u8")], imgs[(32, "u8")])
+    ref = OS.synthesis_network(p, ws, noise=noise)
+    assert psnr(imgs[32], ref) >= 50.0
+    one = net(ws[1:2], noise=[n[1:2] for n in noise]).cpu()       # position in the batch does not matter
+    assert torch.equal(one[0], imgs[32][1])
+    # resized grid: the 32^2 block stretched to 40 x 96 -> up-layers at 40 x 96, 80 x 192 (tiles of 6 x 30 positions do not divide them)
+    net.set_resize(7, target=(40, 96), noise_generator=torch.Generator().manual_seed(5))
+    res = {}
+    for v in (0, 32):
+        L.check(L.lib().maua_synth_set_option(h, b"tconv_fir", v))
+        res[v] = net(ws).cpu()
+    assert tuple(res[0].shape) == (B, 3, 320, 768) and torch.equal(res[0], res[32])
+    net.set_resize(None)
+    L.check(L.lib().maua_synth_set_option(h, b"tconv_fir", 256))
