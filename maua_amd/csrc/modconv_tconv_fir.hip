@@ -24,17 +24,12 @@ namespace maua {
 
 namespace {
 
-constexpr int PTH = 8, PTW = 32;                   // positions per workgroup: 8 rows x 32 columns
-
-constexpr int HW1 = PTW + 1, HPX = (PTH + 1) * HW1;  // 9 x 33 halo pixels
+constexpr int PTW = 32;                            // position columns per workgroup (rows: template parameter, 8 or 16)
+constexpr int HW1 = PTW + 1;                       // halo columns
 constexpr int KB = 64;                             // bytes of K per LDS row (32 bf16 channels = one chunk)
-constexpr int HBUF = HPX * KB;
 constexpr int WROWS = 9 * 32;
 constexpr int WBUF = WROWS * KB;
 constexpr int OFF_H = 2 * WBUF;
-constexpr int NW = 4, NT = NW * 64;
-constexpr int WJ = (WBUF / 1024 + NW - 1) / NW;
-constexpr int HJ = (HPX * 4 + NT - 1) / NT;
 constexpr int ES = 128 * 2 + 16;                   // t tile: [position][class * 32 + ch] bf16, row stride
 
 __device__ __constant__ const int kSlotF[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};  // as modconv_tconv.hip
@@ -75,7 +70,17 @@ __device__ __forceinline__ void fir_hrow(const char* tile, int tr, int xl, int c
 
 }  // namespace
 
-__global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs u) {
+// PTH_ = 8: 4 waves, 75 KB of LDS, two workgroups per CU, 6 x 30 useful positions of 8 x 32 (1.42x MACs).  The kernel is
+// written for any even PTH_; PTH_ = 16 (8 waves, 136 KB, ONE workgroup per CU, 14 x 30 of 16 x 32 = 1.22x MACs) measured
+// 3.78 vs 3.50 ms on the 256^2 -> 512^2 layer at B = 128 - two workgroups out of phase are worth more than the saved rows.
+template <int PTH_>
+__global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel(ConvArgs a, UpfirArgs u) {
+  constexpr int PTH = PTH_, UPR = PTH - 2;           // position rows computed / useful
+  constexpr int HPX = (PTH + 1) * HW1, HBUF = HPX * KB;
+  constexpr int NW = PTH / 2, NT = NW * 64;
+  constexpr int WJ = (WBUF / 1024 + NW - 1) / NW, HJ = (HPX * 4 + NT - 1) / NT;
+  constexpr int FG = NT / 128, FROWS = 2 * UPR / FG;  // FIR thread groups of 120, output rows per group (6 or 7)
+  static_assert(FG * FROWS == 2 * UPR, "output rows must split evenly over the FIR groups");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_off(smem));
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
   // blocks of one (tile, sample) read the same input halo, so they run back to back ON ONE XCD (cb fastest inside an
   // XCD, in groups of <= 8 blocks = <= 2.4 MB of weights, which stay L2-resident next to the halos): x is fetched from
   // HBM once per group instead of once per channel block.  Placement is a speed matter only.
-  const int tiles_x = (a.W + 29) / 30, tiles = tiles_x * ((a.H + 5) / 6), CB = a.Co >> 5;
+  const int tiles_x = (a.W + 29) / 30, tiles = tiles_x * ((a.H + UPR - 1) / UPR), CB = a.Co >> 5;
   const int cbg = CB < 8 ? CB : 8, n_ts = tiles * a.B, per_group = ((n_ts + 7) >> 3) * 8 * cbg;
   const int L = blockIdx.x, grp = L / per_group, Lg = L - grp * per_group;
   const int xcd = Lg & 7, idx = Lg >> 3;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
   if (ts >= n_ts) return;
   const int b = ts / tiles, tile = ts - b * tiles;
   const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int ty0 = tyi * 6 - 1, tx0 = txi * 30 - 1;   // first position of the tile (a one-position frame around 6 x 30)
+  const int ty0 = tyi * UPR - 1, tx0 = txi * 30 - 1;   // first position of the tile (a one-position frame around UPR x 30)
   const char* xb = reinterpret_cast<const char*>(a.x) + (long)b * a.x_bstride * 2;
   const char* wp = reinterpret_cast<const char*>(a.w);
 
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
   for (int j = 0; j < HJ; j++) {
     const int P = (wave + NW * j) * 64 + lane;
     const int hp = P >> 2, q = (P & 3) ^ swz(hp);
-    const int py = (hp * 1986) >> 16;  // hp / 33 for hp < 297
+    const int py = (hp * 1986) >> 16;  // hp / 33 for hp < 561
     const int px = hp - py * HW1;
     const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
     hoff[j] = 0xffffffffu;
@@ -233,10 +238,10 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
   // ---- FIR + epilogue (upfir_epilogue_kernel's arithmetic).  Local t row / column 0 = global t row 2 ty0 / column 2 tx0;
   // local output (yl, xl) = global (2 ty0 + yl, 2 tx0 + xl) reads local t rows yl-1 .. yl+2: yl in [2, 14), xl in [2, 62).
   // A thread owns a 2-column strip x one 16-byte channel piece and walks 6 output rows: 30 strips x 4 pieces x 2 row halves.
-  if (tid < 240) {
+  if (tid < 120 * FG) {
     const int half = tid / 120, w = tid - half * 120;
     const int strip = w >> 2, pc = w & 3;
-    const int xl = 2 + 2 * strip, yl0 = 2 + 6 * half;
+    const int xl = 2 + 2 * strip, yl0 = 2 + FROWS * half;
     const int X = 2 * tx0 + xl, Wo = 2 * a.W, Ho = 2 * a.H;
     const int cho = cb * 32 + pc * 8;
     if (X < Wo) {
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
       fir_hrow(tt, yl0, xl, cho2, hr[1]);
       fir_hrow(tt, yl0 + 1, xl, cho2, hr[2]);
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
+      for (int k = 0; k < FROWS; k++) {
         fir_hrow(tt, yl0 + k + 2, xl, cho2, hr[(k + 3) & 3]);
         const int Y = 2 * ty0 + yl0 + k;
         if (Y < Ho) {
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_fir_kernel(ConvArgs a, UpfirArgs 
 }
 
 bool tconv_fir_supported(int dtype, int Ci, int Co, int H, int W) {
-  return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H >= 8 && W >= 32 && (long)H * W * Ci * 2 < (1L << 32) &&
+  return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H >= 16 && W >= 32 && (long)H * W * Ci * 2 < (1L << 32) &&
          16L * Co * Ci * 2 < (1L << 32);
 }
 
@@ -305,13 +310,14 @@ int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u) 
   MAUA_REQUIRE(u.act == MAUA_ACT_LRELU && u.alpha >= 0.f && u.alpha <= 1.f && u.gain > 0.f, "tconv_fir: lrelu epilogue only");
   MAUA_REQUIRE(!u.noise || (((uintptr_t)u.noise % 8) == 0 && u.noise_bstride % 2 == 0), "tconv_fir: noise must be 8-byte aligned");
   if (a.B == 0) return MAUA_OK;
-  const int tiles = ((a.H + 5) / 6) * ((a.W + 29) / 30), CB = a.Co / 32, cbg = CB < 8 ? CB : 8;
+  const int pth = 8, upr = pth - 2;
+  const int tiles = ((a.H + upr - 1) / upr) * ((a.W + 29) / 30), CB = a.Co / 32, cbg = CB < 8 ? CB : 8;
   MAUA_REQUIRE(CB % cbg == 0, "tconv_fir: channel blocks must split into groups of 8");
   const long n_ts = (long)tiles * a.B, grid = ((n_ts + 7) / 8) * 8 * cbg * (CB / cbg);
   MAUA_REQUIRE(grid < (1L << 31), "tconv_fir: grid too large");
-  const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * HBUF, (size_t)PTH * PTW * ES);
-  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_fir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(tconv_fir_kernel, dim3((unsigned)grid), dim3(NT), smem, stream, a, u);
+  const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * (pth + 1) * HW1 * KB, (size_t)pth * PTW * ES);
+  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_fir_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(tconv_fir_kernel<8>, dim3((unsigned)grid), dim3(256), smem, stream, a, u);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
