@@ -128,6 +128,123 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
+
+// ---- the wide form: 128 x 128 tile, 4 waves of 64 x 64 (2 x 2 MFMA blocks), 128-byte K chunks (4 k-steps = 16 MFMAs per
+// wave between barriers instead of 4), and the tile leaves through LDS as full 16-byte row pieces (bias / residual added in
+// the copy-out) instead of 8-byte scattered stores.  Needs both K parts in whole 128-byte chunks; the kernel above serves
+// the rest (narrow test networks, 96-channel concatenations).
+constexpr int WKCB = 128, WRS = WKCB + 16, WBM = 128, WBN = 128;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
+  constexpr int KC = WKCB / (int)sizeof(T), EPC = 16 / (int)sizeof(T);
+  constexpr int ES = WBN * (int)sizeof(T) + 16, PPP = WBN / EPC;   // epilogue tile row stride, 16-byte pieces per row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* a_s = smem;
+  char* b_s = smem + WBM * WRS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long m0 = (long)blockIdx.x * WBM;
+  const int n0 = blockIdx.y * WBN;
+  const int q = tid & 7, row0 = tid >> 3;  // staging role: 16-byte piece q of rows row0 + 32 i (i < 4), A and W alike
+  const int K = g.K0 + g.K1, stages = K / KC;
+  const T* a0 = reinterpret_cast<const T*>(g.a0);
+  const T* a1 = reinterpret_cast<const T*>(g.a1);
+  const T* w = reinterpret_cast<const T*>(g.w);
+  u32x4 areg[4], breg[4];
+#define GEMMW_LOAD(S)                                                                                        \
+  {                                                                                                          \
+    const int kc_ = (S) * KC + q * EPC;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                         \
+      const long am_ = m0 + row0 + 32 * i;                                                                   \
+      const int wn_ = n0 + row0 + 32 * i;                                                                    \
+      areg[i] = u32x4{0u, 0u, 0u, 0u};                                                                       \
+      if (am_ < g.M)                                                                                         \
+        areg[i] = kc_ < g.K0 ? *reinterpret_cast<const u32x4*>(a0 + am_ * g.lda0 + kc_)                      \
+                             : *reinterpret_cast<const u32x4*>(a1 + am_ * g.lda1 + (kc_ - g.K0));            \
+      breg[i] = u32x4{0u, 0u, 0u, 0u};                                                                       \
+      if (wn_ < g.N) breg[i] = *reinterpret_cast<const u32x4*>(w + (long)wn_ * K + kc_);                     \
+    }                                                                                                        \
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  GEMMW_LOAD(0)
+  for (int s = 0; s < stages; s++) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *reinterpret_cast<u32x4*>(a_s + (row0 + 32 * i) * WRS + q * 16) = areg[i];
+      *reinterpret_cast<u32x4*>(b_s + (row0 + 32 * i) * WRS + q * 16) = breg[i];
+    }
+    __syncthreads();
+    if (s + 1 < stages) GEMMW_LOAD(s + 1)
+#pragma unroll
+    for (int ks = 0; ks < WKCB / 32; ks++) {
+      u32x4 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        af[i] = *reinterpret_cast<const u32x4*>(a_s + (wm * 64 + i * 32 + r) * WRS + ks * 32 + h * 16);
+        bf[i] = *reinterpret_cast<const u32x4*>(b_s + (wn * 64 + i * 32 + r) * WRS + ks * 32 + h * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) GMma<T>::step(acc[i][j], bf[j], af[i]);   // rows = columns n, columns = rows m
+    }
+  }
+#undef GEMMW_LOAD
+  // ---- accumulators -> LDS tile [m][n] (T) -> 16-byte pieces with bias / residual
+  __syncthreads();
+  char* epi = smem;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int m = wm * 64 + i * 32 + r;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        const int n = wn * 64 + j * 32 + 8 * qd + 4 * h;
+        float v[4] = {acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
+        if (g.bias && n0 + n < g.N) {
+          const float4 bv = *reinterpret_cast<const float4*>(g.bias + n0 + n);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if constexpr (sizeof(T) == 2)
+          *reinterpret_cast<uint2*>(epi + m * ES + n * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else
+          *reinterpret_cast<float4*>(epi + m * ES + n * 4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+  }
+  __syncthreads();
+  for (int p = tid; p < WBM * PPP; p += 256) {
+    const int m = p / PPP, pc = p - m * PPP;
+    const long gm = m0 + m;
+    const int gn = n0 + pc * EPC;
+    if (gm >= g.M || gn >= g.N) continue;
+    u32x4 v = *reinterpret_cast<const u32x4*>(epi + m * ES + pc * 16);
+    if (g.res) {
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.res) + gm * g.ldr + gn);
+      if constexpr (sizeof(T) == 2) {
+        // (the bias-added value was rounded to bf16 in the tile; the residual is added to that, like the conv kernels do)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __float_as_uint(__uint_as_float(v[k]) + __uint_as_float(rv[k]));
+      }
+    }
+    *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(g.c) + gm * g.ldc + gn) = v;
+  }
+}
+
 }  // namespace
 
 int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
@@ -137,6 +254,22 @@ int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
                "gemm_nt: K parts must be multiples of 64 bytes");
   MAUA_REQUIRE(g.N % 32 == 0 && g.N > 0 && g.lda0 % 4 == 0 && g.ldc % 4 == 0, "gemm_nt: N must be a multiple of 32");
   if (g.M == 0) return MAUA_OK;
+  const int kcw = dtype == MAUA_BF16 ? 64 : 32;   // channels per 128-byte chunk
+  const int epc = dtype == MAUA_BF16 ? 8 : 4;
+  if (!g.c_f32 && g.K0 % kcw == 0 && g.K1 % kcw == 0 && g.M >= 128 && g.ldc % epc == 0 && (!g.res || g.ldr % epc == 0) &&
+      g.lda0 % epc == 0 && (g.K1 == 0 || g.lda1 % epc == 0)) {
+    const size_t smem = std::max<size_t>((size_t)2 * WBM * WRS, (size_t)WBM * (WBN * (dtype == MAUA_BF16 ? 2 : 4) + 16));
+    dim3 gridw((unsigned)((g.M + WBM - 1) / WBM), (unsigned)((g.N + WBN - 1) / WBN));
+    if (dtype == MAUA_BF16) {
+      MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt128_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(gemm_nt128_kernel<bf16_t>, gridw, dim3(256), smem, stream, g);
+    } else {
+      MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt128_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(gemm_nt128_kernel<float>, gridw, dim3(256), smem, stream, g);
+    }
+    MAUA_HIP_CHECK(hipGetLastError());
+    return MAUA_OK;
+  }
   dim3 grid((unsigned)((g.M + GBM - 1) / GBM), (unsigned)((g.N + GBN - 1) / GBN));
   if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, dim3(256), 0, stream, g);

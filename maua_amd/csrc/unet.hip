@@ -542,6 +542,9 @@ struct maua_unet {
   // sampler graph (maua_ddim_sample_loop)
   hipGraphExec_t graph_exec = nullptr;
   size_t graph_key = 0;
+  float* emb_table = nullptr;        // [n_steps][emb_total]: every step's emb_layers outputs, computed once per sampler loop
+  size_t emb_table_rows = 0;
+  const float* emb_row = nullptr;    // non-NULL during a sampler-loop forward: this step's row (all samples share the timestep)
   hipStream_t cap_stream = nullptr;  // capture happens on a private stream (the caller's may be the legacy NULL stream)
   int graph_failed = 0;              // capture / instantiation failed once: the loop runs eagerly from then on
   float *g_x = nullptr, *g_out = nullptr, *g_pred = nullptr, *g_t = nullptr, *g_cf = nullptr;
@@ -764,8 +767,8 @@ struct Runner {
     double* part = (double*)ar.get(gn_part_bytes(B, C0 + C1, (long)H * W, (int)sizeof(T)));
     int rc = MAUA_OK;
     if (!plan)
-      rc = launch_group_norm<T>(st, x0, C0, x1, C1, B, H, W, g.gamma, g.beta, ss, (long)n->emb_total, silu, mode, y, xr, part,
-                                stats);
+      rc = launch_group_norm<T>(st, x0, C0, x1, C1, B, H, W, g.gamma, g.beta, ss, n->emb_row ? 0L : (long)n->emb_total, silu,
+                                mode, y, xr, part, stats);
     ar.top = mark;
     return rc;
   }
@@ -861,7 +864,9 @@ struct Runner {
     float* e1 = (float*)ar.get((size_t)B * E * 4);
     float* e2 = (float*)ar.get((size_t)B * E * 4);
     emb_all = (float*)ar.get((size_t)B * n->emb_total * 4);
-    if (!plan) {
+    if (!plan && n->emb_row) {
+      emb_all = const_cast<float*>(n->emb_row);   // (read-only; the samples' rows coincide: stride 0 below)
+    } else if (!plan) {
       const int half = mc / 2;
       hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * half + 255) / 256), dim3(256), 0, st, t,
                          n->freqs_loaded ? n->freqs : nullptr, e0, B, mc);
@@ -991,7 +996,7 @@ void maua_unet_destroy(maua_unet* n) {
   for (void* p : n->owned) hipFree(p);
   if (n->arena.base) hipFree(n->arena.base);
   if (n->ones) hipFree(n->ones);
-  for (float* p : {n->g_out, n->g_pred, n->g_t, n->g_cf})  // (g_x is the caller's tensor the graph was captured on)
+  for (float* p : {n->g_out, n->g_pred, n->g_t, n->g_cf, n->emb_table})  // (g_x is the caller's tensor the graph was captured on)
     if (p) hipFree(p);
   delete n;
 }
@@ -1199,8 +1204,38 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
     n->out_cap = out_bytes + pred_bytes;
     if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
   }
+  // every step's timestep projections at once: the timesteps are known up front and shared by the samples, so the stacked
+  // emb_layers GEMV (51 k x 1024 f32 weights at the 256^2 configuration) runs once per loop with n_steps rows instead of
+  // once per step with B rows
+  if (n->emb_table_rows < (size_t)n_steps) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    if (n->emb_table) hipFree(n->emb_table);
+    n->emb_table = nullptr; n->emb_table_rows = 0;
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->emb_table, (size_t)n_steps * n->emb_total * 4));
+    n->emb_table_rows = n_steps;
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+  }
+  {
+    const int E = n->emb_dim, mc = n->mc, half = mc / 2;
+    float *tt, *e0, *e1, *e2;
+    MAUA_HIP_CHECK(hipMalloc((void**)&tt, (size_t)n_steps * (1 + mc + 2 * E) * 4));
+    e0 = tt + n_steps; e1 = e0 + (size_t)n_steps * mc; e2 = e1 + (size_t)n_steps * E;
+    MAUA_HIP_CHECK(hipMemcpyAsync(tt, model_t, (size_t)n_steps * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n_steps * half + 255) / 256), dim3(256), 0, st, tt,
+                       n->freqs_loaded ? n->freqs : nullptr, e0, n_steps, mc);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((E + 3) / 4), dim3(256), 0, st, e0, n->te0_w, n->te0_b, e1, n_steps, mc, E, 0, 1);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((E + 3) / 4), dim3(256), 0, st, e1, n->te2_w, n->te2_b, e2, n_steps, E, E, 0, 0);
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((n->emb_total + 3) / 4), dim3(256), 0, st, e2, n->embw, n->embb, n->emb_table,
+                       n_steps, E, n->emb_total, 1, 0);
+    MAUA_HIP_CHECK(hipGetLastError());
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    hipFree(tt);
+  }
   auto body = [&](int s) -> int {
-    if (int rc = maua_unet_forward(n, x, n->g_t + (size_t)s * B, B, H, W, n->g_out)) return rc;
+    n->emb_row = n->emb_table + (size_t)s * n->emb_total;
+    int rc = maua_unet_forward(n, x, n->g_t + (size_t)s * B, B, H, W, n->g_out);
+    n->emb_row = nullptr;
+    if (rc) return rc;
     return maua_ddim_step(n->ctx, x, n->g_out, nullptr, nullptr, n->g_cf + (size_t)s * B * 8, B, n->in_ch, n->out_ch,
                           (long)H * W, x, n->g_pred);
   };
