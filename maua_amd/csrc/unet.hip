@@ -242,12 +242,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
 //     pixel chunk; a finalize launch of B x 32 threads adds the <= 128 chunk rows;
 //   * the apply pass indexes (sample, row) by blockIdx.y and (pixel, piece) by 32-bit arithmetic, loads its piece's
 //     coefficients as float4s, and in bf16 mode uses the hardware exp / reciprocal for SiLU (exact in f32 mode).
-// The LAST workgroup of a sample to finish (an atomic ticket per sample; the counter returns to zero for the next GroupNorm)
-// adds the chunk rows in their fixed order and writes the sample's 32 (mean, 1 / sqrt(var + eps)) pairs: no finalize launch.
+// (Folding the finalize into this kernel - the last workgroup of a sample, found by an atomic ticket, adds the chunk rows - was
+//  built and measured in round 3: 26.7 -> 35.3 ms per UNet step at B = 8.  A device-scope release fence per workgroup writes
+//  the XCD's L2 back (8 XCDs, one L2 each): far dearer than the ~5 us launch it saves.  The finalize stays its own launch.)
 template <typename T>
 __global__ void gn_partial_group_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1, long HW, int ppc,
-                                        double* __restrict__ part, unsigned* __restrict__ ticket, double cnt, float eps,
-                                        float* __restrict__ stats) {
+                                        double* __restrict__ part) {
   constexpr int EPC = 16 / (int)sizeof(T);
   __shared__ double red[2][1024];
   const int C = C0 + C1, PPP = C / EPC;
@@ -288,40 +288,6 @@ __global__ void gn_partial_group_kernel(const T* __restrict__ x0, int C0, const 
     dst[0] = ts;
     dst[1] = tq;
   }
-  if (!ticket) return;
-  __shared__ int last;
-  __threadfence();   // this workgroup's row is visible device-wide before its ticket
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(ticket + b, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  if (threadIdx.x < 256) {
-    // 32 groups x 8 lanes as in gn_finalize_group_kernel (the same order of additions: bit-identical statistics)
-    const int g = threadIdx.x & 31, j = threadIdx.x >> 5, nchunk = gridDim.x;
-    const volatile double* vp = part;
-    double s2 = 0.0, q2 = 0.0;
-    for (int k = j; k < nchunk; k += 8) {
-      const long o = (((long)b * nchunk + k) * 32 + g) * 2;
-      s2 += vp[o];
-      q2 += vp[o + 1];
-    }
-    red[0][threadIdx.x] = s2;
-    red[1][threadIdx.x] = q2;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int g = threadIdx.x;
-    double s2 = red[0][g], q2 = red[1][g];
-#pragma unroll
-    for (int q = 1; q < 8; q++) { s2 += red[0][q * 32 + g]; q2 += red[1][q * 32 + g]; }
-    const double mean = s2 / cnt;
-    double var = q2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((long)b * 32 + g) * 2] = (float)mean;
-    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  if (threadIdx.x == 0) ticket[b] = 0u;
 }
 
 __global__ __launch_bounds__(256) void gn_finalize_group_kernel(const double* __restrict__ part, int nchunk, double cnt,
@@ -451,7 +417,7 @@ static GnPlan gn_plan(int B, int C, long HW, int esize) {
 template <typename T>
 static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, int C1, int B, int H, int W,
                              const float* gamma, const float* beta, const float* ss, long ss_ld, int silu, int mode, T* y, T* xr,
-                             double* part, float* stats, unsigned* ticket = nullptr) {
+                             double* part, float* stats) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int C = C0 + C1, PPP = C / EPC;
   const long HW = (long)H * W;
@@ -459,13 +425,10 @@ static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, i
   const GnPlan p = gn_plan(B, C, HW, (int)sizeof(T));
   const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
   if (p.fast && (long)B * Ho <= 65535) {
-    // (the in-kernel finalize needs >= 256 threads per workgroup: PPP * RY is 512 except for very narrow networks)
-    const bool fold = ticket && PPP * p.RY >= 256;
     hipLaunchKernelGGL(gn_partial_group_kernel<T>, dim3((unsigned)p.nchunk, B), dim3(PPP * p.RY), 0, st, x0, C0, x1, C1, HW,
-                       p.ppc, part, fold ? ticket : nullptr, (double)HW * (C / 32), 1e-5f, stats);
-    if (!fold)
-      hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
-                         stats);
+                       p.ppc, part);
+    hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
+                       stats);
     hipLaunchKernelGGL(gn_apply_group_kernel<T>, dim3((unsigned)(((long)Wo * PPP + 255) / 256), (unsigned)(B * Ho)), dim3(256),
                        0, st, x0, C0, x1, C1, stats, gamma, beta, ss, ss_ld, silu, mode, y, xr, H, W, Ho, Wo);
   } else {
@@ -574,7 +537,6 @@ struct maua_unet {
   std::vector<void*> owned;
   float* ones = nullptr;
   int ones_b = 0, max_ch = 0;
-  unsigned* gn_ticket = nullptr;   // [4096] zeroed once: per-sample tickets of the GroupNorm statistics' last-workgroup finalize
   Arena arena;
   size_t planned_key = 0;  // B, H, W the arena was planned for
   size_t gather_bytes = 0; // split-K workspace of the gather GEMM at that shape
@@ -746,7 +708,6 @@ int build_structure(maua_unet* n) {
     const bool is_w = kv.first.size() > 7 && kv.first.compare(kv.first.size() - 7, 7, ".weight") == 0;
     kv.second.f32 = is_w ? n->embw + (size_t)r->emb_off * E : n->embb + r->emb_off;
   }
-  if ((rc = dev_alloc(n, &n->gn_ticket, 4096 * sizeof(unsigned)))) return rc;
   n->max_ch = 0;
   for (auto& r : n->res) n->max_ch = std::max(n->max_ch, std::max(r.Cin, r.Cout));
   n->max_ch = std::max(n->max_ch, 32);
@@ -810,7 +771,7 @@ struct Runner {
     int rc = MAUA_OK;
     if (!plan)
       rc = launch_group_norm<T>(st, x0, C0, x1, C1, B, H, W, g.gamma, g.beta, ss, n->emb_row ? 0L : (long)n->emb_total, silu,
-                                mode, y, xr, part, stats, B <= 4096 ? n->gn_ticket : nullptr);
+                                mode, y, xr, part, stats);
     ar.top = mark;
     return rc;
   }
