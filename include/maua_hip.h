@@ -376,7 +376,9 @@ int maua_unet_param_count(maua_unet* net, long* count);
  * weights [N][K], GroupNorm scale / shift [C].  Optional "timestep_embedding.freqs" [model_channels / 2]: the float32
  * frequency table of nn.py timestep_embedding as the host computes it (otherwise computed on the device). */
 int maua_unet_load(maua_unet* net, const char* name, const float* host_data, size_t count);
-/* "route": 0 per-shape routing of the 3x3 convolutions (default), 1 generic kernel only, 2 no split-K gather GEMM */
+/* "route": 0 per-shape routing of the 3x3 convolutions (default), 1 generic kernel only, 2 no split-K gather GEMM;
+ * "psum_off": 1 = GroupNorm statistics always by their own pass over the tensor (default 0: where the LDS-direct convolution
+ * produced the tensor, from the piece sums its epilogue left) */
 int maua_unet_set_option(maua_unet* net, const char* key, int value);
 /* UNetModel.forward(x, timesteps): x device f32 [B][in_channels][H][W], timesteps device f32 [B] (the value the wrapped
  * model of respace.py passes: original timestep index, rescaled to 0..1000), out device f32 [B][out_channels][H][W].

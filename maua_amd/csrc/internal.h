@@ -45,6 +45,10 @@ struct ConvArgs {
   int res_pstride;
   long res_bstride;
   const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
+  // modconv_dma (wide tiles) only: optional side output for a GroupNorm that follows (unet.hip) - per (sample, 8 x 32-pixel tile)
+  // row and 8-channel piece the sum and the sum of squares of the STORED values: psum[b][tile][Co / 8][16] floats
+  // ([0..8) sums, [8..16) sums of squares of the piece's channels).  Saves the statistics pass its read of the tensor.
+  float* psum;
 };
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a);
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
@@ -54,6 +58,7 @@ bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W);
 bool dma_rgb_fusable(int Co);
 bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W);  // 32 / 64 output channels (plain convs: x_pstride / y_pstride / y_coff / res honoured)
 int launch_modconv_dma(hipStream_t stream, const ConvArgs& a);
+int dma_psum_rows(const ConvArgs& a);   // rows per sample of ConvArgs.psum for such a launch
 int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci);
 
 // lowest-resolution layers (modconv_lowres.hip, <= 8x8 input pixels per sample): the GEMM over all samples at once,

@@ -82,7 +82,9 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
   return MAUA_OK;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB>
+// PSUM: also emit ConvArgs.psum (its own instantiation: the 16 accumulators of the copy-out loop cost the 128-register
+// variants a few spilled registers, which the StyleGAN2 path's launches do not pay)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
@@ -414,6 +416,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
     osc[0] = s0.x; osc[1] = s0.y; osc[2] = s0.z; osc[3] = s0.w; osc[4] = s1.x; osc[5] = s1.y; osc[6] = s1.z; osc[7] = s1.w;
   }
+  float ps_s[8], ps_q[8];   // (PSUM) this thread's piece column: sums / sums of squares of what it stores
+#pragma unroll
+  for (int k = 0; k < 8; k++) { ps_s[k] = 0.f; ps_q[k] = 0.f; }
   for (int p = tid; p < BM * PPP; p += NT) {
     const int m = p / PPP, pc = p - m * PPP;
     const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
@@ -430,8 +435,46 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
     }
     *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
+    if constexpr (PSUM) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float f0 = bf2f((bf16_t)(v[k] & 0xffff)), f1 = bf2f((bf16_t)(v[k] >> 16));
+        ps_s[2 * k] += f0; ps_s[2 * k + 1] += f1;
+        ps_q[2 * k] = fmaf(f0, f0, ps_q[2 * k]); ps_q[2 * k + 1] = fmaf(f1, f1, ps_q[2 * k + 1]);
+      }
+    }
+  }
+  if constexpr (PSUM) {
+    // lanes with the same lane % PPP hold the same piece column: fixed-order butterfly over them, then the waves' rows are
+    // added in wave order through LDS (the epilogue tile is dead by now) - ONE row of Co / 8 pieces per workgroup
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int o = PPP; o < 64; o <<= 1) {
+        ps_s[k] += __shfl_xor(ps_s[k], o);
+        ps_q[k] += __shfl_xor(ps_q[k], o);
+      }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [NW][PPP][16]
+    if (lane < PPP) {
+      float* dstl = red + (wave * PPP + lane) * 16;
+#pragma unroll
+      for (int k = 0; k < 8; k++) { dstl[k] = ps_s[k]; dstl[8 + k] = ps_q[k]; }
+    }
+    __syncthreads();
+    if (tid < PPP * 16) {
+      const int pc = tid >> 4, k = tid & 15;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) acc += red[(w * PPP + pc) * 16 + k];
+      a.psum[(((long)b * gridDim.x + blockIdx.x) * (a.Co >> 3) + (n0 >> 3) + pc) * 16 + k] = acc;
+    }
   }
 }
+
+// rows per sample of ConvArgs.psum for a launch of launch_modconv_dma with these arguments
+int dma_psum_rows(const ConvArgs& a) { return (a.H / TH) * (a.W / TW); }   // one row per 8 x 32-pixel tile
 
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
@@ -441,14 +484,14 @@ bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W) {
   return dtype == MAUA_BF16 && Ci % 64 == 0 && (Co == 32 || Co == 64) && H % TH == 0 && W % TW == 0;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
   const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KB + 2 * HALO_PX * KB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
   MAUA_REQUIRE((a.Ci / (KB / 2)) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -466,7 +509,7 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
                "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
   // narrow N tiles (4 waves, 64-byte K rows, two taps per stage): 64 channels = 2 x 2 blocks per wave, 32 = 2 x 1
   if (narrow) {
-    MAUA_REQUIRE(!a.rgb_out && !a.out_scale, "modconv_dma: the narrow tiles carry no toRGB / style scaling");
+    MAUA_REQUIRE(!a.rgb_out && !a.out_scale && !a.psum, "modconv_dma: the narrow tiles carry no toRGB / style scaling / piece sums");
     return a.Co == 64 ? launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
   }
   // (channel-sliced operands and the residual are honoured by every tile shape: the kernel's address arithmetic is shared)
@@ -476,6 +519,10 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   // layers the two-workgroup shape measured the same as the big tile, which also keeps their toRGB fused)
   // (a.variant == 128: the caller asks for the 128-channel tile although 256 would divide - twice the workgroups for
   //  launches that would otherwise leave CUs idle, e.g. the diffusion UNet's 64^2 level at small batch)
+  if (a.psum) {
+    if (a.Co % 256 == 0 && a.variant != 128) return launch_dma_variant<2, 4, 4, 2, 1, 128, true>(stream, a);
+    return launch_dma_variant<4, 2, 2, 2, 2, 64, true>(stream, a);
+  }
   if (a.Co % 256 == 0 && a.variant != 128) return launch_dma_variant<2, 4, 4, 2, 1, 128>(stream, a);
   return launch_dma_variant<4, 2, 2, 2, 2, 64>(stream, a);
 }

@@ -315,6 +315,42 @@ __global__ __launch_bounds__(256) void gn_finalize_group_kernel(const double* __
   }
 }
 
+// Statistics from the piece sums a producing convolution left behind (ConvArgs.psum: per 8 x 32-pixel tile and 8-channel
+// piece, sums and sums of squares of the stored values) - the tensor itself is not read again.  Two sources like everywhere
+// (the decoder's virtual concatenation); 32 groups x 8 lanes, rows j, j + 8, ... per lane, fixed-order LDS tree.
+__global__ __launch_bounds__(256) void gn_finalize_psum_kernel(const float* __restrict__ ps0, int rows0, int C0,
+                                                               const float* __restrict__ ps1, int rows1, int C1, double cnt,
+                                                               float eps, float* __restrict__ stats) {
+  __shared__ double red[2][256];
+  const int g = threadIdx.x & 31, j = threadIdx.x >> 5, b = blockIdx.x;
+  const int np0 = C0 >> 3, np1 = C1 >> 3, ppg = (np0 + np1) >> 5;
+  double s = 0.0, ss = 0.0;
+  for (int pi = 0; pi < ppg; pi++) {
+    const int piece = g * ppg + pi;
+    const bool first = piece < np0;
+    const float* src = first ? ps0 : ps1;
+    const int rows = first ? rows0 : rows1, np = first ? np0 : np1, pc = first ? piece : piece - np0;
+    for (int r = j; r < rows; r += 8) {
+      const float4* p = reinterpret_cast<const float4*>(src + (((long)b * rows + r) * np + pc) * 16);
+      const float4 a0 = p[0], a1 = p[1], q0 = p[2], q1 = p[3];
+      s += (double)a0.x + (double)a0.y + (double)a0.z + (double)a0.w + (double)a1.x + (double)a1.y + (double)a1.z + (double)a1.w;
+      ss += (double)q0.x + (double)q0.y + (double)q0.z + (double)q0.w + (double)q1.x + (double)q1.y + (double)q1.z + (double)q1.w;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (j == 0) {
+#pragma unroll
+    for (int q = 1; q < 8; q++) { s += red[0][q * 32 + g]; ss += red[1][q * 32 + g]; }
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)b * 32 + g) * 2] = (float)mean;
+    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_group_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -417,7 +453,8 @@ static GnPlan gn_plan(int B, int C, long HW, int esize) {
 template <typename T>
 static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, int C1, int B, int H, int W,
                              const float* gamma, const float* beta, const float* ss, long ss_ld, int silu, int mode, T* y, T* xr,
-                             double* part, float* stats) {
+                             double* part, float* stats, const float* ps0 = nullptr, int rows0 = 0, const float* ps1 = nullptr,
+                             int rows1 = 0) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int C = C0 + C1, PPP = C / EPC;
   const long HW = (long)H * W;
@@ -425,10 +462,16 @@ static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, i
   const GnPlan p = gn_plan(B, C, HW, (int)sizeof(T));
   const int Ho = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Wo = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
   if (p.fast && (long)B * Ho <= 65535) {
-    hipLaunchKernelGGL(gn_partial_group_kernel<T>, dim3((unsigned)p.nchunk, B), dim3(PPP * p.RY), 0, st, x0, C0, x1, C1, HW,
-                       p.ppc, part);
-    hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
-                       stats);
+    if (ps0 && (!x1 || ps1) && sizeof(T) == 2) {
+      // every source's producer left its piece sums: no statistics pass over the tensor
+      hipLaunchKernelGGL(gn_finalize_psum_kernel, dim3(B), dim3(256), 0, st, ps0, rows0, C0, ps1, rows1, C1,
+                         (double)HW * (C / 32), 1e-5f, stats);
+    } else {
+      hipLaunchKernelGGL(gn_partial_group_kernel<T>, dim3((unsigned)p.nchunk, B), dim3(PPP * p.RY), 0, st, x0, C0, x1, C1, HW,
+                         p.ppc, part);
+      hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
+                         stats);
+    }
     hipLaunchKernelGGL(gn_apply_group_kernel<T>, dim3((unsigned)(((long)Wo * PPP + 255) / 256), (unsigned)(B * Ho)), dim3(256),
                        0, st, x0, C0, x1, C1, stats, gamma, beta, ss, ss_ld, silu, mode, y, xr, H, W, Ho, Wo);
   } else {
@@ -542,6 +585,7 @@ struct maua_unet {
   size_t gather_bytes = 0; // split-K workspace of the gather GEMM at that shape
   size_t out_cap = 0;      // bytes behind g_out + g_pred
   int route = 0;           // debugging / ablation: 1 = every 3x3 convolution on the generic kernel
+  int psum_off = 0;        // 1: GroupNorm statistics always by their own pass (A/B of the convolution epilogues' piece sums)
   // sampler graph (maua_ddim_sample_loop)
   hipGraphExec_t graph_exec = nullptr;
   size_t graph_key = 0;
@@ -723,20 +767,28 @@ struct Runner {
   bool plan;
   Arena& ar;
   float* emb_all = nullptr;  // [B][emb_total]
+  // piece sums left by the LDS-direct convolution for the GroupNorm that reads its output: tensor -> (buffer, rows per sample)
+  std::unordered_map<const void*, std::pair<const float*, int>> psums;
   float* gather_ws = nullptr;
   size_t gather_ws_bytes = 0;
 
   Runner(maua_unet* n_, hipStream_t s, int B_, bool plan_) : n(n_), st(s), B(B_), plan(plan_), ar(n_->arena) {}
 
   T* alloc(long px, int C) { return (T*)ar.get((size_t)px * C * sizeof(T)); }
+  // room for the piece sums of a [B][H][W][C] tensor an LDS-direct convolution may produce (NULL where it cannot)
+  float* psum_alloc(int H, int W, int C) {
+    if (sizeof(T) != 2 || n->psum_off || H % 8 || W % 32 || C % 128) return nullptr;
+    return (float*)ar.get((size_t)B * (H / 8) * (W / 32) * (C / 8) * 64);
+  }
 
   // y = conv3x3(x) + bias (+ res); x, y, res dense NHWC [B][H][W][.]
-  int conv(const UConv& c, const T* x, T* y, int H, int W, const T* res) {
+  int conv(const UConv& c, const T* x, T* y, int H, int W, const T* res, float* psum = nullptr) {
     const size_t ws_need = gather_conv_supported(n->dtype, c.Cip, c.Cop, H, W) ? gather_conv_workspace(n->dtype, B, H, W, c.Cip, c.Cop) : 0;
     if (plan) {
       if (ws_need > gather_ws_bytes) gather_ws_bytes = ws_need;
       return MAUA_OK;
     }
+    psums.erase(y);
     ConvArgs a{};
     a.x = x; a.x_bstride = (long)H * W * c.Cip; a.w = c.wt; a.s = nullptr; a.d = nullptr; a.noise = nullptr; a.bias = c.bias;
     a.y = y; a.B = B; a.H = H; a.W = W; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
@@ -754,9 +806,16 @@ struct Runner {
         a.variant = 128;
         dma_wgs *= 2;
       }
-      if ((dma_wide || dma_narrow) && (dma_wgs >= 128 || !gather || n->route == 2)) return launch_modconv_dma(st, a);
+      auto dma = [&]() -> int {
+        if (dma_wide && psum) {   // the wide tiles can leave the statistics of what they store
+          a.psum = psum;
+          psums[y] = {psum, dma_psum_rows(a)};
+        }
+        return launch_modconv_dma(st, a);
+      };
+      if ((dma_wide || dma_narrow) && (dma_wgs >= 128 || !gather || n->route == 2)) return dma();
       if (gather && n->route != 2) return launch_conv_gather(st, n->dtype, a, gather_ws);
-      if (dma_wide || dma_narrow) return launch_modconv_dma(st, a);
+      if (dma_wide || dma_narrow) return dma();
     }
     a.s = n->ones;
     return launch_modconv3x3(st, n->dtype, a);
@@ -769,15 +828,24 @@ struct Runner {
     float* stats = (float*)ar.get((size_t)B * 32 * 2 * 4);
     double* part = (double*)ar.get(gn_part_bytes(B, C0 + C1, (long)H * W, (int)sizeof(T)));
     int rc = MAUA_OK;
-    if (!plan)
+    if (!plan) {
+      const float *ps0 = nullptr, *ps1 = nullptr;
+      int rows0 = 0, rows1 = 0;
+      auto it0 = psums.find(x0);
+      if (it0 != psums.end()) { ps0 = it0->second.first; rows0 = it0->second.second; }
+      if (x1) {
+        auto it1 = psums.find(x1);
+        if (it1 != psums.end()) { ps1 = it1->second.first; rows1 = it1->second.second; }
+      }
       rc = launch_group_norm<T>(st, x0, C0, x1, C1, B, H, W, g.gamma, g.beta, ss, n->emb_row ? 0L : (long)n->emb_total, silu,
-                                mode, y, xr, part, stats);
+                                mode, y, xr, part, stats, ps0, rows0, ps1, rows1);
+    }
     ar.top = mark;
     return rc;
   }
 
   // ResBlock on [x0 | x1] (H x W) -> out (dense, Cout channels at the resampled size)
-  int resblock(const URes& r, const T* x0, int C0, const T* x1, int C1, int H, int W, T* out) {
+  int resblock(const URes& r, const T* x0, int C0, const T* x1, int C1, int H, int W, T* out, float* out_psum) {
     const size_t mark = ar.top;
     const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
     const long opx = (long)B * Ho * Wo;
@@ -786,7 +854,8 @@ struct Runner {
     int rc;
     if ((rc = gn(r.n1, x0, C0, x1, C1, H, W, nullptr, 1, r.updown, a1, xr))) return rc;
     T* h1 = alloc(opx, r.Cout);
-    if ((rc = conv(r.c1, a1, h1, Ho, Wo, nullptr))) return rc;
+    float* ps1 = psum_alloc(Ho, Wo, r.Cout);
+    if ((rc = conv(r.c1, a1, h1, Ho, Wo, nullptr, ps1))) return rc;
     T* a2 = alloc(opx, r.Cout);
     if ((rc = gn(r.n2, h1, r.Cout, nullptr, 0, Ho, Wo, emb_all + r.emb_off, 1, 0, a2, nullptr))) return rc;
     const T* resid;
@@ -802,7 +871,7 @@ struct Runner {
     } else {
       resid = r.updown ? xr : x0;  // (Cin == Cout: never a concatenated input)
     }
-    if ((rc = conv(r.c2, a2, out, Ho, Wo, resid))) return rc;
+    if ((rc = conv(r.c2, a2, out, Ho, Wo, resid, out_psum))) return rc;
     ar.top = mark;
     return MAUA_OK;
   }
@@ -843,12 +912,14 @@ struct Runner {
         const URes& r = n->res[l.idx];
         const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
         out = alloc((long)B * Ho * Wo, r.Cout);
-        if (int rc = resblock(r, cur0, c0, cur1, c1, H, W, out)) return rc;
+        float* pso = psum_alloc(Ho, Wo, r.Cout);   // (lives as long as the tensor: later blocks' GroupNorms read it)
+        if (int rc = resblock(r, cur0, c0, cur1, c1, H, W, out, pso)) return rc;
         H = Ho; W = Wo;
         cur0 = out; c0 = r.Cout; cur1 = nullptr; c1 = 0;
       } else {
         const UAttn& at = n->attn[l.idx];
         T* o2 = alloc((long)B * H * W, at.C);
+        psums.erase(o2);
         if (int rc = attention(at, const_cast<T*>(cur0), H, W, o2)) return rc;
         out = o2;
         cur0 = out; c0 = at.C;
@@ -887,7 +958,7 @@ struct Runner {
     std::vector<T*> hs;
     std::vector<int> hs_c;
     T* h = alloc(px, n->conv_in.Cop);
-    if ((rc = conv(n->conv_in, xin, h, H, W, nullptr))) return rc;
+    if ((rc = conv(n->conv_in, xin, h, H, W, nullptr))) return rc;   // (3 -> C input convolution: generic kernel, no piece sums)
     int ch = n->conv_in.Co, hh = H, ww = W;
     hs.push_back(h); hs_c.push_back(ch);
     for (size_t i = 1; i < n->input.size(); i++) {
@@ -1008,6 +1079,12 @@ void maua_unet_destroy(maua_unet* n) {
 // 1 = every convolution on the generic kernel, 2 = never the gather GEMM (parity tests compare the routes)
 int maua_unet_set_option(maua_unet* n, const char* key, int value) {
   MAUA_REQUIRE(n && key, "maua_unet_set_option: NULL argument");
+  if (!strcmp(key, "psum_off")) {
+    n->psum_off = value;
+    n->planned_key = 0;   // (the arena layout changes)
+    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    return MAUA_OK;
+  }
   if (!strcmp(key, "route")) {
     n->route = value;
     if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }

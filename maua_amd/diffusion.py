@@ -205,6 +205,10 @@ class UNetModel(torch.nn.Module):
         L.check(L.lib().maua_unet_graph_active(self._handle(), C.byref(a)))
         return bool(a.value)
 
+    def set_option(self, key, value):
+        """Library options of the network object ("route", "psum_off": see maua_unet_set_option)."""
+        L.check(L.lib().maua_unet_set_option(self._handle(), key.encode(), int(value)))
+
     def set_route(self, route):
         """0: per-shape kernel routing (default), 1: generic 3x3 kernel only, 2: no split-K gather GEMM."""
         L.check(L.lib().maua_unet_set_option(self._handle(), b"route", int(route)))

@@ -140,6 +140,13 @@ def test_unet_forward_matches_oracle(cfgkw, hw):
     assert psnr(got16, want) >= 40.0, psnr(got16, want)
     net16.set_route(1)
     assert psnr(net16(x, t), want) >= 40.0
+    # GroupNorm statistics from the convolution epilogues' piece sums (the LDS-direct route of the wide network) vs the separate
+    # statistics pass: the same f64 statistics up to the f32 rounding of per-tile partial sums
+    net16.set_route(0)
+    net16.set_option("psum_off", 1)
+    sep = net16(x, t)
+    net16.set_option("psum_off", 0)
+    assert psnr(sep, got16) >= 60.0, psnr(sep, got16)
 
 
 def test_schedule_and_ddim_step_match_oracle():
