@@ -307,12 +307,90 @@ def load_nvidia_pt(path, z_dim=512, c_dim=0, w_dim=512, img_resolution=1024, img
                   dtype=dtype)
 
 
+class _PickledObject:
+    """Stand-in for any class of NVIDIA's code base met inside a network pickle: keeps the instance's state, runs nothing."""
+
+    def __init__(self, *a, **k):
+        self._ctor_args = (a, k)
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self._state = state
+
+
+def _persistent_obj(meta):
+    """torch_utils.persistence._reconstruct_persistent_obj without importing the pickled module source: a persistent
+    object's meta carries type='class', class_name, module_src and ``state`` = the instance's __dict__ (for an nn.Module:
+    _parameters / _buffers / _modules ...).  Only the state is kept."""
+    obj = _PickledObject()
+    meta = dict(meta)
+    obj.__dict__.update(meta.get("state") or {})
+    obj._class_name = meta.get("class_name")
+    return obj
+
+
+class _NetworkUnpickler(__import__("pickle").Unpickler):
+    """Reads NVIDIA's network pickles (legacy.load_network_pkl's format, StyleGAN2-ADA-PyTorch / StyleGAN3: a dict with
+    G / D / G_ema persistent objects) WITHOUT NVIDIA's dnnlib / torch_utils / legacy packages and without executing the module
+    source the pickle embeds: tensors, numpy arrays and containers are rebuilt by their own libraries, every other global
+    resolves to an inert stand-in."""
+    SAFE_PREFIXES = ("torch", "numpy", "collections", "builtins", "_codecs", "copyreg")
+
+    def find_class(self, module, name):
+        if module == "torch_utils.persistence" and name == "_reconstruct_persistent_obj":
+            return _persistent_obj
+        if module.split(".")[0] in self.SAFE_PREFIXES:
+            if module == "builtins" and name in ("eval", "exec", "compile", "open", "__import__", "getattr", "setattr"):
+                raise __import__("pickle").UnpicklingError(f"refusing builtins.{name}")
+            return super().find_class(module, name)
+        if name == "EasyDict":            # dnnlib.EasyDict: a dict with attribute access
+            return dict
+        return _PickledObject
+
+
+def _module_state_dict(obj, prefix=""):
+    """nn.Module.state_dict() over the raw __dict__ states of a pickled module tree."""
+    sd = {}
+    for name, t in (getattr(obj, "_parameters", None) or {}).items():
+        if t is not None:
+            sd[prefix + name] = t.detach() if hasattr(t, "detach") else t
+    non_persistent = getattr(obj, "_non_persistent_buffers_set", None) or set()
+    for name, t in (getattr(obj, "_buffers", None) or {}).items():
+        if t is not None and name not in non_persistent:
+            sd[prefix + name] = t
+    for name, child in (getattr(obj, "_modules", None) or {}).items():
+        if child is not None:
+            sd.update(_module_state_dict(child, prefix + name + "."))
+    return sd
+
+
+def nvidia_pkl_state_dict(path, key="G_ema"):
+    """The ``state_dict()`` of a network inside an NVIDIA ``.pkl`` (default: the EMA generator), read with the restricted
+    unpickler above."""
+    with open(path, "rb") as f:
+        data = _NetworkUnpickler(f).load()
+    if not isinstance(data, dict) or key not in data:
+        raise ValueError(f"{path}: not an NVIDIA network pickle (no {key!r} entry)")
+    sd = _module_state_dict(data[key])
+    if not sd:
+        raise ValueError(f"{path}: {key} carries no parameters")
+    return {k: torch.as_tensor(v).float() for k, v in sd.items()}
+
+
 def load_nvidia(path, for_inference=None, dtype=torch.bfloat16):
-    """NVIDIA network pickles (.pkl) are class pickles: unpickling needs NVIDIA's dnnlib / torch_utils / legacy
-    modules (maua/GAN/nv, an un-vendored submodule of the reference).  Convert once with NVIDIA's own tools to
-    ``torch.save({"G_ema": G_ema.state_dict()}, "x.pt")`` and use load_nvidia_pt."""
-    raise NotImplementedError("NVIDIA .pkl network pickles need the nv package (dnnlib, legacy); "
-                              "export G_ema.state_dict() to a .pt and load that")
+    """maua/GAN/load.py:130-164: NVIDIA network pickles.  The reference unpickles them with the un-vendored ``nv`` package
+    (dnnlib, torch_utils.persistence, legacy) - class pickles that embed and exec their own module source.  Here the
+    pickle is read by a restricted unpickler that rebuilds only tensors / arrays / containers and keeps every persistent
+    object's state: G_ema's parameter tree becomes the state dict the NVIDIA ``.pt`` route takes."""
+    if not str(path).endswith(".pkl"):
+        raise ValueError("not a .pkl file")
+    sd = nvidia_pkl_state_dict(path)
+    if any(k.startswith("synthesis.input.") for k in sd):
+        raise NotImplementedError("StyleGAN3 checkpoints are outside the StyleGAN2 render path")
+    res, n_map, w, z = _infer_shape(sd)
+    return _build(sd, res, n_map, bool(for_inference), z_dim=z, w_dim=w, dtype=dtype)
 
 
 def load_flat_state_dict(path, for_inference=False, dtype=torch.bfloat16):

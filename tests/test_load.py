@@ -137,3 +137,92 @@ def test_loaded_network_matches_oracle(tmp_path, for_inference):
     img = G.synthesis(ws).cpu()
     ref = OS.synthesis_network(p, ws_ref, nv_compat=not for_inference)
     assert float((img - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def _fake_nvidia_pickle(path, nv_state, extra_buffers=("resample_filter", "noise_const", "w_avg")):
+    """Write a pickle with the structure of NVIDIA's network pickles (stylegan2-ada-pytorch / stylegan3
+    torch_utils.persistence: every network object reduces to `_reconstruct_persistent_obj(meta)` with meta = EasyDict(type=
+    'class', version, module_src, class_name, state = the module's __dict__); top level dict(G, D, G_ema, ...)) from a flat
+    NVIDIA-layout state dict, using throw-away stand-ins for `torch_utils.persistence` / `dnnlib` that exist only while
+    the file is written."""
+    import pickle
+    import types
+    tu, pers, dn = types.ModuleType("torch_utils"), types.ModuleType("torch_utils.persistence"), types.ModuleType("dnnlib")
+
+    def _reconstruct_persistent_obj(meta):   # never called here: the loader under test must not need it either
+        raise RuntimeError("the real persistence module would exec module_src here")
+    _reconstruct_persistent_obj.__module__ = "torch_utils.persistence"
+    _reconstruct_persistent_obj.__qualname__ = "_reconstruct_persistent_obj"
+    pers._reconstruct_persistent_obj = _reconstruct_persistent_obj
+
+    class EasyDict(dict):
+        def __getattr__(self, name):
+            try:
+                return self[name]
+            except KeyError:
+                raise AttributeError(name)
+    EasyDict.__module__, EasyDict.__qualname__ = "dnnlib", "EasyDict"
+    dn.EasyDict = EasyDict
+    tu.persistence = pers
+    sys.modules.update({"torch_utils": tu, "torch_utils.persistence": pers, "dnnlib": dn})
+    try:
+        class Persistent(torch.nn.Module):
+            def __reduce__(self):
+                meta = EasyDict(type="class", version=6, module_src="raise SystemExit('module source must not run')",
+                                class_name=type(self).__name__, state=dict(self.__dict__))
+                return (_reconstruct_persistent_obj, (meta,), None)
+
+        def build(prefix_items):
+            m = Persistent()
+            children = {}
+            for key, val in prefix_items:
+                head, _, rest = key.partition(".")
+                if rest:
+                    children.setdefault(head, []).append((rest, val))
+                elif head in extra_buffers:
+                    m.register_buffer(head, val.clone())
+                else:
+                    m.register_parameter(head, torch.nn.Parameter(val.clone()))
+            for name, items in children.items():
+                m.add_module(name, build(items))
+            return m
+        G = build(list(nv_state.items()))
+        G.z_dim, G.img_resolution = 512, 16
+        with open(path, "wb") as f:
+            pickle.dump(dict(G=None, D=None, G_ema=G, training_set_kwargs=EasyDict(path="x", use_labels=False), augment_pipe=None), f)
+        return {k: v.detach().clone() for k, v in G.state_dict().items()}
+    finally:
+        for k in ("torch_utils", "torch_utils.persistence", "dnnlib"):
+            sys.modules.pop(k, None)
+
+
+def test_nvidia_network_pickle_without_the_nv_package(tmp_path):
+    """maua/GAN/load.py:130-164 unpickles NVIDIA .pkl files with the un-vendored nv package (class pickles that exec their
+    own module source).  load_nvidia reads the same structure with a restricted unpickler: tensors only, persistent objects
+    reduced to their state, nothing executed."""
+    ck = ML.synthetic_rosinality_checkpoint()
+    nv_state = ML.rosinality_to_nvidia(ck)[0]
+    pkl = tmp_path / "network-snapshot.pkl"
+    want = _fake_nvidia_pickle(pkl, nv_state)
+    assert "torch_utils" not in sys.modules and "dnnlib" not in sys.modules
+    sd = ML.nvidia_pkl_state_dict(str(pkl))
+    assert set(sd) == set(want) and all(torch.equal(sd[k], want[k].float()) for k in want)
+    G = ML.load_network(str(pkl))                     # the first converter in the reference's order takes it
+    assert (G.img_resolution, G.mapping.num_layers, G.synthesis.nv_compat) == (16, 2, True)
+    pt = tmp_path / "nv.pt"
+    torch.save({"G_ema": nv_state}, pt)
+    Gp = ML.load_network(str(pt))
+    a, b = G.synthesis.state_dict(), Gp.synthesis.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    # a pickle without parameters is rejected, and one that names a callable outside tensors / containers never runs it
+    import pickle
+    empty = tmp_path / "empty.pkl"
+    empty.write_bytes(pickle.dumps({"G_ema": None}))
+    with pytest.raises(Exception):
+        ML.nvidia_pkl_state_dict(str(empty))
+    marker = tmp_path / "pwned"
+    bad = tmp_path / "os.pkl"
+    bad.write_bytes(b"cos\nsystem\n(S'touch " + str(marker).encode() + b"'\ntR.")
+    with pytest.raises(Exception):
+        ML.nvidia_pkl_state_dict(str(bad))
+    assert not marker.exists()
