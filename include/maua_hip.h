@@ -222,6 +222,11 @@ int maua_soft_kmeans(maua_ctx* ctx, const float* data, int n, int k, const float
  * published kernel, built by the caller). */
 int maua_fir_decimate(maua_ctx* ctx, const float* x, long n, const float* taps, int ntaps, int stride, int left,
                       float scale, float* out, long n_out);
+/* torch.istft's overlap-add (rosa/spectral.py:24-32) for already-windowed time frames [n_frames][W]: y[t] =
+ * sum_f frames[f][t + start - f hop] / sum_f window[t + start - f hop]^2, t < length.  Used by the tempogram of clips
+ * shorter than win_length (rosa/beat.py:48-49, 66: a non-power-of-two transform, run as a DFT GEMM). */
+int maua_overlap_add(maua_ctx* ctx, const float* frames, int n_frames, int W, int hop, const float* window_dev, long start,
+                     long length, float* y);
 /* spectral.py:193-232 spline_eval (+ step_function when apply_step): out = step(a + f (b + f (c + f d))) with the
  * interval picked like torch.bucketize; knots [n_knots], coef [4][n_knots - 1] (a, b, c, d rows), all device f32. */
 int maua_spline_step(maua_ctx* ctx, const float* x, long n, const float* knots, const float* coef, int n_knots, float h,

@@ -13,6 +13,7 @@ framing the reference's features use).  Every function goes through libmaua_hip.
 basis, Gaussian taps, linspace grids) are built on the host exactly as the reference builds them.
 """
 import ctypes as C
+import math
 
 import numpy as np
 import torch
@@ -459,10 +460,14 @@ def _pow2(n):
 def stft_general(y, n_fft, hop_length, window=None):
     """rosa/spectral.py:10-21 for any power-of-two n_fft <= 2048 and any hop (centre / reflect) -> complex64
     [n_fft // 2 + 1, 1 + len(y) // hop] as a transposed view of the frame-major buffer."""
-    if not _pow2(n_fft) or n_fft > 2048:
-        raise NotImplementedError("the HIP FFT handles power-of-two lengths up to 2048")
     y = _f32(y).reshape(-1)
-    win = _f32(torch.hann_window(n_fft) if window is None else window)
+    win = _f32(torch.hann_window(n_fft) if window is None else window).to(y.device)
+    if not _pow2(n_fft):
+        if n_fft > 2048:
+            raise NotImplementedError("stft: lengths up to 2048")
+        return _stft_dft(y, n_fft, hop_length, win)
+    if n_fft > 2048:
+        raise NotImplementedError("the HIP FFT handles power-of-two lengths up to 2048")
     frames = 1 + y.numel() // hop_length
     out = torch.empty((frames, n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
     L.check(L.lib().maua_stft_general(L.ctx(y.device), L.ptr(y), y.numel(), n_fft, hop_length, L.ptr(win), L.ptr(out)))
@@ -472,9 +477,63 @@ def stft_general(y, n_fft, hop_length, window=None):
 def istft_general(spec, n_fft, hop_length, length, window=None):
     buf = _frame_major(spec if spec.is_cuda else L.dev_tensor(spec, torch.complex64))
     win = _f32(torch.hann_window(n_fft) if window is None else window).to(buf.device)
+    if not _pow2(n_fft):
+        return _istft_dft(buf, n_fft, hop_length, length, win)
     y = torch.empty((int(length),), dtype=torch.float32, device=buf.device)
     L.check(L.lib().maua_istft_general(L.ctx(buf.device), L.ptr(buf), buf.shape[0], n_fft, hop_length, L.ptr(win),
                                        int(length), L.ptr(y)))
+    return y
+
+
+_DFT_CACHE = {}
+
+
+def _dft_matrices(n_fft, window):
+    """Real DFT / inverse real DFT of length n_fft as GEMM operands with the window folded in (host f64 -> f32):
+    fwd [2 nb, n_fft]: row 2k = w cos, row 2k+1 = -w sin;  inv [n_fft, 2 nb]: x[n] = w[n] / N sum_k c_k (Re cos - Im sin),
+    c = 1 at DC / Nyquist and 2 elsewhere, their imaginary parts ignored (what a C2R transform does)."""
+    key = (n_fft, str(window.device), float(window.double().sum()))
+    if key not in _DFT_CACHE:
+        nb = n_fft // 2 + 1
+        w = window.detach().cpu().double()
+        n = torch.arange(n_fft, dtype=torch.float64)
+        k = torch.arange(nb, dtype=torch.float64)
+        ang = 2 * math.pi * ((k[:, None] * n[None, :]) % n_fft) / n_fft
+        fwd = torch.stack([ang.cos() * w, -ang.sin() * w], 1).reshape(2 * nb, n_fft)
+        c = torch.full((nb,), 2.0, dtype=torch.float64)
+        c[0] = 1.0
+        s_im = torch.ones(nb, dtype=torch.float64)
+        s_im[0] = 0.0
+        if n_fft % 2 == 0:
+            c[-1], s_im[-1] = 1.0, 0.0
+        inv = torch.stack([ang.cos() * c[:, None], -ang.sin() * (c * s_im)[:, None]], 1).reshape(2 * nb, n_fft).T * (w / n_fft)[:, None]
+        if len(_DFT_CACHE) >= 8:
+            _DFT_CACHE.clear()
+        _DFT_CACHE[key] = (L.dev_tensor(fwd.float(), torch.float32), L.dev_tensor(inv.float(), torch.float32))
+    return _DFT_CACHE[key]
+
+
+def _stft_dft(y, n_fft, hop_length, win):
+    """stft_general for lengths the Stockham FFT does not take: frames gathered on the device, one exact-f32 GEMM."""
+    pad = n_fft // 2
+    if pad >= y.numel():
+        raise ValueError("stft: reflect padding needs n_fft // 2 < len(y)")
+    padded = torch.cat([y[1:pad + 1].flip(0), y, y[-pad - 1:-1].flip(0)])
+    frames = padded.unfold(0, n_fft, hop_length).contiguous()
+    fwd, _ = _dft_matrices(n_fft, win)
+    out = torch.empty((frames.shape[0], n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
+    L.check(L.lib().maua_matmul_nt(L.ctx(y.device), L.ptr(frames), L.ptr(fwd), L.ptr(out), frames.shape[0], 2 * (n_fft // 2 + 1), n_fft))
+    return torch.view_as_complex(out).T
+
+
+def _istft_dft(buf, n_fft, hop_length, length, win):
+    _, inv = _dft_matrices(n_fft, win)
+    F_ = buf.shape[0]
+    frames = torch.empty((F_, n_fft), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_matmul_nt(L.ctx(buf.device), L.ptr(buf), L.ptr(inv), L.ptr(frames), F_, n_fft, 2 * buf.shape[1]))
+    y = torch.empty((int(length),), dtype=torch.float32, device=buf.device)
+    L.check(L.lib().maua_overlap_add(L.ctx(buf.device), L.ptr(frames), F_, n_fft, hop_length, L.ptr(win), C.c_long(n_fft // 2),
+                                     C.c_long(int(length)), L.ptr(y)))
     return y
 
 
@@ -496,9 +555,8 @@ def plp(y, sr, hop_length=1024, win_length=1024, tempo_min=60, tempo_max=180):
     env = onset_strength(y, sr, hop_length=hop_length, aggregate="median")
     T = env.numel()
     W = min(T, win_length)
-    if not _pow2(W):
-        raise NotImplementedError(f"plp: clips shorter than win_length ({win_length} frames) need a {W}-point FFT; "
-                                  "the HIP FFT handles powers of two")
+    if W < 4:
+        raise ValueError(f"plp: {T} envelope frames are too few for a tempogram")
     ft = fourier_tempogram(onset_envelope=env, sr=sr, hop_length=hop_length, win_length=W)
     buf = _frame_major(ft)                                      # [T + 1, W/2 + 1, 2], owns its memory
     freqs = _f32(fourier_tempo_frequencies(sr, W, hop_length))

@@ -137,8 +137,18 @@ _BASIS_CACHE = {}
 
 def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, sparsity=0.01,
         magnitude=True):
-    """constantq.py:13-115 (vqt with gamma = 0) -> |CQT| [n_bins, frames] on the device (``magnitude=False``: complex)."""
+    """constantq.py:13-26: the CQT is the VQT with gamma = 0."""
+    return vqt(y, sr, hop_length, fmin, n_bins, 0, bins_per_octave, tuning, filter_scale, sparsity, magnitude)
+
+
+def vqt(y, sr, hop_length=1024, fmin=None, n_bins=84, gamma=None, bins_per_octave=12, tuning=0.0, filter_scale=1,
+        sparsity=0.01, magnitude=True):
+    """constantq.py:29-115 -> |VQT| [n_bins, frames] on the device (``magnitude=False``: complex).  ``gamma`` widens the
+    low filters' bandwidth (lengths Q sr / (f + gamma / alpha)); None = the ERB default 24.7 alpha / 0.108 (:53-54)."""
     y = _f32(y).reshape(-1)
+    if gamma is None:
+        gamma = 24.7 * (2.0 ** (1.0 / bins_per_octave) - 1) / 0.108
+    gamma = float(gamma)
     n_octaves = int(np.ceil(float(n_bins) / bins_per_octave))
     n_filters = min(bins_per_octave, n_bins)
     two = 0
@@ -151,7 +161,7 @@ def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning
         tuning = estimate_tuning(y, sr, bins_per_octave=bins_per_octave)
     fmin = fmin * 2.0 ** (tuning / bins_per_octave)
     fmin_t = torch.min(cqt_frequencies(n_bins, fmin, bins_per_octave)[-bins_per_octave:])
-    lengths_full = constant_q_lengths(sr, fmin, n_bins, bins_per_octave, filter_scale)
+    lengths_full = constant_q_lengths(sr, fmin, n_bins, bins_per_octave, filter_scale, gamma)
     dev = y.device
     blocks, my_y, my_sr, my_hop = [], y, float(sr), hop_length
     for i in range(n_octaves):
@@ -161,10 +171,10 @@ def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning
         lo = max(0, hi - n_filters)
         # (the filter bank of an octave depends only on the rates: built on the host once per configuration, kept on the device)
         key = (float(my_sr), float(fmin_t * 2.0 ** -i), n_filters, bins_per_octave, filter_scale, sparsity, lo, hi, i,
-               float(fmin), n_bins, str(dev))
+               float(fmin), n_bins, str(dev), gamma)
         if key not in _BASIS_CACHE:
             with L.host_threads(1):   # dozens of tiny host tensors (0.29 s -> 0.04 s for the seven octaves of one CQT)
-                basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity)
+                basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity, gamma)
                 if n_fft > 2048:
                     raise NotImplementedError(f"cqt: the filters need a {n_fft}-point FFT at sr={sr}; the HIP FFT stops at 2048")
                 basis = basis[n_filters - (hi - lo):] * (np.sqrt(2 ** i) / torch.sqrt(lengths_full[lo:hi])[:, None])

@@ -195,6 +195,26 @@ __global__ __launch_bounds__(256) void fir_decimate_kernel(const float* __restri
   out[i] = acc * scale;
 }
 
+// torch.istft's overlap-add for already windowed time frames [n_frames][W] at any hop: y[t] = sum_f frames[f][p - f hop] /
+// sum_f win[p - f hop]^2 with p = t + start (rosa/spectral.py:24-32; used by the non-power-of-two tempogram of short clips,
+// whose DFT runs as a GEMM).
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ frames, int n_frames, int W, int hop,
+                                                          const float* __restrict__ win, long start, long length,
+                                                          float* __restrict__ y) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= length) return;
+  const long p = t + start;
+  long f_hi = p / hop, f_lo = p - W + 1 <= 0 ? 0 : (p - W + hop) / hop;
+  if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+  float num = 0.f, den = 0.f;
+  for (long f = f_lo; f <= f_hi; f++) {
+    const long n = p - f * hop;
+    num += frames[f * W + n];
+    den = fmaf(win[n], win[n], den);
+  }
+  y[t] = den > 1e-11f ? num / den : 0.f;
+}
+
 // y = step(spline(x)): the soft quantiser of chroma_cens (rosa/spectral.py:164-232).  spline = piecewise cubic
 // a + f (b + f (c + f d)), f = x - knot[idx], idx = (number of knots < x) - 1 clamped to [0, nk - 2] (torch.bucketize);
 // step(w) = h (floor(w - 0.5) + 1 / (2 m) / (1 + exp(-2 alpha r(w)))), r(w) = (w - 0.5) - floor(w - 0.5) - 0.5.
@@ -351,6 +371,17 @@ extern "C" int maua_fir_decimate(maua_ctx* ctx, const float* x, long n, const fl
   if (n_out == 0) return MAUA_OK;
   hipLaunchKernelGGL(maua::fir_decimate_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx->stream, x, n, taps,
                      ntaps, stride, left, scale, out, n_out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+extern "C" int maua_overlap_add(maua_ctx* ctx, const float* frames, int n_frames, int W, int hop, const float* window,
+                                long start, long length, float* y) {
+  MAUA_REQUIRE(ctx && frames && window && y, "maua_overlap_add: NULL argument");
+  MAUA_REQUIRE(n_frames >= 1 && W >= 1 && hop >= 1 && start >= 0 && length >= 0, "maua_overlap_add: bad sizes");
+  if (length == 0) return MAUA_OK;
+  hipLaunchKernelGGL(maua::overlap_add_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, ctx->stream, frames,
+                     n_frames, W, hop, window, start, length, y);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

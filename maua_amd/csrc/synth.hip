@@ -361,8 +361,13 @@ int maua_synth_set_resize(maua_synth* n, int layer, int mode, int target_h, int 
     // native grid of the hooked tensor
     const int nat = layer == 0 ? 4 : n->convs[layer - 1].res;
     if (mode == 1) {
-      MAUA_REQUIRE(pad_left >= 0 && pad_right >= 0 && pad_top >= 0 && pad_bottom >= 0,
-                   "maua_synth_set_resize: negative padding is not supported");
+      // negative entries crop, as F.pad does.  The reference reaches them only through the pre-hook of layer 0
+      // (wrappers/stylegan2.py:294); behind a later layer its toRGB inverse slices with negative bounds and the forward
+      // fails (:313-323, the "TODO negative padding" at :278), so there is no behaviour to reproduce there.
+      MAUA_REQUIRE(layer == 0 || (pad_left >= 0 && pad_right >= 0 && pad_top >= 0 && pad_bottom >= 0),
+                   "maua_synth_set_resize: negative padding (cropping) is only defined at layer 0");
+      MAUA_REQUIRE(-pad_left < nat && -pad_right < nat && -pad_top < nat && -pad_bottom < nat,
+                   "maua_synth_set_resize: a crop must leave part of the layer");
       MAUA_REQUIRE(pad_how >= 0 && pad_how <= 3, "maua_synth_set_resize: unknown padding mode");
       MAUA_REQUIRE(target_h == nat + pad_top + pad_bottom && target_w == nat + pad_left + pad_right,
                    "maua_synth_set_resize: target size must equal the layer size plus the padding");

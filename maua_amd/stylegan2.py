@@ -433,8 +433,7 @@ def resize_strategy(layer_size, target_hw, strategy):
             raise ValueError(f"Resize strategy must be 'pad-<how>-<where>': {strategy}")
         _, how, where = parts
         pad_h, pad_w = th - layer_size, tw - layer_size
-        if pad_h < 0 or pad_w < 0:
-            raise NotImplementedError("negative padding (output smaller than the layer) is a TODO in the reference too")
+        # (negative values crop, as F.pad does at :294; defined at layer 0 only - maua_synth_set_resize says why)
         half = lambda p: (p // 2, round(1e-16 + p / 2))
         if where == "out":
             padding = (*half(pad_w), *half(pad_h))

@@ -97,7 +97,14 @@ def stft_rect(y, n_fft, hop):
 
 
 def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, sparsity=0.01):
-    """constantq.py:13-115 (vqt with gamma = 0)."""
+    """constantq.py:13-26 (vqt with gamma = 0)."""
+    return vqt(y, sr, hop_length, fmin, n_bins, 0, bins_per_octave, tuning, filter_scale, sparsity)
+
+
+def vqt(y, sr, hop_length=1024, fmin=None, n_bins=84, gamma=None, bins_per_octave=12, tuning=0.0, filter_scale=1, sparsity=0.01):
+    """constantq.py:29-115."""
+    if gamma is None:
+        gamma = 24.7 * (2.0 ** (1.0 / bins_per_octave) - 1) / 0.108
     n_octaves = int(np.ceil(float(n_bins) / bins_per_octave))
     n_filters = min(bins_per_octave, n_bins)
     fmin = torch.tensor(C1_HZ).float() if fmin is None else torch.as_tensor(fmin).float()
@@ -113,7 +120,7 @@ def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning
             my_y = resample(my_y, my_sr, my_sr / 2) * np.sqrt(2)
             my_sr /= 2.0
             my_hop //= 2
-        fft_basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity)
+        fft_basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity, gamma)
         fft_basis = fft_basis * np.sqrt(2 ** i)
         resp.append(fft_basis @ stft_rect(my_y, n_fft, my_hop)[:, :-1])
     max_col = min(c.shape[-1] for c in resp)
@@ -126,7 +133,7 @@ def cqt(y, sr, hop_length=1024, fmin=None, n_bins=84, bins_per_octave=12, tuning
         else:
             out[end - n_oct:end] = c[:, :max_col]
         end -= n_oct
-    lengths = constant_q_lengths(sr, fmin, n_bins, bins_per_octave, filter_scale)
+    lengths = constant_q_lengths(sr, fmin, n_bins, bins_per_octave, filter_scale, gamma)
     return out / torch.sqrt(lengths[:, None])
 
 

@@ -419,6 +419,16 @@ def golden_pulse():
          tempo_freqs=beat.fourier_tempo_frequencies(sr))
 
 
+def golden_pulse_short():
+    """pulse on clips shorter than the 1024-frame tempogram window (beat.py:48-49: win_length = len(onset_envelope), an
+    even and an odd non-power-of-two transform): 10 s (300 frames) and 277 frames of the g18 clip."""
+    from maua.audiovisual.audioreactive.selfsupervised.features import audio as FA
+    sr = 30720
+    a = synth_audio(40 * sr, sr, 21)
+    save("g24_pulse_short", sr=np.int64(sr), n=np.int64(40 * sr), seed=np.int64(21), n_even=np.int64(300 * 1024),
+         n_odd=np.int64(277 * 1024), pulse_even=FA.pulse(a[: 300 * 1024], sr), pulse_odd=FA.pulse(a[: 277 * 1024], sr))
+
+
 def golden_classic():
     """Small classic-API pieces: signal.compress / expand (:84-105), latent.eerp / copeerp (:46-51), audio.low_pass /
     high_pass / band_pass (:96-112; scipy Butterworth on the host)."""
@@ -533,6 +543,31 @@ def golden_cqt():
          basis_abs_sum=dense.abs().sum(1), resp=torch.view_as_real(resp), pitch_idx=nz, pitch_val=pitch[nz[:, 0], nz[:, 1]],
          mag_val=mag[nz[:, 0], nz[:, 1]], tuning=np.float32(float(tuning)), cq_to_chroma=m,
          lengths_full=CQ.constant_q_lengths(sr, fmin, n_bins=252, bins_per_octave=36))
+
+
+def golden_vqt():
+    """The variable-Q pieces (gamma != 0) of rosa/constantq.py the reference can run here: filter lengths, filter bank,
+    sparsified FFT basis and the top octave's response at the ERB default gamma = 24.7 alpha / 0.108 (constantq.py:53-54)
+    and at gamma = 5 (the octave recursion needs the un-vendored torchaudio.resample)."""
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import spectral as _SP  # noqa: F401
+    from maua.audiovisual.audioreactive.selfsupervised.features.rosa import constantq as CQ
+    y = torch.from_numpy(np.load(HERE / "g09_audio_clip.npz")["audio"])
+    sr = 30720
+    fmin = torch.tensor(32.70319566257483).float()
+    out = {}
+    for tag, bpo, gamma in (("erb", 36, 24.7 * (2.0 ** (1.0 / 36) - 1) / 0.108), ("g5", 12, 5.0)):
+        n_bins = 7 * bpo
+        top = CQ.cqt_frequencies(n_bins, fmin, bins_per_octave=bpo)[-bpo:]
+        filters, lengths = CQ.constant_q(sr, fmin=top.min(), n_bins=bpo, bins_per_octave=bpo, gamma=gamma)
+        fft_basis, n_fft, _ = getattr(CQ, "__cqt_filter_fft")(sr, top.min(), bpo, bpo, 1, 0.01, gamma=gamma)
+        dense = fft_basis.to_dense()
+        resp = getattr(CQ, "__cqt_response")(y, n_fft, 1024, fft_basis)
+        out.update({f"{tag}_gamma": np.float64(gamma), f"{tag}_bpo": np.int64(bpo), f"{tag}_lengths": lengths,
+                    f"{tag}_filt_abs_sum": filters.abs().sum(1), f"{tag}_n_fft": np.int64(n_fft),
+                    f"{tag}_basis_nnz": (dense != 0).sum(1), f"{tag}_basis_abs_sum": dense.abs().sum(1),
+                    f"{tag}_basis_rows": torch.view_as_real(dense[[0, bpo // 2, bpo - 1]]), f"{tag}_resp": torch.view_as_real(resp),
+                    f"{tag}_lengths_full": CQ.constant_q_lengths(sr, fmin, n_bins=n_bins, bins_per_octave=bpo, gamma=gamma)})
+    save("g23_vqt", **out)
 
 
 def segment_inputs(seed=3, T=640, C=12, n_sections=5):

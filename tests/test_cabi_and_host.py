@@ -112,12 +112,14 @@ def test_wrappers_structure():
     # other sizes go through the feature-space resize, which needs the HIP device (no CPU fallback)
     from maua_amd._lib import MauaHipError
     from maua_amd.stylegan2 import resize_strategy
-    with pytest.raises(MauaHipError):
-        StyleGAN2(model_file=None, output_size=(1920, 1080))
+    if not torch.cuda.is_available():
+        with pytest.raises(MauaHipError):
+            StyleGAN2(model_file=None, output_size=(1920, 1080))
     assert resize_strategy(4, (4, 8), "stretch") == dict(mode="stretch")
     assert resize_strategy(16, (17, 30), "pad-0.5-left") == dict(mode="pad", padding=(14, 0, 0, 1), pad_how="constant",
                                                                  pad_value=0.5)
     assert resize_strategy(4, (5, 7), "pad-reflect-out")["padding"] == (1, 2, 0, 1)
+    assert resize_strategy(4, (3, 4), "pad-0-out")["padding"] == (0, 0, -1, 0)       # negative = crop, as F.pad (:256-259, :294)
     with pytest.raises(ValueError):
         resize_strategy(4, (4, 8), "pad-zero")  # the reference's CLI default does not parse there either (Q7)
     sd = G.synthesizer.G_synth.state_dict()

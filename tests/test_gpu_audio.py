@@ -349,6 +349,42 @@ def test_pulse_and_general_stft(golden):
     assert float((err < 5e-3).float().mean()) > 0.98, float(err.max())
 
 
+def test_pulse_on_short_clips(golden):
+    """Clips shorter than the 1024-frame tempogram window transform at the envelope's own length (rosa/beat.py:48-49): an
+    even (300) and an odd (277) non-power-of-two size, run as exact-f32 DFT GEMMs + overlap-add on the device, against the
+    reference's outputs (g24); the general STFT / iSTFT at such sizes against torch."""
+    import ctypes as C
+    import maua_amd.audio as A
+    from maua_amd import _lib as L
+    from maua_amd.pipeline import synthetic_audio
+    g = golden("g24_pulse_short")
+    x = torch.randn(900, generator=torch.Generator().manual_seed(5))
+    for n_fft, hop in [(300, 1), (277, 1), (100, 25), (37, 5)]:
+        want = torch.stft(x, n_fft, hop, window=torch.hann_window(n_fft), center=True, pad_mode="reflect", return_complex=True)
+        got = A.stft_general(x.cuda(), n_fft, hop)
+        assert got.shape == want.shape and rel(got, want) < 5e-6, (n_fft, hop)
+        back = A.istft_general(got, n_fft, hop, 900)
+        assert rel(back, torch.istft(want, n_fft, hop, window=torch.hann_window(n_fft), length=900)) < 2e-5, (n_fft, hop)
+    # the overlap-add entry on its own: hop 3, window 8
+    fr = torch.randn(11, 8, generator=torch.Generator().manual_seed(6))
+    win = torch.hann_window(8)
+    want = torch.zeros(8 + 3 * 10)
+    den = torch.zeros_like(want)
+    for f in range(11):
+        want[3 * f: 3 * f + 8] += fr[f]
+        den[3 * f: 3 * f + 8] += win * win
+    frd, wd = fr.cuda(), win.cuda()
+    y = torch.empty(25, device="cuda")
+    L.check(L.lib().maua_overlap_add(L.ctx(y.device), L.ptr(frd), 11, 8, 3, L.ptr(wd), C.c_long(4), C.c_long(25), L.ptr(y)))
+    assert rel(y, (want / den)[4:29]) < 1e-6
+    a = synthetic_audio(int(g["n"]), int(g["sr"]), int(g["seed"])).cuda()
+    for tag in ("even", "odd"):
+        p = A.pulse(a[: int(g[f"n_{tag}"])], int(g["sr"]))
+        assert p.shape == g[f"pulse_{tag}"].shape
+        err = (p.cpu() - g[f"pulse_{tag}"]).abs().squeeze()
+        assert float((err < 5e-3).float().mean()) > 0.98, (tag, float(err.max()))
+
+
 def test_classic_compress_eerp(golden):
     """signal.compress / expand and latent.eerp / copeerp vs the reference's outputs (g19)."""
     from maua_amd.audiovisual import audioreactive as ar

@@ -71,6 +71,23 @@ def test_cqt_equals_oracle(clip):
         Q.cqt(clip, SR, 1000, n_bins=252, bins_per_octave=36)
 
 
+def test_vqt_matches_reference_fixture_and_oracle(clip, golden):
+    """gamma != 0 (constantq.py:29-115): the top octave against the reference's own response (g23), the seven-octave
+    transform against the oracle, for the ERB default (gamma=None) and an explicit gamma."""
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    g = golden("g23_vqt")
+    for tag in ("erb", "g5"):
+        bpo, gamma = int(g[f"{tag}_bpo"]), float(g[f"{tag}_gamma"])
+        top = float(OC.cqt_frequencies(7 * bpo, torch.tensor(OC.C1_HZ).float(), bpo)[-bpo:].min())
+        got = Q.vqt(clip, SR, 1024, fmin=top, n_bins=bpo, gamma=gamma, bins_per_octave=bpo, magnitude=False).cpu()
+        want = torch.view_as_complex(torch.as_tensor(g[f"{tag}_resp"]).contiguous()) / torch.sqrt(torch.as_tensor(g[f"{tag}_lengths"]))[:, None]
+        close(torch.view_as_real(got), torch.view_as_real(want), 5e-5)
+        full = Q.vqt(clip, SR, 1024, n_bins=7 * bpo, gamma=None if tag == "erb" else gamma, bins_per_octave=bpo).cpu()
+        close(full, OC.vqt(clip, SR, 1024, n_bins=7 * bpo, gamma=gamma, bins_per_octave=bpo).abs(), 1e-4)
+    assert torch.equal(Q.vqt(clip, SR, 1024, n_bins=84, gamma=0), Q.cqt(clip, SR, 1024, n_bins=84))
+
+
 def test_spline_quantize_equals_oracle():
     from maua_amd import cqt as Q
     from oracle import cqt as OC

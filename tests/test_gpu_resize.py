@@ -60,6 +60,8 @@ def _net(res, dt, seed=3):
 CASES = [
     dict(layer=0, mode="stretch", target=(3, 5)),                                   # pre-hook on the const input
     dict(layer=0, mode="pad", target=(4, 7), padding=(1, 2, 0, 0), pad_how="reflect"),
+    dict(layer=0, mode="pad", target=(3, 4), padding=(0, 0, -1, 0), pad_how="constant"),   # negative padding = crop (F.pad)
+    dict(layer=0, mode="pad", target=(3, 6), padding=(1, 1, 0, -1), pad_how="reflect"),    # crop one side, pad the other
     dict(layer=2, mode="stretch", target=(6, 11)),                                  # after bs.1.conv0 (8x8 -> 6x11)
     dict(layer=3, mode="stretch", target=(12, 7)),                                  # after bs.1.conv1
     dict(layer=4, mode="pad", target=(19, 22), padding=(2, 4, 1, 2), pad_how="constant", pad_value=0.3),
@@ -68,7 +70,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: f"L{c['layer']}-{c['mode']}")
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"L{c['layer']}-{c['mode']}-{c['target'][0]}x{c['target'][1]}")
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_synthesis_with_resize_matches_oracle(case, dt):
     from oracle import stylegan2 as OS
@@ -131,6 +133,14 @@ def test_wrapper_output_size_and_noise_kwargs():
     assert G.output_hw == (72, 96) and tuple(syn.forward(ws).shape) == (2, 3, 72, 96)
     syn.change_output_resolution((64, 64), "stretch", 2)
     assert G.output_hw == (64, 64)
+    # an output smaller than the network's: negative padding crops at layer 0 (the pre-hook's F.pad, :294); behind a later
+    # layer the reference's toRGB inverse slices with negative bounds and fails (:278 TODO, :313-323) - rejected here
+    syn.change_output_resolution((48, 64), "pad-0-out", 0)
+    assert G.layer_size(0) == (4, 3) and G.output_hw == (64, 48) and tuple(syn.forward(ws).shape) == (2, 3, 64, 48)
+    from maua_amd._lib import MauaHipError
+    with pytest.raises(MauaHipError, match="layer 0"):
+        syn.change_output_resolution((48, 64), "pad-0-out", 2)
+    syn.change_output_resolution((64, 64), "stretch", 2)
 
 
 def test_resize_state_survives_repeats_and_is_per_instance(tmp_path):

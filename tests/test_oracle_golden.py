@@ -367,6 +367,17 @@ def test_pulse(golden):
     close(A.pulse(a, sr), g["pulse"], 2e-3)
 
 
+def test_pulse_short_clips(golden):
+    """clips shorter than the tempogram window: the transform length is the envelope length (even 300, odd 277) - g24."""
+    from maua_amd.pipeline import synthetic_audio
+    g = golden("g24_pulse_short")
+    a = synthetic_audio(int(g["n"]), int(g["sr"]), int(g["seed"]))
+    for tag in ("even", "odd"):
+        p = A.pulse(a[: int(g[f"n_{tag}"])], int(g["sr"]))
+        assert p.shape == g[f"pulse_{tag}"].shape
+        close(p, g[f"pulse_{tag}"], 2e-3)
+
+
 def test_cqt_pieces(golden):
     """N3 constant-Q chain: every piece the reference can run here (g21, make_golden.py:golden_cqt)."""
     from oracle import cqt as OC
@@ -429,6 +440,36 @@ def test_cqt_host_setup_matches_oracle_and_fixture(golden):
     oxs, ocoef = OC.quantiser_coeffs()
     close(xs, oxs, 0)
     close(coef, torch.as_tensor(ocoef, dtype=torch.float32), 1e-6)
+
+
+def test_vqt_pieces(golden):
+    """variable-Q (gamma != 0, constantq.py:29-115): filter lengths, sparsified basis and the top octave's response of the
+    oracle AND the host set-up of maua_amd/cqt.py against the reference fixture g23 (make_golden.py:golden_vqt)."""
+    from maua_amd import cqt as Q
+    from oracle import cqt as OC
+    g = golden("g23_vqt")
+    y = golden("g09_audio_clip")["audio"]
+    sr = 30720
+    fmin = torch.tensor(OC.C1_HZ).float()
+    for tag in ("erb", "g5"):
+        bpo, gamma = int(g[f"{tag}_bpo"]), float(g[f"{tag}_gamma"])
+        top = OC.cqt_frequencies(7 * bpo, fmin, bpo)[-bpo:]
+        for M in (OC, Q):
+            basis, n_fft, lengths = M.cqt_filter_fft(sr, top.min(), bpo, bpo, 1, 0.01, gamma)
+            assert n_fft == int(g[f"{tag}_n_fft"])
+            close(lengths, g[f"{tag}_lengths"], 1e-6)
+            assert torch.equal((basis != 0).sum(1), g[f"{tag}_basis_nnz"])
+            close(torch.view_as_real(basis[[0, bpo // 2, bpo - 1]]), g[f"{tag}_basis_rows"], 1e-5)
+            close(basis.abs().sum(1), g[f"{tag}_basis_abs_sum"], 1e-5)
+            close(M.constant_q_lengths(sr, fmin, 7 * bpo, bpo, 1, gamma), g[f"{tag}_lengths_full"], 1e-6)
+        basis, n_fft, _ = OC.cqt_filter_fft(sr, top.min(), bpo, bpo, 1, 0.01, gamma)
+        close(torch.view_as_real(basis @ OC.stft_rect(y, n_fft, 1024)[:, :-1]), g[f"{tag}_resp"], 2e-5)
+    # gamma = None is the ERB default; gamma = 0 is the CQT
+    assert abs(float(g["erb_gamma"]) - 24.7 * (2.0 ** (1.0 / 36) - 1) / 0.108) < 1e-12
+    a = OC.vqt(y, sr, 1024, n_bins=72, gamma=0, bins_per_octave=12)
+    assert torch.equal(a, OC.cqt(y, sr, 1024, n_bins=72, bins_per_octave=12))
+    v = OC.vqt(y, sr, 1024, n_bins=252, bins_per_octave=36)
+    assert v.shape == (252, len(y) // 1024) and bool(torch.isfinite(torch.view_as_real(v)).all())
 
 
 def test_sinc_resample_oracle_properties():
