@@ -238,7 +238,7 @@ def measured_traffic(kernel_name, batch=None):
         return None, f"profiles/traffic.json unreadable: {e}"
 
 
-def extra_diffusion(batch=8, steps=100, size=256):
+def extra_diffusion(batch=16, steps=100, size=256):
     """configs[3]: guided-diffusion UNet (guided.py:171-190's architecture, random init), `steps`-step DDIM at `size`^2 -
     one hipGraph per sampler loop; timed after one untimed loop.  Own roofline: algorithmic FLOPs of the UNet."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
