@@ -435,6 +435,10 @@ int maua_gather_frames(maua_comm* comm, const uint8_t* send, const long* bytes_p
  * while chunk k + 1 renders, so the root's ingress hides behind the render.  The root's own piece is not moved. */
 int maua_gather_frames_at(maua_comm* comm, const uint8_t* send, const long* bytes_per_rank, uint8_t* recv_base,
                           const long* offsets_per_rank, int root);
+/* the stream this communicator's transfers are enqueued on (default: the context's stream).  The streamed gather gives it a
+ * side stream that waits on an event of the render stream, so that a round travels while the next chunk renders
+ * (use_ctx_stream != 0: back to the context's stream). */
+int maua_comm_set_stream(maua_comm* comm, void* stream, int use_ctx_stream);
 int maua_comm_destroy(maua_comm* comm);
 
 #ifdef __cplusplus

@@ -72,7 +72,11 @@ struct maua_comm {
   maua_ctx* ctx;
   void* comm;
   int rank, world;
+  bool own_stream = false;   // maua_comm_set_stream: the transfers run on `stream` instead of the context's
+  hipStream_t stream = nullptr;
 };
+
+static hipStream_t comm_stream(const maua_comm* c) { return c->own_stream ? c->stream : c->ctx->stream; }
 
 extern "C" {
 
@@ -94,6 +98,15 @@ int maua_comm_init(maua_ctx* ctx, const maua_comm_id* id, int rank, int world, m
   return MAUA_OK;
 }
 
+// the stream the communicator's transfers are enqueued on from now on (the streamed gather's side stream); use_ctx_stream != 0
+// returns to the context's stream
+int maua_comm_set_stream(maua_comm* comm, void* stream, int use_ctx_stream) {
+  MAUA_REQUIRE(comm, "maua_comm_set_stream: comm is NULL");
+  comm->own_stream = !use_ctx_stream;
+  comm->stream = (hipStream_t)stream;
+  return MAUA_OK;
+}
+
 int maua_comm_destroy(maua_comm* comm) {
   if (!comm) return MAUA_OK;
   int rc = comm->comm ? g_rccl.comm_destroy(comm->comm) : 0;
@@ -106,7 +119,7 @@ int maua_gather_frames(maua_comm* comm, const uint8_t* send, const long* bytes_p
   MAUA_REQUIRE(root >= 0 && root < comm->world, "maua_gather_frames: root outside [0, world)");
   const long mine = bytes_per_rank[comm->rank];
   MAUA_REQUIRE(mine >= 0 && (mine == 0 || send), "maua_gather_frames: this rank's shard is missing");
-  hipStream_t st = comm->ctx->stream;
+  hipStream_t st = comm_stream(comm);
   if (comm->rank != root) {
     if (mine == 0) return MAUA_OK;
     if (int rc = g_rccl.send(send, (size_t)mine, /*ncclUint8*/ 1, root, comm->comm, st)) return rccl_fail("ncclSend", rc);
@@ -139,7 +152,7 @@ int maua_gather_frames_at(maua_comm* comm, const uint8_t* send, const long* byte
   MAUA_REQUIRE(comm && bytes_per_rank && offsets_per_rank, "maua_gather_frames_at: NULL argument");
   MAUA_REQUIRE(root >= 0 && root < comm->world, "maua_gather_frames_at: root outside [0, world)");
   const long mine = bytes_per_rank[comm->rank];
-  hipStream_t st = comm->ctx->stream;
+  hipStream_t st = comm_stream(comm);
   if (comm->rank != root) {
     if (mine <= 0) return MAUA_OK;
     MAUA_REQUIRE(send, "maua_gather_frames_at: this rank's piece is missing");

@@ -160,8 +160,12 @@ class StreamingGather:
         self._reqs = []
         self._side = None
         if self.device.type == "cuda" and world > 1:
+            import ctypes as C
+            from . import _lib as L
             self._side = torch.cuda.Stream(device=self.device)
             self._comm = _cabi_comm(rank, world, self.device)
+            # this communicator's transfers run on the side stream from here on (finish() hands it back)
+            L.check(L.lib().maua_comm_set_stream(self._comm, C.c_void_p(self._side.cuda_stream), 0))
 
     def n_rounds(self, r=None):
         lo, hi = self.ranges[self.rank if r is None else r]
@@ -224,5 +228,7 @@ class StreamingGather:
             q.wait()
         self._reqs = []
         if self._side is not None:
+            from . import _lib as L
             torch.cuda.current_stream(self.device).wait_stream(self._side)
+            L.check(L.lib().maua_comm_set_stream(self._comm, None, 1))   # the communicator is shared with gather_frames_cabi
         return self.clip if self.rank == self.dst else None

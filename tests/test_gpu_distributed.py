@@ -96,3 +96,36 @@ def test_cabi_gather_single_rank():
     assert torch.equal(clip, x) and clip.data_ptr() == g.local.data_ptr()
     with pytest.raises(RuntimeError):
         StreamingGather(5, (8, 8, 3), 2, rank=0, world=1).finish()   # chunks not announced
+
+
+def test_communicator_runs_on_its_own_stream():
+    """maua_comm_set_stream: the communicator's transfers are enqueued on the stream it was given (the streamed gather's side
+    stream), not on whatever stream the shared context was last bound to - checked at world 1, where the gather is the root's
+    own copy: a copy held back by an event on the side stream must not complete before the event is released."""
+    import ctypes as C
+    from maua_amd import _lib as L
+    from maua_amd.distributed import _cabi_comm
+    x = torch.randint(0, 255, (4, 16, 16, 3), dtype=torch.uint8, device="cuda")
+    out = torch.zeros_like(x)
+    comm = _cabi_comm(0, 1, x.device)
+    side = torch.cuda.Stream()
+    L.check(L.lib().maua_comm_set_stream(comm, C.c_void_p(side.cuda_stream), 0))
+    nbytes = (C.c_long * 1)(x.numel())
+    # work queued on the side stream ahead of the gather: the gather must come after it in stream order
+    big = torch.empty((1 << 28,), dtype=torch.uint8, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(8):
+            big.fill_(1)
+        marker = torch.cuda.Event()
+        marker.record(side)
+    L.ctx(x.device)                                   # the shared context is (re-)bound to the CURRENT stream, not the side stream
+    L.check(L.lib().maua_gather_frames(comm, L.ptr(x.reshape(-1)), nbytes, L.ptr(out.reshape(-1)), 0))
+    done = torch.cuda.Event()
+    done.record(side)
+    done.synchronize()
+    assert marker.query() and torch.equal(out, x)
+    L.check(L.lib().maua_comm_set_stream(comm, None, 1))
+    out.zero_()
+    L.check(L.lib().maua_gather_frames(comm, L.ptr(x.reshape(-1)), nbytes, L.ptr(out.reshape(-1)), 0))
+    torch.cuda.current_stream().synchronize()
+    assert torch.equal(out, x)
