@@ -35,6 +35,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
 DEFAULT_BATCH = 128
+CLIP_LEG_TIMEOUT_S = 240   # watchdog of the clip leg's exchange at N > 1 (the leg itself takes about a second)
 
 
 def parse():
@@ -374,39 +375,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- clip leg: this rank's whole frame range once (3600 / N frames, ceil((hi - lo) / B) steps) into a resident
-    # buffer, the u8 shards travelling to rank 0 CHUNK BY CHUNK on a side stream while the next batch renders (RCCL
-    # point-to-point over xGMI, distributed.StreamingGather) - the real end of a sharded render.  `sustained` = until
-    # every rank has rendered its range; `gather_ms` = what is left of the exchange after that (the non-overlapped rest)
-    del out_u8
-    from maua_amd.distributed import StreamingGather
     n_local = hi - lo
-    fence()
-    sg = StreamingGather(T_FRAMES, (RES, RES, 3), B, dtype=torch.uint8, device=device, rank=rank, world=world)
-    fence()
-    tc = time.perf_counter()
-    for off, b in sg.chunks():
-        i = lo + off
-        net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=sg.local[off:off + b])
-        sg.chunk_done()
-    done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(device))
-    done.synchronize()                      # the render stream only: the side stream may still be sending
-    clip_s = time.perf_counter() - tc
-    full = sg.finish()
-    fence()
-    total_s = time.perf_counter() - tc
-    gather_ms = None
-    if dist is not None:
-        t = torch.tensor([clip_s, total_s], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        clip_s, total_s = float(t[0].item()), float(t[1].item())
-        gather_ms = max(0.0, total_s - clip_s) * 1e3
-    if rank == 0:
-        assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
-    del full, sg
 
-    if rank == 0:
+    def build_result(clip_s, gather_ms):
+        """rank 0's JSON line from the timed steps (+ the clip leg's numbers when it ran)"""
         frames = world * B * a.steps
         rows = layer_table(net)
         per_fwd = len(rows)
@@ -461,9 +433,9 @@ def main():
             "roofline": roof, "kernels": roof_all, "gather_ms": gather_ms,
             # sustained: every rank's whole shard once, after the timed steps (max over ranks); e2e adds the set-up of
             # rank 0 (weight init + upload, synthetic audio, audio pre-pass, latent schedule, mapper, noise planes)
-            "sustained": {"clip_frames": T_FRAMES, "frames_per_gpu": n_local, "seconds": clip_s,
-                          "fps": T_FRAMES / clip_s},
-            "e2e": {"clip_frames": T_FRAMES, "setup_s": setup_s, "render_s": clip_s,
+            "sustained": None if clip_s is None else {"clip_frames": T_FRAMES, "frames_per_gpu": n_local, "seconds": clip_s,
+                                                      "fps": T_FRAMES / clip_s},
+            "e2e": None if clip_s is None else {"clip_frames": T_FRAMES, "setup_s": setup_s, "render_s": clip_s,
                     "gather_s": (gather_ms or 0.0) / 1e3,
                     "seconds": setup_s + clip_s + (gather_ms or 0.0) / 1e3,
                     "fps": T_FRAMES / (setup_s + clip_s + (gather_ms or 0.0) / 1e3),
@@ -472,6 +444,57 @@ def main():
                                 "context / first import"},
         }
         res["config"]["gather"] = "streamed: finished chunks of frames_per_step frames travel to rank 0 on a side stream during the render"
+        return res
+
+    # ---- clip leg: this rank's whole frame range once (3600 / N frames, ceil((hi - lo) / B) steps) into a resident
+    # buffer, the u8 shards travelling to rank 0 CHUNK BY CHUNK on a side stream while the next batch renders (RCCL
+    # point-to-point over xGMI, distributed.StreamingGather) - the real end of a sharded render.  `sustained` = until
+    # every rank has rendered its range; `gather_ms` = what is left of the exchange after that (the non-overlapped rest)
+    del out_u8
+    from maua_amd.distributed import StreamingGather
+    # The exchange of the clip leg is the one part of this file that a 1-GPU box cannot exercise (N > 1: RCCL point-to-point
+    # rounds on a side stream).  A watchdog keeps a stuck exchange from taking the measured headline down with it: after
+    # CLIP_LEG_TIMEOUT_S every rank leaves, rank 0 first prints the line of the timed steps with the clip keys set to null.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            res = build_result(None, None)
+            res["clip_leg"] = f"no result within {CLIP_LEG_TIMEOUT_S} s - the streamed gather did not finish"
+            print(json.dumps(res), flush=True)
+        os._exit(0 if rank == 0 else 1)
+    watchdog = threading.Timer(CLIP_LEG_TIMEOUT_S, give_up)
+    watchdog.daemon = True
+    if world > 1:
+        watchdog.start()
+    fence()
+    sg = StreamingGather(T_FRAMES, (RES, RES, 3), B, dtype=torch.uint8, device=device, rank=rank, world=world)
+    fence()
+    tc = time.perf_counter()
+    for off, b in sg.chunks():
+        i = lo + off
+        net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=sg.local[off:off + b])
+        sg.chunk_done()
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(device))
+    done.synchronize()                      # the render stream only: the side stream may still be sending
+    clip_s = time.perf_counter() - tc
+    full = sg.finish()
+    fence()
+    total_s = time.perf_counter() - tc
+    gather_ms = None
+    if dist is not None:
+        t = torch.tensor([clip_s, total_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        clip_s, total_s = float(t[0].item()), float(t[1].item())
+        gather_ms = max(0.0, total_s - clip_s) * 1e3
+    watchdog.cancel()
+    if rank == 0:
+        assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
+    del full, sg
+
+    if rank == 0:
+        res = build_result(clip_s, gather_ms)
         if world == 1 and not a.no_extras:
             # the other single-GPU BASELINE configs, as extra keys (each with its own metric / roofline; never part of `value`)
             del latents, noise
