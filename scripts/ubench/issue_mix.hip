@@ -5,7 +5,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-enum { IDLE = 0, VALU = 1, MFMA = 2, LDSR = 3, MIX = 4 };
+enum { IDLE = 0, VALU = 1, MFMA = 2, LDSR = 3, MIX = 4, VMED = 5, VCVT = 6, VFMA1 = 7 };
 __device__ __forceinline__ void work(int kind, int iters, float* v, f32x16& a0, f32x16& a1, f32x16& a2, const u32x4* lds, u32x4& sink) {
   bf16x8 a = {0}, b = {0};
   for (int it = 0; it < iters; it++) {
@@ -14,6 +14,27 @@ __device__ __forceinline__ void work(int kind, int iters, float* v, f32x16& a0, 
       for (int j = 0; j < 10; j++)
 #pragma unroll
         for (int i = 0; i < 32; i++) v[i] = fmaf(v[i], 1.0001f, 0.5f);
+    } else if (kind == VMED) {   // 320 unpaired VALU instructions (v_med3_f32: no packed form exists)
+#pragma unroll
+      for (int j = 0; j < 10; j++)
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = __builtin_amdgcn_fmed3f(v[i], v[(i + 1) & 31], 0.25f);
+    } else if (kind == VCVT) {   // 320 x v_cvt_pk_bf16_f32 (two values -> one register)
+#pragma unroll
+      for (int j = 0; j < 10; j++)
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+          typedef __bf16 hb2 __attribute__((ext_vector_type(2)));
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          f2 t = {v[i], v[(i + 1) & 31]};
+          hb2 c = __builtin_convertvector(t, hb2);
+          v[i] = __uint_as_float(__builtin_bit_cast(unsigned, c) | 0x3f000000u);
+        }
+    } else if (kind == VFMA1) {  // 320 unpaired v_fma_f32 (a different multiplier per register defeats the pairing)
+#pragma unroll
+      for (int j = 0; j < 10; j++)
+#pragma unroll
+        for (int i = 0; i < 32; i++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(v[(i + 7) & 31]), "v"(v[(i + 13) & 31]));
     } else if (kind == MFMA) {
 #pragma unroll
       for (int j = 0; j < 12; j++) {
@@ -58,14 +79,15 @@ int main() {
   float* out; long long* cyc;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&cyc, 256 * 8 * 8);
   const int iters = 200;
-  const char* nm[] = {"idle", "320 VALU", "36 MFMA", "48 ds_read_b128", "36 MFMA + 48 ds_read"};
+  const char* nm[] = {"idle", "320 VALU", "36 MFMA", "48 ds_read_b128", "36 MFMA + 48 ds_read", "320 v_med3", "320 v_cvt_pk_bf16 (+or)", "320 v_fma_f32 unpaired"};
   int pairs[][2] = {{VALU, IDLE}, {MFMA, IDLE}, {LDSR, IDLE}, {MIX, IDLE}, {VALU, VALU}, {VALU, MFMA}, {MFMA, VALU}, {VALU, LDSR}, {LDSR, VALU},
-                    {VALU, MIX}, {MIX, VALU}, {MFMA, LDSR}, {MIX, MFMA}, {MIX, MIX}, {LDSR, LDSR}};
+                    {VALU, MIX}, {MIX, VALU}, {MFMA, LDSR}, {MIX, MFMA}, {MIX, MIX}, {LDSR, LDSR},
+                    {VMED, IDLE}, {VMED, MFMA}, {MFMA, VMED}, {VMED, MIX}, {VMED, VMED}, {VCVT, IDLE}, {VCVT, MFMA}, {VFMA1, IDLE}, {VFMA1, MFMA}, {MFMA, VFMA1}, {VFMA1, MIX}};
   for (auto& p : pairs) {
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, out, cyc, p[0], p[1], iters);
     hipDeviceSynchronize();
     long long h[8]; (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-    printf("A(older) = %-22s B = %-22s : A %.0f  B %.0f cycles/iter\n", nm[p[0]], nm[p[1]], (double)h[0] / iters, (double)h[4] / iters);
+    printf("A(older) = %-26s B = %-26s : A %.0f  B %.0f cycles/iter\n", nm[p[0]], nm[p[1]], (double)h[0] / iters, (double)h[4] / iters);
   }
   return 0;
 }

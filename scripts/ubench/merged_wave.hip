@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr int LDS_ELEMS = 48 * 64 + 64;
 
 // ---- S: one wave per SIMD.  MODE bit 0 = MFMAs, bit 1 = VALU, bit 2 = LDS reads
-template <int MODE, bool PIN>
+template <int MODE, bool PIN, bool PLAIN = false>
 __global__ __launch_bounds__(256) void ks(float* out, long long* cyc, int iters) {
   extern __shared__ u32x4 lds[];
   for (int i = threadIdx.x; i < LDS_ELEMS; i += blockDim.x) lds[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void ks(float* out, long long* cyc, int iters)
       if (MODE & 2) {
         const int nv = (j & 1) ? 6 : 5;      // 418 per step
 #pragma unroll
-        for (int q = 0; q < nv; q++) { v[vk % 64] = fmaf(v[vk % 64], 1.0001f, 0.5f); vk++; }
+        for (int q = 0; q < nv; q++) {
+          if (PLAIN) v[vk % 64] = __builtin_amdgcn_fmed3f(v[vk % 64], v[(vk + 1) % 64], 0.25f);
+          else v[vk % 64] = fmaf(v[vk % 64], 1.0001f, 0.5f);
+          vk++;
+        }
       }
       if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
@@ -108,6 +112,89 @@ __global__ __launch_bounds__(512) void kd(float* out, long long* cyc, int iters)
   if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
+
+// ---- the same question with the 4-pass 16x16x32 instruction (half the flops per instruction: 152 per step for the same work)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int MODE>
+__global__ __launch_bounds__(256) void ks16(float* out, long long* cyc, int iters) {
+  extern __shared__ u32x4 lds[];
+  for (int i = threadIdx.x; i < LDS_ELEMS; i += blockDim.x) lds[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32x4* p = lds + lane;
+  u32x4 w[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) { w[i] = p[(i % 48) * 64]; w[i][0] += i; }
+  f32x4 acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) acc[i] = f32x4{0};
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) v[i] = threadIdx.x * 0.001f + i;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+    int vk = 0;
+#pragma unroll
+    for (int j = 0; j < 152; j++) {
+      if (MODE & 1)
+        acc[j % 12] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[j % 24]), __builtin_bit_cast(bf16x8, w[(j + 7) % 24]), acc[j % 12], 0, 0, 0);
+      if (MODE & 2) {
+        const int nv = (j & 3) == 3 ? 2 : 3;      // 418 per step
+#pragma unroll
+        for (int q = 0; q < nv; q++) { v[vk % 64] = fmaf(v[vk % 64], 1.0001f, 0.5f); vk++; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0;
+  for (int i = 0; i < 64; i++) r += v[i];
+  for (int i = 0; i < 12; i++)
+    for (int e = 0; e < 4; e++) r += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+  if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+// scalar (unpaired) VALU beside the 8-pass instruction: v_max / v_med3 cannot be packed
+template <int MODE>
+__global__ __launch_bounds__(256) void ksmax(float* out, long long* cyc, int iters) {
+  extern __shared__ u32x4 lds[];
+  for (int i = threadIdx.x; i < LDS_ELEMS; i += blockDim.x) lds[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32x4* p = lds + lane;
+  u32x4 w[24];
+#pragma unroll
+  for (int i = 0; i < 24; i++) { w[i] = p[(i % 48) * 64]; w[i][0] += i; }
+  f32x16 acc[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[i] = f32x16{0};
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) v[i] = threadIdx.x * 0.001f + i;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; it++) {
+    int vk = 0;
+#pragma unroll
+    for (int j = 0; j < 76; j++) {
+      if (MODE & 1) acc[j % 6] = MFMA(w[j % 24], w[(j + 7) % 24], acc[j % 6]);
+      if (MODE & 2) {
+        const int nv = (j & 1) ? 6 : 5;
+#pragma unroll
+        for (int q = 0; q < nv; q++) { v[vk % 64] = __builtin_amdgcn_fmed3f(v[vk % 64], v[(vk + 1) % 64], 0.25f); vk++; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  long long t1 = __builtin_amdgcn_s_memtime();
+  float r = 0;
+  for (int i = 0; i < 64; i++) r += v[i];
+  for (int i = 0; i < 6; i++)
+    for (int e = 0; e < 16; e++) r += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+  if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int threads, float* out, long long* cyc) {
   const int iters = 400;
@@ -140,5 +227,13 @@ int main() {
   run("D  two waves/SIMD, phases in sequence, barrier per step", kd<false, true>, 512, out, cyc);
   run("D  ... without the barrier", kd<false, false>, 512, out, cyc);
   run("D  ... producer weights in registers, barrier", kd<true, true>, 512, out, cyc);
+  run("S  one wave/SIMD, UNPAIRED VALU (v_med3): MFMA + VALU", ks<3, true, true>, 256, out, cyc);
+  run("S  one wave/SIMD, UNPAIRED VALU (v_med3): MFMA + VALU + LDS, groups pinned", ks<7, true, true>, 256, out, cyc);
+  run("16x16x32: MFMA only (152)", ks16<1>, 256, out, cyc);
+  run("16x16x32: VALU only (418, paired by the compiler)", ks16<2>, 256, out, cyc);
+  run("16x16x32: MFMA + VALU interleaved 1 : 2.75", ks16<3>, 256, out, cyc);
+  run("32x32x16 + UNPAIRED VALU (v_med3): MFMA only", ksmax<1>, 256, out, cyc);
+  run("32x32x16 + UNPAIRED VALU (v_med3): VALU only (418)", ksmax<2>, 256, out, cyc);
+  run("32x32x16 + UNPAIRED VALU (v_med3): both", ksmax<3>, 256, out, cyc);
   return 0;
 }
