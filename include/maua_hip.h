@@ -396,6 +396,22 @@ int maua_unet_forward(maua_unet* net, const float* x, const float* timesteps, in
  * sample (may alias x) and pred_xstart (or NULL): [B][C][HW]. */
 int maua_ddim_step(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* noise,
                    const float* coef, int B, int C, int Cm, long HW, float* sample, float* pred_xstart);
+/* gaussian_diffusion.py p_sample (guided.py:302-303, sampler "p"): ancestral step of an epsilon model with learned-range
+ * variance (model_out [B][2 C][H][W]), clip_denoised False; cond_grad (or NULL): condition_mean.  noise [B][C][H][W].
+ * coef: device f32 [B][8] = {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1,
+ * posterior_mean_coef2, posterior_log_variance_clipped, log(betas), t != 0, 0}. */
+int maua_p_sample_step(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* noise,
+                       const float* coef, int B, int C, long HW, float* sample, float* pred_xstart);
+/* plms_sample (guided.py:308-311, sampler "plms"; the sampler of the guided-diffusion fork the reference vendors as an
+ * empty submodule: published algorithm - pseudo linear multistep, Liu et al. 2022): one model evaluation -> eps (after the
+ * optional condition_score), its pred_xstart, the unconditioned pred_xstart; coef = maua_ddim_step's table. */
+int maua_plms_eps(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* coef, int B,
+                  int C, int Cm, long HW, float* eps, float* pred_xstart, float* pred_xstart_orig);
+/* ... and the update: eps' = (sum_i weights[i] eps_list[i]) / divisor (n_eps <= 4; host arrays of device pointers / floats), pred' from
+ * eps', sample = (pred' sqrt(ac_prev) + sqrt(1 - ac_prev) eps') (t != 0) + pred_xstart (t == 0).  coef: device f32 [B][8] =
+ * {sqrt_recip_ac, sqrt_recipm1_ac, sqrt(ac_prev), sqrt(1 - ac_prev), t != 0, 0, 0, 0}. */
+int maua_plms_update(maua_ctx* ctx, const float* x, const float* const* eps_list, const float* weights, int n_eps,
+                     float divisor, const float* pred_xstart, const float* coef, int B, long chw, float* sample);
 /* out[b] = ab[b][0] * x[b] + ab[b][1] * y[b] over rows of `row` floats: q_sample (guided.py:331, gaussian_diffusion.py) */
 int maua_axpby_rows(maua_ctx* ctx, const float* x, const float* y, const float* ab, int B, long row, float* out);
 /* 1 when the last maua_ddim_sample_loop(use_graph = 1) replayed a captured hipGraph, 0 when it ran launch by launch */

@@ -521,6 +521,80 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict_
   if (pred_out) pred_out[idx] = pred;
 }
 
+// gaussian_diffusion.py p_sample (ancestral step) for an epsilon model with learned-range variance (learn_sigma: the second half
+// of the model's channels interpolates between the posterior and the beta log-variance), clip_denoised False, optional
+// condition_mean.  cf[b] = {sqrt_recip_ac, sqrt_recipm1_ac, posterior_mean_coef1, posterior_mean_coef2,
+// posterior_log_variance_clipped, log(beta), nonzero_mask, 0}.
+__global__ __launch_bounds__(256) void p_sample_step_kernel(const float* __restrict__ x, const float* __restrict__ model_out,
+                                                            const float* __restrict__ grad, const float* __restrict__ noise,
+                                                            const float* __restrict__ cf, int C, long HW, long total,
+                                                            float* __restrict__ sample, float* __restrict__ pred_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long chw = (long)C * HW;
+  const int b = (int)(idx / chw);
+  const long rem = idx - (long)b * chw;
+  const float* k = cf + b * 8;
+  const float xv = x[idx];
+  const float* mo = model_out + (long)b * 2 * chw;
+  const float eps = mo[rem], vv = mo[chw + rem];
+  const float frac = (vv + 1.f) / 2.f;
+  const float logvar = frac * k[5] + (1.f - frac) * k[4];
+  const float pred = k[0] * xv - k[1] * eps;                 // _predict_xstart_from_eps
+  float mean = k[2] * pred + k[3] * xv;                      // q_posterior_mean_variance
+  if (grad) mean = mean + expf(logvar) * grad[idx];          // condition_mean: mean + variance * gradient
+  sample[idx] = mean + k[6] * expf(0.5f * logvar) * noise[idx];
+  if (pred_out) pred_out[idx] = pred;
+}
+
+// One model evaluation of plms_sample (the pseudo linear multistep sampler of the guided-diffusion fork the reference
+// vendors as a submodule): pred_orig = x0 from the network's epsilon; with a condition gradient the score is conditioned
+// (condition_score) -> pred; eps = _predict_eps_from_xstart(x, t, pred).  cf[b] = maua_ddim_step's coefficients.
+__global__ __launch_bounds__(256) void plms_eps_kernel(const float* __restrict__ x, const float* __restrict__ model_out,
+                                                       const float* __restrict__ grad, const float* __restrict__ cf, int C,
+                                                       int Cm, long HW, long total, float* __restrict__ eps_out,
+                                                       float* __restrict__ pred_out, float* __restrict__ pred_orig_out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long chw = (long)C * HW;
+  const int b = (int)(idx / chw);
+  const long rem = idx - (long)b * chw;
+  const float* k = cf + b * 8;
+  const float xv = x[idx];
+  const float eps_m = model_out[(long)b * Cm * HW + rem];
+  const float pred_orig = k[0] * xv - k[1] * eps_m;
+  float pred = pred_orig;
+  if (grad) {
+    float e = (k[0] * xv - pred) / k[1];
+    e = e - k[2] * grad[idx];
+    pred = k[0] * xv - k[1] * e;
+  }
+  eps_out[idx] = (k[0] * xv - pred) / k[1];
+  if (pred_out) pred_out[idx] = pred;
+  if (pred_orig_out) pred_orig_out[idx] = pred_orig;
+}
+
+// The multistep update: eps' = (sum_i w[i] * eps_i) / div (i < n: Adams-Bashforth weights, or (1, 1) / 2 for the improved-Euler start),
+// pred' = _predict_xstart_from_eps(x, t, eps'), mean = pred' sqrt(ac_prev) + sqrt(1 - ac_prev) eps',
+// sample = mean * nonzero + pred * (1 - nonzero).  cf[b] = {sqrt_recip_ac, sqrt_recipm1_ac, sqrt(ac_prev), sqrt(1 - ac_prev),
+// nonzero_mask, 0, 0, 0}
+struct PlmsEps { const float* e[4]; float w[4]; float div; int n; };
+__global__ __launch_bounds__(256) void plms_update_kernel(const float* __restrict__ x, PlmsEps pe, const float* __restrict__ pred,
+                                                          const float* __restrict__ cf, long chw, long total,
+                                                          float* __restrict__ sample) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / chw);
+  const float* k = cf + b * 8;
+  // (separately rounded products and sums, left to right, then the division: the order of the reference's expression)
+  float ep = __fmul_rn(pe.w[0], pe.e[0][idx]);
+  for (int i = 1; i < pe.n; i++) ep = __fadd_rn(ep, __fmul_rn(pe.w[i], pe.e[i][idx]));
+  ep = ep / pe.div;
+  const float pp = k[0] * x[idx] - k[1] * ep;
+  const float mean = pp * k[2] + k[3] * ep;
+  sample[idx] = mean * k[4] + pred[idx] * (1.f - k[4]);
+}
+
 // out = a[b] * x + c[b] * y (q_sample: sqrt(ac) * x_start + sqrt(1 - ac) * noise), per-sample coefficients
 __global__ __launch_bounds__(256) void axpby_rows_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ ab, long row, long total,
@@ -1191,6 +1265,58 @@ int maua_ddim_step(maua_ctx* ctx, const float* x, const float* model_out, const 
   const long total = (long)B * C * HW;
   hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, model_out,
                      cond_grad, noise, coef, C, Cm, HW, total, sample, pred_xstart);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// One p_sample update (gaussian_diffusion.py p_sample + p_mean_variance with learned-range variance, epsilon model,
+// clip_denoised False; cond_grad = cond_fn(x, t) or NULL: condition_mean).  model_out [B][2 C][H][W]; noise [B][C][H][W];
+// coef: device f32 [B][8] = {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,
+// posterior_log_variance_clipped, log(betas), t != 0, 0}.
+int maua_p_sample_step(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* noise,
+                       const float* coef, int B, int C, long HW, float* sample, float* pred_xstart) {
+  MAUA_REQUIRE(ctx, "maua_p_sample_step: ctx is NULL");
+  if (B == 0 || HW == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && model_out && noise && coef && sample && C > 0, "maua_p_sample_step: NULL argument");
+  const long total = (long)B * C * HW;
+  hipLaunchKernelGGL(p_sample_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, model_out,
+                     cond_grad, noise, coef, C, HW, total, sample, pred_xstart);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// plms_sample's get_model_output: eps (after the optional condition_score), its pred_xstart and the unconditioned one.
+// coef: maua_ddim_step's table.
+int maua_plms_eps(maua_ctx* ctx, const float* x, const float* model_out, const float* cond_grad, const float* coef, int B,
+                  int C, int Cm, long HW, float* eps, float* pred_xstart, float* pred_xstart_orig) {
+  MAUA_REQUIRE(ctx, "maua_plms_eps: ctx is NULL");
+  if (B == 0 || HW == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && model_out && coef && eps && C > 0 && Cm >= C, "maua_plms_eps: NULL argument");
+  const long total = (long)B * C * HW;
+  hipLaunchKernelGGL(plms_eps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, model_out,
+                     cond_grad, coef, C, Cm, HW, total, eps, pred_xstart, pred_xstart_orig);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// plms_sample's update from n_eps (1..4) epsilon tensors: eps' = (sum_i weights[i] eps_list[i]) / divisor, accumulated left to
+// right like the reference's expressions ((3 e1 - e2) / 2, (23 e1 - 16 e2 + 5 e3) / 12, ...); coef: device f32 [B][8] = {sqrt_recip_ac, sqrt_recipm1_ac, sqrt(ac_prev),
+// sqrt(1 - ac_prev), t != 0, 0, 0, 0}.
+int maua_plms_update(maua_ctx* ctx, const float* x, const float* const* eps_list, const float* weights, int n_eps,
+                     float divisor, const float* pred_xstart, const float* coef, int B, long chw, float* sample) {
+  MAUA_REQUIRE(ctx, "maua_plms_update: ctx is NULL");
+  if (B == 0 || chw == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && eps_list && weights && pred_xstart && coef && sample && n_eps >= 1 && n_eps <= 4, "maua_plms_update: bad argument");
+  MAUA_REQUIRE(divisor != 0.f, "maua_plms_update: divisor is zero");
+  PlmsEps pe{};
+  pe.n = n_eps; pe.div = divisor;
+  for (int i = 0; i < n_eps; i++) {
+    MAUA_REQUIRE(eps_list[i], "maua_plms_update: NULL epsilon tensor");
+    pe.e[i] = eps_list[i]; pe.w[i] = weights[i];
+  }
+  const long total = (long)B * chw;
+  hipLaunchKernelGGL(plms_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, pe, pred_xstart,
+                     coef, chw, total, sample);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

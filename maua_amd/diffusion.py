@@ -14,7 +14,8 @@ What is NOT here, and why: CLIP / LPIPS prompts (un-vendored models, no network 
 caller-supplied objects with ``scale``, ``set_targets(prompts)`` and ``__call__(img, t) -> d loss / d img``; the
 conditioning speeds "fast" / "regular" differentiate THROUGH a network (secondary model / the UNet) with autograd, which
 an inference library does not have - ``speed="hyper"`` (guided.py:248-249: the x0 estimate from the known noise, whose
-Jacobian is 1 / alpha) is implemented exactly.  The "p" and "plms" samplers are not implemented (configs[3] names DDIM).
+Jacobian is 1 / alpha) is implemented exactly.  All three samplers of guided.py:302-311 exist ("ddim": configs[3]; "p";
+"plms": the fork's sampler restated from its published algorithm).
 """
 import ctypes as C
 import math
@@ -276,6 +277,12 @@ class SpacedDiffusion:
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
         self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
         self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        # q(x_{t-1} | x_t, x_0) (p_sample)
+        self.posterior_variance = b * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:])) \
+            if len(b) > 1 else np.log(np.maximum(self.posterior_variance, 1e-20))
+        self.posterior_mean_coef1 = b * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(1.0 - b) / (1.0 - self.alphas_cumprod)
 
     # -- helpers ---------------------------------------------------------------------------------------------
     def model_timesteps(self, t):
@@ -333,6 +340,99 @@ class SpacedDiffusion:
                                        L.ptr(noise if eta != 0.0 else None), L.ptr(cf), B, Cc, out.shape[1],
                                        C.c_long(x[0, 0].numel()), L.ptr(sample), L.ptr(pred)))
         return {"sample": sample, "pred_xstart": pred}
+
+    def p_sample(self, model, x, t, clip_denoised=False, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
+        """gaussian_diffusion.py p_sample (guided.py:302-303): one ancestral step with the learned-range variance ->
+        {"sample", "pred_xstart"}; ``cond_fn``: condition_mean (mean + variance * gradient)."""
+        if clip_denoised or denoised_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn (the reference passes clip_denoised=False)")
+        x = L.dev_tensor(x, torch.float32)
+        mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
+        out = model(x, mt)
+        B, Cc = x.shape[0], x.shape[1]
+        if out.shape[1] != 2 * Cc:
+            raise NotImplementedError("p_sample needs the learned-range variance channels (learn_sigma)")
+        grad = None if cond_fn is None else L.dev_tensor(cond_fn(x, mt), torch.float32)
+        noise = torch.randn_like(x) if noise is None else L.dev_tensor(noise, torch.float32)
+        tt = torch.as_tensor(t).long().cpu().reshape(-1)
+        cf = torch.zeros((len(tt), 8), dtype=torch.float32)
+        cf[:, 0] = self._f32(self.sqrt_recip_alphas_cumprod, tt)
+        cf[:, 1] = self._f32(self.sqrt_recipm1_alphas_cumprod, tt)
+        cf[:, 2] = self._f32(self.posterior_mean_coef1, tt)
+        cf[:, 3] = self._f32(self.posterior_mean_coef2, tt)
+        cf[:, 4] = self._f32(self.posterior_log_variance_clipped, tt)
+        cf[:, 5] = self._f32(np.log(self.betas), tt)
+        cf[:, 6] = (tt != 0).float()
+        cf = L.dev_tensor(cf, torch.float32)
+        sample, pred = torch.empty_like(x), torch.empty_like(x)
+        L.check(L.lib().maua_p_sample_step(L.ctx(x.device), L.ptr(x), L.ptr(out), L.ptr(grad), L.ptr(noise), L.ptr(cf), B, Cc,
+                                           C.c_long(x[0, 0].numel()), L.ptr(sample), L.ptr(pred)))
+        return {"sample": sample, "pred_xstart": pred}
+
+    def _plms_model_output(self, model, x, t, cond_fn):
+        """plms_sample's get_model_output -> (eps, pred_xstart after condition_score, unconditioned pred_xstart)"""
+        mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
+        out = model(x, mt)
+        grad = None if cond_fn is None else L.dev_tensor(cond_fn(x, mt), torch.float32)
+        cf = L.dev_tensor(self.step_coefficients(t), torch.float32)
+        eps, pred, pred_orig = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        L.check(L.lib().maua_plms_eps(L.ctx(x.device), L.ptr(x), L.ptr(out), L.ptr(grad), L.ptr(cf), x.shape[0], x.shape[1],
+                                      out.shape[1], C.c_long(x[0, 0].numel()), L.ptr(eps), L.ptr(pred), L.ptr(pred_orig)))
+        return eps, pred, pred_orig
+
+    def _plms_update(self, x, t, eps_list, weights, divisor, pred):
+        tt = torch.as_tensor(t).long().cpu().reshape(-1)
+        abp = self._f32(self.alphas_cumprod_prev, tt)
+        cf = torch.zeros((len(tt), 8), dtype=torch.float32)
+        cf[:, 0] = self._f32(self.sqrt_recip_alphas_cumprod, tt)
+        cf[:, 1] = self._f32(self.sqrt_recipm1_alphas_cumprod, tt)
+        cf[:, 2] = torch.sqrt(abp)
+        cf[:, 3] = torch.sqrt(1 - abp)
+        cf[:, 4] = (tt != 0).float()
+        cf = L.dev_tensor(cf, torch.float32)
+        ptrs = (C.c_void_p * len(eps_list))(*[e.data_ptr() for e in eps_list])
+        ws = (C.c_float * len(weights))(*weights)
+        sample = torch.empty_like(x)
+        L.check(L.lib().maua_plms_update(L.ctx(x.device), L.ptr(x), ptrs, ws, len(eps_list), C.c_float(divisor), L.ptr(pred),
+                                         L.ptr(cf), x.shape[0], C.c_long(x[0].numel()), L.ptr(sample)))
+        return sample
+
+    def plms_sample(self, model, x, t, clip_denoised=False, denoised_fn=None, cond_fn=None, model_kwargs=None,
+                    cond_fn_with_grad=False, order=2, old_out=None):
+        """plms_sample of the guided-diffusion fork behind maua's submodule (guided.py:308-311; un-vendored: the published
+        pseudo linear multistep sampler, Liu et al. 2022, as that fork states it): the first call of an order > 1 run takes a
+        pseudo improved-Euler step (a second model evaluation at t - 1), later calls the Adams-Bashforth combination of the
+        last ``order`` epsilons.  -> {"sample", "pred_xstart" (unconditioned), "old_eps"}; pass the result back as ``old_out``."""
+        if clip_denoised or denoised_fn is not None or cond_fn_with_grad:
+            raise NotImplementedError("clip_denoised / denoised_fn / cond_fn_with_grad")
+        if not int(order) or not 1 <= order <= 4:
+            raise ValueError("order is invalid (should be int from 1-4).")
+        x = L.dev_tensor(x, torch.float32)
+        t = torch.as_tensor(t).long()
+        eps, pred, pred_orig = self._plms_model_output(model, x, t, cond_fn)
+        if order > 1 and old_out is None:
+            old_eps = [eps]
+            # mean_pred = pred * sqrt(ac_prev) + sqrt(1 - ac_prev) * eps: the update with eps' = eps - but on `pred`, not on a
+            # prediction re-derived from eps (the same value up to rounding; the reference uses out["pred_xstart"] here)
+            tt = t.cpu().reshape(-1)
+            abp = self._f32(self.alphas_cumprod_prev, tt)
+            ab2 = L.dev_tensor(torch.stack([torch.sqrt(abp), torch.sqrt(1 - abp)], 1).contiguous(), torch.float32)
+            mean_pred = torch.empty_like(x)
+            L.check(L.lib().maua_axpby_rows(L.ctx(x.device), L.ptr(pred), L.ptr(eps), L.ptr(ab2), x.shape[0],
+                                            C.c_long(x[0].numel()), L.ptr(mean_pred)))
+            eps_2, _, _ = self._plms_model_output(model, mean_pred, t - 1, cond_fn)
+            sample = self._plms_update(x, t, [eps, eps_2], [1.0, 1.0], 2.0, pred)
+        else:
+            old_eps = [] if old_out is None else list(old_out["old_eps"])
+            old_eps.append(eps)
+            cur_order = min(order, len(old_eps))
+            newest_first = old_eps[::-1][:cur_order]
+            weights, div = {1: ([1.0], 1.0), 2: ([3.0, -1.0], 2.0), 3: ([23.0, -16.0, 5.0], 12.0),
+                            4: ([55.0, -59.0, 37.0, -9.0], 24.0)}[cur_order]
+            sample = self._plms_update(x, t, newest_first, weights, div, pred)
+        if len(old_eps) >= order:
+            old_eps.pop(0)
+        return {"sample": sample, "pred_xstart": pred_orig, "old_eps": old_eps}
 
     def ddim_sample_loop(self, model, x, start_step=None, n_steps=None, use_graph=True):
         """The unconditioned loop inside the library (one hipGraph per shape): t = start_step, start_step - 1, ...
@@ -478,19 +578,21 @@ class ImageTarget:
 
 
 class GuidedDiffusion(torch.nn.Module):
-    """guided.py:277-339 (sampler "ddim").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
+    """guided.py:277-339 (samplers "ddim", "p", "plms").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
     checkpoint name (file must exist, see create_models) or ready objects (tests, bench)."""
 
     def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
                  ddim_eta=0, plms_order=2, speed="hyper", model=None, diffusion=None, allow_random_init=False,
                  dtype=torch.bfloat16):
         super().__init__()
-        if sampler != "ddim":
-            raise NotImplementedError('only sampler="ddim" (BASELINE configs[3]) is implemented')
+        if sampler not in ("ddim", "p", "plms"):
+            raise NotImplementedError()
         if model is None:
-            model, diffusion, _ = create_models(checkpoint=model_checkpoint, timestep_respacing=f"ddim{timesteps}",
+            model, diffusion, _ = create_models(checkpoint=model_checkpoint,   # (:292: "ddimN" spacing only for DDIM)
+                                                timestep_respacing=f"ddim{timesteps}" if sampler == "ddim" else str(timesteps),
                                                 use_secondary=False, allow_random_init=allow_random_init, dtype=dtype)
         self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
+        self.sampler, self.plms_order = sampler, plms_order
         mods = [gm for gm in grad_modules if gm.scale != 0]
         self.conditioning = GradientGuidedConditioning(diffusion, None, mods, speed=speed) if mods else None
         self.device = device
@@ -508,14 +610,20 @@ class GuidedDiffusion(torch.nn.Module):
         x = self.diffusion.q_sample(img, t, noise)
         if n_steps <= 0:
             return None  # (the reference returns out["pred_xstart"] of out = None here, i.e. raises)
-        if self.conditioning is None and self.ddim_eta == 0:
+        if self.sampler == "ddim" and self.conditioning is None and self.ddim_eta == 0:
             return self.diffusion.ddim_sample_loop(self.model, x, start_step, n_steps)[1]
         if self.conditioning is not None:
             self.conditioning.set_targets([p.to(img) for p in prompts], noise)
         out = None
-        for _ in range(n_steps):
-            out = self.diffusion.ddim_sample(self.model, x, t, clip_denoised=False, cond_fn=self.conditioning,
-                                             model_kwargs={}, eta=self.ddim_eta)
+        for _ in range(n_steps):   # guided.py:302-311, :333-337
+            if self.sampler == "ddim":
+                out = self.diffusion.ddim_sample(self.model, x, t, clip_denoised=False, cond_fn=self.conditioning,
+                                                 model_kwargs={}, eta=self.ddim_eta)
+            elif self.sampler == "p":
+                out = self.diffusion.p_sample(self.model, x, t, clip_denoised=False, cond_fn=self.conditioning, model_kwargs={})
+            else:
+                out = self.diffusion.plms_sample(self.model, x, t, clip_denoised=False, cond_fn=self.conditioning,
+                                                 model_kwargs={}, order=self.plms_order, old_out=out)
             x = out["sample"]
             t = t - 1
         return out["pred_xstart"]

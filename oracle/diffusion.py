@@ -281,6 +281,10 @@ class Schedule:
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
         self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
         self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = b * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = b * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(1.0 - b) / (1.0 - self.alphas_cumprod)
 
     def model_timesteps(self, t):
         """_WrappedModel.__call__: spaced index -> the timestep the network sees."""
@@ -322,6 +326,67 @@ def ddim_step(sch, model_output, x, t, cond_grad=None, eta=0.0, noise=None):
     if noise is None:
         noise = torch.zeros_like(x)
     return mean_pred + nonzero * sigma * noise, pred
+
+
+def p_sample_step(sch, model_output, x, t, noise, cond_grad=None):
+    """gaussian_diffusion.py p_sample + p_mean_variance (ModelVarType.LEARNED_RANGE, ModelMeanType.EPSILON, clip_denoised
+    False) + condition_mean.  -> (sample, pred_xstart)."""
+    C = x.shape[1]
+    eps, var_values = model_output[:, :C], model_output[:, C:]
+    min_log = _ex(sch.posterior_log_variance_clipped, t, x.shape)
+    max_log = _ex(np.log(sch.betas), t, x.shape)
+    frac = (var_values + 1) / 2
+    log_variance = frac * max_log + (1 - frac) * min_log
+    variance = torch.exp(log_variance)
+    pred = _ex(sch.sqrt_recip_alphas_cumprod, t, x.shape) * x - _ex(sch.sqrt_recipm1_alphas_cumprod, t, x.shape) * eps
+    mean = _ex(sch.posterior_mean_coef1, t, x.shape) * pred + _ex(sch.posterior_mean_coef2, t, x.shape) * x
+    if cond_grad is not None:
+        mean = mean.float() + variance * cond_grad.float()
+    nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+    return mean + nonzero * torch.exp(0.5 * log_variance) * noise, pred
+
+
+def plms_sample(sch, model_fn, x, t, cond_fn=None, order=2, old_out=None):
+    """plms_sample of the guided-diffusion fork the reference's (empty) submodule points at - un-vendored, restated from the
+    published pseudo linear multistep sampler (Liu et al. 2022) in that fork's form: ``model_fn(x, t)`` -> network output at
+    the spaced index t.  -> dict(sample, pred_xstart (unconditioned), old_eps)."""
+    def get_model_output(xx, tt):
+        out = model_fn(xx, tt)
+        C = xx.shape[1]
+        c1, c2 = _ex(sch.sqrt_recip_alphas_cumprod, tt, xx.shape), _ex(sch.sqrt_recipm1_alphas_cumprod, tt, xx.shape)
+        pred_orig = c1 * xx - c2 * out[:, :C]
+        pred = pred_orig
+        if cond_fn is not None:
+            e = (c1 * xx - pred) / c2
+            e = e - (1 - _ex(sch.alphas_cumprod, tt, xx.shape)).sqrt() * cond_fn(xx, sch.model_timesteps(tt))
+            pred = c1 * xx - c2 * e
+        return (c1 * xx - pred) / c2, pred, pred_orig
+    c1, c2 = _ex(sch.sqrt_recip_alphas_cumprod, t, x.shape), _ex(sch.sqrt_recipm1_alphas_cumprod, t, x.shape)
+    abp = _ex(sch.alphas_cumprod_prev, t, x.shape)
+    eps, pred, pred_orig = get_model_output(x, t)
+    if order > 1 and old_out is None:
+        old_eps = [eps]
+        mean_pred = pred * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps
+        eps_2, _, _ = get_model_output(mean_pred, t - 1)
+        eps_prime = (eps + eps_2) / 2
+    else:
+        old_eps = [] if old_out is None else list(old_out["old_eps"])
+        old_eps.append(eps)
+        cur = min(order, len(old_eps))
+        if cur == 1:
+            eps_prime = old_eps[-1]
+        elif cur == 2:
+            eps_prime = (3 * old_eps[-1] - old_eps[-2]) / 2
+        elif cur == 3:
+            eps_prime = (23 * old_eps[-1] - 16 * old_eps[-2] + 5 * old_eps[-3]) / 12
+        else:
+            eps_prime = (55 * old_eps[-1] - 59 * old_eps[-2] + 37 * old_eps[-3] - 9 * old_eps[-4]) / 24
+    pred_prime = c1 * x - c2 * eps_prime
+    mean_pred = pred_prime * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps_prime
+    if len(old_eps) >= order:
+        old_eps.pop(0)
+    nonzero = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
+    return {"sample": mean_pred * nonzero + pred * (1 - nonzero), "pred_xstart": pred_orig, "old_eps": old_eps}
 
 
 @torch.no_grad()

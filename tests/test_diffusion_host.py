@@ -101,3 +101,43 @@ def test_oracle_blocks_against_torch_modules():
     # timestep embedding: cos | sin halves, unit frequency first
     e = OD.timestep_embedding(torch.tensor([0.0, 10.0]), 8)
     assert torch.equal(e[0], torch.tensor([1.0, 1, 1, 1, 0, 0, 0, 0])) and abs(float(e[1, 0]) - math.cos(10.0)) < 1e-6
+
+
+def test_p_and_plms_restatements_closed_forms():
+    """The oracle's p_sample / plms_sample restatements (un-vendored upstream: parity unpinned) against what can be said about
+    them without the upstream code: (i) order-1 PLMS is the eta = 0 DDIM update (Liu et al. 2022, Song et al. 2021: the same
+    transfer function); (ii) at order 2 the first call costs two model evaluations (improved Euler) and later ones one, the
+    epsilon history holds order - 1 entries; (iii) p_sample with frac = 0 / 1 uses exactly the posterior / beta variance, its
+    mean is the posterior mean of the predicted x0, and at t = 0 no noise is added; (iv) the Adams-Bashforth weights sum to 1."""
+    sch = OD.Schedule(1000, "50", True)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    mo = torch.randn(2, 6, 8, 8, generator=g)
+    t = torch.tensor([31, 7])
+    calls = []
+
+    def fn(xx, tt):
+        calls.append(tt.clone())
+        return mo
+    o1 = OD.plms_sample(sch, fn, x, t, order=1, old_out={"old_eps": []})
+    ws, wp = OD.ddim_step(sch, mo, x, t)
+    assert float((o1["sample"] - ws).abs().max()) <= 2e-6 * float(ws.abs().max()) and torch.equal(o1["pred_xstart"], wp)
+    calls.clear()
+    o2 = OD.plms_sample(sch, fn, x, t, order=2, old_out=None)
+    assert len(calls) == 2 and torch.equal(calls[1], t - 1) and len(o2["old_eps"]) == 1
+    o3 = OD.plms_sample(sch, fn, o2["sample"], t - 1, order=2, old_out=o2)
+    assert len(calls) == 3 and len(o3["old_eps"]) == 1
+    for w, d in (([3, -1], 2), ([23, -16, 5], 12), ([55, -59, 37, -9], 24)):
+        assert sum(w) == d
+    nz = torch.randn(2, 3, 8, 8, generator=g)
+    for frac_v, table in ((-1.0, sch.posterior_log_variance_clipped), (1.0, np.log(sch.betas))):
+        m = mo.clone()
+        m[:, 3:] = frac_v
+        s, pred = OD.p_sample_step(sch, m, x, t, nz)
+        c1 = torch.from_numpy(sch.posterior_mean_coef1)[t].float().view(-1, 1, 1, 1)
+        c2 = torch.from_numpy(sch.posterior_mean_coef2)[t].float().view(-1, 1, 1, 1)
+        sd = torch.exp(0.5 * torch.from_numpy(table)[t].float()).view(-1, 1, 1, 1)
+        assert torch.allclose(s, c1 * pred + c2 * x + sd * nz, rtol=0, atol=1e-6)
+    s0, p0 = OD.p_sample_step(sch, mo, x, torch.tensor([0, 0]), nz)
+    c1 = float(sch.posterior_mean_coef1[0])
+    assert abs(c1 - 1.0) < 1e-12 and torch.allclose(s0, p0, atol=1e-6)       # t = 0: the mean is the predicted x0, no noise

@@ -175,6 +175,68 @@ def test_schedule_and_ddim_step_match_oracle():
         assert rel(out["sample"], ws) <= 2e-6 and rel(out["pred_xstart"], wp) <= 2e-6
 
 
+def test_p_and_plms_samplers_match_oracle():
+    """guided.py:302-311: the "p" (ancestral, learned-range variance, condition_mean) and "plms" (pseudo linear multistep,
+    orders 1-4, improved-Euler start, condition_score) samplers, step by step against the oracle's restatements with a
+    fixed-output model, then "plms" / "p" chains on a small UNet through GuidedDiffusion."""
+    from maua_amd.diffusion import GuidedDiffusion, SpacedDiffusion, space_timesteps
+    sch = OD.Schedule(1000, "50", True)
+    sd = SpacedDiffusion(space_timesteps(1000, "50"), OD.linear_betas(1000), rescale_timesteps=True)
+    for name in ("posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.array_equal(getattr(sd, name), getattr(sch, name)), name
+    g = torch.Generator().manual_seed(11)
+    t = torch.tensor([49, 20, 0])
+    x, nz = torch.randn(3, 3, 16, 16, generator=g), torch.randn(3, 3, 16, 16, generator=g)
+    grad = 0.1 * torch.randn(3, 3, 16, 16, generator=g)
+    outs = {}
+
+    def model_cpu(xx, tt):     # a deterministic "network": a per-step pattern + a linear function of its input
+        key = tuple(int(v) for v in torch.as_tensor(tt).reshape(-1))
+        if key not in outs:
+            gg = torch.Generator().manual_seed(sum((i + 1) * (v + 7) for i, v in enumerate(key)))
+            outs[key] = torch.randn(xx.shape[0], 6, 16, 16, generator=gg) * 0.7
+        return outs[key] + 0.1 * torch.cat([xx, -xx], 1)
+
+    class Dev:
+        def __call__(self, xx, ts):
+            idx = torch.tensor([sch.timestep_map.index(int(round(float(v) * sch.original_num_steps / 1000.0))) for v in ts.cpu()])
+            return model_cpu(xx.cpu(), idx).cuda()
+    for gr in (None, grad):
+        cond = None if gr is None else (lambda xx, ts: gr.cuda())
+        out = sd.p_sample(Dev(), x, t, cond_fn=cond, noise=nz)
+        ws, wp = OD.p_sample_step(sch, model_cpu(x, t), x, t, nz, gr)
+        assert rel(out["sample"], ws) <= 3e-6 and rel(out["pred_xstart"], wp) <= 2e-6
+    # plms: chains of five steps at every order (t stays > 0 except for the last sample of the batch at order 1)
+    for order in (1, 2, 3, 4):
+        for gr in (None, grad):
+            cond_d = None if gr is None else (lambda xx, ts: gr.cuda())
+            cond_o = None if gr is None else (lambda xx, ts: gr)
+            tt, xd, xo, od, oo = torch.tensor([30, 12, 6]), x.clone(), x.clone(), None, None
+            for step in range(5):
+                od = sd.plms_sample(Dev(), xd, tt, cond_fn=cond_d, order=order, old_out=od)
+                oo = OD.plms_sample(sch, model_cpu, xo, tt, cond_fn=cond_o, order=order, old_out=oo)
+                assert len(od["old_eps"]) == len(oo["old_eps"])
+                assert rel(od["sample"], oo["sample"]) <= 2e-5 and rel(od["pred_xstart"], oo["pred_xstart"]) <= 2e-5, (order, step)
+                xd, xo, tt = od["sample"], oo["sample"].clone(), tt - 1
+    # through GuidedDiffusion on a small UNet (exact-f32 mode): "plms" order 2 and "p" against the oracle's chain
+    cfg, p, net = _build(SMALL, torch.float32)
+    sch2 = OD.Schedule(1000, "20", True)
+    sd2 = SpacedDiffusion(space_timesteps(1000, "20"), OD.linear_betas(1000), rescale_timesteps=True)
+    img, nz2 = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 3, 64, 64, generator=g)
+    gd = GuidedDiffusion([], sampler="plms", timesteps=20, model=net, diffusion=sd2, plms_order=2)
+    got = gd.forward(img, [], 0.4, t_end=0.7, noise=nz2)            # start_step 8, 6 steps
+    tt = torch.tensor([8, 8])
+    xo, oo = OD.q_sample(sch2, img, tt, nz2), None
+    fn = lambda xx, t_: OD.unet_forward(p, cfg, xx, sch2.model_timesteps(t_))
+    with torch.no_grad():
+        for _ in range(6):
+            oo = OD.plms_sample(sch2, fn, xo, tt, order=2, old_out=oo)
+            xo, tt = oo["sample"], tt - 1
+    assert rel(got, oo["pred_xstart"]) <= 5e-4
+    with pytest.raises(NotImplementedError):
+        GuidedDiffusion([], sampler="euler", timesteps=20, model=net, diffusion=sd2)
+
+
 def test_guided_diffusion_forward_and_sampler_loop():
     """GuidedDiffusion.forward with the reference's start / step arithmetic on a small UNet: the in-library loop (one
     hipGraph), the eager step-by-step path and the oracle agree; a conditioning gradient (speed="hyper") changes the
