@@ -331,20 +331,38 @@ def _persistent_obj(meta):
     return obj
 
 
+def _safe_storage_from_bytes(b):
+    """torch.storage._load_from_bytes with the tensors-only unpickler (the stock one calls torch.load(weights_only=False) on
+    the embedded bytes, i.e. runs whatever pickle they hold)."""
+    import io
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
 class _NetworkUnpickler(__import__("pickle").Unpickler):
     """Reads NVIDIA's network pickles (legacy.load_network_pkl's format, StyleGAN2-ADA-PyTorch / StyleGAN3: a dict with
-    G / D / G_ema persistent objects) WITHOUT NVIDIA's dnnlib / torch_utils / legacy packages and without executing the module
-    source the pickle embeds: tensors, numpy arrays and containers are rebuilt by their own libraries, every other global
-    resolves to an inert stand-in."""
-    SAFE_PREFIXES = ("torch", "numpy", "collections", "builtins", "_codecs", "copyreg")
+    G / D / G_ema persistent objects) WITHOUT NVIDIA's dnnlib / torch_utils / legacy packages and without executing anything
+    the file names: an explicit allow-list rebuilds tensors, parameters, numpy arrays and plain containers (a tensor's
+    storage through torch's tensors-only loader); every other global - NVIDIA's classes, torch.nn modules, os.system -
+    resolves to an inert stand-in that only keeps the state it is handed."""
+    ALLOWED = {
+        ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch", "Size"), ("torch", "device"),
+        ("collections", "OrderedDict"), ("_codecs", "encode"), ("copyreg", "_reconstructor"),
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+        ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    }
+    BUILTINS = ("dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                "slice", "range", "object")
 
     def find_class(self, module, name):
         if module == "torch_utils.persistence" and name == "_reconstruct_persistent_obj":
             return _persistent_obj
-        if module.split(".")[0] in self.SAFE_PREFIXES:
-            if module == "builtins" and name in ("eval", "exec", "compile", "open", "__import__", "getattr", "setattr"):
-                raise __import__("pickle").UnpicklingError(f"refusing builtins.{name}")
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _safe_storage_from_bytes
+        if (module, name) in self.ALLOWED or (module == "builtins" and name in self.BUILTINS):
             return super().find_class(module, name)
+        if module == "torch" and (name.endswith("Storage") or isinstance(getattr(torch, name, None), torch.dtype)):
+            return getattr(torch, name)
         if name == "EasyDict":            # dnnlib.EasyDict: a dict with attribute access
             return dict
         return _PickledObject

@@ -220,6 +220,20 @@ def test_nvidia_network_pickle_without_the_nv_package(tmp_path):
     empty.write_bytes(pickle.dumps({"G_ema": None}))
     with pytest.raises(Exception):
         ML.nvidia_pkl_state_dict(str(empty))
+    # a tensor whose embedded storage bytes are themselves a hostile pickle: the stock torch.storage._load_from_bytes would
+    # run it (torch.load(weights_only=False)); the reader hands them to the tensors-only loader, which refuses
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {tmp_path / 'pwned2'}",))
+    import io
+    inner = io.BytesIO()
+    pickle.dump(Evil(), inner)
+    nested = tmp_path / "nested.pkl"
+    nested.write_bytes(b"\x80\x02}q\x00X\x05\x00\x00\x00G_emaq\x01ctorch.storage\n_load_from_bytes\nq\x02" +
+                       pickle.dumps(inner.getvalue(), 2)[2:-1] + b"\x85Rs.")
+    with pytest.raises(Exception):
+        ML.nvidia_pkl_state_dict(str(nested))
+    assert not (tmp_path / "pwned2").exists()
     marker = tmp_path / "pwned"
     bad = tmp_path / "os.pkl"
     bad.write_bytes(b"cos\nsystem\n(S'touch " + str(marker).encode() + b"'\ntR.")
