@@ -106,7 +106,8 @@ int maua_synth_num_layers(const maua_synth* net);  /* synthesis layers in execut
  *  mode 0 "stretch": bicubic (align_corners False) to (target_h, target_w); the block's toRGB output is resized back
  *          and the block's image forward again, as the reference's rgb / img hooks do.
  *  mode 1 "pad-<how>-<where>": F.pad by (pad_left, pad_right, pad_top, pad_bottom) with pad_how (maua_pad_mode) /
- *          pad_value; inverse = crop.  Negative padding is rejected (a TODO in the reference as well).
+ *          pad_value; inverse = crop.  Negative entries crop, as F.pad does - at layer 0 only (the pre-hook, :294): behind a
+ *          later layer the reference's toRGB inverse slices with negative bounds and its forward fails (:278, :313-323).
  *  fill_noise_host: optional [C][target_h][target_w] f32 added to the resized FEATURES (the reference draws it once
  *          per hook from the per-channel mean/std of the first resized batch, :233-248; the caller owns the RNG).
  * Later layers need noise of their new size: maua_synth_layer_size reports it, maua_synth_load accepts a noise_const of
