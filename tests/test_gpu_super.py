@@ -44,6 +44,35 @@ def test_rrdbnet_matches_oracle(dt, blocks):
     assert int((u8.cpu().int() - want.int()).abs().max()) <= (1 if dt == torch.bfloat16 else 0)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_full_depth_rrdbnet_matches_oracle(dt):
+    """configs[4]'s generator at its released depth (RealESRGAN_x4plus: 23 RRDB blocks = 345 trunk convolutions) on a
+    non-square 96 x 136 image -> 384 x 544, against the oracle (a few seconds of CPU)."""
+    from maua_amd.super import RRDBNet
+    from oracle import super as OSR
+    net = RRDBNet(num_block=23, dtype=dt, generator=torch.Generator().manual_seed(7))
+    p = net.state_dict()
+    g = torch.Generator().manual_seed(8)
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    p["conv_last.bias"] = torch.full((3,), 0.5)
+    p["conv_last.weight"] = p["conv_last.weight"] * 0.1
+    net.load_state_dict(p)
+    x = torch.rand(1, 3, 96, 136, generator=g)
+    y = net(x, clamp=False).cpu()        # the raw output (random weights of this depth leave [0, 1]; RealESRGANer clamps later)
+    with torch.no_grad():
+        ref = OSR.rrdbnet_raw(p, x, 23)
+    assert y.shape == ref.shape == (1, 3, 384, 544) and bool(torch.isfinite(ref).all()) and float(ref.std()) > 1e-3
+    scale = float(ref.abs().max())
+    if dt == torch.float32:
+        assert float((y - ref).abs().max()) <= 1e-4 * scale, float((y - ref).abs().max()) / scale
+    else:
+        mse = float(((y - ref) ** 2).mean())
+        rng = float(ref.max() - ref.min())
+        assert 10 * np.log10(rng * rng / mse) >= 38.0, 10 * np.log10(rng * rng / mse)
+
+
 def test_realesrgan_wrapper_and_render_pipeline():
     """The reference's call shapes (load_model / upscale, realesrgan.py:22-49) and the configs[4] pipeline: StyleGAN2
     frames -> [0,1] -> 4x up-scaler -> u8, per frame on the device.  A missing checkpoint is an error (the reference
