@@ -321,7 +321,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("MAUA_BENCH_BACKEND", "nccl")   # ("gloo": scripts/two_ranks_one_gpu.py, control flow on a 1-GPU box)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from maua_amd import _lib as L
     from maua_amd import pipeline
@@ -461,7 +465,7 @@ def main():
         if rank == 0:
             res = build_result(None, None)
             res["clip_leg"] = f"no result within {CLIP_LEG_TIMEOUT_S} s - the streamed gather did not finish"
-            print(json.dumps(res), flush=True)
+            print("\n" + json.dumps(res), flush=True)   # (own line even behind a partly flushed RCCL message)
         os._exit(0)
     watchdog = threading.Timer(CLIP_LEG_TIMEOUT_S, give_up)
     watchdog.daemon = True
@@ -496,7 +500,7 @@ def main():
         if rank == 0:
             res = build_result(None, None)
             res["clip_leg"] = f"failed: {type(e).__name__}: {e}"
-            print(json.dumps(res), flush=True)
+            print("\n" + json.dumps(res), flush=True)   # (own line even behind a partly flushed RCCL message)
         os._exit(0)
     watchdog.cancel()
     if rank == 0:
@@ -517,7 +521,8 @@ def main():
                     res[key] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_seconds)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        print(("\n" if world > 1 else "") + json.dumps(res), flush=True)   # (N > 1: own line even behind a partly flushed RCCL message)
     if dist is not None:
         dist.destroy_process_group()
 
