@@ -505,10 +505,12 @@ def main():
     watchdog.cancel()
     if rank == 0:
         assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
+    gather_transport = sg.transport
     del full, sg
 
     if rank == 0:
         res = build_result(clip_s, gather_ms)
+        res["config"]["gather"] += f"; transport: {gather_transport}"
         if world == 1 and not a.no_extras:
             # the other single-GPU BASELINE configs, as extra keys (each with its own metric / roofline; never part of `value`)
             del latents, noise

@@ -163,9 +163,26 @@ class StreamingGather:
             import ctypes as C
             from . import _lib as L
             self._side = torch.cuda.Stream(device=self.device)
-            self._comm = _cabi_comm(rank, world, self.device)
-            # this communicator's transfers run on the side stream from here on (finish() hands it back)
-            L.check(L.lib().maua_comm_set_stream(self._comm, C.c_void_p(self._side.cuda_stream), 0))
+            self._comm, err = None, None
+            try:
+                self._comm = _cabi_comm(rank, world, self.device)
+            except Exception as e:   # (the library's own communicator could not be built on this rank)
+                err = e
+            # every rank takes the same transport: the library's RCCL rounds, or - if any rank has no communicator -
+            # torch.distributed's own point-to-point calls on the same side stream
+            flag = torch.tensor([0 if self._comm is None else 1], device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if dist.get_backend() != "nccl":
+                    raise err if err is not None else RuntimeError("a peer rank could not build its RCCL communicator")
+                import warnings
+                warnings.warn(f"StreamingGather: maua_comm_init failed on a rank ({err}); using torch.distributed isend / irecv")
+                self._comm = None
+            else:
+                # this communicator's transfers run on the side stream from here on (finish() hands it back)
+                L.check(L.lib().maua_comm_set_stream(self._comm, C.c_void_p(self._side.cuda_stream), 0))
+        self.transport = ("none (one rank)" if world == 1 else "torch.distributed isend / irecv" if self._side is None or
+                          getattr(self, "_comm", None) is None else "maua_gather_frames_at (RCCL point-to-point, C ABI)")
 
     def n_rounds(self, r=None):
         lo, hi = self.ranges[self.rank if r is None else r]
@@ -191,7 +208,7 @@ class StreamingGather:
         if self.world == 1:
             return
         pieces = self._round_pieces(k)
-        if self._side is not None:
+        if self._side is not None and self._comm is not None:
             import ctypes as C
             from . import _lib as L
             ev = torch.cuda.Event()
@@ -206,16 +223,26 @@ class StreamingGather:
                 recv = self.clip.view(torch.uint8).reshape(-1) if self.rank == self.dst else None
                 L.check(L.lib().maua_gather_frames_at(self._comm, L.ptr(send), nbytes, L.ptr(recv), offs, self.dst))
             return
-        # CPU / gloo
-        if self.rank == self.dst:
-            for r, (n, o) in enumerate(pieces):
-                if r != self.rank and n:
-                    self._reqs.append(dist.irecv(self.clip[o:o + n], src=r))
+        # torch.distributed point-to-point: CPU tensors over gloo (the tests), or device tensors over torch's own RCCL group
+        # when the library's communicator is unavailable (then on the side stream, behind the render's event)
+        def post():
+            if self.rank == self.dst:
+                for r, (n, o) in enumerate(pieces):
+                    if r != self.rank and n:
+                        self._reqs.append(dist.irecv(self.clip[o:o + n], src=r))
+            else:
+                n, _ = pieces[self.rank]
+                if n:
+                    off = k * self.chunk
+                    self._reqs.append(dist.isend(self.local[off:off + n].contiguous(), dst=self.dst))
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                post()
         else:
-            n, _ = pieces[self.rank]
-            if n:
-                off = k * self.chunk
-                self._reqs.append(dist.isend(self.local[off:off + n].contiguous(), dst=self.dst))
+            post()
 
     def finish(self):
         """Every chunk announced: wait for the transfers; the root returns the clip."""
@@ -224,11 +251,17 @@ class StreamingGather:
         if self.world > 1 and self.rank == self.dst:
             # rounds this rank has no chunk in cannot exist (rank 0 owns the longest range)
             assert all(self.n_rounds(r) <= self.n_rounds() for r in range(self.world))
-        for q in self._reqs:
-            q.wait()
+        if self._side is not None and self._comm is None:
+            with torch.cuda.stream(self._side):
+                for q in self._reqs:
+                    q.wait()
+        else:
+            for q in self._reqs:
+                q.wait()
         self._reqs = []
         if self._side is not None:
             from . import _lib as L
             torch.cuda.current_stream(self.device).wait_stream(self._side)
-            L.check(L.lib().maua_comm_set_stream(self._comm, None, 1))   # the communicator is shared with gather_frames_cabi
+            if self._comm is not None:
+                L.check(L.lib().maua_comm_set_stream(self._comm, None, 1))   # the communicator is shared with gather_frames_cabi
         return self.clip if self.rank == self.dst else None
