@@ -104,6 +104,31 @@ def test_full_clip_onset_chain_and_bin_assignments_match_oracle():
     assert rel(A.percussive(y), OA.percussive(y)) <= 2e-5
 
 
+def test_full_clip_sampler_features_match_oracle():
+    """BASELINE configs[1], the whole 120 s clip: every feature the self-supervised sampler computes on it (selfsupervised/mir.py:9,
+    AFEATFNS + pulse) against the oracle at the clip's own size - 3600 frames, seven CQT octaves over 3 686 400 samples, the
+    1024-frame tempogram - not only on the 4 s / 40 s fixtures (the oracle needs ~5 s of CPU for all of them)."""
+    import maua_amd.audio as A
+    from maua_amd.pipeline import synthetic_audio
+    from oracle import cqt as OC
+    sr, T = 30720, 3600
+    y = synthetic_audio(T * 1024, sr)
+    yd = y.cuda()
+    chroma_d, chroma_o = A.chromagram(yd, sr), OC.chromagram(y, sr)
+    assert chroma_d.shape == chroma_o.shape == (T, 12) and rel(chroma_d, chroma_o) <= 2e-3     # CENS: quantiser steps
+    assert float((chroma_d.cpu() - chroma_o).abs().mean()) <= 2e-5
+    assert rel(A.tonnetz(chroma=chroma_o.T.contiguous().cuda()), OA.tonnetz_from_chroma(chroma_o.T)) <= 2e-6     # [12, T] in
+    assert rel(A.tonnetz(yd, sr), OA.tonnetz_from_chroma(chroma_o.T)) <= 2e-3                                  # the whole chain
+    assert rel(A.mfcc(yd, sr), OA.mfcc(y, sr)) <= 5e-5
+    assert rel(A.spectral_contrast(yd, sr), OA.spectral_contrast(y, sr)) <= 3e-4
+    assert rel(A.spectral_flatness(yd, sr), OA.spectral_flatness(y)) <= 5e-5
+    assert rel(A.drop_strength(yd, sr), OA.drop_strength(y)) <= 5e-5
+    p_d, p_o = A.pulse(yd, sr), OA.pulse(y, sr)
+    assert p_d.shape == p_o.shape == (T, 1)
+    err = (p_d.cpu() - p_o).abs().squeeze()
+    assert float((err < 5e-3).float().mean()) > 0.98, float(err.max())       # (peak-bin ties, as on the g18 fixture)
+
+
 def test_bench_latent_schedule_matches_oracle_on_a_frame_subset():
     """bench.py's own latent schedule at T = 3600 (pipeline.synthetic_clip_latents: mapper -> two spline-loop schedules
     blended by the full clip's onset envelope -> gaussian sigma 2) against the oracle composition, on a strided subset of
