@@ -737,13 +737,17 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
   const int strips = (Wo + 125) / 126;
   // items = (sample, row segment, strip), about nine per CU (a segment costs five extra steps); one persistent workgroup
   // per CU takes a contiguous run of them
-  int nseg = std::max(1, (9 * cus + strips * up.B - 1) / (strips * up.B));
-  nseg = std::min(nseg, std::max(1, up.H / 32));
-  const int seg_rows = (up.H + nseg - 1) / nseg;
-  nseg = (up.H + seg_rows - 1) / seg_rows;
-  const int n_items = strips * nseg * up.B;
-  const int wgs = std::min(n_items, cus);
-  const int ipw = (n_items + wgs - 1) / wgs;
+  // the number of row segments that minimises a workgroup's step count: items per workgroup x (rows of a segment + 5)
+  int nseg = 1, seg_rows = up.H, n_items = strips * up.B, ipw = (n_items + cus - 1) / cus;
+  {
+    long best = -1;
+    for (int cand = 1; cand <= std::max(1, up.H / 32); cand++) {
+      const int rows = (up.H + cand - 1) / cand, segs = (up.H + rows - 1) / rows;
+      const int items = strips * segs * up.B, per = (items + std::min(items, cus) - 1) / std::min(items, cus);
+      const long cost = (long)per * (rows + 5);
+      if (best < 0 || cost < best) { best = cost; nseg = segs; seg_rows = rows; n_items = items; ipw = per; }
+    }
+  }
   static long long* dbg = nullptr;
   if (want_dbg && !dbg) { (void)hipMalloc((void**)&dbg, 16 * 8); (void)hipMemset(dbg, 0, 128); }
   hipLaunchKernelGGL(kern, dim3((n_items + ipw - 1) / ipw), dim3(512), smem, stream, A, seg_rows, nseg, strips, n_items,
