@@ -359,7 +359,9 @@ static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   // persistent workgroups: ~2 per CU over all samples, each walks the tiles of ONE sample (its styles are baked
   // into the register-resident weights)
   constexpr int WG_PER_CU = CI == 64 ? 2 : 3;
-  int per_sample = std::max(1, std::min(n_tiles, (256 * WG_PER_CU + a.B - 1) / a.B));
+  // (rounded DOWN: one workgroup more than the resident slots puts a second, almost empty round of workgroups behind the
+  //  first - a batch of 112 ran 1.5x slower per frame than one of 128 with the rounding up)
+  int per_sample = std::max(1, std::min(n_tiles, (256 * WG_PER_CU) / a.B));
   hipLaunchKernelGGL(kern, dim3(per_sample, a.B), dim3(256), smem, stream, a);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
