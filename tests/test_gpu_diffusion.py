@@ -185,6 +185,28 @@ def test_full_size_unet_matches_oracle():
     assert torch.equal(pa, pb) and torch.equal(xa, xb)
 
 
+def test_default_512_configuration_matches_oracle():
+    """guided.py:282's default checkpoint is the 512 x 512 model: seven levels with channel_mult (0.5, 1, 1, 2, 2, 4, 4) (a
+    128-channel first level), attention at ds 16 / 32 / 64, 558.0 M parameters.  create_models builds it; one forward on a
+    256 x 256 input (the network is convolutional; a quarter of the oracle's CPU time) against the oracle."""
+    from maua_amd.diffusion import create_models
+    model, diffusion, _ = create_models("uncondImageNet512", "ddim100", allow_random_init=True, dtype=torch.float32,
+                                        generator=torch.Generator().manual_seed(0))
+    assert model.channel_mult == (0.5, 1, 1, 2, 2, 4, 4) and tuple(model.attention_resolutions) == (16, 32, 64)
+    p = {k: v.float() for k, v in model.state_dict().items()}
+    assert sum(v.numel() for v in p.values()) == 557_973_638
+    cfg = OD.unet_config(image_size=512)
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([300.0])
+    with torch.no_grad():
+        want = OD.unet_forward(p, cfg, x, t)
+    assert rel(model(x, t), want) <= 2e-4
+    del model
+    torch.cuda.empty_cache()
+    m16, _, _ = create_models("uncondImageNet512", "ddim100", allow_random_init=True, generator=torch.Generator().manual_seed(0))
+    assert psnr(m16(x, t), want) >= 40.0
+
+
 def test_schedule_and_ddim_step_match_oracle():
     """SpacedDiffusion("ddim100") tables, model timesteps, q_sample and one ddim step (with and without a conditioning
     gradient) vs the oracle's float64 / float32 restatement."""
