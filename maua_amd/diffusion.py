@@ -516,7 +516,7 @@ class GradientGuidedConditioning(torch.nn.Module):
     """guided.py:212-274 with speed="hyper": img = (x - sigma * noise) / alpha is the clean-image estimate from the KNOWN
     noise; the grad modules return d loss / d img, and d img / d x = 1 / alpha, so cond_fn = -sum(grads) / alpha."""
 
-    def __init__(self, diffusion, model, grad_modules, speed="hyper"):
+    def __init__(self, diffusion, model, grad_modules, speed="fast"):
         super().__init__()
         if speed != "hyper":
             raise NotImplementedError('speed "fast" / "regular" back-propagate through a network; use speed="hyper"')
@@ -578,11 +578,12 @@ class ImageTarget:
 
 
 class GuidedDiffusion(torch.nn.Module):
-    """guided.py:277-339 (samplers "ddim", "p", "plms").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
+    """guided.py:277-339 (samplers "ddim", "p", "plms"; the reference's defaults, incl. speed="fast" - which, with grad
+    modules, needs autograd through the secondary model and is refused: pass speed="hyper").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
     checkpoint name (file must exist, see create_models) or ready objects (tests, bench)."""
 
     def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
-                 ddim_eta=0, plms_order=2, speed="hyper", model=None, diffusion=None, allow_random_init=False,
+                 ddim_eta=0, plms_order=2, speed="fast", model=None, diffusion=None, allow_random_init=False,
                  dtype=torch.bfloat16):
         super().__init__()
         if sampler not in ("ddim", "p", "plms"):
@@ -663,7 +664,7 @@ def sample(prompts: List, audio=None, sr=None, fps=30, n_frames=None, size=(256,
     [-1, 1], prompt index per frame)."""
     if model is None:
         model, diffusion, _ = create_models("uncondImageNet256", f"ddim{timesteps}")
-    gd = GuidedDiffusion(grad_modules or [], timesteps=timesteps, model=model, diffusion=diffusion)
+    gd = GuidedDiffusion(grad_modules or [], timesteps=timesteps, model=model, diffusion=diffusion, speed="hyper")
     if audio is not None:
         idx = onset_prompt_schedule(audio, sr, fps, len(prompts))
         n_frames = len(idx) if n_frames is None else min(n_frames, len(idx))
