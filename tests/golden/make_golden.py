@@ -429,6 +429,80 @@ def golden_pulse_short():
          n_odd=np.int64(277 * 1024), pulse_even=FA.pulse(a[: 300 * 1024], sr), pulse_odd=FA.pulse(a[: 277 * 1024], sr))
 
 
+SIGNATURES = [  # (reference file under maua/, qualified name there, our module, our qualified name)
+    ("audiovisual/generate.py", "generate_audiovisal_from_patch", "maua_amd.audiovisual.generate", "generate_audiovisal_from_patch"),
+    ("audiovisual/audioreactive/selfsupervised/sample.py", "generate", "maua_amd.audiovisual.sample", "generate"),
+    ("audiovisual/audioreactive/selfsupervised/sample.py", "load_audio", "maua_amd.audio_io", "load_audio"),
+    ("audiovisual/audioreactive/selfsupervised/patch.py", "Patch.__init__", "maua_amd.audiovisual.sample", "Patch.__init__"),
+    ("audiovisual/audioreactive/selfsupervised/patch.py", "Patch.forward", "maua_amd.audiovisual.sample", "Patch.forward"),
+    ("audiovisual/audioreactive/selfsupervised/latent.py", "latent_patch", "maua_amd.latent", "latent_patch"),
+    ("audiovisual/audioreactive/selfsupervised/noise.py", "noise_patch", "maua_amd.noise", "noise_patch"),
+    ("audiovisual/audioreactive/selfsupervised/mir.py", "retrieve_music_information", "maua_amd.audiovisual.sample", "retrieve_music_information"),
+    ("audiovisual/patches/base/__init__.py", "MauaPatch.__init__", "maua_amd.audiovisual.patches.base", "MauaPatch.__init__"),
+    ("audiovisual/patches/base/__init__.py", "MauaPatch.force_output_size", "maua_amd.audiovisual.patches.base", "MauaPatch.force_output_size"),
+    ("GAN/wrappers/stylegan2.py", "StyleGAN2Synthesizer.__init__", "maua_amd.stylegan2", "StyleGAN2Synthesizer.__init__"),
+    ("GAN/wrappers/stylegan2.py", "StyleGAN2Synthesizer.forward", "maua_amd.stylegan2", "StyleGAN2Synthesizer.forward"),
+    ("GAN/wrappers/stylegan2.py", "StyleGAN2Synthesizer.change_output_resolution", "maua_amd.stylegan2", "StyleGAN2Synthesizer.change_output_resolution"),
+    ("GAN/wrappers/stylegan2.py", "StyleGAN2Synthesizer.make_noise_pyramid", "maua_amd.stylegan2", "StyleGAN2Synthesizer.make_noise_pyramid"),
+    ("GAN/wrappers/stylegan.py", "StyleGANMapper.__init__", "maua_amd.stylegan2", "StyleGAN2Mapper.__init__"),
+    ("GAN/wrappers/stylegan.py", "StyleGANMapper.forward", "maua_amd.stylegan2", "StyleGAN2Mapper.forward"),
+    ("GAN/wrappers/stylegan.py", "StyleGAN.__init__", "maua_amd.stylegan2", "StyleGAN2.__init__"),
+    ("GAN/wrappers/stylegan.py", "StyleGAN.get_z_latents", "maua_amd.stylegan2", "StyleGAN2.get_z_latents"),
+    ("GAN/wrappers/stylegan.py", "StyleGAN.get_w_latents", "maua_amd.stylegan2", "StyleGAN2.get_w_latents"),
+    ("GAN/wrappers/stylegan.py", "StyleGAN.forward", "maua_amd.stylegan2", "StyleGAN2.forward"),
+    ("GAN/wrappers/__init__.py", "MauaGenerator.render", "maua_amd.stylegan2", "StyleGAN2.render"),
+    ("GAN/wrappers/__init__.py", "get_generator_class", "maua_amd.stylegan2", "get_generator_class"),
+    ("GAN/load.py", "load_network", "maua_amd.load", "load_network"),
+    ("GAN/load.py", "load_nvidia", "maua_amd.load", "load_nvidia"),
+    ("GAN/load.py", "load_nvidia_pt", "maua_amd.load", "load_nvidia_pt"),
+    ("GAN/load.py", "load_rosinality2ada", "maua_amd.load", "load_rosinality2ada"),
+    ("GAN/wrappers/inference/ops.py", "bias_act", "maua_amd.ops", "bias_act"),
+    ("GAN/wrappers/inference/ops.py", "upfirdn2d", "maua_amd.ops", "upfirdn2d"),
+    ("GAN/wrappers/inference/ops.py", "upsample2d", "maua_amd.ops", "upsample2d"),
+    ("GAN/wrappers/inference/ops.py", "modulated_conv2d", "maua_amd.ops", "modulated_conv2d"),
+    ("GAN/wrappers/inference/ops.py", "conv2d_resample", "maua_amd.ops", "conv2d_resample"),
+    ("GAN/wrappers/inference/ops.py", "setup_filter", "maua_amd.ops", "setup_filter"),
+    ("ops/video.py", "VideoWriter.__init__", "maua_amd.video", "VideoWriter.__init__"),
+    ("diffusion/processors/guided.py", "GuidedDiffusion.__init__", "maua_amd.diffusion", "GuidedDiffusion.__init__"),
+    ("diffusion/processors/guided.py", "GuidedDiffusion.forward", "maua_amd.diffusion", "GuidedDiffusion.forward"),
+    ("diffusion/processors/guided.py", "create_models", "maua_amd.diffusion", "create_models"),
+    ("diffusion/processors/guided.py", "GradientGuidedConditioning.__init__", "maua_amd.diffusion", "GradientGuidedConditioning.__init__"),
+    ("super/image/models/realesrgan.py", "load_model", "maua_amd.super", "load_model"),
+    ("super/image/models/realesrgan.py", "upscale", "maua_amd.super", "upscale"),
+]
+
+
+def golden_signatures():
+    """The call signatures (argument names in order + the source text of their defaults) of every reference function / method
+    the host layer mirrors, read from the reference's source with ``ast`` (nothing is imported or executed): the drop-in
+    surface as data.  tests/test_cabi_and_host.py holds maua_amd's signatures to it."""
+    import ast
+    import json
+    out = []
+    cache = {}
+    for path, qual, our_mod, our_qual in SIGNATURES:
+        if path not in cache:
+            cache[path] = ast.parse((Path(REF) / "maua" / path).read_text())
+        node = None
+        parts = qual.split(".")
+        for top in cache[path].body:
+            if len(parts) == 1 and isinstance(top, ast.FunctionDef) and top.name == parts[0]:
+                node = top
+            if len(parts) == 2 and isinstance(top, ast.ClassDef) and top.name == parts[0]:
+                for sub in top.body:
+                    if isinstance(sub, ast.FunctionDef) and sub.name == parts[1]:
+                        node = sub
+        assert node is not None, (path, qual)
+        a = node.args
+        names = [x.arg for x in a.posonlyargs + a.args]
+        defaults = [None] * (len(names) - len(a.defaults)) + [ast.unparse(d) for d in a.defaults]
+        args = [[n, d] for n, d in zip(names, defaults)] + [[x.arg, None if d is None else ast.unparse(d)] for x, d in zip(a.kwonlyargs, a.kw_defaults)]
+        out.append({"reference": f"maua/{path}:{node.lineno}", "name": qual, "ours": [our_mod, our_qual], "args": args,
+                    "varargs": a.vararg.arg if a.vararg else None, "varkw": a.kwarg.arg if a.kwarg else None})
+    (HERE / "g25_signatures.json").write_text(json.dumps(out, indent=0))
+    print("g25_signatures.json", len(out), "signatures")
+
+
 def golden_classic():
     """Small classic-API pieces: signal.compress / expand (:84-105), latent.eerp / copeerp (:46-51), audio.low_pass /
     high_pass / band_pass (:96-112; scipy Butterworth on the host)."""

@@ -289,3 +289,42 @@ def test_bench_layer_table_matches_the_profile_slots():
     # the real class agrees with the stand-in on the shapes (cheap: no weights are drawn)
     assert [s[1:] for s in Shapes().layer_shapes()] == [tuple(s[1:]) for s in SynthesisNetwork.layer_shapes_for(1024)] \
         if hasattr(SynthesisNetwork, "layer_shapes_for") else True
+
+
+def test_host_layer_signatures_match_the_reference():
+    """The drop-in surface as data: argument names, their order and their defaults of every reference function / method the
+    host layer mirrors (tests/golden/g25_signatures.json, read from the reference's source with ast by make_golden.py) against
+    inspect.signature of ours.  Extra trailing keyword arguments of ours are allowed (dtype, generator, allow_random_init ...);
+    the stated exceptions are defaults that name a CPU device (there is no CPU path) and container spellings."""
+    import importlib
+    import inspect
+    import json
+    from pathlib import Path
+    sigs = json.loads((Path(__file__).parent / "golden" / "g25_signatures.json").read_text())
+    assert len(sigs) >= 35
+    immaterial = {"device", "postprocess_fn"}                      # cuda-if-available / torch.device("cpu") / lambda x: x
+    for e in sigs:
+        obj = importlib.import_module(e["ours"][0])
+        for part in e["ours"][1].split("."):
+            obj = getattr(obj, part)
+        ours = inspect.signature(obj).parameters
+        names = [n for n, p in ours.items() if p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD)]
+        ref_names = [a[0] for a in e["args"]]
+        assert names[:len(ref_names)] == ref_names, (e["name"], e["reference"], ref_names, names)
+        for n, d in e["args"]:
+            p = ours[n]
+            if d is None:   # (required in the reference; ours may add a default - random init for a missing checkpoint, say)
+                continue
+            assert p.default is not inspect._empty, (e["name"], n, "the reference has a default")
+            if n in immaterial:
+                continue
+            try:
+                want = eval(d, {"torch": torch})
+            except Exception:
+                continue                                             # (defaults that are expressions over other names)
+            got = p.default
+            if isinstance(want, (list, tuple)) or (torch.is_tensor(want) and want.dim() > 0):
+                want, got = [float(v) for v in want], [float(v) for v in got]
+            elif torch.is_tensor(want):
+                want, got = float(want), float(got)
+            assert got == want, (e["name"], e["reference"], n, d, p.default)
