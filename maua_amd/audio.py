@@ -34,12 +34,25 @@ def _default_framing(n_fft, hop_length):
 
 
 # ------------------------------------------------------------------------------------------------ spectra
-def stft(y, n_fft=2048, hop_length=1024, center=True, window=None, pad_mode="reflect", return_complex=True):
+def _window_tensor(window, n_fft):
+    """rosa/spectral.py:10-32's ``window`` argument: a window FUNCTION (default torch.hann_window), None = rectangular (what
+    torch.stft does without a window), or a ready tensor.  -> None for the Hann window of the fast path, else the tensor."""
+    if window is torch.hann_window:
+        return None
+    if window is None:
+        return torch.ones(n_fft)
+    return window(n_fft) if callable(window) else window
+
+
+def stft(y, n_fft=2048, hop_length=1024, center=True, window=torch.hann_window, pad_mode="reflect", return_complex=True):
     """-> complex64 [n_fft//2 + 1, 1 + len(y)//hop] (a transposed view of the frame-major device buffer)."""
     if not center or pad_mode != "reflect":
         raise NotImplementedError("center=True / reflect padding only")
-    if not _default_framing(n_fft, hop_length):
-        return stft_general(y, n_fft, hop_length, window)
+    if not return_complex:
+        raise NotImplementedError("return_complex=True only")
+    win = _window_tensor(window, n_fft)
+    if win is not None or not _default_framing(n_fft, hop_length):
+        return stft_general(y, n_fft, hop_length, win)
     y = _f32(y).reshape(-1)
     frames = 1 + y.numel() // HOP
     out = torch.empty((frames, N_BINS, 2), dtype=torch.float32, device=y.device)
@@ -53,9 +66,12 @@ def _frame_major(spec):
     return torch.view_as_real(s.contiguous())
 
 
-def istft(spec, n_fft=2048, hop_length=1024, center=True, window=None, length=None):
-    if not _default_framing(n_fft, hop_length):
-        return istft_general(spec, n_fft, hop_length, hop_length * (spec.shape[1] - 1) if length is None else length, window)
+def istft(spec, n_fft=2048, hop_length=1024, center=True, window=torch.hann_window, length=None):
+    if not center:
+        raise NotImplementedError("center=True only")
+    win = _window_tensor(window, n_fft)
+    if win is not None or not _default_framing(n_fft, hop_length):
+        return istft_general(spec, n_fft, hop_length, hop_length * (spec.shape[1] - 1) if length is None else length, win)
     spec = L.dev_tensor(spec, torch.complex64) if not spec.is_cuda else spec
     buf = _frame_major(spec)
     frames = buf.shape[0]
@@ -66,8 +82,9 @@ def istft(spec, n_fft=2048, hop_length=1024, center=True, window=None, length=No
     return y
 
 
-def spectrogram(y, n_fft=2048, hop_length=1024, power=1, **_):
-    D = stft(y, n_fft, hop_length)[:, :-1]
+def spectrogram(y, n_fft=2048, hop_length=1024, power=1, window=torch.hann_window, center=True, pad_mode="reflect"):
+    """spectral.py:59-62 (the last STFT column is dropped)."""
+    D = stft(y, n_fft, hop_length, center, window, pad_mode)[:, :-1]
     buf = _frame_major(D)
     mag = torch.empty(buf.shape[:2], dtype=torch.float32, device=buf.device)
     L.check(L.lib().maua_magnitude(L.ctx(buf.device), L.ptr(buf), C.c_long(mag.numel()), C.c_float(float(power)),
@@ -137,12 +154,13 @@ def mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, dtype=torch.float
     return (weights * enorm[:, None]).to(dtype)
 
 
-def melspectrogram(y, sr, n_fft=2048, hop_length=1024, power=2.0, fmax=None, keep_last=False, **_):
+def melspectrogram(y, sr, n_fft=2048, hop_length=1024, window=torch.hann_window, center=True, pad_mode="reflect", power=2.0,
+                   fmax=None, keep_last=False):
     """spectral.py:65-70 (drops the last STFT column like the in-tree spectrogram, :59-62); ``keep_last``: librosa's
     own framing (1 + len // hop frames), what the classic mir.onsets(type="rosa") sees."""
     if power != 2.0:
         raise NotImplementedError("power must be 2 (the onset path)")
-    D = stft(y, n_fft, hop_length)
+    D = stft(y, n_fft, hop_length, center, window, pad_mode)
     buf = _frame_major(D)
     T = buf.shape[0] - (0 if keep_last else 1)
     basis = _f32(mel(sr, n_fft, fmax=fmax))
@@ -161,7 +179,7 @@ def power_to_db(magnitude, ref_value=1.0, amin=1e-10, top_db=80.0):
     return log_spec
 
 
-def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=None, fmax=11025.0, keep_last=False):
+def onset_strength(y, sr, hop_length=1024, n_fft=2048, aggregate=torch.mean, fmax=11025.0, keep_last=False):
     """beat.py:10-23 -> [T] on device.  ``aggregate``: None / torch.mean, or "median" (what plp passes, beat.py:44).
     ``fmax``: the in-tree function fixes 11 025 Hz; librosa's own default (the classic mir.onsets) is sr / 2."""
     if n_fft != N_FFT:
@@ -263,7 +281,7 @@ def gaussian_taps(sigma, n_frames, causal=None, classic=False):
     return k / k.sum(), radius
 
 
-def gaussian_filter(x, sigma, mode="circular", causal=None, _classic=False):
+def gaussian_filter(x, sigma, mode="circular", causal=1, _classic=False):
     """processing.py:11-49 (ignores ``causal``, like the reference's selfsupervised version).  Filters along
     dim 0; any trailing shape."""
     x = _f32(x)
@@ -403,9 +421,10 @@ def tonnetz(y=None, sr=None, chroma_fn=None, chroma=None):
     return _matmul_nt(chn.T.contiguous(), phi.to(ch.device))     # [T, 6]
 
 
-def spectral_flatness(y, sr=None, n_fft=2048, hop_length=1024, amin=1e-10, power=2.0, **_):
+def spectral_flatness(y, sr=None, n_fft=2048, hop_length=1024, window=torch.hann_window, center=True, pad_mode="reflect",
+                      amin=1e-10, power=2.0):
     """features/audio.py:118-126 -> [T, 1]."""
-    buf = _frame_major(stft(y, n_fft, hop_length))
+    buf = _frame_major(stft(y, n_fft, hop_length, center, window, pad_mode))
     T = buf.shape[0] - 1                                         # spectrogram drops the last column
     out = torch.empty((T,), dtype=torch.float32, device=buf.device)
     L.check(L.lib().maua_spectral_flatness(L.ctx(buf.device), L.ptr(buf), T, buf.shape[1], C.c_float(amin),
@@ -437,9 +456,10 @@ def contrast_bands(sr, n_fft=2048, fmin=200.0, n_bands=6, quantile=0.02):
     return out
 
 
-def spectral_contrast(y, sr, n_fft=2048, hop_length=1024, fmin=200.0, n_bands=6, quantile=0.02, linear=False, **_):
+def spectral_contrast(y, sr, n_fft=2048, hop_length=1024, window=torch.hann_window, center=True, pad_mode="reflect", fmin=200.0,
+                      n_bands=6, quantile=0.02, linear=False):
     """features/audio.py:76-115 -> [T, n_bands + 1]."""
-    buf = _frame_major(stft(y, n_fft, hop_length))
+    buf = _frame_major(stft(y, n_fft, hop_length, center, window, pad_mode))
     T = buf.shape[0] - 1
     bands = contrast_bands(sr, n_fft, fmin, n_bands, quantile)
     valley = torch.empty((len(bands), T), dtype=torch.float32, device=buf.device)
@@ -543,11 +563,15 @@ def fourier_tempo_frequencies(sr, win_length=1024, hop_length=1024, device="cpu"
     return torch.linspace(0, float(rate) / 2, int(1 + win_length // 2), device=device)
 
 
-def fourier_tempogram(y=None, sr=22050, onset_envelope=None, hop_length=1024, win_length=1024):
+def fourier_tempogram(y=None, sr=22050, onset_envelope=None, hop_length=1024, win_length=1024, center=True,
+                      window=torch.hann_window):
     """beat.py:31-39: STFT of the onset envelope with hop 1."""
     if onset_envelope is None:
         onset_envelope = onset_strength(y, sr, hop_length=hop_length)
-    return stft_general(onset_envelope, win_length, 1)
+    if not center:
+        raise NotImplementedError("center=True only")
+    win = _window_tensor(window, win_length)
+    return stft_general(onset_envelope, win_length, 1, win)
 
 
 def plp(y, sr, hop_length=1024, win_length=1024, tempo_min=60, tempo_max=180):

@@ -24,8 +24,10 @@ C1_HZ = 32.70319566257483  # librosa.note_to_hz("C1")
 
 
 # ------------------------------------------------------------------------------------------------ host-side set-up
-def cqt_frequencies(n_bins, fmin, bins_per_octave=12):
-    return fmin * 2.0 ** (torch.arange(0, n_bins, dtype=torch.float) / bins_per_octave)
+def cqt_frequencies(n_bins, fmin, bins_per_octave=12, tuning=0.0):
+    """constantq.py:209-212"""
+    correction = 2.0 ** (float(tuning) / bins_per_octave)
+    return correction * fmin * 2.0 ** (torch.arange(0, n_bins, dtype=torch.float) / bins_per_octave)
 
 
 def constant_q_lengths(sr, fmin, n_bins=84, bins_per_octave=12, filter_scale=1, gamma=0):
@@ -34,8 +36,11 @@ def constant_q_lengths(sr, fmin, n_bins=84, bins_per_octave=12, filter_scale=1, 
     return (float(filter_scale) / alpha) * sr / (freq + gamma / alpha)
 
 
-def constant_q(sr, fmin, n_bins, bins_per_octave, filter_scale=1, gamma=0):
-    """constantq.py:237-283 (pad_fft=True): Hann-windowed complex exponentials, L1-normalised, centred in 2^k taps."""
+def constant_q(sr, fmin=None, n_bins=84, bins_per_octave=12, filter_scale=1, pad_fft=True, gamma=0):
+    """constantq.py:223-283 (pad_fft=True): Hann-windowed complex exponentials, L1-normalised, centred in 2^k taps."""
+    if not pad_fft:
+        raise NotImplementedError("pad_fft=True only (what the transform calls)")
+    fmin = torch.tensor(C1_HZ).float() if fmin is None else fmin
     lengths = constant_q_lengths(sr, fmin, n_bins, bins_per_octave, filter_scale, gamma)
     freqs = fmin * (2.0 ** (torch.arange(n_bins, dtype=torch.float) / bins_per_octave))
     max_len = int(2.0 ** (torch.ceil(torch.log2(max(lengths)))))
@@ -53,7 +58,7 @@ def constant_q(sr, fmin, n_bins, bins_per_octave, filter_scale=1, gamma=0):
 def cqt_filter_fft(sr, fmin, n_bins, bins_per_octave, filter_scale=1, sparsity=0.01, gamma=0.0):
     """constantq.py:142-189: FFT of the filter bank (non-negative frequencies), rows sparsified at `sparsity` of their
     magnitude mass - kept dense here, the dropped entries are zeros."""
-    basis, lengths = constant_q(sr, fmin, n_bins, bins_per_octave, filter_scale, gamma)
+    basis, lengths = constant_q(sr, fmin, n_bins, bins_per_octave, filter_scale, True, gamma)
     n_fft = basis.shape[1]
     fft_basis = torch.fft.fft(basis * (lengths[:, None] / float(n_fft)), n=n_fft, dim=1)[:, : n_fft // 2 + 1]
     mags = fft_basis.abs()
@@ -89,10 +94,15 @@ def resample_half(y):
 
 
 # ------------------------------------------------------------------------------------------------ pitch.py
-def piptrack(y, sr, n_fft=2048, fmin=150.0, fmax=4000.0, threshold=0.1):
+def piptrack(y, sr, n_fft=2048, hop_length=None, fmin=150.0, fmax=4000.0, threshold=0.1, window=torch.hann_window, center=True,
+             pad_mode="reflect"):
     """pitch.py:27-87 -> (pitches, mags) [1 + n_fft/2, frames] (hop = n_fft // 4: torch.stft's default, the reference
     passes hop_length=None; last STFT column dropped like its spectrogram)."""
-    D = stft_general(y, n_fft, n_fft // 4)[:, :-1]
+    if not center or pad_mode != "reflect":
+        raise NotImplementedError("center=True / reflect padding only")
+    from .audio import _window_tensor
+    hop = n_fft // 4 if hop_length is None else int(hop_length)
+    D = stft_general(y, n_fft, hop, _window_tensor(window, n_fft))[:, :-1]
     buf = _frame_major(D)
     T, nb = buf.shape[0], buf.shape[1]
     S = torch.empty((T, nb), dtype=torch.float32, device=buf.device)

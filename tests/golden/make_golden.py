@@ -469,6 +469,39 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("diffusion/processors/guided.py", "GradientGuidedConditioning.__init__", "maua_amd.diffusion", "GradientGuidedConditioning.__init__"),
     ("super/image/models/realesrgan.py", "load_model", "maua_amd.super", "load_model"),
     ("super/image/models/realesrgan.py", "upscale", "maua_amd.super", "upscale"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "chromagram", "maua_amd.audio", "chromagram"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "tonnetz", "maua_amd.audio", "tonnetz"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "mfcc", "maua_amd.audio", "mfcc"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "spectral_contrast", "maua_amd.audio", "spectral_contrast"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "spectral_flatness", "maua_amd.audio", "spectral_flatness"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "rms", "maua_amd.audio", "rms"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "drop_strength", "maua_amd.audio", "drop_strength"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "onsets", "maua_amd.audio", "onsets"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "pulse", "maua_amd.audio", "pulse"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "harmonic", "maua_amd.audio", "harmonic"),
+    ("audiovisual/audioreactive/selfsupervised/features/audio.py", "percussive", "maua_amd.audio", "percussive"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "stft", "maua_amd.audio", "stft"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "istft", "maua_amd.audio", "istft"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "spectrogram", "maua_amd.audio", "spectrogram"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "melspectrogram", "maua_amd.audio", "melspectrogram"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "mel", "maua_amd.audio", "mel"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/spectral.py", "dct", "maua_amd.audio", "dct"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/beat.py", "onset_strength", "maua_amd.audio", "onset_strength"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/beat.py", "plp", "maua_amd.audio", "plp"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/beat.py", "fourier_tempogram", "maua_amd.audio", "fourier_tempogram"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/beat.py", "fourier_tempo_frequencies", "maua_amd.audio", "fourier_tempo_frequencies"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "gaussian_filter", "maua_amd.audio", "gaussian_filter"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "median_filter2d", "maua_amd.audio", "median_filter2d"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "emphasize", "maua_amd.audio", "emphasize"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "normalize", "maua_amd.audio", "normalize"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "cqt", "maua.audiovisual.audioreactive.selfsupervised.features.rosa.constantq", "cqt"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "vqt", "maua.audiovisual.audioreactive.selfsupervised.features.rosa.constantq", "vqt"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "constant_q", "maua_amd.cqt", "constant_q"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "constant_q_lengths", "maua_amd.cqt", "constant_q_lengths"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "cqt_frequencies", "maua_amd.cqt", "cqt_frequencies"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "piptrack", "maua_amd.cqt", "piptrack"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "estimate_tuning", "maua_amd.cqt", "estimate_tuning"),
+    ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "pitch_tuning", "maua_amd.cqt", "pitch_tuning"),
 ]
 
 

@@ -323,6 +323,10 @@ def test_host_layer_signatures_match_the_reference():
             except Exception:
                 continue                                             # (defaults that are expressions over other names)
             got = p.default
+            if callable(want):   # torch.hann_window, torch.mean, a lambda: ours names the same callable, or None for "that default"
+                assert got is None or got is want or (callable(got) and getattr(got, "__name__", "") == getattr(want, "__name__", "?")), \
+                    (e["name"], e["reference"], n, d, got)
+                continue
             if isinstance(want, (list, tuple)) or (torch.is_tensor(want) and want.dim() > 0):
                 want, got = [float(v) for v in want], [float(v) for v in got]
             elif torch.is_tensor(want):

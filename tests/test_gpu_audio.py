@@ -410,6 +410,36 @@ def test_pulse_on_short_clips(golden):
         assert float((err < 5e-3).float().mean()) > 0.98, (tag, float(err.max()))
 
 
+def test_stft_window_argument_follows_the_reference():
+    """rosa/spectral.py:10-32: ``window`` is a window FUNCTION (default torch.hann_window), None means rectangular (torch.stft
+    without a window - what the constant-Q transform asks for), a tensor is taken as is; spectrogram / melspectrogram /
+    spectral_flatness / spectral_contrast / piptrack pass it through in the reference's argument positions."""
+    import maua_amd.audio as A
+    from maua_amd import cqt as Q
+    g = torch.Generator().manual_seed(8)
+    y = torch.randn(20480, generator=g)
+    yd = y.cuda()
+    kw = dict(n_fft=2048, hop_length=1024, center=True, pad_mode="reflect", return_complex=True)
+    hann = torch.stft(y, window=torch.hann_window(2048), **kw)
+    rect = torch.stft(y, window=torch.ones(2048), **kw)
+    ham = torch.stft(y, window=torch.hamming_window(2048), **kw)
+    assert rel(A.stft(yd), hann) < 3e-6
+    assert rel(A.stft(yd, window=torch.hann_window), hann) < 3e-6
+    assert rel(A.stft(yd, window=None), rect) < 3e-6
+    assert rel(A.stft(yd, window=torch.hamming_window), ham) < 3e-6
+    assert rel(A.stft(yd, 2048, 1024, True, torch.hamming_window(2048)), ham) < 3e-6
+    assert rel(A.istft(A.stft(yd, window=torch.hamming_window), window=torch.hamming_window, length=len(y)), y) < 2e-5
+    assert rel(A.spectrogram(yd, 2048, 1024, 1, torch.hamming_window), ham[:, :-1].abs()) < 5e-6
+    assert rel(A.spectrogram(yd), hann[:, :-1].abs()) < 5e-6
+    fl_h, fl_r = A.spectral_flatness(yd, 20480), A.spectral_flatness(yd, 20480, window=None)
+    assert float((fl_h - fl_r).abs().max()) > 1e-4              # the argument reaches the transform
+    with pytest.raises(NotImplementedError):
+        A.stft(yd, center=False)
+    p_h, _ = Q.piptrack(yd, 20480)
+    p_r, _ = Q.piptrack(yd, 20480, window=None)
+    assert p_h.shape == p_r.shape and not torch.equal(p_h, p_r)
+
+
 def test_classic_compress_eerp(golden):
     """signal.compress / expand and latent.eerp / copeerp vs the reference's outputs (g19)."""
     from maua_amd.audiovisual import audioreactive as ar
