@@ -2,8 +2,8 @@
 envelope post-processing and latent builders, all executed on the HIP device."""
 import torch
 
-from ..audio import (gaussian_filter as _gf_selfsup, harmonic, hpss, istft, melspectrogram, onset_strength, percussive,  # noqa
-                     rms as _rms, spectrogram, stft)
+from ..audio import (gaussian_filter as _gf_selfsup, harmonic as _harmonic, hpss, istft, melspectrogram, onset_strength,  # noqa
+                     percussive as _percussive, rms as _rms, spectrogram, stft)
 from ..audio_io import load_audio as _load
 from ..latent import (copeerp, eerp, multi_weighted, select_modulo, single_weighted, slerp, slerp_loops,  # noqa
                       spline_loops, tempo_loops)
@@ -29,7 +29,7 @@ def onsets(audio, sr, type="mm", prepercussive=4, hop_length=512):
     last column, spectral.py:59-62, is not on this path)."""
     a = torch.as_tensor(audio)
     if prepercussive:
-        a = percussive(a, margin=8.0, hop_length=hop_length)
+        a = _percussive(a, margin=8.0, hop_length=hop_length)
     if type == "mm":
         if hop_length != 512:
             raise NotImplementedError('onsets(type="mm") runs at madmom\'s framing of the reference (hop 512)')
@@ -42,6 +42,17 @@ def onsets(audio, sr, type="mm", prepercussive=4, hop_length=512):
 
 def rms(audio, sr):
     return _rms(torch.as_tensor(audio), sr).squeeze(-1)
+
+
+def harmonic(audio, sr, margin=8):
+    """audio.py:85-88: librosa.effects.harmonic(y, margin) - median-filter HPSS at librosa's own framing (n_fft 2048, hop 512;
+    librosa un-vendored: the published effect, on the HPSS kernels of the self-supervised path)."""
+    return _harmonic(torch.as_tensor(audio), margin=float(margin), hop_length=512)
+
+
+def percussive(audio, sr, margin=8):
+    """audio.py:91-93, see harmonic."""
+    return _percussive(torch.as_tensor(audio), margin=float(margin), hop_length=512)
 
 
 def _butter(audio, sr, cutoff, kind, db_per_octave):

@@ -469,6 +469,30 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("diffusion/processors/guided.py", "GradientGuidedConditioning.__init__", "maua_amd.diffusion", "GradientGuidedConditioning.__init__"),
     ("super/image/models/realesrgan.py", "load_model", "maua_amd.super", "load_model"),
     ("super/image/models/realesrgan.py", "upscale", "maua_amd.super", "upscale"),
+    ("audiovisual/audioreactive/signal.py", "resample", "maua_amd.audiovisual.audioreactive", "resample"),
+    ("audiovisual/audioreactive/signal.py", "normalize", "maua_amd.audiovisual.audioreactive", "normalize"),
+    ("audiovisual/audioreactive/signal.py", "percentile", "maua_amd.audiovisual.audioreactive", "percentile"),
+    ("audiovisual/audioreactive/signal.py", "percentile_clip", "maua_amd.audiovisual.audioreactive", "percentile_clip"),
+    ("audiovisual/audioreactive/signal.py", "compress", "maua_amd.audiovisual.audioreactive", "compress"),
+    ("audiovisual/audioreactive/signal.py", "expand", "maua_amd.audiovisual.audioreactive", "expand"),
+    ("audiovisual/audioreactive/signal.py", "gaussian_filter", "maua_amd.audiovisual.audioreactive", "gaussian_filter"),
+    ("audiovisual/audioreactive/latent.py", "single_weighted", "maua_amd.audiovisual.audioreactive", "single_weighted"),
+    ("audiovisual/audioreactive/latent.py", "multi_weighted", "maua_amd.audiovisual.audioreactive", "multi_weighted"),
+    ("audiovisual/audioreactive/latent.py", "select_modulo", "maua_amd.audiovisual.audioreactive", "select_modulo"),
+    ("audiovisual/audioreactive/latent.py", "eerp", "maua_amd.audiovisual.audioreactive", "eerp"),
+    ("audiovisual/audioreactive/latent.py", "copeerp", "maua_amd.audiovisual.audioreactive", "copeerp"),
+    ("audiovisual/audioreactive/latent.py", "slerp", "maua_amd.audiovisual.audioreactive", "slerp"),
+    ("audiovisual/audioreactive/latent.py", "slerp_loops", "maua_amd.audiovisual.audioreactive", "slerp_loops"),
+    ("audiovisual/audioreactive/latent.py", "spline_loops", "maua_amd.audiovisual.audioreactive", "spline_loops"),
+    ("audiovisual/audioreactive/latent.py", "tempo_loops", "maua_amd.audiovisual.audioreactive", "tempo_loops"),
+    ("audiovisual/audioreactive/audio.py", "load_audio", "maua_amd.audiovisual.audioreactive", "load_audio"),
+    ("audiovisual/audioreactive/audio.py", "harmonic", "maua_amd.audiovisual.audioreactive", "harmonic"),
+    ("audiovisual/audioreactive/audio.py", "percussive", "maua_amd.audiovisual.audioreactive", "percussive"),
+    ("audiovisual/audioreactive/audio.py", "low_pass", "maua_amd.audiovisual.audioreactive", "low_pass"),
+    ("audiovisual/audioreactive/audio.py", "high_pass", "maua_amd.audiovisual.audioreactive", "high_pass"),
+    ("audiovisual/audioreactive/audio.py", "band_pass", "maua_amd.audiovisual.audioreactive", "band_pass"),
+    ("audiovisual/audioreactive/mir.py", "onsets", "maua_amd.audiovisual.audioreactive", "onsets"),
+    ("audiovisual/audioreactive/selfsupervised/latent.py", "spline_loop_latents", "maua_amd.latent", "spline_loop_latents"),
     ("audiovisual/audioreactive/selfsupervised/features/audio.py", "chromagram", "maua_amd.audio", "chromagram"),
     ("audiovisual/audioreactive/selfsupervised/features/audio.py", "tonnetz", "maua_amd.audio", "tonnetz"),
     ("audiovisual/audioreactive/selfsupervised/features/audio.py", "mfcc", "maua_amd.audio", "mfcc"),

@@ -440,6 +440,18 @@ def test_stft_window_argument_follows_the_reference():
     assert p_h.shape == p_r.shape and not torch.equal(p_h, p_r)
 
 
+def test_classic_harmonic_percussive_signature():
+    """audio.py:85-93 of the classic namespace: harmonic(audio, sr, margin=8) / percussive(audio, sr, margin=8) - the second
+    positional argument is the sampling rate, not the margin - at librosa's framing (hop 512), against the oracle's HPSS at that hop."""
+    from maua_amd.audiovisual import audioreactive as ar
+    from maua_amd.pipeline import synthetic_audio
+    sr = 30720
+    y = synthetic_audio(sr * 3, sr, 4)
+    assert rel(ar.harmonic(y.cuda(), sr), OA.harmonic(y, 8.0, hop=512)) < 5e-5
+    assert rel(ar.percussive(y.cuda(), sr), OA.percussive(y, 8.0, hop=512)) < 5e-5
+    assert rel(ar.percussive(y.cuda(), sr, 3), OA.percussive(y, 3.0, hop=512)) < 5e-5
+
+
 def test_classic_compress_eerp(golden):
     """signal.compress / expand and latent.eerp / copeerp vs the reference's outputs (g19)."""
     from maua_amd.audiovisual import audioreactive as ar
