@@ -24,6 +24,34 @@ C1_HZ = 32.70319566257483  # librosa.note_to_hz("C1")
 
 
 # ------------------------------------------------------------------------------------------------ host-side set-up
+def note_to_hz(note):
+    """convert.py:25-26 (librosa.note_to_hz: scientific pitch notation, A4 = 440 Hz) -> float32 tensor."""
+    import re
+    names = [note] if isinstance(note, str) else list(note)
+    out = []
+    for nm in names:
+        m = re.match(r"^([A-Ga-g])([#b!]*)(-?\d*)(?:([+-]\d+))?$", nm.strip())
+        if not m:
+            raise ValueError(f"Improper note format: {nm}")
+        pitch = {"C": 0, "D": 2, "E": 4, "F": 5, "G": 7, "A": 9, "B": 11}[m.group(1).upper()]
+        offset = sum({"#": 1, "b": -1, "!": -1}[c] for c in m.group(2))
+        octave = int(m.group(3)) if m.group(3) else 0
+        cents = int(m.group(4)) * 1e-2 if m.group(4) else 0.0
+        midi = 12 * (octave + 1) + pitch + offset + cents
+        out.append(440.0 * 2.0 ** ((midi - 69.0) / 12.0))
+    return torch.tensor(out[0] if isinstance(note, str) else out).float()
+
+
+def hz_to_octs(frequencies, tuning=0.0, bins_per_octave=12):
+    """convert.py:15-17"""
+    return torch.log2(torch.as_tensor(frequencies) / (float(440.0 * 2.0 ** (tuning / bins_per_octave)) / 16))
+
+
+def hz_to_midi(frequencies):
+    """convert.py:20-21"""
+    return 12 * (np.log2(frequencies) - np.log2(440.0)) + 69
+
+
 def cqt_frequencies(n_bins, fmin, bins_per_octave=12, tuning=0.0):
     """constantq.py:209-212"""
     correction = 2.0 ** (float(tuning) / bins_per_octave)

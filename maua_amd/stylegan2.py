@@ -322,11 +322,14 @@ class MappingNetwork(torch.nn.Module):
     incl. the x @ w quirk."""
 
     @L.host_threads(1)
-    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, lr_multiplier=0.01, nv_compat=False,
-                 generator=None):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None, activation="lrelu",
+                 lr_multiplier=0.01, w_avg_beta=0.998, nv_compat=False, generator=None):
         super().__init__()
         if c_dim != 0:
             raise NotImplementedError("class conditioning is not on the render path")
+        if layer_features not in (None, w_dim) or activation != "lrelu":
+            raise NotImplementedError("the reference networks' mapper: w_dim-wide lrelu layers")
+        self.w_avg_beta = w_avg_beta   # (a training-time decay: unused at inference, kept for the constructor's signature)
         self.z_dim, self.c_dim, self.w_dim, self.num_ws, self.num_layers = z_dim, c_dim, w_dim, num_ws, num_layers
         self.lr_multiplier, self.nv_compat = lr_multiplier, nv_compat
         feats = [z_dim] + [w_dim] * num_layers

@@ -469,6 +469,22 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("diffusion/processors/guided.py", "GradientGuidedConditioning.__init__", "maua_amd.diffusion", "GradientGuidedConditioning.__init__"),
     ("super/image/models/realesrgan.py", "load_model", "maua_amd.super", "load_model"),
     ("super/image/models/realesrgan.py", "upscale", "maua_amd.super", "upscale"),
+    ("GAN/wrappers/inference/stylegan2.py", "FullyConnectedLayer.__init__", "maua_amd.modules", "FullyConnectedLayer.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "FullyConnectedLayer.forward", "maua_amd.modules", "FullyConnectedLayer.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "Conv2dLayer.__init__", "maua_amd.modules", "Conv2dLayer.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "Conv2dLayer.forward", "maua_amd.modules", "Conv2dLayer.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisLayer.__init__", "maua_amd.modules", "SynthesisLayer.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisLayer.forward", "maua_amd.modules", "SynthesisLayer.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "ToRGBLayer.__init__", "maua_amd.modules", "ToRGBLayer.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "ToRGBLayer.forward", "maua_amd.modules", "ToRGBLayer.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisBlock.__init__", "maua_amd.modules", "SynthesisBlock.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisBlock.forward", "maua_amd.modules", "SynthesisBlock.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "MappingNetwork.__init__", "maua_amd.stylegan2", "MappingNetwork.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "MappingNetwork.forward", "maua_amd.stylegan2", "MappingNetwork.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisNetwork.__init__", "maua_amd.stylegan2", "SynthesisNetwork.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "SynthesisNetwork.forward", "maua_amd.stylegan2", "SynthesisNetwork.forward"),
+    ("GAN/wrappers/inference/stylegan2.py", "Generator.__init__", "maua_amd.load", "Generator.__init__"),
+    ("GAN/wrappers/inference/stylegan2.py", "Generator.forward", "maua_amd.load", "Generator.forward"),
     ("audiovisual/audioreactive/signal.py", "resample", "maua_amd.audiovisual.audioreactive", "resample"),
     ("audiovisual/audioreactive/signal.py", "normalize", "maua_amd.audiovisual.audioreactive", "normalize"),
     ("audiovisual/audioreactive/signal.py", "percentile", "maua_amd.audiovisual.audioreactive", "percentile"),
