@@ -82,6 +82,11 @@ int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight, const floa
 /* replaces render/ffmpeg.py:72 (.add(1).div(2)) + ops/io.py:47-70 tensor2bytes:
  * u8 = round_half_even(clamp((x+1)/2, 0, 1) * 255), NCHW f32 [B,3,H,W] -> HWC u8 [B,H,W,3]. */
 int maua_pack_rgb8(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int H, int W);
+/* ops/io.py:47-70 tensor2bytes itself, any value range and channel count (ops/video.py:66 feeds every frame of a
+ * VideoWriter through it): u8 = round_half_even((clamp(x, mn, mx) - mn) / (mx - mn) * 255), NCHW f32 [B,C,H,W] -> HWC u8.
+ * The range is double like the Python scalars: mx - mn is formed in double and then rounded to f32, every other step is f32. */
+int maua_tensor2bytes(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int C, int H, int W, double value_min,
+                      double value_max);
 
 /* ---- B2: synthesis network (parameters uploaded once, batched forwards) ------------------------- */
 /* replaces inference/stylegan2.py:385-436 SynthesisNetwork(w_dim, img_resolution, img_channels=3,

@@ -189,6 +189,29 @@ int launch_pack_rgb8(hipStream_t stream, const float* img, uint8_t* out, int B, 
   return MAUA_OK;
 }
 
+// ops/io.py:47-70 tensor2bytes for any value range and channel count, in the reference's operation order: clamp(mn, mx) - mn,
+// / (mx - mn), * 255, round half to even -> u8, NCHW -> HWC
+__global__ __launch_bounds__(256) void tensor2bytes_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, long total,
+                                                           int Cc, long HW, float mn, float mx, float width) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // output element (b, pixel, channel)
+  if (i >= total) return;
+  const int c = (int)(i % Cc);
+  const long bp = i / Cc, b = bp / HW, q = bp - b * HW;
+  float v = img[(b * Cc + c) * HW + q];
+  v = fminf(fmaxf(v, mn), mx);
+  v = __fdiv_rn(__fsub_rn(v, mn), width);
+  out[i] = (uint8_t)__float2int_rn(__fmul_rn(v, 255.0f));
+}
+
+int launch_tensor2bytes(hipStream_t stream, const float* img, uint8_t* out, int B, int Cc, int H, int W, double mn, double mx) {
+  const long total = (long)B * Cc * H * W;
+  if (total == 0) return MAUA_OK;
+  hipLaunchKernelGGL(tensor2bytes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, out, total, Cc,
+                     (long)H * W, (float)mn, (float)mx, (float)(mx - mn));   // the width is formed in double, like the Python scalar
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ layout converters
 // NCHW f32/bf16 <-> NHWC T with channel padding (operator-level API plumbing; LDS-transposed 32x32 tiles so both
 // sides are coalesced).
@@ -284,6 +307,15 @@ int maua_pack_rgb8(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int
   if ((long)B * H * W == 0) return MAUA_OK;
   MAUA_REQUIRE(img && out_hwc, "maua_pack_rgb8: NULL argument");
   return maua::launch_pack_rgb8(ctx->stream, img, out_hwc, B, H, W);
+}
+
+int maua_tensor2bytes(maua_ctx* ctx, const float* img, uint8_t* out_hwc, int B, int C, int H, int W, double value_min,
+                      double value_max) {
+  MAUA_REQUIRE(ctx, "maua_tensor2bytes: ctx is NULL");
+  if ((long)B * C * H * W == 0) return MAUA_OK;
+  MAUA_REQUIRE(img && out_hwc && C > 0, "maua_tensor2bytes: NULL argument");
+  MAUA_REQUIRE(value_max > value_min, "maua_tensor2bytes: empty value range");
+  return maua::launch_tensor2bytes(ctx->stream, img, out_hwc, B, C, H, W, value_min, value_max);
 }
 
 }  // extern "C"

@@ -64,6 +64,21 @@ def bias_act(x, b=None, act="linear", alpha=None, gain=None, clamp=None):
     return y
 
 
+def get_activation_defaults(activation):
+    """(alpha, gain) as scalar tensors - inference/ops.py:23-41; an unknown name gives the linear pair."""
+    a, g = _DEFAULTS.get(activation, (0.0, 1.0))
+    return torch.tensor(a), torch.tensor(g)
+
+
+def activate(x, act, alpha):
+    """The bare activation of inference/ops.py:44-62 on a tensor of any shape (no bias, gain 1, no clamp); an unknown
+    name is the identity, like the reference's final else."""
+    if act not in L.ACTS or act == "linear":
+        return x
+    x = L.dev_tensor(x)
+    return bias_act(x.reshape(1, 1, 1, -1), None, act, alpha=alpha, gain=1.0).reshape(x.shape)
+
+
 def upfirdn2d(x, f, up=1, down=1, padding=(0, 0, 0, 0), gain=1):
     x = L.dev_tensor(x)
     n, c, h, w = x.shape

@@ -3,9 +3,11 @@ import numpy as np
 import torch
 
 
-def tensor2bytes(t):
-    """maua/ops/io.py:47-70 with value_range (0,1): [1,C,H,W] -> uint8 [H,W,C] (round half to even)."""
-    return t.squeeze(0).permute(1, 2, 0).clamp(0, 1).sub(0).div(1).mul(255).round().byte().cpu().numpy()
+def tensor2bytes(t, value_range=(0, 1)):
+    """maua/ops/io.py:47-70: [1,C,H,W] -> uint8 [H,W,C]; clamp, shift, true division by the range width, * 255, round half to
+    even - every step rounded to float32 (the values of a host tensor; pinned by g14 / g26)."""
+    mn, mx = value_range
+    return t.squeeze(0).permute(1, 2, 0).clamp(mn, mx).sub(mn).div(mx - mn).mul(255).round().byte().cpu().numpy()
 
 
 def frames_to_u8(img):

@@ -383,6 +383,15 @@ def golden_io():
     img.view(-1)[: len(vals)] = vals
     b = np.frombuffer(RIO.tensor2bytes(img), dtype=np.uint8).reshape(4, 8, 3)
     save("g14_tensor2bytes", img=img, bytes=b)
+    # other value ranges and a 1-channel image (ops/video.py passes the writer's value_range through)
+    out = {}
+    for k, (mn, mx, c) in enumerate([(-1, 1, 3), (0, 255, 3), (-0.5, 2.5, 1), (0.1, 0.7, 4)]):
+        x = torch.rand(1, c, 5, 7, generator=g) * (mx - mn) * 1.2 + mn - 0.1 * (mx - mn)
+        ties = mn + (mx - mn) * (torch.tensor([0.5, 1.5, 2.5, 126.5, 127.5, 253.5, 254.5]) / 255)
+        x.view(-1)[: len(ties)] = ties
+        out[f"img{k}"], out[f"range{k}"] = x, torch.tensor([mn, mx], dtype=torch.float64)
+        out[f"bytes{k}"] = np.frombuffer(RIO.tensor2bytes(x, (mn, mx)), dtype=np.uint8).reshape(5, 7, c)
+    save("g26_tensor2bytes_ranges", **out)
 
 
 def golden_features():
@@ -463,6 +472,11 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("GAN/wrappers/inference/ops.py", "conv2d_resample", "maua_amd.ops", "conv2d_resample"),
     ("GAN/wrappers/inference/ops.py", "setup_filter", "maua_amd.ops", "setup_filter"),
     ("ops/video.py", "VideoWriter.__init__", "maua_amd.video", "VideoWriter.__init__"),
+    ("ops/video.py", "VideoWriter.write", "maua_amd.video", "VideoWriter.write"),
+    ("ops/video.py", "write_video", "maua_amd.video", "write_video"),
+    ("ops/io.py", "tensor2bytes", "maua_amd.video", "tensor2bytes"),
+    ("GAN/wrappers/inference/ops.py", "get_activation_defaults", "maua_amd.ops", "get_activation_defaults"),
+    ("GAN/wrappers/inference/ops.py", "activate", "maua_amd.ops", "activate"),
     ("diffusion/processors/guided.py", "GuidedDiffusion.__init__", "maua_amd.diffusion", "GuidedDiffusion.__init__"),
     ("diffusion/processors/guided.py", "GuidedDiffusion.forward", "maua_amd.diffusion", "GuidedDiffusion.forward"),
     ("diffusion/processors/guided.py", "create_models", "maua_amd.diffusion", "create_models"),

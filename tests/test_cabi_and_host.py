@@ -163,7 +163,7 @@ def test_video_writer_raw_fallback(tmp_path):
     assert meta["frames"] == 3 and meta["width"] == 6
     with pytest.raises(TypeError):
         with VideoWriter(str(out), (6, 4), 30) as v:
-            v.write(torch.zeros(4, 6, 3))
+            v.write(torch.zeros(4, 6, 3, dtype=torch.int32))
 
 
 def test_generate_cli_argument_surface():
@@ -246,7 +246,7 @@ def test_video_writer_pipes_frames_to_ffmpeg(tmp_path, monkeypatch):
         for f in frames:
             vw.write(f)               # blocks while the 2-slot queue is full (the consumer sleeps first)
         with pytest.raises(TypeError):
-            vw.write(torch.zeros(8, 12, 3))
+            vw.write(torch.zeros(8, 12, 3, dtype=torch.int32))
     got = np.frombuffer(out.read_bytes(), dtype=np.uint8).reshape(21, 8, 12, 3)
     assert np.array_equal(got, torch.cat(frames).numpy()) and vw.frames_written == 21
     cmd = (tmp_path / "clip.mp4.cmd").read_text().split()

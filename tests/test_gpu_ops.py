@@ -1,6 +1,7 @@
 """HIP operator layer (through the C ABI) vs the oracle and the reference-generated goldens.  GPU only."""
 from math import sqrt
 
+import numpy as np
 import pytest
 import torch
 
@@ -183,6 +184,66 @@ def test_modconv_linearity_full_size(M):
     b = M.modulated_conv2d(x2, wt, s, padding=1, demodulate=False)
     c = M.modulated_conv2d(x1 + x2, wt, s, padding=1, demodulate=False)
     assert relerr(c, a + b) <= 1e-5
+
+
+def test_tensor2bytes_value_ranges(golden, tmp_path):
+    """ops/io.py:47-70 with the value ranges ops/video.py passes through: the reference's own bytes (g14, g26), the oracle on a
+    batch, and the VideoWriter / write_video path on float frames."""
+    import json
+    import shutil
+    from oracle import io as OIO
+    from maua_amd.video import VideoWriter, tensor2bytes, tensor2bytes_device, write_video
+    import maua.ops.io
+    import maua.ops.video
+    assert maua.ops.io.tensor2bytes is tensor2bytes and maua.ops.video.write_video is write_video
+    g = golden("g14_tensor2bytes")
+    assert tensor2bytes(g["img"]) == g["bytes"].numpy().tobytes()
+    g = golden("g26_tensor2bytes_ranges")
+    for k in range(4):
+        rng = tuple(g[f"range{k}"].tolist())
+        assert tensor2bytes(g[f"img{k}"].cuda(), rng) == g[f"bytes{k}"].numpy().tobytes(), k
+    gen = torch.Generator().manual_seed(5)
+    seq = torch.rand(37, 3, 18, 26, generator=gen) * 3 - 1.5
+    want = np.stack([OIO.tensor2bytes(f[None], (-1, 1)) for f in seq])
+    assert np.array_equal(tensor2bytes_device(seq, (-1, 1)).cpu().numpy(), want)
+    assert tensor2bytes_device(seq[:0], (-1, 1)).shape == (0, 18, 26, 3)
+    with pytest.raises(Exception):
+        tensor2bytes_device(seq, (1, 1))
+    with pytest.raises(ValueError):
+        tensor2bytes(seq)
+    if shutil.which("ffmpeg"):
+        return
+    out = tmp_path / "seq.mp4"                      # raw fallback: the sink holds exactly the packed frames
+    write_video(seq.numpy(), str(out), fps=30, value_range=(-1, 1))
+    raw = np.fromfile(str(out) + ".rgb24", dtype=np.uint8).reshape(37, 18, 26, 3)
+    assert np.array_equal(raw, want) and json.loads(open(str(out) + ".json").read())["frames"] == 37
+    with VideoWriter(str(out), (26, 18), 30, None, 0, None, "slow", False, (-1.5, 1.5)) as v:   # the reference's positions
+        v.write(seq[:2].cuda())
+        v.write(torch.from_numpy(want[2]))
+    raw = np.fromfile(str(out) + ".rgb24", dtype=np.uint8).reshape(3, 18, 26, 3)
+    assert np.array_equal(raw[:2], np.stack([OIO.tensor2bytes(f[None], (-1.5, 1.5)) for f in seq[:2]]))
+    assert np.array_equal(raw[2], want[2])
+
+
+def test_activation_helpers():
+    """inference/ops.py:23-62 get_activation_defaults / activate on tensors of any shape."""
+    from math import sqrt
+    from oracle import ops as OO
+    import maua.GAN.wrappers.inference.ops as NS
+    from maua_amd import ops
+    assert NS.activate is ops.activate and NS.get_activation_defaults is ops.get_activation_defaults
+    for act, (a, g) in {"relu": (0.0, sqrt(2)), "lrelu": (0.2, sqrt(2)), "tanh": (0.0, 1.0), "swish": (0.0, sqrt(2)),
+                        "linear": (0.0, 1.0), "nonsense": (0.0, 1.0)}.items():
+        da, dg = ops.get_activation_defaults(act)
+        assert torch.equal(da, torch.tensor(a)) and torch.equal(dg, torch.tensor(g)) and da.ndim == 0
+    gen = torch.Generator().manual_seed(2)
+    for shape in [(7,), (3, 5), (2, 3, 4, 5), (2, 2, 2, 2, 3)]:
+        x = torch.randn(*shape, generator=gen) * 3
+        for act in ["relu", "lrelu", "tanh", "sigmoid", "elu", "selu", "softplus", "swish"]:
+            got = ops.activate(x.cuda(), act, 0.3).cpu()
+            assert got.shape == x.shape and relerr(got, OO._activate(x, act, 0.3)) <= 2e-6, (act, shape)
+    x = torch.randn(4, 4).cuda()
+    assert ops.activate(x, "linear", 0.2) is x and ops.activate(x, "anything-else", 0.2) is x
 
 
 def test_pack_rgb8(M, golden):

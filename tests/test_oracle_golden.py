@@ -325,6 +325,10 @@ def test_noise_patch_graphs(golden):
 def test_tensor2bytes(golden):
     g = golden("g14_tensor2bytes")
     assert np.array_equal(OIO.tensor2bytes(g["img"]), g["bytes"].numpy())
+    g = golden("g26_tensor2bytes_ranges")
+    for k in range(4):
+        mn, mx = g[f"range{k}"].tolist()
+        assert np.array_equal(OIO.tensor2bytes(g[f"img{k}"], (mn, mx)), g[f"bytes{k}"].numpy()), k
 
 
 def test_features_n3(golden):
