@@ -228,6 +228,14 @@ int maua_soft_kmeans(maua_ctx* ctx, const float* data, int n, int k, const float
  * published kernel, built by the caller). */
 int maua_fir_decimate(maua_ctx* ctx, const float* x, long n, const float* taps, int ntaps, int stride, int left,
                       float scale, float* out, long n_out);
+/* replaces audioreactive/audio.py:96-112 low_pass / high_pass / band_pass (scipy.signal.sosfilt over the decoded clip, float64)
+ * and the lfilter under the biquads of selfsupervised/features/processing.py:142-151.  sos_host [n_sections][6] = b0 b1 b2 a0 a1 a2
+ * per section (HOST array, scipy's layout), x / y [n] device float64 (y may be x); zero initial state.  Every section is scipy's
+ * direct form II transposed sample for sample; the clip is cut into 128-sample chunks whose start states come from a scan. */
+int maua_sosfilt(maua_ctx* ctx, const double* sos_host, int n_sections, const double* x, long n, double* y);
+/* replaces processing.py:154-155 contrast_enhance (torchaudio.functional.contrast, un-vendored: the published formula)
+ * y = sin(t + enhancement_amount / 750 * sin(4 t)), t = x pi / 2;  enhancement_amount in [0, 100]. */
+int maua_contrast(maua_ctx* ctx, const float* x, long n, float enhancement_amount, float* y);
 /* torch.istft's overlap-add (rosa/spectral.py:24-32) for already-windowed time frames [n_frames][W]: y[t] =
  * sum_f frames[f][t + start - f hop] / sum_f window[t + start - f hop]^2, t < length.  Used by the tempogram of clips
  * shorter than win_length (rosa/beat.py:48-49, 66: a non-power-of-two transform, run as a DFT GEMM). */

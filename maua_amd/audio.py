@@ -359,6 +359,87 @@ def emphasize(envs, strength, percentile):
     return y.reshape(shape)
 
 
+def _biquad(waveform, b, a):
+    """torchaudio.functional.biquad = lfilter(waveform, a, b, clamp=True) for one second-order section (torchaudio un-vendored:
+    the published filter; the recurrence runs in float64 on the device and is rounded to float32 once, torchaudio's runs in the
+    waveform's float32)."""
+    from .signal import sosfilt
+    x = _f32(waveform)
+    y = sosfilt([[b[0], b[1], b[2], a[0], a[1], a[2]]], x)
+    out = torch.empty_like(x)
+    one = torch.ones((1,), dtype=torch.float32, device=x.device)
+    y32 = y.float()
+    L.check(L.lib().maua_clamp(L.ctx(x.device), L.ptr(y32), None, L.ptr(one), C.c_float(-1.0), C.c_float(0.0),
+                               C.c_long(x.numel()), L.ptr(out)))
+    return out
+
+
+def low_pass(audio, sr, fmax=200):
+    """processing.py:142-143: torchaudio.functional.lowpass_biquad(audio, sr, fmax) (Q = 0.707; RBJ cookbook coefficients)."""
+    w0 = 2 * math.pi * fmax / sr
+    alpha = math.sin(w0) / 2 / 0.707
+    b0 = (1 - math.cos(w0)) / 2
+    return _biquad(audio, (b0, 1 - math.cos(w0), b0), (1 + alpha, -2 * math.cos(w0), 1 - alpha))
+
+
+def high_pass(audio, sr, fmin=4000):
+    """processing.py:150-151: torchaudio.functional.highpass_biquad(audio, sr, fmin) (Q = 0.707)."""
+    w0 = 2 * math.pi * fmin / sr
+    alpha = math.sin(w0) / 2.0 / 0.707
+    b0 = (1 + math.cos(w0)) / 2
+    return _biquad(audio, (b0, -1 - math.cos(w0), b0), (1 + alpha, -2 * math.cos(w0), 1 - alpha))
+
+
+def mid_pass(audio, sr, fmin=200, fmax=4000):
+    """processing.py:146-147, as written there: the HIGH pass runs at fmax and the LOW pass at fmin."""
+    return low_pass(high_pass(audio, sr, fmax), sr, fmin)
+
+
+def contrast_enhance(audio, sr, strength=75):
+    """processing.py:154-155: torchaudio.functional.contrast(audio, strength)."""
+    x = _f32(audio)
+    y = torch.empty_like(x)
+    L.check(L.lib().maua_contrast(L.ctx(x.device), L.ptr(x), C.c_long(x.numel()), C.c_float(float(strength)), L.ptr(y)))
+    return y
+
+
+def _clamp_columns(signal, bound):
+    """clamp every column of a [T] / [T, C] signal by its own device-scalar bounds: bound(col) -> (lo or None, hi or None)."""
+    x = _f32(signal)
+    cols = x.reshape(x.shape[0], -1)
+    inf = torch.full((1,), float("inf"), dtype=torch.float32, device=x.device)
+    out = []
+    for col in cols.unbind(1):
+        col = col.contiguous()
+        lo, hi = bound(col)
+        y = torch.empty_like(col)
+        L.check(L.lib().maua_clamp(L.ctx(x.device), L.ptr(col), L.ptr(lo), L.ptr(inf if hi is None else hi),
+                                   C.c_float(float("-inf")), C.c_float(0.0), C.c_long(col.numel()), L.ptr(y)))
+        out.append(y)
+    return torch.stack(out, dim=1).reshape(x.shape)
+
+
+def clamp_upper_percentile(signal, percentile):
+    """processing.py:125-126: clamp(signal, None, torch.quantile(signal, percentile / 100, dim=0))."""
+    return _clamp_columns(signal, lambda col: (None, order_stat(col, 2, q=percentile / 100)[0]))
+
+
+def clamp_lower_percentile(signal, percentile):
+    """processing.py:129-130: clamp(signal, torch.quantile(signal, percentile / 100, dim=0), None)."""
+    return _clamp_columns(signal, lambda col: (order_stat(col, 2, q=percentile / 100)[0], None))
+
+
+def clamp_peaks_percentile(signal, percent):
+    """processing.py:102-122: every column clamped from above at the ``percent`` quantile (torch.quantile) of its local peaks
+    (strictly greater than both neighbours, indices clamped at the ends) -> [T, C] ([T, 1] for a 1-D signal)."""
+    def bound(col):
+        mask = torch.empty((col.numel(),), dtype=torch.uint8, device=col.device)
+        L.check(L.lib().maua_peak_mask(L.ctx(col.device), L.ptr(col), col.numel(), L.ptr(mask)))
+        return None, order_stat(col, 2, q=percent / 100, mask=mask)[0]
+    x = _f32(signal)
+    return _clamp_columns(x.unsqueeze(1) if x.ndim < 2 else x, bound)
+
+
 def drop_strength(audio, sr):
     """features/audio.py:40-41 -> [T, 1, 1] (the reference unsqueezes the [T, 1] envelope once more)."""
     return emphasize(gaussian_filter(rms(audio, sr), 10), strength=10, percentile=50).unsqueeze(1)

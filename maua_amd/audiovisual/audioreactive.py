@@ -7,7 +7,8 @@ from ..audio import (gaussian_filter as _gf_selfsup, harmonic as _harmonic, hpss
 from ..audio_io import load_audio as _load
 from ..latent import (copeerp, eerp, multi_weighted, select_modulo, single_weighted, slerp, slerp_loops,  # noqa
                       spline_loops, tempo_loops)
-from ..signal import compress, expand, gaussian_filter, normalize, percentile, percentile_clip, resample  # noqa
+from ..signal import (compress, expand, gaussian_filter, normalize, percentile, percentile_clip, resample,  # noqa
+                      sosfilt)
 
 
 def load_audio(audio_file, offset=0, duration=-1, cache=True):
@@ -56,12 +57,11 @@ def percussive(audio, sr, margin=8):
 
 
 def _butter(audio, sr, cutoff, kind, db_per_octave):
-    """maua/audiovisual/audioreactive/audio.py:96-112: a Butterworth IIR (scipy sosfilt) over the decoded numpy
-    signal — a serial recurrence on the host, once per clip, exactly as the reference runs it (scipy is a listed
-    dependency of the reference and part of this image)."""
-    from scipy import signal as sps
-    a = audio.detach().cpu().numpy() if isinstance(audio, torch.Tensor) else audio
-    return sps.sosfilt(sps.butter(db_per_octave, cutoff, kind, fs=sr, output="sos"), a)
+    """maua/audiovisual/audioreactive/audio.py:96-112: ``signal.sosfilt(signal.butter(db_per_octave, cutoff, kind, fs=sr,
+    output="sos"), audio)``.  The filter design (at most 12 second-order sections) stays scipy's, as in the reference; the
+    recurrence over the clip runs on the device (signal.sosfilt -> maua_sosfilt)."""
+    from scipy.signal import butter
+    return sosfilt(butter(db_per_octave, cutoff, kind, fs=sr, output="sos"), audio)
 
 
 def low_pass(audio, sr, fmax=200, db_per_octave=12):

@@ -215,6 +215,86 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
   y[t] = den > 1e-11f ? num / den : 0.f;
 }
 
+// ------------------------------------------------------------------------------------ IIR second-order sections
+// scipy.signal.sosfilt (audioreactive/audio.py:96-112: Butterworth low / high / band pass over the decoded clip) and the biquads of
+// processing.py:142-151, as a blocked linear recurrence.  One section in scipy's direct form II transposed,
+//   y = b0 x + z0;  z0' = b1 x - a1 y + z1;  z1' = b2 x - a2 y          (float64, the same operation order, no contraction)
+// is linear in its state: after L samples z = P z_start + f with P = A^L, A = [[-a1, 1], [-a2, 0]] and f the end state of the same
+// chunk started from zero.  (1) every chunk's f in parallel, (2) the chunk start states by a two-level scan, (3) every chunk
+// again from its true start state - within a chunk the arithmetic is scipy's, sample for sample.
+struct SosSection {
+  double b0, b1, b2, a1, a2;
+  double P[4];    // A^L
+  double Pm[4];   // P^m: m chunks per scan thread
+};
+
+__device__ __forceinline__ double sos_step(const SosSection& c, double x, double& z0, double& z1) {
+  const double y = __dadd_rn(__dmul_rn(c.b0, x), z0);
+  z0 = __dadd_rn(__dsub_rn(__dmul_rn(c.b1, x), __dmul_rn(c.a1, y)), z1);
+  z1 = __dsub_rn(__dmul_rn(c.b2, x), __dmul_rn(c.a2, y));
+  return y;
+}
+
+__global__ __launch_bounds__(64) void sos_chunk_kernel(const double* __restrict__ x, long n, int L, long n_chunks, SosSection c,
+                                                       double* __restrict__ f) {
+  const long ch = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= n_chunks) return;
+  const long lo = ch * L, hi = lo + L < n ? lo + L : n;
+  double z0 = 0.0, z1 = 0.0;
+  for (long i = lo; i < hi; i++) sos_step(c, x[i], z0, z1);
+  f[2 * ch] = z0;
+  f[2 * ch + 1] = z1;
+}
+
+// start state of every chunk: S[0] = 0, S[c + 1] = P S[c] + f[c].  256 threads, m consecutive chunks each.
+__global__ __launch_bounds__(256) void sos_boundary_kernel(const double* __restrict__ f, long n_chunks, int m, SosSection c,
+                                                           double* __restrict__ S) {
+  __shared__ double run[256][2];
+  const int t = threadIdx.x;
+  const long lo = (long)t * m, hi = lo + m < n_chunks ? lo + m : n_chunks;
+  double v0 = 0.0, v1 = 0.0;
+  for (long k = lo; k < hi; k++) {
+    const double w0 = c.P[0] * v0 + c.P[1] * v1 + f[2 * k], w1 = c.P[2] * v0 + c.P[3] * v1 + f[2 * k + 1];
+    v0 = w0, v1 = w1;
+  }
+  run[t][0] = v0, run[t][1] = v1;
+  __syncthreads();
+  if (t == 0) {
+    double r0 = 0.0, r1 = 0.0;
+    for (int k = 0; k < 256; k++) {
+      const double e0 = run[k][0], e1 = run[k][1];
+      run[k][0] = r0, run[k][1] = r1;                       // state at the start of thread k's run
+      const double w0 = c.Pm[0] * r0 + c.Pm[1] * r1 + e0, w1 = c.Pm[2] * r0 + c.Pm[3] * r1 + e1;
+      r0 = w0, r1 = w1;
+    }
+  }
+  __syncthreads();
+  v0 = run[t][0], v1 = run[t][1];
+  for (long k = lo; k < hi; k++) {
+    S[2 * k] = v0, S[2 * k + 1] = v1;
+    const double w0 = c.P[0] * v0 + c.P[1] * v1 + f[2 * k], w1 = c.P[2] * v0 + c.P[3] * v1 + f[2 * k + 1];
+    v0 = w0, v1 = w1;
+  }
+}
+
+__global__ __launch_bounds__(64) void sos_apply_kernel(const double* x, long n, int L, long n_chunks, SosSection c,
+                                                       const double* __restrict__ S, double* y) {   // x may alias y
+  const long ch = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= n_chunks) return;
+  const long lo = ch * L, hi = lo + L < n ? lo + L : n;
+  double z0 = S[2 * ch], z1 = S[2 * ch + 1];
+  for (long i = lo; i < hi; i++) y[i] = sos_step(c, x[i], z0, z1);
+}
+
+// torchaudio.functional.contrast (processing.py:154-155 contrast_enhance): sin(t + amount / 750 sin(4 t)), t = x pi / 2.
+__global__ __launch_bounds__(256) void contrast_kernel(const float* __restrict__ x, long n, float contrast, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float t1 = __fmul_rn(x[i], 1.57079632679489661923f);
+  const float t2 = __fmul_rn(contrast, sinf(__fmul_rn(t1, 4.0f)));
+  y[i] = sinf(__fadd_rn(t1, t2));
+}
+
 // y = step(spline(x)): the soft quantiser of chroma_cens (rosa/spectral.py:164-232).  spline = piecewise cubic
 // a + f (b + f (c + f d)), f = x - knot[idx], idx = (number of knots < x) - 1 clamped to [0, nk - 2] (torch.bucketize);
 // step(w) = h (floor(w - 0.5) + 1 / (2 m) / (1 + exp(-2 alpha r(w)))), r(w) = (w - 0.5) - floor(w - 0.5) - 0.5.
@@ -382,6 +462,59 @@ extern "C" int maua_overlap_add(maua_ctx* ctx, const float* frames, int n_frames
   if (length == 0) return MAUA_OK;
   hipLaunchKernelGGL(maua::overlap_add_kernel, dim3((unsigned)((length + 255) / 256)), dim3(256), 0, ctx->stream, frames,
                      n_frames, W, hop, window, start, length, y);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+static void mat2_mul(const double* a, const double* b, double* o) {
+  const double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2], a[2] * b[1] + a[3] * b[3]};
+  for (int i = 0; i < 4; i++) o[i] = r[i];
+}
+static void mat2_pow(const double* a, long e, double* o) {
+  double base[4] = {a[0], a[1], a[2], a[3]}, acc[4] = {1.0, 0.0, 0.0, 1.0};
+  for (; e > 0; e >>= 1) {
+    if (e & 1) mat2_mul(acc, base, acc);
+    mat2_mul(base, base, base);
+  }
+  for (int i = 0; i < 4; i++) o[i] = acc[i];
+}
+
+extern "C" int maua_sosfilt(maua_ctx* ctx, const double* sos_host, int n_sections, const double* x, long n, double* y) {
+  MAUA_REQUIRE(ctx, "maua_sosfilt: ctx is NULL");
+  MAUA_REQUIRE(n_sections >= 1 && sos_host, "maua_sosfilt: need at least one section");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y && n > 0, "maua_sosfilt: NULL argument");
+  const int L = 128;
+  const long n_chunks = (n + L - 1) / L;
+  const int m = (int)((n_chunks + 255) / 256);
+  if (int rc = maua::scratch_reserve(ctx, (size_t)n_chunks * 4 * sizeof(double))) return rc;
+  double* f = (double*)ctx->scratch;
+  double* S = f + 2 * n_chunks;
+  const unsigned grid = (unsigned)((n_chunks + 63) / 64);
+  for (int k = 0; k < n_sections; k++) {
+    const double* r = sos_host + 6 * k;
+    MAUA_REQUIRE(r[3] != 0.0, "maua_sosfilt: a0 of a section is zero");
+    maua::SosSection c;
+    c.b0 = r[0] / r[3], c.b1 = r[1] / r[3], c.b2 = r[2] / r[3], c.a1 = r[4] / r[3], c.a2 = r[5] / r[3];
+    const double A[4] = {-c.a1, 1.0, -c.a2, 0.0};
+    mat2_pow(A, L, c.P);
+    mat2_pow(c.P, m, c.Pm);
+    const double* src = k == 0 ? x : y;
+    hipLaunchKernelGGL(maua::sos_chunk_kernel, dim3(grid), dim3(64), 0, ctx->stream, src, n, L, n_chunks, c, f);
+    hipLaunchKernelGGL(maua::sos_boundary_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)f, n_chunks, m, c, S);
+    hipLaunchKernelGGL(maua::sos_apply_kernel, dim3(grid), dim3(64), 0, ctx->stream, src, n, L, n_chunks, c, (const double*)S, y);
+  }
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+extern "C" int maua_contrast(maua_ctx* ctx, const float* x, long n, float enhancement_amount, float* y) {
+  MAUA_REQUIRE(ctx, "maua_contrast: ctx is NULL");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(x && y, "maua_contrast: NULL argument");
+  MAUA_REQUIRE(enhancement_amount >= 0.f && enhancement_amount <= 100.f, "maua_contrast: enhancement_amount outside [0, 100]");
+  hipLaunchKernelGGL(maua::contrast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n,
+                     enhancement_amount / 750.0f, y);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

@@ -2,6 +2,7 @@
 resample :5-24, normalize :27-38, percentile :41-52, percentile_clip :55-81, gaussian_filter :108-157)."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -67,3 +68,22 @@ def compress(signal, threshold, ratio, invert=False):
 def expand(signal, threshold, ratio, invert=False):
     """signal.py:103-105: alias of compress"""
     return compress(signal, threshold, ratio, invert)
+
+
+def sosfilt(sos, x):
+    """scipy.signal.sosfilt(sos, x) along the last axis on the device: float64, zero initial state (maua_sosfilt - every section
+    is scipy's direct form II transposed, sample for sample, over 128-sample chunks whose start states come from a scan).
+    ``sos`` [n_sections, 6] is a host array (36 numbers at most on this path).  A numpy signal comes back as numpy, like scipy's;
+    a tensor comes back as a float64 device tensor."""
+    sos = np.ascontiguousarray(np.asarray(sos, dtype=np.float64))
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError("sos must have shape [n_sections, 6]")
+    as_numpy = not isinstance(x, torch.Tensor)
+    xd = L.dev_tensor(torch.as_tensor(np.asarray(x)) if as_numpy else x.detach(), torch.float64)
+    y = torch.empty_like(xd)
+    n = xd.shape[-1] if xd.ndim else 0
+    rows_in, rows_out = xd.reshape(-1, n) if n else xd.reshape(0, 0), y.reshape(-1, n) if n else y.reshape(0, 0)
+    for r in range(rows_in.shape[0]):
+        L.check(L.lib().maua_sosfilt(L.ctx(xd.device), sos.ctypes.data_as(C.c_void_p), sos.shape[0], L.ptr(rows_in[r]),
+                                     C.c_long(n), L.ptr(rows_out[r])))
+    return y.cpu().numpy() if as_numpy else y

@@ -11,6 +11,8 @@ Follows the reference's pure-torch librosa re-implementation:
 STFT framing / overlap-add are written out explicitly (numpy-style) instead of calling torch.stft, so that the
 frame <-> sample mapping the HIP kernels must reproduce is stated once, here.
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -265,6 +267,70 @@ def emphasize(envs, strength, percentile):
     x = x / mx
     x = x * (1 + torch.tanh(strength * (x - torch.quantile(x, q=percentile / 100, dim=0))))
     return (x * mx) + mn
+
+
+def clamp_upper_percentile(signal, percentile):
+    """processing.py:125-126"""
+    return torch.clamp(signal, max=torch.quantile(signal, percentile / 100, dim=0))
+
+
+def clamp_lower_percentile(signal, percentile):
+    """processing.py:129-130"""
+    return torch.clamp(signal, min=torch.quantile(signal, percentile / 100, dim=0))
+
+
+def clamp_peaks_percentile(signal, percent):
+    """processing.py:102-122: upper clamp of every column at the quantile of its local peaks."""
+    from .signal import peak_mask
+    if signal.ndim < 2:
+        signal = signal.unsqueeze(1)
+    return torch.stack([c.clamp(max=torch.quantile(c[peak_mask(c)], percent / 100)) for c in signal.unbind(1)], dim=1)
+
+
+def sosfilt(sos, x):
+    """audioreactive/audio.py:96-112 run scipy.signal.sosfilt (a listed dependency of the reference, present in this image): the
+    oracle of the device recurrence is scipy itself, float64."""
+    from scipy import signal
+    return signal.sosfilt(np.asarray(sos, dtype=np.float64), np.asarray(x, dtype=np.float64))
+
+
+def butter_pass(audio, sr, cutoff, kind, db_per_octave=12):
+    """audioreactive/audio.py:96-112 low_pass / high_pass / band_pass as written there."""
+    from scipy import signal
+    return signal.sosfilt(signal.butter(db_per_octave, cutoff, kind, fs=sr, output="sos"), audio)
+
+
+def _biquad(x, b, a):
+    """torchaudio.functional.biquad (un-vendored: lfilter with clamp=True as published; parity unpinned).  Computed in float64 and
+    rounded once - torchaudio's own recurrence runs in the waveform's float32."""
+    from scipy import signal
+    y = signal.lfilter(np.asarray(b, dtype=np.float64) / a[0], np.asarray(a, dtype=np.float64) / a[0], x.double().numpy())
+    return torch.from_numpy(y).clamp(-1, 1).float()
+
+
+def low_pass(audio, sr, fmax=200, q=0.707):
+    """processing.py:142-143 lowpass_biquad (RBJ cookbook)"""
+    w0 = 2 * math.pi * fmax / sr
+    al, cs = math.sin(w0) / 2 / q, math.cos(w0)
+    return _biquad(audio, [(1 - cs) / 2, 1 - cs, (1 - cs) / 2], [1 + al, -2 * cs, 1 - al])
+
+
+def high_pass(audio, sr, fmin=4000, q=0.707):
+    """processing.py:150-151 highpass_biquad"""
+    w0 = 2 * math.pi * fmin / sr
+    al, cs = math.sin(w0) / 2 / q, math.cos(w0)
+    return _biquad(audio, [(1 + cs) / 2, -1 - cs, (1 + cs) / 2], [1 + al, -2 * cs, 1 - al])
+
+
+def mid_pass(audio, sr, fmin=200, fmax=4000):
+    """processing.py:146-147 (high pass at fmax, then low pass at fmin - as written)"""
+    return low_pass(high_pass(audio, sr, fmax), sr, fmin)
+
+
+def contrast_enhance(audio, strength=75):
+    """processing.py:154-155 torchaudio.functional.contrast as published"""
+    t1 = audio * (math.pi / 2)
+    return torch.sin(t1 + (strength / 750.0) * torch.sin(t1 * 4))
 
 
 def drop_strength(audio):

@@ -416,6 +416,30 @@ def golden_features():
          chroma=chroma, tonnetz=FA.tonnetz(a, sr, chroma_fn=lambda a_, sr_: chroma))
 
 
+def golden_processing():
+    """processing.py:102-130 clamp_peaks_percentile / clamp_upper_percentile / clamp_lower_percentile (torch.quantile only; the
+    torchaudio biquads of the same file cannot run here) and audioreactive/audio.py:96-112's call into scipy - the reference
+    module imports librosa, so its one-line bodies are run as written there: sosfilt(butter(db, f, kind, fs=sr, output="sos"), y)."""
+    from scipy import signal
+    from maua.audiovisual.audioreactive.selfsupervised.features import processing as FP
+    g = torch.Generator().manual_seed(31)
+    e1 = torch.rand(400, generator=g) ** 2
+    e3 = torch.rand(257, 3, generator=g)
+    e3[::7, 1] = e3[3, 1]                      # ties
+    sr = 22050
+    t = np.arange(2048) / sr                   # a short clip: the whole-length comparisons run against scipy itself in the tests
+    rng = np.random.default_rng(5)
+    y = np.sin(2 * np.pi * 60 * t) + 0.5 * np.sin(2 * np.pi * 900 * t) + 0.25 * np.sin(2 * np.pi * 6000 * t) + 0.1 * rng.standard_normal(t.size)
+    save("g27_processing", e1=e1, e3=e3, sr=np.int64(sr), y=y,
+         peaks_1d_90=FP.clamp_peaks_percentile(e1, 90), peaks_3_50=FP.clamp_peaks_percentile(e3, 50),
+         upper_1d_75=FP.clamp_upper_percentile(e1, 75), upper_3_20=FP.clamp_upper_percentile(e3, 20),
+         lower_1d_30=FP.clamp_lower_percentile(e1, 30), lower_3_95=FP.clamp_lower_percentile(e3, 95),
+         low_200_12=signal.sosfilt(signal.butter(12, 200, "low", fs=sr, output="sos"), y),
+         low_100_24=signal.sosfilt(signal.butter(24, 100, "low", fs=sr, output="sos"), y),
+         high_3000_12=signal.sosfilt(signal.butter(12, 3000, "high", fs=sr, output="sos"), y),
+         band_200_3000_12=signal.sosfilt(signal.butter(12, [200, 3000], "band", fs=sr, output="sos"), y))
+
+
 def golden_pulse():
     """features/audio.py:72-73 pulse = plp(percussive(audio)) (rosa/beat.py:42-75) on a 40 s synthetic clip (1200 frames:
     the tempogram window is 1024 frames)."""
@@ -548,6 +572,13 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("audiovisual/audioreactive/selfsupervised/features/processing.py", "median_filter2d", "maua_amd.audio", "median_filter2d"),
     ("audiovisual/audioreactive/selfsupervised/features/processing.py", "emphasize", "maua_amd.audio", "emphasize"),
     ("audiovisual/audioreactive/selfsupervised/features/processing.py", "normalize", "maua_amd.audio", "normalize"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "clamp_peaks_percentile", "maua_amd.audio", "clamp_peaks_percentile"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "clamp_upper_percentile", "maua_amd.audio", "clamp_upper_percentile"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "clamp_lower_percentile", "maua_amd.audio", "clamp_lower_percentile"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "low_pass", "maua_amd.audio", "low_pass"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "mid_pass", "maua_amd.audio", "mid_pass"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "high_pass", "maua_amd.audio", "high_pass"),
+    ("audiovisual/audioreactive/selfsupervised/features/processing.py", "contrast_enhance", "maua_amd.audio", "contrast_enhance"),
     ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "cqt", "maua.audiovisual.audioreactive.selfsupervised.features.rosa.constantq", "cqt"),
     ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "vqt", "maua.audiovisual.audioreactive.selfsupervised.features.rosa.constantq", "vqt"),
     ("audiovisual/audioreactive/selfsupervised/features/rosa/constantq.py", "constant_q", "maua_amd.cqt", "constant_q"),

@@ -181,14 +181,15 @@ def test_generate_cli_argument_surface():
         G.main([])  # --audio_file / --model_file are required
 
 
-def test_pass_filters_match_reference(golden):
-    """audio.py:96-112 low / high / band pass (host scipy Butterworth, like the reference) vs its outputs (g19)."""
+def test_pass_filters_have_no_host_path():
+    """audio.py:96-112 low / high / band pass: the recurrence runs on the device (maua_sosfilt; parity in
+    test_gpu_audio.py::test_iir_filters_and_percentile_clamps) - without one the call fails instead of filtering on the host."""
+    import torch
+    from maua_amd._lib import MauaHipError
     from maua_amd.audiovisual import audioreactive as ar
-    g = golden("g19_classic")
-    x = g["x"].numpy()
-    for fn, key, args in [(ar.low_pass, "low", (200,)), (ar.high_pass, "high", (3000,)), (ar.band_pass, "band", (200, 3000))]:
-        y = fn(x, 30720, *args)
-        assert np.allclose(y, g[key].numpy(), rtol=1e-9, atol=1e-12), key
+    if not torch.cuda.is_available():
+        with pytest.raises(MauaHipError):
+            ar.low_pass(np.zeros(1000), 30720, 200)
 
 
 def test_maua_namespace_resolves_to_the_native_package():

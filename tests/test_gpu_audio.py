@@ -600,3 +600,61 @@ def test_sinc_resample_and_load_audio(tmp_path):
     assert 0.45 < float(a.abs().max()) <= 0.51  # mono mean of (sine, 0)
     mono = torch.from_numpy(pcm[:, 0].astype(np.float32) / 32768.0 / 2)[sr // 2: sr // 2 + sr]
     assert float((a - OA.sinc_resample(mono, sr, 10240)).abs().max()) < 1e-5
+
+
+def test_iir_filters_and_percentile_clamps(golden):
+    """Device IIR (maua_sosfilt) vs scipy - the reference's own dependency for audioreactive/audio.py:96-112 - on the g27 vectors and
+    at whole-clip length; the classic low / high / band pass through it; processing.py's biquads, contrast and percentile clamps vs
+    the reference's outputs (g27) / the oracle."""
+    import numpy as np
+    from scipy import signal as sps
+    import maua_amd.audio as A
+    from maua_amd import signal as S
+    from maua_amd.audiovisual import audioreactive as ar
+    from oracle import audio as OA
+    import maua.audiovisual.audioreactive.selfsupervised.features.processing as NS
+    import maua.audiovisual.audioreactive.audio as NSA
+    assert NS.clamp_peaks_percentile is A.clamp_peaks_percentile and NS.mid_pass is A.mid_pass and NSA.low_pass is ar.low_pass
+    g = golden("g27_processing")
+    y, sr = g["y"].numpy(), int(g["sr"])
+
+    def err(got, want):
+        return float(np.abs(np.asarray(got) - np.asarray(want)).max() / (np.abs(np.asarray(want)).max() + 1e-300))
+    for name, got in [("low_200_12", ar.low_pass(y, sr)), ("low_100_24", ar.low_pass(y, sr, 100, 24)),
+                      ("high_3000_12", ar.high_pass(y, sr)), ("band_200_3000_12", ar.band_pass(y, sr))]:
+        assert isinstance(got, np.ndarray) and got.dtype == np.float64 and err(got, g[name].numpy()) < (1e-9 if name == "low_100_24" else 1e-10), name   # 12 cascaded
+        # sections with poles at 1 - 0.014: a last-bit difference in a chunk's start state is amplified like any rounding error
+    c = golden("g19_classic")                                # the round-2 vectors of the same three calls
+    for fn, key, args in [(ar.low_pass, "low", (200,)), (ar.high_pass, "high", (3000,)), (ar.band_pass, "band", (200, 3000))]:
+        assert err(fn(c["x"].numpy(), 30720, *args), c[key].numpy()) < 1e-10, key
+    # whole-clip length (2-level scan: 28 800 chunks), a tensor in -> a float64 device tensor out, 2-D rows, ragged tail, n < chunk
+    rng = np.random.default_rng(8)
+    long = rng.standard_normal(3_686_400) * 0.3
+    for sos in [sps.butter(12, 200, "low", fs=44100, output="sos"), sps.butter(12, [200, 3000], "band", fs=44100, output="sos"),
+                sps.butter(24, 100, "low", fs=44100, output="sos")]:
+        got = S.sosfilt(sos, torch.from_numpy(long).cuda())
+        assert got.is_cuda and got.dtype == torch.float64
+        assert err(got.cpu().numpy(), sps.sosfilt(sos, long)) < 1e-9
+    sos = sps.butter(4, 0.2, output="sos")
+    for n in (1, 5, 127, 128, 129, 1000, 32769):
+        x = rng.standard_normal((2, n))
+        assert err(S.sosfilt(sos, x), sps.sosfilt(sos, x)) < 1e-13, n
+    assert S.sosfilt(sos, np.zeros(0)).shape == (0,)
+    with pytest.raises(ValueError):
+        S.sosfilt(np.zeros((2, 5)), long[:10])
+    # the selfsupervised biquads / contrast (published torchaudio forms: parity unpinned) vs the oracle's float64 restatement
+    a = torch.from_numpy(long[:200_000]).float().clamp(-1, 1)
+    assert rel(A.low_pass(a.cuda(), 44100), OA.low_pass(a, 44100)) < 1e-6
+    assert rel(A.high_pass(a.cuda(), 44100), OA.high_pass(a, 44100)) < 1e-6
+    assert rel(A.mid_pass(a.cuda(), 44100), OA.mid_pass(a, 44100)) < 1e-6
+    loud = a * 4                                           # the biquad's output clamp to [-1, 1]
+    lp = A.low_pass(loud.cuda(), 44100, 8000)
+    assert float(lp.abs().max()) == 1.0 and rel(lp, OA.low_pass(loud, 44100, 8000)) < 1e-6
+    assert rel(A.contrast_enhance(a.cuda(), 44100), OA.contrast_enhance(a)) < 1e-6
+    assert rel(A.contrast_enhance(a.cuda(), 44100, 20), OA.contrast_enhance(a, 20)) < 1e-6
+    # percentile clamps: the reference's own outputs
+    for name, fn, sig, arg in [("peaks_1d_90", A.clamp_peaks_percentile, "e1", 90), ("peaks_3_50", A.clamp_peaks_percentile, "e3", 50),
+                               ("upper_1d_75", A.clamp_upper_percentile, "e1", 75), ("upper_3_20", A.clamp_upper_percentile, "e3", 20),
+                               ("lower_1d_30", A.clamp_lower_percentile, "e1", 30), ("lower_3_95", A.clamp_lower_percentile, "e3", 95)]:
+        got = fn(g[sig].cuda(), arg).cpu()
+        assert got.shape == g[name].shape and rel(got, g[name]) < 1e-6, name

@@ -1,6 +1,8 @@
 """Pin the oracle: every oracle function vs fixtures produced by the reference itself
 (tests/golden/make_golden.py).  CPU only."""
+import math
 from math import sqrt
+
 
 import numpy as np
 import pytest
@@ -348,6 +350,36 @@ def test_features_n3(golden):
     close(A.tonnetz_from_chroma(g["chroma"]), g["tonnetz"], 1e-6)
     a12 = synthetic_audio(int(g["n12"]), sr, int(g["seed12"]))
     close(A.drop_strength(a12), g["drop_strength"], 2e-5)
+
+
+def test_processing_clamps_and_filters(golden):
+    """processing.py clamp_*_percentile vs the reference's outputs; the Butterworth passes vs the reference's scipy call (g27);
+    closed forms of the published biquads / contrast (torchaudio un-vendored: parity unpinned)."""
+    g = golden("g27_processing")
+    for name, fn, arg in [("peaks_1d_90", A.clamp_peaks_percentile, 90), ("upper_1d_75", A.clamp_upper_percentile, 75),
+                          ("lower_1d_30", A.clamp_lower_percentile, 30)]:
+        assert torch.equal(fn(g["e1"], arg), g[name]), name
+    for name, fn, arg in [("peaks_3_50", A.clamp_peaks_percentile, 50), ("upper_3_20", A.clamp_upper_percentile, 20),
+                          ("lower_3_95", A.clamp_lower_percentile, 95)]:
+        assert torch.equal(fn(g["e3"], arg), g[name]), name
+    y, sr = g["y"].numpy(), int(g["sr"])
+    assert np.array_equal(A.butter_pass(y, sr, 200, "low"), g["low_200_12"].numpy())
+    assert np.array_equal(A.butter_pass(y, sr, 100, "low", 24), g["low_100_24"].numpy())
+    assert np.array_equal(A.butter_pass(y, sr, 3000, "high"), g["high_3000_12"].numpy())
+    assert np.array_equal(A.butter_pass(y, sr, [200, 3000], "band"), g["band_200_3000_12"].numpy())
+    # biquads: unit DC gain of the low pass, zero DC gain of the high pass, -3 dB at the corner (Q = 0.707)
+    n = 1 << 15
+    t = torch.arange(n) / 16000.0
+    assert abs(float(A.low_pass(torch.full((n,), 0.5), 16000, 300)[-1]) - 0.5) < 1e-6
+    assert abs(float(A.high_pass(torch.full((n,), 0.5), 16000, 300)[-1])) < 1e-6
+    tone = 0.5 * torch.sin(2 * math.pi * 300 * t)
+    for f in (A.low_pass, A.high_pass):
+        amp = f(tone, 16000, 300)[n // 2:].abs().max()
+        assert abs(float(amp) / 0.5 - 10 ** (-3 / 20)) < 2e-3
+    x = torch.linspace(-1, 1, 101)
+    c = A.contrast_enhance(x, 75)
+    assert float(c[0]) == pytest.approx(-1, abs=1e-6) and abs(float(c[50])) < 1e-6 and float(c[-1]) == pytest.approx(1, abs=1e-6)
+    assert torch.allclose(A.contrast_enhance(x, 0), torch.sin(x * (math.pi / 2)))
 
 
 def test_resample(golden):
