@@ -277,70 +277,101 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   const float alpha = a.act == MAUA_ACT_LINEAR ? 1.f : a.alpha;
   const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f && !a.prelu;
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
+  // Per N tile the global operands are requested as groups (the WM noise values; the demodulation / bias / next-layer-style vectors
+  // of the tile's 16 channels), each group one round trip; loaded inside the activation's branches every load was waited for alone.
 #pragma unroll
-  for (int i = 0; i < WM; i++) {
-    const int m = (wm * WM + i) * 32 + r;
-    const int ty = m >> g.tw_log2, tx = m & (tw - 1);
-    const int gy = ty0 + ty, gx = tx0 + tx;
-    const bool inside = gy < a.H && gx < a.W;
+  for (int j = 0; j < WN; j++) {
+    // a 32-channel group never straddles an output parity (Co % 32 == 0): phase and channel base are wave-uniform
+    const int nvb = n0 + (wn * WN + j) * 32;
+    const int ph = g.phases == 1 ? 0 : (nvb >= a.Co) + (nvb >= 2 * a.Co) + (nvb >= 3 * a.Co);
+    const int cob = nvb - ph * a.Co;
+    const int pa = ph >> (a.up - 1), pb = ph & (a.up - 1);
+    float nzr[WM];
 #pragma unroll
-    for (int j = 0; j < WN; j++) {
-      // a 32-channel group never straddles an output parity (Co % 32 == 0): phase and channel base are wave-uniform
-      const int nvb = n0 + (wn * WN + j) * 32;
-      const int ph = g.phases == 1 ? 0 : (nvb >= a.Co) + (nvb >= 2 * a.Co) + (nvb >= 3 * a.Co);
-      const int cob = nvb - ph * a.Co;
-      const int pa = ph >> (a.up - 1), pb = ph & (a.up - 1);
-      float nz = 0.f;
-      if (nb && inside) nz = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb] * a.noise_strength;
+    for (int i = 0; i < WM; i++) nzr[i] = 0.f;
+    if (nb) {
 #pragma unroll
-      for (int qd = 0; qd < 4; qd++) {
-        const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive virtual channels (tile-local)
-        const int co = cob + 8 * qd + 4 * h;
-        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
-        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);
-        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        float v[4];
-        if (fast) {
+      for (int i = 0; i < WM; i++) {
+        const int m = (wm * WM + i) * 32 + r;
+        const int gy = ty0 + (m >> g.tw_log2), gx = tx0 + (m & (tw - 1));
+        if (gy < a.H && gx < a.W) nzr[i] = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb];
+      }
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
-            t = fmaxf(t, t * alpha);
-            v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+      for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength;
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < 4; q0 += 2) {   // two register groups (8 channels) per round trip
+      float4 dq[2], bq[2], sq[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        dq[q] = sq[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int co0 = cob + 8 * q0 + 4 * h;
+      if (a.d) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) dq[q] = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co0 + 8 * q);
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) bq[q] = *reinterpret_cast<const float4*>(a.bias + co0 + 8 * q);
+      }
+      if (a.out_scale) {  // the layer that reads these features wants them pre-multiplied by its styles
+#pragma unroll
+        for (int q = 0; q < 2; q++) sq[q] = *reinterpret_cast<const float4*>(a.out_scale + (long)b * a.Co + co0 + 8 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        const int m = (wm * WM + i) * 32 + r;
+        const int ty = m >> g.tw_log2, tx = m & (tw - 1);
+        const int gy = ty0 + ty, gx = tx0 + tx;
+        const bool inside = gy < a.H && gx < a.W;
+        const float nz = nzr[i];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int qd = q0 + q;
+          const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive virtual channels (tile-local)
+          const int co = co0 + 8 * q;
+          const float dd[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w}, bb[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+          float v[4];
+          if (fast) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
+              t = fmaxf(t, t * alpha);
+              v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+            }
+          } else if (a.prelu) {  // PReLU: per-channel slope on the negative side
+            const float4 pv = *reinterpret_cast<const float4*>(a.prelu + co);
+            const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k];
+              t = (t >= 0.f ? t : t * pp[k]) * a.gain;
+              if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+              v[k] = t;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
+              if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+              v[k] = t;
+            }
           }
-        } else if (a.prelu) {  // PReLU: per-channel slope on the negative side
-          const float4 pv = *reinterpret_cast<const float4*>(a.prelu + co);
-          const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+          if (a.out_scale) { v[0] *= sq[q].x; v[1] *= sq[q].y; v[2] *= sq[q].z; v[3] *= sq[q].w; }
+          if (a.res && inside) {  // residual connection (RRDB blocks): added after activation, gain and clamp
+            const T* rp = reinterpret_cast<const T*>(a.res) + (long)b * a.res_bstride +
+                          ((long)gy * a.W + gx) * a.res_pstride + co;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k];
-            t = (t >= 0.f ? t : t * pp[k]) * a.gain;
-            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-            v[k] = t;
+            for (int k = 0; k < 4; k++) v[k] += Elem<T>::load(rp + k);
           }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
-            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-            v[k] = t;
-          }
+          char* dst = epi + m * ES + nl * (int)sizeof(T);
+          if constexpr (sizeof(T) == 2)
+            *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          else
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        if (a.out_scale) {  // the layer that reads these features wants them pre-multiplied by its styles
-          const float4 sv4 = *reinterpret_cast<const float4*>(a.out_scale + (long)b * a.Co + co);
-          v[0] *= sv4.x; v[1] *= sv4.y; v[2] *= sv4.z; v[3] *= sv4.w;
-        }
-        if (a.res && inside) {  // residual connection (RRDB blocks): added after activation, gain and clamp
-          const T* rp = reinterpret_cast<const T*>(a.res) + (long)b * a.res_bstride +
-                        ((long)gy * a.W + gx) * a.res_pstride + co;
-#pragma unroll
-          for (int k = 0; k < 4; k++) v[k] += Elem<T>::load(rp + k);
-        }
-        char* dst = epi + m * ES + nl * (int)sizeof(T);
-        if constexpr (sizeof(T) == 2)
-          *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        else
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }

@@ -286,50 +286,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const float alpha = a.act == MAUA_ACT_LINEAR ? 1.f : a.alpha;
   const bool fast = (a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR) && alpha >= 0.f && alpha <= 1.f && a.gain > 0.f && !a.prelu;
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
+  // Global operands first, grouped: the WM noise values, then per N tile the demodulation / bias (/ PReLU slope) vectors of its 16
+  // channels - each group is ONE round trip.  (Loaded where they were used, inside the activation's branches, every load was waited
+  // for on its own: ~ 3 serial round trips for each of the WM x WN x 4 register groups of the tile.)
+  float nzr[WM];
 #pragma unroll
-  for (int i = 0; i < WM; i++) {
-    const int ty = wm * WM + i;
-    const int m = ty * 32 + r;
-    const int gy = ty0 + ty, gx = tx0 + r;
-    float nz = 0.f;
-    if (nb) nz = nb[(long)gy * a.W + gx] * a.noise_strength;
+  for (int i = 0; i < WM; i++) nzr[i] = 0.f;
+  if (nb) {
 #pragma unroll
-    for (int j = 0; j < WN; j++) {
+    for (int i = 0; i < WM; i++) nzr[i] = nb[(long)(ty0 + wm * WM + i) * a.W + tx0 + r];
 #pragma unroll
-      for (int qd = 0; qd < 4; qd++) {
-        const int nl = (wn * WN + j) * 32 + 8 * qd + 4 * h;  // first of 4 consecutive channels (tile-local)
-        const int co = n0 + nl;
-        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
-        if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);
-        const float dd[4] = {dv.x, dv.y, dv.z, dv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        float v[4];
-        if (fast) {
+    for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength;
+  }
+  constexpr int QG = KB == 64 ? 2 : 4;   // register groups per round trip (the 128-register variants take them in halves)
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
-            t = fmaxf(t, t * alpha);
-            v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+  for (int j = 0; j < WN; j++) {
+#pragma unroll
+    for (int q0 = 0; q0 < 4; q0 += QG) {
+      float4 dq[QG], bq[QG];
+#pragma unroll
+      for (int q = 0; q < QG; q++) {
+        dq[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+        bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int nl0 = (wn * WN + j) * 32 + 4 * h + 8 * q0;   // + 8 q: first of 4 consecutive channels (tile-local)
+      if (a.d) {
+#pragma unroll
+        for (int q = 0; q < QG; q++) dq[q] = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + n0 + nl0 + 8 * q);
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int q = 0; q < QG; q++) bq[q] = *reinterpret_cast<const float4*>(a.bias + n0 + nl0 + 8 * q);
+      }
+#pragma unroll
+      for (int i = 0; i < WM; i++) {
+        const int m = (wm * WM + i) * 32 + r;
+        const float nz = nzr[i];
+#pragma unroll
+        for (int q = 0; q < QG; q++) {
+          const int nl = nl0 + 8 * q, qd = q0 + q;
+          const float dd[4] = {dq[q].x, dq[q].y, dq[q].z, dq[q].w}, bb[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
+          float v[4];
+          if (fast) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = fmaf(acc[i][j][qd * 4 + k], dd[k] * a.gain, (nz + bb[k]) * a.gain);
+              t = fmaxf(t, t * alpha);
+              v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);
+            }
+          } else if (a.prelu) {  // PReLU: per-channel slope on the negative side
+            const float4 pv = *reinterpret_cast<const float4*>(a.prelu + n0 + nl);
+            const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k];
+              t = (t >= 0.f ? t : t * pp[k]) * a.gain;
+              if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+              v[k] = t;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
+              if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+              v[k] = t;
+            }
           }
-        } else if (a.prelu) {  // PReLU: per-channel slope on the negative side
-          const float4 pv = *reinterpret_cast<const float4*>(a.prelu + co);
-          const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k];
-            t = (t >= 0.f ? t : t * pp[k]) * a.gain;
-            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-            v[k] = t;
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float t = activate(acc[i][j][qd * 4 + k] * dd[k] + nz + bb[k], a.act, a.alpha) * a.gain;
-            if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-            v[k] = t;
-          }
+          *reinterpret_cast<uint2*>(epi + m * ES + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
-        *reinterpret_cast<uint2*>(epi + m * ES + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       }
     }
   }

@@ -221,6 +221,42 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
 #undef TD_B
 #undef TD_STEP
 
+  // ---- the epilogue's global operands are requested BEFORE the tile is written: per-channel vectors and the thread's noise values
+  // (one float2 per output row) are in flight across the two barriers and the first three FIR rows instead of being waited for row
+  // by row (every wait would also have drained the row's stores: 6 exposed round trips per thread, 1.88 of the kernel's 3.5 ms).
+  // Local t row / column 0 = global t row 2 ty0 / column 2 tx0; local output (yl, xl) = global (2 ty0 + yl, 2 tx0 + xl) reads local
+  // t rows yl-1 .. yl+2: yl in [2, 14), xl in [2, 62).  A thread owns a 2-column strip x one 16-byte channel piece and walks 6
+  // output rows: 30 strips x 4 pieces x 2 row halves.
+  const int fhalf = tid / 120, fw = tid - fhalf * 120;
+  const int strip = fw >> 2, pc = fw & 3;
+  const int xl = 2 + 2 * strip, yl0 = 2 + FROWS * fhalf;
+  const int X = 2 * tx0 + xl, Wo = 2 * a.W, Ho = 2 * a.H;
+  const int cho = cb * 32 + pc * 8;
+  const bool fir_on = tid < 120 * FG && X < Wo;
+  f32x2_t dv[4], bv[4], sv[4];
+  float2 nzv[FROWS];
+#pragma unroll
+  for (int k = 0; k < FROWS; k++) nzv[k] = make_float2(0.f, 0.f);
+  if (fir_on) {
+#pragma unroll
+    for (int e4 = 0; e4 < 8; e4 += 4) {
+      const float4 s4 = u.out_scale ? *reinterpret_cast<const float4*>(u.out_scale + (long)b * a.Co + cho + e4)
+                                    : make_float4(1.f, 1.f, 1.f, 1.f);
+      sv[e4 / 2] = f32x2_t{s4.x, s4.y}; sv[e4 / 2 + 1] = f32x2_t{s4.z, s4.w};
+      const float4 d4 = u.d ? *reinterpret_cast<const float4*>(u.d + (long)b * a.Co + cho + e4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 b4 = u.bias ? *reinterpret_cast<const float4*>(u.bias + cho + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[e4 / 2] = f32x2_t{d4.x, d4.y}; dv[e4 / 2 + 1] = f32x2_t{d4.z, d4.w};
+      bv[e4 / 2] = f32x2_t{b4.x, b4.y}; bv[e4 / 2 + 1] = f32x2_t{b4.z, b4.w};
+    }
+    if (u.noise) {
+      const float* nb = u.noise + (long)b * u.noise_bstride;
+#pragma unroll
+      for (int k = 0; k < FROWS; k++) {
+        const int Y = 2 * ty0 + yl0 + k;
+        if (Y < Ho) nzv[k] = *reinterpret_cast<const float2*>(nb + (long)Y * Wo + X);
+      }
+    }
+  }
   // ---- t tile -> LDS [position][class * 32 + ch] as bf16 (the rounding of the two-launch path's HBM tensor)
   __syncthreads();
   char* tt = smem;
@@ -235,32 +271,13 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
             make_uint2(pack2bf(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), pack2bf(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
   }
   __syncthreads();
-  // ---- FIR + epilogue (upfir_epilogue_kernel's arithmetic).  Local t row / column 0 = global t row 2 ty0 / column 2 tx0;
-  // local output (yl, xl) = global (2 ty0 + yl, 2 tx0 + xl) reads local t rows yl-1 .. yl+2: yl in [2, 14), xl in [2, 62).
-  // A thread owns a 2-column strip x one 16-byte channel piece and walks 6 output rows: 30 strips x 4 pieces x 2 row halves.
-  if (tid < 120 * FG) {
-    const int half = tid / 120, w = tid - half * 120;
-    const int strip = w >> 2, pc = w & 3;
-    const int xl = 2 + 2 * strip, yl0 = 2 + FROWS * half;
-    const int X = 2 * tx0 + xl, Wo = 2 * a.W, Ho = 2 * a.H;
-    const int cho = cb * 32 + pc * 8;
-    if (X < Wo) {
-      f32x2_t dv[4], bv[4], sv[4];
-#pragma unroll
-      for (int e4 = 0; e4 < 8; e4 += 4) {
-        const float4 s4 = u.out_scale ? *reinterpret_cast<const float4*>(u.out_scale + (long)b * a.Co + cho + e4)
-                                      : make_float4(1.f, 1.f, 1.f, 1.f);
-        sv[e4 / 2] = f32x2_t{s4.x, s4.y}; sv[e4 / 2 + 1] = f32x2_t{s4.z, s4.w};
-        const float4 d4 = u.d ? *reinterpret_cast<const float4*>(u.d + (long)b * a.Co + cho + e4) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 b4 = u.bias ? *reinterpret_cast<const float4*>(u.bias + cho + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dv[e4 / 2] = f32x2_t{d4.x, d4.y}; dv[e4 / 2 + 1] = f32x2_t{d4.z, d4.w};
-        bv[e4 / 2] = f32x2_t{b4.x, b4.y}; bv[e4 / 2 + 1] = f32x2_t{b4.z, b4.w};
-      }
+  // ---- FIR + epilogue (upfir_epilogue_kernel's arithmetic)
+  {
+    if (fir_on) {
 #pragma unroll
       for (int e = 0; e < 4; e++) { dv[e] *= 0.0625f * u.gain; bv[e] *= u.gain; }
       const float nzs = u.noise_strength * u.gain;
       const float cl = u.clamp >= 0.f ? u.clamp : 3.0e38f;
-      const float* nb = u.noise ? u.noise + (long)b * u.noise_bstride : nullptr;
       char* yb = reinterpret_cast<char*>(u.y) + (long)b * Ho * Wo * a.Co * 2;
       const int cho2 = pc * 16;
       f32x2_t hr[4][2][4];
@@ -272,12 +289,7 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
         fir_hrow(tt, yl0 + k + 2, xl, cho2, hr[(k + 3) & 3]);
         const int Y = 2 * ty0 + yl0 + k;
         if (Y < Ho) {
-          float nz[2] = {0.f, 0.f};
-          if (nb) {
-            const float2 n2 = *reinterpret_cast<const float2*>(nb + (long)Y * Wo + X);
-            nz[0] = n2.x * nzs;
-            nz[1] = n2.y * nzs;
-          }
+          const float nz[2] = {nzv[k].x * nzs, nzv[k].y * nzs};
 #pragma unroll
           for (int j = 0; j < 2; j++) {
             f32x2_t o[4];
