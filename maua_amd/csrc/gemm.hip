@@ -203,6 +203,21 @@ __global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
   // ---- accumulators -> LDS tile [m][n] (T) -> 16-byte pieces with bias / residual
   __syncthreads();
   char* epi = smem;
+  // the bias pieces of the wave's 8 column groups in one round trip (each used to be loaded, and waited for, inside its branch)
+  float4 bq[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) bq[j][qd] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias) {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        const int n = wn * 64 + j * 32 + 8 * qd + 4 * h;
+        if (n0 + n < g.N) bq[j][qd] = *reinterpret_cast<const float4*>(g.bias + n0 + n);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int m = wm * 64 + i * 32 + r;
@@ -211,11 +226,9 @@ __global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {
         const int n = wn * 64 + j * 32 + 8 * qd + 4 * h;
-        float v[4] = {acc[i][j][qd * 4], acc[i][j][qd * 4 + 1], acc[i][j][qd * 4 + 2], acc[i][j][qd * 4 + 3]};
-        if (g.bias && n0 + n < g.N) {
-          const float4 bv = *reinterpret_cast<const float4*>(g.bias + n0 + n);
-          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-        }
+        const float4 bv = bq[j][qd];
+        const float v[4] = {acc[i][j][qd * 4] + bv.x, acc[i][j][qd * 4 + 1] + bv.y, acc[i][j][qd * 4 + 2] + bv.z,
+                            acc[i][j][qd * 4 + 3] + bv.w};
         if constexpr (sizeof(T) == 2)
           *reinterpret_cast<uint2*>(epi + m * ES + n * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         else
@@ -223,14 +236,29 @@ __global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
       }
   }
   __syncthreads();
-  for (int p = tid; p < WBM * PPP; p += 256) {
+  static_assert((WBM * PPP) % 256 == 0, "whole copy-out steps");
+  constexpr int NIT = WBM * PPP / 256;
+  u32x4 rvs[NIT];   // residual pieces of all copy-out steps: one round trip
+  if (g.res) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int p = tid + it * 256, m = p / PPP, pc = p - m * PPP;
+      const long gm = m0 + m;
+      const int gn = n0 + pc * EPC;
+      rvs[it] = u32x4{0u, 0u, 0u, 0u};
+      if (gm < g.M && gn < g.N) rvs[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.res) + gm * g.ldr + gn);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int p = tid + it * 256;
     const int m = p / PPP, pc = p - m * PPP;
     const long gm = m0 + m;
     const int gn = n0 + pc * EPC;
     if (gm >= g.M || gn >= g.N) continue;
     u32x4 v = *reinterpret_cast<const u32x4*>(epi + m * ES + pc * 16);
     if (g.res) {
-      const u32x4 rv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.res) + gm * g.ldr + gn);
+      const u32x4 rv = rvs[it];
       if constexpr (sizeof(T) == 2) {
         // (the bias-added value was rounded to bf16 in the tile; the residual is added to that, like the conv kernels do)
 #pragma unroll

@@ -443,7 +443,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   float ps_s[8], ps_q[8];   // (PSUM) this thread's piece column: sums / sums of squares of what it stores
 #pragma unroll
   for (int k = 0; k < 8; k++) { ps_s[k] = 0.f; ps_q[k] = 0.f; }
-  for (int p = tid; p < BM * PPP; p += NT) {
+  // the residual pieces of all of this thread's copy-out steps are requested up front (one round trip instead of one per step)
+  static_assert((BM * PPP) % NT == 0, "whole copy-out steps");
+  constexpr int NIT = BM * PPP / NT;
+  u32x4 rvs[NIT];
+  if (rb) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int p = tid + it * NT, m = p / PPP, pc = p - m * PPP;
+      const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
+      rvs[it] = *reinterpret_cast<const u32x4*>(rb + (pix * a.res_pstride + n0 + pc * 8) * 2);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int p = tid + it * NT;
     const int m = p / PPP, pc = p - m * PPP;
     const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
     u32x4 v = *reinterpret_cast<const u32x4*>(epi + m * ES + pc * 16);
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * osc[2 * k], bf2f((bf16_t)(v[k] >> 16)) * osc[2 * k + 1]);
     }
     if (rb) {   // residual added to the activated output (RRDB: out = conv5(..) * 0.2 + x); both operands bf16
-      const u32x4 rv = *reinterpret_cast<const u32x4*>(rb + (pix * a.res_pstride + n0 + pc * 8) * 2);
+      const u32x4 rv = rvs[it];
 #pragma unroll
       for (int k = 0; k < 4; k++)
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
