@@ -4,7 +4,7 @@
 set -e
 src=$1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-gpu-rdc -Iinclude --cuda-device-only -S "$src" -o /tmp/_audit.s 2>/dev/null
-awk '/^_ZN4maua[^ ]*:/ {name=$1}
+awk '/^_Z[A-Za-z0-9_]*:/ {name=$1}
      /global_load_(dword|ushort|ubyte|short)/ && !/lds/ {loads[name]++; pend=3; next}
      pend > 0 { if ($0 ~ /s_waitcnt vmcnt\(0\)/) {hot[name]++; pend=0} else pend-- }
      END {for (k in loads) printf "%5d loads %5d waited-at-once  %s\n", loads[k], hot[k], substr(k, 1, 110)}' /tmp/_audit.s | sort -k3 -n -r
