@@ -55,6 +55,11 @@ int maua_ctx_sync(maua_ctx* ctx);
  * "dma_conv" (default 1): maua_modconv2d runs eligible shapes (bf16, 3x3, up 1, Ci % 64 == 0, Co % 128 == 0,
  * H % 8 == 0, W % 32 == 0) on the LDS-direct-load kernel of the synthesis hot path. */
 int maua_ctx_set_option(maua_ctx* ctx, const char* key, int value);
+/* Measurement aid (bench.py `sustained_sclk_mhz`): enqueue a one-thread kernel on the ctx stream that writes two device counters
+ * to stamp_dev[0..1] (device memory, 2 x u64): [0] the shader-cycle counter (ticks with the power-managed shader clock), [1] the
+ * constant-rate 100 MHz counter.  Two stamps around a region: (d[0] / d[1]) x 100 MHz = the average shader clock inside it.
+ * No reference counterpart (the reference publishes no throughput measurement). */
+int maua_ctx_clock_stamp(maua_ctx* ctx, unsigned long long* stamp_dev);
 void maua_ctx_destroy(maua_ctx* ctx);
 
 /* ---- B1: operator layer (NCHW contiguous, like the reference tensors) --------------------------- */

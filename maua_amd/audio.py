@@ -593,10 +593,12 @@ def _dft_matrices(n_fft, window):
     """Real DFT / inverse real DFT of length n_fft as GEMM operands with the window folded in (host f64 -> f32):
     fwd [2 nb, n_fft]: row 2k = w cos, row 2k+1 = -w sin;  inv [n_fft, 2 nb]: x[n] = w[n] / N sum_k c_k (Re cos - Im sin),
     c = 1 at DC / Nyquist and 2 elsewhere, their imaginary parts ignored (what a C2R transform does)."""
-    key = (n_fft, str(window.device), float(window.double().sum()))
+    # keyed on the window's CONTENTS: two windows of one length and equal sum (an asymmetric window and its flip) must not share
+    # matrices with the first one folded in
+    w = window.detach().cpu().double()
+    key = (n_fft, str(window.device), hash(w.numpy().tobytes()))
     if key not in _DFT_CACHE:
         nb = n_fft // 2 + 1
-        w = window.detach().cpu().double()
         n = torch.arange(n_fft, dtype=torch.float64)
         k = torch.arange(nb, dtype=torch.float64)
         ang = 2 * math.pi * ((k[:, None] * n[None, :]) % n_fft) / n_fft

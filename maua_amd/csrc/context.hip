@@ -21,6 +21,15 @@ int scratch_reserve(maua_ctx* ctx, size_t bytes) {
 }
 }  // namespace maua
 
+namespace {
+// stamp[0] = shader-cycle counter (s_memtime: ticks with the shader clock, so it follows the power-managed frequency),
+// stamp[1] = constant-rate counter (s_memrealtime, 100 MHz)
+__global__ void clock_stamp_kernel(unsigned long long* stamp) {
+  stamp[0] = __builtin_amdgcn_s_memtime();
+  stamp[1] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+
 extern "C" {
 
 const char* maua_version(void) { return "maua_hip 0.1 (gfx950)"; }
@@ -57,6 +66,13 @@ int maua_ctx_set_option(maua_ctx* ctx, const char* key, int value) {
 int maua_ctx_sync(maua_ctx* ctx) {
   MAUA_REQUIRE(ctx != nullptr, "maua_ctx_sync: ctx is NULL");
   MAUA_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  return MAUA_OK;
+}
+
+int maua_ctx_clock_stamp(maua_ctx* ctx, unsigned long long* stamp_dev) {
+  MAUA_REQUIRE(ctx && stamp_dev, "maua_ctx_clock_stamp: NULL argument");
+  hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, ctx->stream, stamp_dev);
+  MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 

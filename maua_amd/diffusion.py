@@ -333,6 +333,10 @@ class SpacedDiffusion:
             grad = L.dev_tensor(cond_fn(x, mt), torch.float32)
         if eta != 0.0 and noise is None:
             noise = torch.randn_like(x)
+        if noise is not None:   # a caller's tensor: onto the device, f32, contiguous, and of the sample's shape (the kernel takes a raw pointer)
+            noise = L.dev_tensor(noise, torch.float32)
+            if tuple(noise.shape) != tuple(x.shape):
+                raise ValueError(f"ddim_sample: noise shape {tuple(noise.shape)} != sample shape {tuple(x.shape)}")
         cf = L.dev_tensor(self.step_coefficients(t, eta), torch.float32)
         sample, pred = torch.empty_like(x), torch.empty_like(x)
         B, Cc = x.shape[0], x.shape[1]

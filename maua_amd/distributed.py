@@ -35,9 +35,23 @@ def maybe_init_process_group(backend=None):
 _comm = {}
 
 
+def _want_cabi(transport=None):
+    """Which transport carries device frames between ranks: "cabi" (default: the library's own RCCL communicator,
+    ``maua_gather_frames*``) or "torch" (torch.distributed point-to-point calls on torch's RCCL group) - argument, else the
+    MAUA_GATHER environment variable (``bench.py --gather torch`` sets it)."""
+    t = (transport or os.environ.get("MAUA_GATHER", "cabi")).lower()
+    if t not in ("cabi", "torch"):
+        raise ValueError(f"gather transport must be 'cabi' or 'torch', not {t!r}")
+    return t == "cabi"
+
+
 def _cabi_comm(rank, world, device):
-    """RCCL communicator of the C-ABI (maua_comm_*), one per process; the 128-byte id travels by a torch.distributed
-    broadcast (any initialised backend)."""
+    """RCCL communicator of the C-ABI (maua_comm_*), one per process - COLLECTIVE, and it returns the same answer on every
+    rank: the communicator, or ``(None, reason)`` everywhere if ANY rank could not build its part (then the callers take
+    torch.distributed's point-to-point path together).  Every rank executes the same two collectives in the same order
+    whatever fails where: (1) a broadcast of [status byte | 128-byte id] from rank 0 - rank 0 broadcasts status 0 if
+    ``maua_comm_unique_id`` itself failed (RCCL not loadable, ``ncclGetUniqueId`` error) instead of skipping the broadcast -,
+    (2) a MIN all-reduce of "my maua_comm_init succeeded"."""
     import ctypes as C
     from . import _lib as L
     key = (rank, world, torch.device(device).index)
@@ -45,39 +59,68 @@ def _cabi_comm(rank, world, device):
         return _comm[key]
     lib = L.lib()
     idbuf = (C.c_char * 128)()
+    status, err = 1, None
     if rank == 0:
-        L.check(lib.maua_comm_unique_id(idbuf))
-    t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).clone()
+        try:
+            L.check(lib.maua_comm_unique_id(idbuf))
+        except Exception as e:   # noqa: BLE001 - reported below, after every rank has left the broadcast
+            status, err = 0, e
+    t = torch.tensor([status] + list(bytes(idbuf.raw)), dtype=torch.uint8)
+    cdev = device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
     if world > 1:
-        dev = device if dist.get_backend() == "nccl" else "cpu"
-        t = t.to(dev)
+        t = t.to(cdev)
         dist.broadcast(t, src=0)
         t = t.cpu()
-    idbuf.raw = bytes(t.tolist())
-    comm = C.c_void_p()
-    L.check(lib.maua_comm_init(L.ctx(device), idbuf, rank, world, C.byref(comm)))
-    _comm[key] = comm
-    return comm
+    status = int(t[0])
+    comm = None
+    if status:
+        idbuf.raw = bytes(t[1:].tolist())
+        c = C.c_void_p()
+        try:
+            L.check(lib.maua_comm_init(L.ctx(device), idbuf, rank, world, C.byref(c)))
+            comm = c
+        except Exception as e:   # noqa: BLE001
+            err = e
+    elif err is None:
+        err = RuntimeError("rank 0 could not create the RCCL unique id")
+    if world > 1:
+        flag = torch.tensor([0 if comm is None else 1], device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                lib.maua_comm_destroy(comm)
+                comm = None
+            if err is None:
+                err = RuntimeError("a peer rank could not build its RCCL communicator")
+    if comm is None:
+        return None, err          # (not cached: a later call may try again, collectively)
+    _comm[key] = (comm, None)
+    return _comm[key]
 
 
 def gather_frames_cabi(local, n_frames, rank=None, world=None, dst=0):
-    """The same gather through the library's own entry point (``maua_gather_frames``: grouped RCCL send / recv on the
-    render stream, exact shard sizes, no padding); ``local`` is this rank's packed u8 shard on the device."""
+    """The gather through the library's own entry point (``maua_gather_frames``: grouped RCCL send / recv on the render
+    stream, exact shard sizes, no padding); ``local`` is this rank's packed u8 shard on the device.  Collective; if any
+    rank has no communicator every rank falls back to ``_gather_p2p`` (same result, torch.distributed transport)."""
     import ctypes as C
+    import warnings
     from . import _lib as L
     if rank is None or world is None:
         rank, world = world_info()
     sizes = [frame_range(n_frames, r, world) for r in range(world)]
-    per = local[0].numel() * local.element_size() if local.shape[0] else 0
-    if world > 1 and per == 0:   # an empty shard does not know the frame size: ask the ranks that have frames
-        t = torch.tensor([per], dtype=torch.int64, device=local.device if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per = int(t.item())
-    nbytes = (C.c_long * world)(*[(hi - lo) * per for lo, hi in sizes])
+    # bytes per frame from the trailing dimensions: known on every rank, also on one whose shard is empty (n_frames < world) -
+    # no rank-dependent collective here
+    per = local.element_size()
+    for d in local.shape[1:]:
+        per *= int(d)
     local = local.contiguous()
     assert local.shape[0] == sizes[rank][1] - sizes[rank][0], "shard does not match frame_range"
+    comm, err = _cabi_comm(rank, world, local.device)
+    if comm is None:
+        warnings.warn(f"gather_frames: the library's RCCL communicator is unavailable ({err}); using torch.distributed send / recv")
+        return _gather_p2p(local, n_frames, rank, world, dst)
+    nbytes = (C.c_long * world)(*[(hi - lo) * per for lo, hi in sizes])
     out = torch.empty((n_frames, *local.shape[1:]), dtype=local.dtype, device=local.device) if rank == dst else None
-    comm = _cabi_comm(rank, world, local.device)
     L.check(L.lib().maua_gather_frames(comm, L.ptr(local.view(torch.uint8).reshape(-1)) if local.numel() else None, nbytes,
                                        L.ptr(out.view(torch.uint8).reshape(-1)) if out is not None else None, dst))
     return out
@@ -107,16 +150,17 @@ def _gather_p2p(local, n_frames, rank, world, dst):
     return out
 
 
-def gather_frames(local, n_frames, rank=None, world=None, dst=0):
+def gather_frames(local, n_frames, rank=None, world=None, dst=0, transport=None):
     """Gather per-rank frame shards [n_r, ...] (contiguous ranges from ``frame_range``) into [n_frames, ...] on ``dst``;
     other ranks get None.  Exact shard sizes, one transfer per rank, received in place (no padding, no concatenation):
-    on the device through the library's own ``maua_gather_frames`` (grouped RCCL send / recv over xGMI), on the CPU
-    (gloo: the tests) through torch.distributed point-to-point calls."""
+    on the device through the library's own ``maua_gather_frames`` (grouped RCCL send / recv over xGMI; ``transport="torch"``
+    or MAUA_GATHER=torch: torch.distributed's point-to-point calls instead, also the automatic fallback when the library's
+    communicator cannot be built on some rank), on the CPU (gloo: the tests) through torch.distributed point-to-point calls."""
     if rank is None or world is None:
         rank, world = world_info()
     if world == 1:
         return local
-    if local.is_cuda:
+    if local.is_cuda and _want_cabi(transport):
         return gather_frames_cabi(local, n_frames, rank, world, dst)
     return _gather_p2p(local, n_frames, rank, world, dst)
 
@@ -137,7 +181,8 @@ class StreamingGather:
     send theirs - rank 0 owns the longest range (``frame_range``), so it has a chunk in every round.  CPU tensors
     (gloo) follow the same protocol with torch.distributed isend / irecv (the tests)."""
 
-    def __init__(self, n_frames, frame_shape, chunk, dtype=torch.uint8, device=None, rank=None, world=None, dst=0):
+    def __init__(self, n_frames, frame_shape, chunk, dtype=torch.uint8, device=None, rank=None, world=None, dst=0,
+                 transport=None):
         if rank is None or world is None:
             rank, world = world_info()
         if dst != 0:
@@ -163,22 +208,18 @@ class StreamingGather:
             import ctypes as C
             from . import _lib as L
             self._side = torch.cuda.Stream(device=self.device)
-            self._comm, err = None, None
-            try:
-                self._comm = _cabi_comm(rank, world, self.device)
-            except Exception as e:   # (the library's own communicator could not be built on this rank)
-                err = e
-            # every rank takes the same transport: the library's RCCL rounds, or - if any rank has no communicator -
-            # torch.distributed's own point-to-point calls on the same side stream
-            flag = torch.tensor([0 if self._comm is None else 1], device=self.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if dist.get_backend() != "nccl":
-                    raise err if err is not None else RuntimeError("a peer rank could not build its RCCL communicator")
-                import warnings
-                warnings.warn(f"StreamingGather: maua_comm_init failed on a rank ({err}); using torch.distributed isend / irecv")
-                self._comm = None
-            else:
+            # every rank takes the same transport: the library's RCCL rounds, or - if any rank has no communicator (or the
+            # caller asked for it) - torch.distributed's own point-to-point calls on the same side stream.  _cabi_comm is
+            # collective and answers identically everywhere, so no rank can be left alone in a collective.
+            self._comm, err = (None, None)
+            if _want_cabi(transport):
+                self._comm, err = _cabi_comm(rank, world, self.device)
+                if self._comm is None:
+                    if dist.get_backend() != "nccl":
+                        raise err
+                    import warnings
+                    warnings.warn(f"StreamingGather: the library's RCCL communicator is unavailable ({err}); using torch.distributed isend / irecv")
+            if self._comm is not None:
                 # this communicator's transfers run on the side stream from here on (finish() hands it back)
                 L.check(L.lib().maua_comm_set_stream(self._comm, C.c_void_p(self._side.cuda_stream), 0))
         self.transport = ("none (one rank)" if world == 1 else "torch.distributed isend / irecv" if self._side is None or

@@ -100,3 +100,70 @@ def test_streamed_and_one_shot_gather(world, T, chunk):
         p.join(120)
         assert p.exitcode == 0
     assert all(res[r] for r in range(world)), res
+
+
+class _FakeLib:
+    """Stand-in for the C-ABI library's communicator entry points: fails where told to (no GPU / RCCL needed)."""
+
+    def __init__(self, fail_id, fail_init):
+        self.fail_id, self.fail_init, self.destroyed = fail_id, fail_init, 0
+
+    def maua_comm_unique_id(self, buf):
+        if self.fail_id:
+            return 1
+        buf.raw = bytes(range(128))
+        return 0
+
+    def maua_comm_init(self, ctx, idbuf, rank, world, out):
+        assert bytes(idbuf.raw) == bytes(range(128))   # every rank received rank 0's id
+        return 1 if self.fail_init else 0
+
+    def maua_comm_destroy(self, comm):
+        self.destroyed += 1
+        return 0
+
+
+def _worker_agree(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import maua_amd._lib as L
+    import maua_amd.distributed as D
+    assert D.maybe_init_process_group("gloo") == (rank, world)
+    fake = _FakeLib(fail_id=(case == "id" and rank == 0), fail_init=(case == "init" and rank == 1))
+    L.lib = lambda: fake
+    L.ctx = lambda device=None: None
+
+    def check(rc):
+        if rc:
+            raise RuntimeError("injected failure")
+    L.check = check
+    comm, err = D._cabi_comm(rank, world, "cpu")
+    # the collectives that follow must line up on every rank (a rank stuck in _cabi_comm would hang this all_reduce)
+    t = torch.tensor([1 if comm is None else 0])
+    dist.all_reduce(t)
+    q.put((rank, comm is None, err is not None, int(t.item()), fake.destroyed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ok", "id", "init"])
+def test_rccl_communicator_agreement_never_splits_the_ranks(case):
+    """rank 0 failing before the id broadcast (RCCL not loadable) or one rank failing in maua_comm_init must end
+    with EVERY rank holding no communicator (and falling back together), never with ranks waiting in different collectives."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_agree, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    none = [r[1] for r in res]
+    assert none == [case != "ok"] * world, res
+    assert all(r[3] == (world if case != "ok" else 0) for r in res)
+    if case != "ok":
+        assert all(r[2] for r in res)                     # every rank can say why
+    if case == "init":
+        assert [r[4] for r in res] == [1, 0, 1], res       # the ranks that had built theirs released them

@@ -107,7 +107,7 @@ def test_communicator_runs_on_its_own_stream():
     from maua_amd.distributed import _cabi_comm
     x = torch.randint(0, 255, (4, 16, 16, 3), dtype=torch.uint8, device="cuda")
     out = torch.zeros_like(x)
-    comm = _cabi_comm(0, 1, x.device)
+    comm, _ = _cabi_comm(0, 1, x.device)
     side = torch.cuda.Stream()
     L.check(L.lib().maua_comm_set_stream(comm, C.c_void_p(side.cuda_stream), 0))
     nbytes = (C.c_long * 1)(x.numel())
