@@ -435,6 +435,23 @@ int maua_plms_update(maua_ctx* ctx, const float* x, const float* const* eps_list
 int maua_axpby_rows(maua_ctx* ctx, const float* x, const float* y, const float* ab, int B, long row, float* out);
 /* 1 when the last maua_ddim_sample_loop(use_graph = 1) replayed a captured hipGraph, 0 when it ran launch by launch */
 int maua_unet_graph_active(maua_unet* net, int* active);
+
+/* ---- secondary diffusion model: the network behind the reference's DEFAULT guidance speed ("fast")
+ * Replaces maua/diffusion/processors/guided.py:68-143 (SecondaryDiffusionImageNet2.forward -> DiffusionOutput(v, pred, eps)) and the
+ * torch.autograd.grad(img, x, img_grad) of GradientGuidedConditioning.forward (:236-272), which differentiates through it: the library
+ * has no autograd, so the vector-Jacobian product is evaluated on the transposed network (csrc/secondary.hip).
+ * Convolutions are numbered 0..23 in execution order (maua_amd/diffusion.py maps the reference's state-dict keys).
+ * forward: x [B][3][H][W] f32, t [B] f32 (the cosine-schedule time in [0, 1]); H, W multiples of 32; any of v / pred / eps may be NULL.
+ * vjp: g_v = d loss / d v  ->  g_x = (d v / d x)^T g_v, using the activations of the LAST forward (same B, H, W).  Device pointers. */
+typedef struct maua_secondary maua_secondary;
+int maua_secondary_create(maua_ctx* ctx, int dtype, maua_secondary** out);
+void maua_secondary_destroy(maua_secondary* net);
+int maua_secondary_conv_shape(int index, int* ci, int* co);
+/* what: 0 = weight [Co][Ci][3][3] (host), 1 = bias [Co], 2 = timestep_embed.weight [8] (index ignored) */
+int maua_secondary_load(maua_secondary* net, int index, int what, const float* host_data, size_t count);
+int maua_secondary_forward(maua_secondary* net, const float* x, const float* t, int B, int H, int W, float* v_out, float* pred_out,
+                           float* eps_out);
+int maua_secondary_vjp(maua_secondary* net, const float* g_v, int B, int H, int W, float* g_x);
 /* operator-level forms of the UNet's building blocks, NHWC tensors in `dtype` (guided_diffusion/unet.py, nn.py):
  * QKVAttentionLegacy.forward - qkv [B][T][3 * heads * head_ch] with channel = head * 3 ch + {q | k | v} * ch + c (what
  * `qkv.reshape(bs * n_heads, ch * 3, length).split(ch, dim=1)` sees) -> out [B][T][heads * head_ch]; head_ch 32 or 64 */

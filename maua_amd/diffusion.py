@@ -10,12 +10,17 @@ Drop-in surface (same names, arguments and defaults):
 The network runs behind the C ABI (``maua_unet_*``, csrc/unet.hip); the sampler's arithmetic is ``maua_ddim_step`` /
 ``maua_axpby_rows``; schedules are float64 numpy on the host exactly like gaussian_diffusion.py builds them.
 
-What is NOT here, and why: CLIP / LPIPS prompts (un-vendored models, no network for weights) - ``grad_modules`` are
-caller-supplied objects with ``scale``, ``set_targets(prompts)`` and ``__call__(img, t) -> d loss / d img``; the
-conditioning speeds "fast" / "regular" differentiate THROUGH a network (secondary model / the UNet) with autograd, which
-an inference library does not have - ``speed="hyper"`` (guided.py:248-249: the x0 estimate from the known noise, whose
-Jacobian is 1 / alpha) is implemented exactly.  All three samplers of guided.py:302-311 exist ("ddim": configs[3]; "p";
-"plms": the fork's sampler restated from its published algorithm).
+Conditioning speeds (guided.py:212-274): "fast" - the reference's DEFAULT (:287) - differentiates through the in-tree secondary
+model (``SecondaryDiffusionImageNet2``, :68-143): forward and vector-Jacobian product run behind ``maua_secondary_*``
+(csrc/secondary.hip evaluates the transposed network by hand; pinned by tests/golden/g28_secondary.npz, which the reference's own
+classes generated); "hyper" (:248-249: the x0 estimate from the known noise, Jacobian 1 / alpha) is exact; "regular"
+back-propagates through the 553 M-parameter UNet itself and is refused.  All three samplers of guided.py:302-311 exist ("ddim":
+configs[3]; "p"; "plms": the fork's sampler restated from its published algorithm).
+
+What is NOT here, and why: the reference's text prompts go through CLIP / LPIPS perceptors (maua/grad.py:48-199: un-vendored
+models, no network for weights) - **parity of text-prompt guidance is unpinnable here**.  ``grad_modules`` are caller-supplied
+objects with the contract of maua/grad.py:15-25 (``scale``, ``set_targets(prompts)``, ``__call__(img, t) -> d loss / d img`` on the
+device); ``MSEGuide`` (image targets) is the one shipped, and BASELINE configs[3] is measured with it.
 """
 import ctypes as C
 import math
@@ -510,21 +515,150 @@ def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diff
     elif not allow_random_init:
         raise FileNotFoundError(f"{path} not found (the reference downloads it; this box has no network): place the file "
                                 "there or pass allow_random_init=True")
-    if use_secondary:
-        raise NotImplementedError("the secondary model serves the autograd-based 'fast' conditioning (see the module "
-                                  "docstring); use speed='hyper'")
-    return model, diffusion, None
+    secondary = None
+    if use_secondary:   # guided.py:198-205
+        spath = "modelzoo/secondary_model_imagenet_2.pth"
+        secondary = SecondaryDiffusionImageNet2(dtype=dtype, generator=generator)
+        if os.path.exists(spath):
+            secondary.load_state_dict(torch.load(spath, map_location="cpu"))
+        elif not allow_random_init:
+            raise FileNotFoundError(f"{spath} not found (the reference downloads it; this box has no network): place the file "
+                                    "there or pass allow_random_init=True")
+    return model, diffusion, secondary
+
+
+def secondary_conv_keys():
+    """State-dict key prefixes of SecondaryDiffusionImageNet2's 24 convolutions in execution order (what torch names the nested
+    Sequential / SkipBlock modules of guided.py:77-134), index = the C ABI's convolution number."""
+    keys = ["net.0.0", "net.1.0"]
+    pfx = "net.2.main"
+    for _ in range(4):
+        keys += [pfx + ".1.0", pfx + ".2.0"]
+        pfx += ".3.main"
+    keys += [pfx + f".{i}.0" for i in (1, 2, 3, 4)]
+    for _ in range(4):
+        pfx = pfx[:-len(".3.main")]
+        keys += [pfx + ".4.0", pfx + ".5.0"]
+    return keys + ["net.3.0", "net.4"]
+
+
+class DiffusionOutput:
+    """guided.py:33-37"""
+
+    def __init__(self, v, pred, eps):
+        self.v, self.pred, self.eps = v, pred, eps
+
+
+class SecondaryDiffusionImageNet2(torch.nn.Module):
+    """guided.py:68-143 on the device: ``forward(input, t) -> DiffusionOutput(v, pred, eps)`` and - what the "fast" conditioning
+    needs instead of autograd - ``vjp(g_v) -> (d v / d input)^T g_v`` for the input of the LAST forward.  State-dict keys are the
+    reference's (``timestep_embed.weight``, ``net.<...>.weight / .bias``), so its checkpoint loads unchanged.  ``dtype``:
+    torch.bfloat16 (default) or torch.float32 (exact-f32 MFMA mode; the reference keeps this model in fp32)."""
+
+    def __init__(self, dtype=torch.bfloat16, generator=None):
+        super().__init__()
+        self.dtype = dtype
+        self._keys = secondary_conv_keys()
+        g = generator if generator is not None else torch.Generator().manual_seed(0)
+        ci, co = C.c_int(), C.c_int()
+        self._params = {"timestep_embed.weight": torch.randn(8, 1, generator=g)}
+        for i, k in enumerate(self._keys):   # torch's Conv2d default scale (kaiming-uniform bound 1 / sqrt(fan_in)) as a normal
+            L.check(L.lib().maua_secondary_conv_shape(i, C.byref(ci), C.byref(co)))
+            self._params[k + ".weight"] = torch.randn(co.value, ci.value, 3, 3, generator=g) / math.sqrt(3.0 * 9 * ci.value)
+            self._params[k + ".bias"] = torch.randn(co.value, generator=g) / math.sqrt(3.0 * 9 * ci.value)
+        self._net = None
+
+    def state_dict(self, *a, **k):
+        return dict(self._params)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        extra = [k for k in sd if k not in self._params]
+        if strict and (missing or extra):
+            raise RuntimeError(f"SecondaryDiffusionImageNet2.load_state_dict: missing {missing[:4]}, unexpected {extra[:4]}")
+        for k, v in sd.items():
+            if k in self._params:
+                v = torch.as_tensor(v).detach().float().cpu()
+                if tuple(v.shape) != tuple(self._params[k].shape):
+                    raise RuntimeError(f"{k}: shape {tuple(v.shape)} != {tuple(self._params[k].shape)}")
+                self._params[k] = v.contiguous()
+        self._destroy()
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=True):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def _destroy(self):
+        if self._net is not None:
+            L.lib().maua_secondary_destroy(self._net)
+            self._net = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._net is None:
+            net = C.c_void_p()
+            L.check(L.lib().maua_secondary_create(L.ctx("cuda"), L.dtype_id(self.dtype), C.byref(net)))
+            lib = L.lib()
+
+            def up(i, what, t):
+                t = t.contiguous().float()
+                L.check(lib.maua_secondary_load(net, i, what, C.c_void_p(t.data_ptr()), C.c_size_t(t.numel())))
+            up(0, 2, self._params["timestep_embed.weight"].reshape(-1))
+            for i, k in enumerate(self._keys):
+                up(i, 0, self._params[k + ".weight"])
+                up(i, 1, self._params[k + ".bias"])
+            self._net = net
+        return self._net
+
+    def forward(self, input, t):
+        x = L.dev_tensor(input, torch.float32)
+        t = L.dev_tensor(torch.as_tensor(t), torch.float32).reshape(-1)
+        B, _, H, W = x.shape
+        if t.numel() != B:
+            raise ValueError("one timestep per sample")
+        v, pred, eps = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        net = self._handle()
+        L.ctx(x.device)
+        L.check(L.lib().maua_secondary_forward(net, L.ptr(x), L.ptr(t), B, H, W, L.ptr(v), L.ptr(pred), L.ptr(eps)))
+        self._last = (B, H, W)
+        return DiffusionOutput(v, pred, eps)
+
+    def vjp(self, g_v):
+        """(d v / d input)^T g_v for the input of the last ``forward``."""
+        g = L.dev_tensor(g_v, torch.float32)
+        B, H, W = self._last
+        if tuple(g.shape) != (B, 3, H, W):
+            raise ValueError(f"vjp: gradient shape {tuple(g.shape)} does not match the last forward {(B, 3, H, W)}")
+        out = torch.empty_like(g)
+        L.check(L.lib().maua_secondary_vjp(self._handle(), L.ptr(g), B, H, W, L.ptr(out)))
+        return out
 
 
 class GradientGuidedConditioning(torch.nn.Module):
-    """guided.py:212-274 with speed="hyper": img = (x - sigma * noise) / alpha is the clean-image estimate from the KNOWN
-    noise; the grad modules return d loss / d img, and d img / d x = 1 / alpha, so cond_fn = -sum(grads) / alpha."""
+    """guided.py:212-274.  speed="hyper": img = (x - sigma * noise) / alpha is the clean-image estimate from the KNOWN noise; the grad
+    modules return d loss / d img, and d img / d x = 1 / alpha, so cond_fn = -sum(grads) / alpha.  speed="fast" (the reference's
+    default): img = pred * sigma + x * (1 - sigma) with pred = x * a_c - v(x, t_c) * s_c from the secondary model at the cosine time
+    t_c = atan2(sigma, alpha) * 2 / pi (a_c, s_c = cos, sin(t_c * pi / 2)), so
+        -J^T g = -[(sigma * a_c + 1 - sigma) * g - sigma * s_c * (d v / d x)^T g]
+    with the last term from ``SecondaryDiffusionImageNet2.vjp`` (the reference gets the same number from torch.autograd.grad)."""
 
     def __init__(self, diffusion, model, grad_modules, speed="fast"):
         super().__init__()
-        if speed != "hyper":
-            raise NotImplementedError('speed "fast" / "regular" back-propagate through a network; use speed="hyper"')
-        self.speed, self.grad_modules = speed, list(grad_modules)
+        if speed not in ("hyper", "fast"):
+            raise NotImplementedError('speed "regular" back-propagates through the UNet itself; use "fast" (default) or "hyper"')
+        if speed == "fast" and not hasattr(model, "vjp"):
+            raise ValueError('speed="fast" needs the secondary model (create_models(use_secondary=True))')
+        self.speed, self.model, self.grad_modules = speed, model, list(grad_modules)
         self.timestep_map = list(diffusion.timestep_map)
         self.sqrt_alphas_cumprod = torch.from_numpy(diffusion.sqrt_alphas_cumprod).float()
         self.sqrt_one_minus_alphas_cumprod = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod).float()
@@ -535,22 +669,38 @@ class GradientGuidedConditioning(torch.nn.Module):
         for gm in self.grad_modules:
             gm.set_targets(prompts)
 
-    def forward(self, x, t, kw={}):
-        ot = t.clone()
-        idx = torch.tensor([self.timestep_map.index(int(v)) for v in t.long().cpu()])
-        alpha, sigma = self.sqrt_alphas_cumprod[idx], self.sqrt_one_minus_alphas_cumprod[idx]
-        x = L.dev_tensor(x, torch.float32)
-        ab = L.dev_tensor(torch.stack([1 / alpha, -sigma / alpha], 1).contiguous(), torch.float32)
-        img = torch.empty_like(x)
-        L.check(L.lib().maua_axpby_rows(L.ctx(x.device), L.ptr(x), L.ptr(self.noise), L.ptr(ab), x.shape[0],
-                                        C.c_long(x[0].numel()), L.ptr(img)))
+    def _sum_grads(self, img, ot):
         img_grad = torch.zeros_like(img)
         for gm in self.grad_modules:
             sub = gm(img, ot)
             if torch.isnan(sub).any():
                 sub = torch.zeros_like(img)
             img_grad += sub
-        return -img_grad / alpha.to(x.device).reshape(-1, 1, 1, 1)
+        return img_grad
+
+    def forward(self, x, t, kw={}):
+        ot = t.clone()
+        idx = torch.tensor([self.timestep_map.index(int(v)) for v in t.long().cpu()])
+        alpha, sigma = self.sqrt_alphas_cumprod[idx], self.sqrt_one_minus_alphas_cumprod[idx]
+        x = L.dev_tensor(x, torch.float32)
+        B, row = x.shape[0], C.c_long(x[0].numel())
+        lib, ctx = L.lib(), L.ctx(x.device)
+        img = torch.empty_like(x)
+        if self.speed == "hyper":
+            ab = L.dev_tensor(torch.stack([1 / alpha, -sigma / alpha], 1).contiguous(), torch.float32)
+            L.check(lib.maua_axpby_rows(ctx, L.ptr(x), L.ptr(self.noise), L.ptr(ab), B, row, L.ptr(img)))
+            return -self._sum_grads(img, ot) / alpha.to(x.device).reshape(-1, 1, 1, 1)
+        cosine_t = torch.atan2(sigma, alpha) * 2 / math.pi                           # :252
+        pred = self.model(x, cosine_t).pred                                          # :253
+        ab = L.dev_tensor(torch.stack([sigma, 1 - sigma], 1).contiguous(), torch.float32)
+        L.check(lib.maua_axpby_rows(ctx, L.ptr(pred), L.ptr(x), L.ptr(ab), B, row, L.ptr(img)))     # :254
+        g = self._sum_grads(img, ot)
+        a_c, s_c = torch.cos(cosine_t * math.pi / 2), torch.sin(cosine_t * math.pi / 2)
+        jv = self.model.vjp(g)                                                       # (d v / d x)^T g
+        cf = L.dev_tensor(torch.stack([-(sigma * a_c + 1 - sigma), sigma * s_c], 1).contiguous(), torch.float32)
+        out = torch.empty_like(x)
+        L.check(lib.maua_axpby_rows(ctx, L.ptr(g), L.ptr(jv), L.ptr(cf), B, row, L.ptr(out)))        # :268 (the minus sign folded in)
+        return out
 
 
 class MSEGuide:
@@ -582,24 +732,30 @@ class ImageTarget:
 
 
 class GuidedDiffusion(torch.nn.Module):
-    """guided.py:277-339 (samplers "ddim", "p", "plms"; the reference's defaults, incl. speed="fast" - which, with grad
-    modules, needs autograd through the secondary model and is refused: pass speed="hyper").  ``model_checkpoint`` / ``model`` + ``diffusion``: either the reference's
-    checkpoint name (file must exist, see create_models) or ready objects (tests, bench)."""
+    """guided.py:277-339 with the reference's defaults (samplers "ddim", "p", "plms"; speed "fast" = the secondary model, or
+    "hyper").  ``model_checkpoint`` / ``model`` + ``diffusion`` (+ ``secondary_model``): either the reference's checkpoint name
+    (files must exist, see create_models) or ready objects (tests, bench)."""
 
     def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
-                 ddim_eta=0, plms_order=2, speed="fast", model=None, diffusion=None, allow_random_init=False,
+                 ddim_eta=0, plms_order=2, speed="fast", model=None, diffusion=None, secondary_model=None, allow_random_init=False,
                  dtype=torch.bfloat16):
         super().__init__()
         if sampler not in ("ddim", "p", "plms"):
             raise NotImplementedError()
-        if model is None:
-            model, diffusion, _ = create_models(checkpoint=model_checkpoint,   # (:292: "ddimN" spacing only for DDIM)
-                                                timestep_respacing=f"ddim{timesteps}" if sampler == "ddim" else str(timesteps),
-                                                use_secondary=False, allow_random_init=allow_random_init, dtype=dtype)
-        self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
-        self.sampler, self.plms_order = sampler, plms_order
         mods = [gm for gm in grad_modules if gm.scale != 0]
-        self.conditioning = GradientGuidedConditioning(diffusion, None, mods, speed=speed) if mods else None
+        if model is None:
+            model, diffusion, secondary_model = create_models(            # (:292: "ddimN" spacing only for DDIM)
+                checkpoint=model_checkpoint, timestep_respacing=f"ddim{timesteps}" if sampler == "ddim" else str(timesteps),
+                use_secondary=speed == "fast", allow_random_init=allow_random_init, dtype=dtype)
+        elif speed == "fast" and secondary_model is None and mods:
+            secondary_model = SecondaryDiffusionImageNet2(dtype=dtype) if allow_random_init else None
+            if secondary_model is None:
+                raise ValueError('speed="fast" with ready objects needs secondary_model= (or allow_random_init=True)')
+        self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
+        self.secondary_model = secondary_model
+        self.sampler, self.plms_order = sampler, plms_order
+        self.conditioning = GradientGuidedConditioning(diffusion, secondary_model if speed == "fast" else model, mods,   # :297-302
+                                                       speed=speed) if mods else None
         self.device = device
         self.original_num_steps = diffusion.original_num_steps
         self.timestep_map = diffusion.timestep_map
@@ -662,13 +818,14 @@ def onset_prompt_schedule(audio, sr, fps, n_prompts, percentile=90):
 @torch.no_grad()
 def sample(prompts: List, audio=None, sr=None, fps=30, n_frames=None, size=(256, 256), timesteps=100,
            t_start: Optional[float] = None, model=None, diffusion=None, grad_modules=None, seed=0, batch=4, init=None,
-           verbose=False):
+           verbose=False, speed="hyper", secondary_model=None):
     """configs[3]: one 100-step DDIM sample per video frame, the active prompt switched on the clip's onset bins.
     ``prompts``: list of prompt objects (what the grad modules' set_targets understands).  -> ([n_frames, 3, H, W] in
     [-1, 1], prompt index per frame)."""
     if model is None:
         model, diffusion, _ = create_models("uncondImageNet256", f"ddim{timesteps}")
-    gd = GuidedDiffusion(grad_modules or [], timesteps=timesteps, model=model, diffusion=diffusion, speed="hyper")
+    gd = GuidedDiffusion(grad_modules or [], timesteps=timesteps, model=model, diffusion=diffusion, speed=speed,
+                         secondary_model=secondary_model)   # speed="fast" (the reference's default) needs the secondary model
     if audio is not None:
         idx = onset_prompt_schedule(audio, sr, fps, len(prompts))
         n_frames = len(idx) if n_frames is None else min(n_frames, len(idx))

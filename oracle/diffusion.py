@@ -407,3 +407,88 @@ def guided_diffusion_forward(p, cfg, sch, img, t_start, t_end=1, noise=None, con
         x, pred = ddim_step(sch, out, x, t, grad)
         t = t - 1
     return pred
+
+
+# ------------------------------------------------------------------------------------------------ secondary model ("fast" guidance)
+# maua/diffusion/processors/guided.py:20-143 (in-tree, plain PyTorch): the small v-prediction UNet the reference's DEFAULT
+# conditioning speed ("fast", guided.py:287) differentiates through, and :236-272 the conditioning itself.  Unlike the rest of
+# this file this part IS pinned: tests/golden/g28_secondary.npz was generated by tests/golden/make_golden.py from the reference's
+# own SecondaryDiffusionImageNet2 / GradientGuidedConditioning classes on weights from secondary_random_params() below.
+SECONDARY_CS = (64, 128, 128, 256, 256, 512)
+
+
+def secondary_conv_plan():
+    """The 24 3x3 convolutions in execution order: (state-dict key prefix, Ci, Co, relu).  Key prefixes are what torch names
+    the nested Sequential / SkipBlock modules of guided.py:77-134 ("net.2.main.1.0" = first ConvBlock inside the first SkipBlock)."""
+    c = SECONDARY_CS
+    plan = [("net.0.0", 3 + 16, c[0], True), ("net.1.0", c[0], c[0], True)]
+    pfx = "net.2.main"
+    down = [(c[0], c[1], c[1]), (c[1], c[2], c[2]), (c[2], c[3], c[3]), (c[3], c[4], c[4])]
+    for ci, cm, co in down:      # [down, ConvBlock, ConvBlock, SkipBlock(...), ConvBlock, ConvBlock, up]
+        plan += [(pfx + ".1.0", ci, cm, True), (pfx + ".2.0", cm, co, True)]
+        pfx += ".3.main"
+    plan += [(pfx + ".1.0", c[4], c[5], True), (pfx + ".2.0", c[5], c[5], True), (pfx + ".3.0", c[5], c[5], True),
+             (pfx + ".4.0", c[5], c[4], True)]
+    ups = [(c[4] * 2, c[4], c[3]), (c[3] * 2, c[3], c[2]), (c[2] * 2, c[2], c[1]), (c[1] * 2, c[1], c[0])]
+    for ci, cm, co in ups:
+        pfx = pfx[:-len(".3.main")]
+        plan += [(pfx + ".4.0", ci, cm, True), (pfx + ".5.0", cm, co, True)]
+    plan += [("net.3.0", c[0] * 2, c[0], True), ("net.4", c[0], 3, False)]
+    return plan
+
+
+def secondary_random_params(seed=0):
+    """Seeded weights of the architecture, independent of torch's RNG stream (numpy PCG64, keys in plan order): the SAME
+    function feeds the reference when the fixture is made and the HIP path / this restatement when it is checked."""
+    rng = np.random.default_rng(seed)
+    p = {"timestep_embed.weight": torch.from_numpy(rng.standard_normal((8, 1)).astype(np.float32))}
+    for key, ci, co, _ in secondary_conv_plan():
+        p[key + ".weight"] = torch.from_numpy((rng.standard_normal((co, ci, 3, 3)) * math.sqrt(2.0 / (9 * ci))).astype(np.float32))
+        p[key + ".bias"] = torch.from_numpy((rng.standard_normal((co,)) * 0.05).astype(np.float32))
+    return p
+
+
+def secondary_forward(p, x, t):
+    """guided.py:136-143: -> (v, pred, eps).  x [B, 3, H, W] (H, W multiples of 32), t [B] in [0, 1] (the cosine-schedule time)."""
+    f = 2 * math.pi * t[:, None] @ p["timestep_embed.weight"].T                      # FourierFeatures :57-66
+    emb = torch.cat([f.cos(), f.sin()], dim=-1)
+    h = torch.cat([x, emb[:, :, None, None].expand(-1, -1, x.shape[2], x.shape[3])], dim=1)
+    plan = secondary_conv_plan()
+
+    def conv(i, h):
+        key, _, _, relu = plan[i]
+        h = F.conv2d(h, p[key + ".weight"], p[key + ".bias"], padding=1)
+        return F.relu(h) if relu else h
+    h = conv(1, conv(0, h))
+    skips = []
+    for lvl in range(4):
+        skips.append(h)
+        h = conv(3 + 2 * lvl, conv(2 + 2 * lvl, F.avg_pool2d(h, 2)))
+    skips.append(h)
+    h = F.avg_pool2d(h, 2)
+    for i in range(10, 14):
+        h = conv(i, h)
+    for lvl in range(4):
+        h = torch.cat([F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=False), skips.pop()], dim=1)
+        h = conv(15 + 2 * lvl, conv(14 + 2 * lvl, h))
+    h = torch.cat([F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=False), skips.pop()], dim=1)
+    v = conv(23, conv(22, h))
+    alphas, sigmas = torch.cos(t * math.pi / 2)[:, None, None, None], torch.sin(t * math.pi / 2)[:, None, None, None]
+    return v, x * alphas - v * sigmas, x * sigmas + v * alphas
+
+
+def fast_conditioning(p, sch, grad_fn, x, t):
+    """guided.py:236-272 with speed="fast": t = the respaced model's timesteps (as cond_fn receives them); ``grad_fn(img, t)`` ->
+    d loss / d img (the sum over the grad modules).  -> -J^T grad, J = d img / d x through the secondary model (torch
+    autograd on the restatement above: this is the checker, the product evaluates the transposed network by hand)."""
+    idx = torch.tensor([list(sch.timestep_map).index(int(v)) for v in t.long()])
+    alpha = torch.from_numpy(sch.sqrt_alphas_cumprod).float()[idx]
+    sigma = torch.from_numpy(sch.sqrt_one_minus_alphas_cumprod).float()[idx]
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_()
+        cosine_t = torch.atan2(sigma, alpha) * 2 / math.pi
+        pred = secondary_forward(p, xx, cosine_t)[1]
+        s = sigma.reshape(-1, 1, 1, 1)
+        img = pred * s + xx * (1 - s)
+        g = grad_fn(img.detach(), t)
+        return -torch.autograd.grad(img, xx, g)[0]

@@ -37,7 +37,7 @@ ABSENT = {"librosa", "madmom", "torchaudio", "openunmix", "torchcubicspline", "t
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, name, path, target=None):
-        if name.startswith("maua.GAN.nv"):  # un-vendored git submodule (empty directory in the reference tree)
+        if name.startswith("maua.GAN.nv") or name.startswith("maua.submodules"):  # un-vendored git submodules (empty directories in the reference tree)
             return importlib.machinery.ModuleSpec(name, self, is_package=True)
         if name.split(".")[0] in ABSENT:
             try:  # prefer the real module when the image has it
@@ -868,6 +868,50 @@ def golden_load():
                     "strict_load_ok": strict_ok, "reference_raises_on_conv_noise_weight": raises, "keys": entry}
     (HERE / "g15_load_keymap.json").write_text(json.dumps(out, indent=0, sort_keys=True))
     print("g15_load_keymap.json", {k: len(v["keys"]) for k, v in out.items()})
+
+
+def golden_secondary():
+    """g28: the reference's in-tree secondary diffusion model (guided.py:68-143) and its default "fast" conditioning
+    (:212-274) - forward outputs (v, pred, eps) and the conditioning gradient -J^T g that GradientGuidedConditioning.forward
+    returns, computed by the reference's own classes.  Weights: oracle.diffusion.secondary_random_params(seed) loaded with
+    strict=True (this also pins the state-dict key plan); the un-vendored guided_diffusion submodule is a stub (guided.py
+    imports it at module scope; neither class below touches it)."""
+    from types import SimpleNamespace
+    import maua.diffusion.processors.guided as RG
+    from oracle import diffusion as OD
+    seed = 5
+    params = OD.secondary_random_params(seed)
+    net = RG.SecondaryDiffusionImageNet2()
+    missing = net.load_state_dict(params, strict=True)
+    net.eval().requires_grad_(False)
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 64, 96
+    x = torch.randn(B, 3, H, W, generator=g)
+    tc = torch.tensor([0.15, 0.85])
+    out = net(x, tc)
+    # the conditioning: a diffusion stand-in carrying exactly the attributes GradientGuidedConditioning reads
+    sch = OD.Schedule(1000, "ddim100")
+    diffusion = SimpleNamespace(timestep_map=list(sch.timestep_map), sqrt_alphas_cumprod=sch.sqrt_alphas_cumprod,
+                                sqrt_one_minus_alphas_cumprod=sch.sqrt_one_minus_alphas_cumprod)
+    target = torch.randn(3, H, W, generator=g) * 0.5
+
+    class MSE(torch.nn.Module):   # a grad module in the sense of maua/grad.py:15-25: scale, set_targets, forward(img, t) -> d loss / d img
+        scale = 1000.0
+
+        def set_targets(self, prompts):
+            pass
+
+        def forward(self, img, t):
+            return (2.0 * self.scale / img[0].numel()) * (img - target)
+    cond = RG.GradientGuidedConditioning(diffusion, net, [MSE()], speed="fast")
+    steps = torch.tensor([7, 61])                                     # indices into the respaced schedule
+    t_model = torch.tensor([float(sch.timestep_map[int(i)]) for i in steps])   # what cond_fn receives (rescale_timesteps: the original steps)
+    xt = torch.randn(B, 3, H, W, generator=g)
+    cond.set_targets([], torch.zeros_like(xt))
+    grad = cond(xt, t_model)
+    save("g28_secondary", seed=np.int64(seed), x=x, t=tc, v=out.v, pred=out.pred, eps=out.eps, target=target, steps=steps,
+         t_model=t_model, xt=xt, cond_grad=grad, mse_scale=np.float32(1000.0))
+    print("  strict load:", missing)
 
 
 if __name__ == "__main__":

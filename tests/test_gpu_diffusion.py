@@ -356,3 +356,135 @@ def test_onset_prompt_schedule_and_sample():
     b, _ = sample(prompts, wav, 1024 * fps, fps, n_frames=6, size=(64, 64), timesteps=5, model=net, diffusion=sd,
                   grad_modules=[MSEGuide(100.0)], seed=4)
     assert tuple(a.shape) == (6, 3, 64, 64) and torch.equal(ia, idx[:6]) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+# ------------------------------------------------------------------------------------------------ secondary model / "fast" guidance
+def _secondary(dt, seed):
+    from maua_amd.diffusion import SecondaryDiffusionImageNet2
+    net = SecondaryDiffusionImageNet2(dtype=dt)
+    p = OD.secondary_random_params(seed)
+    net.load_state_dict(p, strict=True)       # the reference's own state-dict keys (pinned by g28's strict load into its class)
+    return net, p
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_secondary_model_forward_matches_the_reference_fixture(golden, dt):
+    """SecondaryDiffusionImageNet2.forward on the device against g28 = the outputs of the REFERENCE's class (guided.py:68-143) on the
+    same weights (64 x 96 input: every level has a non-square grid, the bottleneck is 2 x 3).  exact-f32 mode <= 1e-4 of the
+    output's maximum over 24 chained convolutions, bf16 PSNR >= 40 dB."""
+    g = golden("g28_secondary")
+    net, _ = _secondary(dt, int(g["seed"]))
+    out = net(g["x"], g["t"])
+    for got, want in ((out.v, g["v"]), (out.pred, g["pred"]), (out.eps, g["eps"])):
+        if dt == torch.float32:
+            assert rel(got, want) <= 1e-4
+        else:
+            assert psnr(got, want) >= 40.0
+
+
+def test_secondary_model_vjp_matches_autograd_on_the_oracle():
+    """maua_secondary_vjp = (d v / d x)^T g evaluated on the transposed network against torch.autograd on the restatement (which
+    g28 pins to the reference): random upstream gradient, two shapes, exact-f32 <= 2e-4; and a second vjp on the same forward state
+    gives the same answer (the stored activations are not consumed); bf16 cosine similarity >= 0.99 (measured 0.997: ReLU masks
+    of activations within a bf16 ulp of zero flip)."""
+    from maua_amd.diffusion import SecondaryDiffusionImageNet2
+    p = OD.secondary_random_params(3)
+    for (B, H, W) in ((1, 32, 32), (2, 64, 96)):
+        g = torch.Generator().manual_seed(H + W)
+        x, t, gv = torch.randn(B, 3, H, W, generator=g), torch.rand(B, generator=g), torch.randn(B, 3, H, W, generator=g)
+        with torch.enable_grad():
+            xx = x.clone().requires_grad_()
+            v = OD.secondary_forward(p, xx, t)[0]
+            want = torch.autograd.grad(v, xx, gv)[0]
+        for dt in (torch.float32, torch.bfloat16):
+            net = SecondaryDiffusionImageNet2(dtype=dt)
+            net.load_state_dict(p)
+            net(x, t)
+            got = net.vjp(gv).cpu()
+            if dt == torch.float32:
+                assert rel(got, want) <= 2e-4, (B, H, W, rel(got, want))
+                assert torch.equal(net.vjp(gv).cpu(), got)
+            else:
+                cos = float((got * want).sum() / (got.norm() * want.norm()))
+                assert cos >= 0.99, (B, H, W, cos)
+    with pytest.raises(Exception):
+        net.vjp(torch.zeros(1, 3, 32, 32))     # not the shape of the last forward
+
+
+def test_fast_conditioning_matches_the_reference_gradient(golden):
+    """GradientGuidedConditioning(speed="fast") - the reference's default - against g28's cond_grad, which the REFERENCE's own
+    GradientGuidedConditioning.forward computed with torch.autograd through its secondary model (guided.py:236-272): same weights,
+    same x_t, same timesteps, an MSE grad module of the same scale.  48 chained convolutions (forward + transposed network): the
+    f32 mode (bf16 hi + lo operand splits on the matrix cores, ~2^-16 per product) lands at 4e-4 of the gradient's norm, 1.6e-3 of
+    its maximum; bf16 within 5 %."""
+    from maua_amd.diffusion import GradientGuidedConditioning, ImageTarget, MSEGuide, SpacedDiffusion, space_timesteps
+    g = golden("g28_secondary")
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim100"), OD.linear_betas(1000), rescale_timesteps=True)
+    for dt, tol_l2, tol_max in ((torch.float32, 1e-3, 5e-3), (torch.bfloat16, 5e-2, 0.25)):
+        net, _ = _secondary(dt, int(g["seed"]))
+        guide = MSEGuide(scale=float(g["mse_scale"]))
+        cond = GradientGuidedConditioning(sd, net, [guide], speed="fast")
+        cond.set_targets([ImageTarget(g["target"])], torch.zeros_like(g["xt"]))
+        got = cond(g["xt"], g["t_model"]).cpu()
+        want = g["cond_grad"]
+        l2 = float((got - want).norm() / want.norm())
+        assert l2 <= tol_l2 and rel(got, want) <= tol_max, (dt, l2, rel(got, want))
+
+
+def test_guided_diffusion_reference_defaults_and_grad_module_contract():
+    """GuidedDiffusion with the reference's DEFAULT arguments (sampler "ddim", speed "fast": guided.py:277-288) runs end to end with
+    a stand-in perceptor that follows maua/grad.py:15-25's contract on the device (scale / set_targets(prompts) / __call__(img, t)
+    -> d loss / d img): the module sees device images of the sampler's shape and the respaced model timesteps, a zero-scale module
+    is dropped (:299), the guided result differs from the unguided one and moves TOWARDS the module's target, and the "fast" and
+    "hyper" speeds agree on the direction of the first step's gradient."""
+    from maua_amd.diffusion import GuidedDiffusion, SpacedDiffusion, SecondaryDiffusionImageNet2, space_timesteps
+    cfg, p, net = _build(SMALL, torch.float32)
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim20"), OD.linear_betas(1000), rescale_timesteps=True)
+    sec = SecondaryDiffusionImageNet2(dtype=torch.float32)
+    sec.load_state_dict(OD.secondary_random_params(1))
+    calls = []
+
+    class StandInPerceptor:    # "CLIPGrads" shaped: a fixed random linear embedding of the image, pulled towards the prompt's embedding
+        def __init__(self, scale):
+            self.scale = scale
+            self.proj = torch.randn(16, 3 * 64 * 64, generator=torch.Generator().manual_seed(3)).cuda() / 110.0
+            self.target = None
+
+        def set_targets(self, prompts):
+            self.target = torch.stack([pr.embedding for pr in prompts]).mean(0).cuda()
+
+        def __call__(self, img, t):
+            assert img.is_cuda and img.dtype == torch.float32 and tuple(img.shape[1:]) == (3, 64, 64)
+            calls.append([int(v) for v in t])
+            e = img.reshape(img.shape[0], -1) @ self.proj.T                    # the "perceptor"
+            return (self.scale * 2.0 * (e - self.target) @ self.proj).reshape(img.shape)
+
+    class Prompt:
+        def __init__(self, emb):
+            self.embedding = emb
+
+        def to(self, *_a, **_k):
+            return self
+    g = torch.Generator().manual_seed(4)
+    img, nz = torch.randn(2, 3, 64, 64, generator=g), torch.randn(2, 3, 64, 64, generator=g)
+    emb = torch.randn(16, generator=g)
+    per, off = StandInPerceptor(0.05), StandInPerceptor(0.0)
+    gd = GuidedDiffusion([per, off], timesteps=20, model=net, diffusion=sd, secondary_model=sec)     # defaults: ddim, speed="fast"
+    assert gd.conditioning.speed == "fast" and gd.conditioning.grad_modules == [per]
+    guided = gd.forward(img, [Prompt(emb)], 0.3, t_end=0.6, noise=nz)
+    plain = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd).forward(img, [], 0.3, t_end=0.6, noise=nz)
+    assert torch.isfinite(guided).all() and len(calls) == 6 and all(len(c) == 2 for c in calls)
+    assert all(c[0] in sd.timestep_map for c in calls) and calls[0][0] > calls[-1][0]      # model timesteps, descending
+    dist = lambda im: float(((im.reshape(2, -1) @ per.proj.T) - per.target).norm())
+    assert dist(guided) < dist(plain)
+    fast = gd.conditioning(sd.q_sample(img, torch.tensor([6, 6]), nz), torch.tensor([float(sd.timestep_map[6])] * 2))
+    hyp = GuidedDiffusion([per], timesteps=20, model=net, diffusion=sd, speed="hyper")
+    hyp.conditioning.set_targets([Prompt(emb)], L_dev(nz))
+    hg = hyp.conditioning(sd.q_sample(img, torch.tensor([6, 6]), nz), torch.tensor([float(sd.timestep_map[6])] * 2))
+    cos = float((fast * hg).sum() / (fast.norm() * hg.norm()))
+    assert cos > 0.0, cos
+
+
+def L_dev(t):
+    from maua_amd import _lib as L
+    return L.dev_tensor(t, torch.float32)

@@ -607,3 +607,20 @@ def test_mm_onset_oracle_properties():
         assert all(int(p) % 8 in (3, 4, 5) for p in peaks) and len({int(p) // 8 for p in peaks}) == 5, name
     env = OM.mm_onset_envelope(z.numpy(), 30720)
     assert env.shape == (40,) and env.min() >= 0 and env.max() <= 1
+
+
+def test_secondary_diffusion_model_and_fast_conditioning_match_the_reference(golden):
+    """g28 (generated by the reference's own SecondaryDiffusionImageNet2 + GradientGuidedConditioning(speed="fast"),
+    guided.py:68-143, :212-274): the restatement's v / pred / eps and the conditioning gradient -J^T g.  The first
+    reference-pinned fixture of oracle/diffusion.py."""
+    from oracle import diffusion as OD
+    g = golden("g28_secondary")
+    p = OD.secondary_random_params(int(g["seed"]))
+    v, pred, eps = OD.secondary_forward(p, g["x"], g["t"])
+    for got, want in ((v, g["v"]), (pred, g["pred"]), (eps, g["eps"])):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    sch = OD.Schedule(1000, "ddim100")
+    target, scale = g["target"], float(g["mse_scale"])
+    grad = OD.fast_conditioning(p, sch, lambda img, tt: (2.0 * scale / img[0].numel()) * (img - target), g["xt"], g["t_model"])
+    want = g["cond_grad"]
+    assert float((grad - want).abs().max()) <= 2e-5 * float(want.abs().max()) and float(want.abs().max()) > 0
