@@ -289,32 +289,39 @@ def extra_diffusion(batch=16, steps=100, size=256):
                          "gflop_per_forward_per_sample": gf, "traffic": None, "traffic_note": "unmeasured (no PMC pass for this leg)"}}
 
 
-def extra_upscale(steps=3):
-    """configs[4], one GPU's slice: 1024^2 StyleGAN2 frame -> RealESRGAN x4 (23 RRDB blocks, random init) -> 4096^2 u8."""
+def extra_upscale(steps=3, frames=8, upscale_batch=4):
+    """configs[4], one GPU's slice, through the product path (audiovisual/sample.py generate(upscale=...) runs exactly this per
+    batch): `frames` 1024^2 StyleGAN2 frames rendered in one call -> RealESRGANer.enhance_frames (x4plus: 23 RRDB blocks, random
+    init; the reference's enhance arithmetic per frame: / 255, reflect pre_pad 10 -> 1034^2, network, crop, clamp, round),
+    `upscale_batch` frames per network call -> 4096^2 u8 frames on the device."""
     from maua_amd.stylegan2 import SynthesisNetwork
-    from maua_amd.super import RRDBNet
+    from maua_amd.super import load_model
     G = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(0))
-    S = RRDBNet(num_block=23, dtype=torch.bfloat16)
-    ws = torch.randn(1, G.num_ws, W_DIM, generator=torch.Generator().manual_seed(1)).cuda()
-    img = torch.empty((1, 3, RES, RES), device="cuda")
-    u8 = torch.empty((1, 4 * RES, 4 * RES, 3), dtype=torch.uint8, device="cuda")
+    up = load_model("x4plus", dtype=torch.bfloat16, allow_random_init=True)
+    ws = torch.randn(frames, G.num_ws, W_DIM, generator=torch.Generator().manual_seed(1)).cuda()
+    u8 = torch.empty((frames, RES, RES, 3), dtype=torch.uint8, device="cuda")
 
     def step():
-        G(ws, out=img)
-        S(img.add(1).div(2).clamp_(0, 1), rgb8_out=u8)
-    step()
+        G(ws, rgb8_out=u8)
+        for k in range(0, frames, upscale_batch):
+            big = up.enhance_frames(u8[k:k + upscale_batch])
+        return big
+    big = step()
+    assert tuple(big.shape) == (min(upscale_batch, frames), 4 * RES, 4 * RES, 3) and big.dtype == torch.uint8
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / (steps * frames)
     f, g = 64, 32
     rdb = 9 * sum((f + k * g) * (f if k == 4 else g) for k in range(5))
     macs_px = 23 * 3 * rdb + 9 * (3 * f + f * f) + 9 * f * f * 4 + 9 * f * f * 16 + 9 * f * f * 16 + 9 * f * 3 * 16
-    tf = 2 * macs_px * RES * RES / 1e12 / dt
+    tf = 2 * macs_px * RES * RES / 1e12 / dt     # algorithmic: the 1024^2 frame (the pre_pad border's 2 % extra pixels are not counted)
     return {"metric": "frames/sec per GPU, 1024^2 StyleGAN2 render -> RealESRGAN x4 -> 4096^2 u8 (configs[4], one GPU's slice)",
             "value": 1.0 / dt, "unit": "frames/s", "ms_per_frame": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+            "frames_per_render_call": frames, "frames_per_upscaler_call": upscale_batch,
+            "path": "SynthesisNetwork(rgb8_out) -> RealESRGANer.enhance_frames (pre_pad 10), what generate(upscale='x4plus') runs per batch",
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                          "traffic": None, "traffic_note": "unmeasured (no PMC pass for this leg)"}}
 

@@ -150,9 +150,18 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
              seed: Optional[int] = None, latent_seeds: Optional[str] = None, fps: float = 30, audio_offset: float = 0,
              audio_duration: Optional[float] = None, downscale_factor: float = 4, aspect_ratio: float = 1,
              batch_size: int = 32, device: str = "cuda", tempo: Optional[float] = None, out_dir: str = "output",
-             reference_tail: bool = False, dtype=torch.bfloat16):
+             reference_tail: bool = False, dtype=torch.bfloat16, upscale: Optional[str] = None, upscale_batch: int = 4,
+             upscale_random_init: bool = False):
     """sample.py:36-101.  ``reference_tail=True`` reproduces the reference loop's dropped tail.
-    ``tempo``: BPM for the "loop" sub-patches; None = estimated from the onset envelope like the reference (mir.py:27-30)."""
+    ``tempo``: BPM for the "loop" sub-patches; None = estimated from the onset envelope like the reference (mir.py:27-30).
+
+    ``upscale`` = one of the reference's RealESRGAN model names (super/image/models/realesrgan.py:13-19) fuses BASELINE
+    configs[4] into the render: every batch of frames goes render -> x4 (``upscale_batch`` frames per network call,
+    RealESRGANer.enhance's arithmetic per frame) -> writer without leaving the device - what the reference does in two passes
+    through a video file (generate, then super/video/frame_by_frame.py:22-33).  A 4096^2 frame is 48 MiB (3600 frames: 169 GB),
+    so there is NO gather in this mode: every rank encodes its own contiguous frame range into ``<stem>_partRRR.mp4`` and rank 0
+    joins the parts in order (ffmpeg concat demuxer, stream copy; without ffmpeg the raw parts and the list stay) -
+    returns (joined file | list file, None)."""
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31, size=()).item())
     rank, world = world_info()
@@ -182,6 +191,9 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     # the network renders output_size rounded to the resize layer's multiple (wrappers/stylegan2.py:115-120); the
     # reference writes those frames into a writer opened at out_size — here they are resampled to out_size first
     rh, rw = G.synthesizer.G_synth.output_hw
+    if upscale is not None:
+        return _generate_upscaled(G, latents, noise, T, lo, hi, rank, world, batch_size, upscale, upscale_batch, upscale_random_init,
+                                  dtype, out_file, fps, audio_file, audio_offset, audio_duration, patch, (rw, rh))
     # frames travel to rank 0 chunk by chunk while the next batch renders (RCCL point-to-point over xGMI; rank 0 renders
     # straight into the clip buffer)
     sg = StreamingGather(T, (rh, rw, 3), batch_size, dtype=torch.uint8, device="cuda", rank=rank, world=world)
@@ -206,6 +218,48 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
     return out_file, frames
 
 
+def _generate_upscaled(G, latents, noise, T, lo, hi, rank, world, batch_size, model_name, upscale_batch, random_init, dtype,
+                       out_file, fps, audio_file, audio_offset, audio_duration, patch, render_wh):
+    """configs[4]: this rank's frames lo .. hi as render -> RealESRGAN x4 -> its own writer; rank 0 joins the parts."""
+    import shutil
+    import subprocess
+    import torch.distributed as dist
+    from ..super import load_model
+    up = load_model(model_name, dtype=dtype, allow_random_init=random_init)
+    rw, rh = render_wh
+    s = up.scale
+    stem = out_file[: -len(".mp4")] + f"_{model_name}_{s * rw}x{s * rh}"
+    part = f"{stem}_part{rank:03d}.mp4"
+    u8 = torch.empty((batch_size, rh, rw, 3), dtype=torch.uint8, device="cuda")
+    n_written = 0
+    with VideoWriter(part, (s * rw, s * rh), fps) as video:
+        for i in range(lo, hi, batch_size):
+            b = min(batch_size, hi - i)
+            nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
+            G.synthesizer(latents=latents[i:i + b], rgb8_out=u8[:b], **nz)
+            for k in range(0, b, upscale_batch):
+                video.write(up.enhance_frames(u8[k:min(b, k + upscale_batch)]))
+                n_written += min(b, k + upscale_batch) - k
+    assert n_written == hi - lo
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return None, None
+    parts = [f"{stem}_part{r:03d}.mp4" for r in range(world) if frame_range(T, r, world)[1] > frame_range(T, r, world)[0]]
+    lst = stem + "_parts.txt"
+    Path(lst).write_text("".join(f"file '{Path(p).name}'\n" for p in parts))
+    patch.save(stem + ".json")
+    joined = stem + ".mp4"
+    if shutil.which("ffmpeg") and all(Path(p).exists() for p in parts):
+        cmd = ["ffmpeg", "-y", "-loglevel", "error", "-f", "concat", "-safe", "0", "-i", lst]
+        wav = audio_file if str(audio_file).lower().endswith(".wav") else None
+        if wav:
+            cmd += ["-ss", str(audio_offset)] + (["-t", str(audio_duration)] if audio_duration else []) + ["-i", wav, "-c:a", "aac"]
+        subprocess.run(cmd + ["-c:v", "copy", joined], check=True)
+        return joined, None
+    return lst, None
+
+
 def main(argv=None):
     torch.set_num_threads(min(torch.get_num_threads(), 8))   # host side = small tensors (see _lib.host_threads)
     ap = argparse.ArgumentParser(description="argparse shim for the reference's fire.Fire(generate): same names/defaults")
@@ -223,6 +277,9 @@ def main(argv=None):
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--tempo", type=float, default=None, help="BPM of the loop sub-patches (default: estimated from the onset envelope)")
     ap.add_argument("--reference_tail", action="store_true")
+    ap.add_argument("--upscale", default=None, help="RealESRGAN model name: render -> x4 per frame, one part file per rank (configs[4])")
+    ap.add_argument("--upscale_batch", type=int, default=4)
+    ap.add_argument("--upscale_random_init", action="store_true")
     a = ap.parse_args(argv)
     from ..distributed import maybe_init_process_group
     maybe_init_process_group()

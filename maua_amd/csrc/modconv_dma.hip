@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r = lane & 31, h = lane >> 5;
-  const int tiles_x = a.W >> 5;
+  const int tiles_x = (a.W + TW - 1) >> 5;   // (narrow plain convolutions may overhang the image: their stores are masked)
   const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
   const int b = blockIdx.y, n0 = blockIdx.z * BN;
@@ -451,7 +451,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int p = tid + it * NT, m = p / PPP, pc = p - m * PPP;
-      const long pix = (long)(ty0 + (m >> 5)) * a.W + tx0 + (m & 31);
+      const int yy = min(ty0 + (m >> 5), a.H - 1), xx = min(tx0 + (m & 31), a.W - 1);   // (overhanging pixels read a valid one)
+      const long pix = (long)yy * a.W + xx;
       rvs[it] = *reinterpret_cast<const u32x4*>(rb + (pix * a.res_pstride + n0 + pc * 8) * 2);
     }
   }
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       for (int k = 0; k < 4; k++)
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
     }
-    *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
+    if (ty0 + (m >> 5) < a.H && tx0 + (m & 31) < a.W) *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
     if constexpr (PSUM) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -518,8 +519,10 @@ bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
 }
 // ... and the narrow plain convolutions of the RRDB up-scaler (super.hip): 32 or 64 output channels, K a multiple of 64
+// (any H, W >= one tile: tiles that overhang the image read zeros - the convolution's own padding - and mask their stores;
+//  RealESRGANer's pre_pad makes a 1024^2 frame 1034 x 1034)
 bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W) {
-  return dtype == MAUA_BF16 && Ci % 64 == 0 && (Co == 32 || Co == 64) && H % TH == 0 && W % TW == 0;
+  return dtype == MAUA_BF16 && Ci % 64 == 0 && (Co == 32 || Co == 64) && H >= TH && W >= TW;
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false>
@@ -531,7 +534,7 @@ static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
   auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  dim3 grid((a.H / TH) * (a.W / TW), a.B, a.Co / BN);
+  dim3 grid(((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
@@ -548,6 +551,7 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   // narrow N tiles (4 waves, 64-byte K rows, two taps per stage): 64 channels = 2 x 2 blocks per wave, 32 = 2 x 1
   if (narrow) {
     MAUA_REQUIRE(!a.rgb_out && !a.out_scale && !a.psum, "modconv_dma: the narrow tiles carry no toRGB / style scaling / piece sums");
+    MAUA_REQUIRE((a.H % TH == 0 && a.W % TW == 0) || !a.noise, "modconv_dma: overhanging tiles take no noise operand");
     return a.Co == 64 ? launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
   }
   // (channel-sliced operands and the residual are honoured by every tile shape: the kernel's address arithmetic is shared)

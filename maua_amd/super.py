@@ -261,6 +261,30 @@ class RealESRGANer:
             raise NotImplementedError("outscale != scale (a cv2 Lanczos resize in realesrgan; not used by the reference)")
         return res, "RGB"
 
+    @torch.inference_mode()
+    def enhance_frames(self, frames_u8):
+        """``enhance`` for a BATCH of frames that never leave the device (BASELINE configs[4]: render -> x4 per frame): uint8
+        [B, H, W, 3] RGB as the renderer packs them -> uint8 [B, scale H, scale W, 3].  Per frame exactly enhance()'s arithmetic
+        (x / 255, reflect pre_pad on the right / bottom, the network, crop, clamp to [0, 1], round(255 x)); the reference reaches
+        the same frames through a video file (super/video/frame_by_frame.py:22-33: decoded frame / 255 -> upscale -> writer)."""
+        from . import ops
+        f = torch.as_tensor(frames_u8)
+        if f.dtype != torch.uint8 or f.ndim != 4 or f.shape[-1] != 3:
+            raise ValueError("enhance_frames expects uint8 [B, H, W, 3] frames")
+        f = f.cuda()
+        b, h, w, _ = f.shape
+        x = f.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+        if self.pre_pad:
+            x = ops.pad2d(x, (0, self.pre_pad, 0, self.pre_pad), "reflect")
+        s = self.scale
+        if self.tile_size > 0:
+            out = self._tile_process(x)[:, :, : h * s, : w * s]
+            return out.clamp_(0, 1).mul_(255.0).round_().byte().permute(0, 2, 3, 1).contiguous()
+        # the network packs round(255 clamp(y)) itself (same rounding as enhance's .round()); the pre_pad border is cut from the u8 frames
+        u8 = torch.empty((b, x.shape[2] * s, x.shape[3] * s, 3), dtype=torch.uint8, device=x.device)
+        self.model(x, rgb8_out=u8)
+        return u8[:, : h * s, : w * s].contiguous() if self.pre_pad else u8
+
     def _tile_process(self, x):
         """RealESRGANer.tile_process: ceil(H / tile) x ceil(W / tile) tiles."""
         import math

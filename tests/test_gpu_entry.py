@@ -176,3 +176,31 @@ def test_python_m_maua_audiovisual_generate(wav, tmp_path):
     if not shutil.which("ffmpeg"):
         meta = json.loads(open(tmp_path / "clip_None_stretch_256x256.mp4.json").read())
         assert meta["frames"] == 32 and (meta["width"], meta["height"]) == (256, 256)
+
+
+def test_sample_generate_with_fused_upscale(wav_long, tmp_path):
+    """BASELINE configs[4] as a product call: generate(..., upscale=...) renders 256^2 frames and up-scales every batch x4 on the
+    device (RealESRGANer.enhance's arithmetic per frame, several frames per network call) straight into this rank's writer - no
+    gather (a 4096^2 frame is 48 MiB).  Without ffmpeg the raw part is inspected: frame count, geometry, and frame 5 is
+    enhance() of the frame the plain render produces for the same seed (bf16, another batch size -> another summation order in
+    the convolutions: PSNR >= 35 dB between the u8 images)."""
+    import shutil
+    from maua_amd.audiovisual.sample import generate
+    from maua_amd.super import load_model
+    out, frames = generate(wav_long, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path / "a"),
+                           upscale="x4plus-anime", upscale_batch=3, upscale_random_init=True)
+    assert frames is None and "x4plus-anime_1024x1024" in out
+    plain_file, plain = generate(wav_long, None, seed=5, fps=30, downscale_factor=4, batch_size=8, out_dir=str(tmp_path / "b"))
+    assert tuple(plain.shape) == (352, 256, 256, 3)
+    if not shutil.which("ffmpeg"):
+        assert out.endswith("_parts.txt")
+        part = str(tmp_path / "a") + "/" + open(out).read().split("'")[1]
+        meta = json.loads(open(part + ".json").read())
+        assert meta["frames"] == 352 and (meta["width"], meta["height"]) == (1024, 1024)
+        raw = np.memmap(part + ".rgb24", dtype=np.uint8, mode="r").reshape(352, 1024, 1024, 3)
+        model = load_model("x4plus-anime", allow_random_init=True)
+        want = model.enhance(plain[5].float().cpu().numpy())[0]
+        d = np.asarray(raw[5]).astype(np.float64) - want.astype(np.float64)
+        assert 10 * np.log10(255.0 ** 2 / max(float((d ** 2).mean()), 1e-12)) >= 35.0
+    else:
+        assert out.endswith(".mp4")

@@ -172,3 +172,96 @@ def test_rrdb_trunk_on_lds_direct_kernel_matches_generic_and_oracle(monkeypatch)
     assert outs["1"].shape == ref.shape == (2, 3, 128, 256)
     assert _psnr(outs["1"], ref) >= 40.0 and _psnr(outs["0"], ref) >= 40.0, (_psnr(outs["1"], ref), _psnr(outs["0"], ref))
     assert _psnr(outs["1"], outs["0"]) >= 50.0, _psnr(outs["1"], outs["0"])   # same bf16 operands, residual rounded once more
+
+
+def test_enhance_frames_equals_enhance_per_frame_on_ragged_sizes():
+    """RealESRGANer.enhance_frames (the batched device form configs[4]'s fused pipeline calls) gives, frame by frame, the u8
+    image of enhance() - f32 and bf16, on sizes that are no multiple of the LDS-direct kernel's 8 x 32 tile once pre_pad = 10 is
+    added (72 + 10 = 82 rows, 96 + 10 = 106 columns: overhanging tiles with masked stores in bf16), whole-image and tiled.  The
+    batch changes which tile shapes / split-K routes the convolutions take, i.e. the order of the f32 sums, so values that sit on
+    a rounding boundary may land on the other side: exact-f32 mode <= 1 LSB on <= 0.1 % of the values; in bf16 every layer's
+    output is rounded, a flipped rounding travels through the 90 layers behind it: PSNR >= 35 dB between the two u8 images (the
+    bar bf16 meets against the fp32 oracle is 38 dB).  The bf16 result on such a size agrees the same way with the generic
+    kernel's (MAUA_RRDB_DMA=0)."""
+
+    def close8(a, b, frac):
+        d = (a.int() - b.int()).abs()
+        if frac is not None:
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= frac, (int(d.max()), float((d > 0).float().mean()))
+        else:
+            ps = 10 * np.log10(255.0 ** 2 / max(float((d.float() ** 2).mean()), 1e-12))
+            assert ps >= 35.0, ps
+    import os
+    from maua_amd.super import load_model
+    g = torch.Generator().manual_seed(5)
+    frames = (torch.rand(3, 72, 96, 3, generator=g) * 255).round().byte()
+    for dt in (torch.float32, torch.bfloat16):
+        for tile in (0, 40):
+            model = load_model("x4plus-anime", dtype=dt, allow_random_init=True, tile=tile)
+            got = model.enhance_frames(frames.cuda()).cpu()
+            assert tuple(got.shape) == (3, 288, 384, 3) and got.dtype == torch.uint8
+            for i in range(3):
+                want = torch.from_numpy(model.enhance(frames[i].float().numpy())[0])
+                close8(got[i], want, 1e-3 if dt == torch.float32 else None)
+    model = load_model("x4plus-anime", dtype=torch.bfloat16, allow_random_init=True)
+    a = model.enhance_frames(frames.cuda()).cpu()
+    os.environ["MAUA_RRDB_DMA"] = "0"
+    try:
+        generic = load_model("x4plus-anime", dtype=torch.bfloat16, allow_random_init=True)
+        b = generic.enhance_frames(frames.cuda()).cpu()
+    finally:
+        del os.environ["MAUA_RRDB_DMA"]
+    close8(a, b, None)
+
+
+def test_full_size_upscale_1024_to_4096_u8():
+    """configs[4] at its real shape: one 1024^2 StyleGAN2 frame -> RealESRGAN x4plus (23 blocks, bf16) -> 4096^2 u8
+    through the product call (enhance_frames: pre_pad 10 -> 1034^2 input, overhanging tiles).  Checked (i) against oracle/super.py
+    on a 256 x 256 crop of the INPUT that contains the frame's top-left corner: the network is convolutional, so the crop's output
+    equals the full frame's wherever the crop's other borders are further away than the information that reaches a pixel - compared
+    on the 512 x 512 output block at the corner, bf16 vs the fp32 oracle: PSNR >= 35 dB, <= 2 % of the u8 values off by more than 2;
+    (ii) tiling invariance at full size: enhance_frames with tile = 512 (tile_pad 10) agrees with the whole-image pass away from
+    tile seams the same way (PSNR >= 35 dB over the frame; identical where no seam is within reach is not guaranteed by the
+    published tiling either); (iii) the frame is not saturated or constant."""
+    from maua_amd.stylegan2 import SynthesisNetwork
+    from maua_amd.super import load_model
+    from oracle import super as OSR
+    G = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(0))
+    ws = torch.randn(1, G.num_ws, 512, generator=torch.Generator().manual_seed(1))
+    u8 = torch.empty((1, 1024, 1024, 3), dtype=torch.uint8, device="cuda")
+    img = torch.empty((1, 3, 1024, 1024), device="cuda")
+    G(ws, out=img, rgb8_out=u8)
+    # (a random-init generator's image is heavy-tailed: rescale into the u8 range like the non-saturating test of the render)
+    frame = (img[0] / (3 * img.std())).clamp(-1, 1).add(1).mul(127.5).round().byte().permute(1, 2, 0).contiguous()[None]
+    assert 20 < float(frame.float().std()) and float(((frame > 0) & (frame < 255)).float().mean()) > 0.9
+    model = load_model("x4plus", dtype=torch.bfloat16, allow_random_init=True)
+    # a random-init up-scaler saturates its output; the last convolution is rescaled (the image is linear in it) so that the
+    # 4096^2 frame sits inside the u8 range: mean 0.5, standard deviation 0.15
+    p = model.model.state_dict()
+    probe = model.model(frame[:, :128, :128].permute(0, 3, 1, 2).float().div(255).cuda(), clamp=False)
+    k = 0.15 / float(probe.std())
+    p["conv_last.weight"] = p["conv_last.weight"] * k
+    p["conv_last.bias"] = p["conv_last.bias"] * k + (0.5 - k * float(probe.mean()))
+    model.model.load_state_dict(p)
+    model.model.set_channel_flip(True)
+    big = model.enhance_frames(frame)
+    assert tuple(big.shape) == (1, 4096, 4096, 3) and big.dtype == torch.uint8
+    assert float(big.float().std()) > 5 and float(((big > 0) & (big < 255)).float().mean()) > 0.5
+
+    def psnr8(a, b):
+        mse = float(((a.float() - b.float()) ** 2).mean())
+        return 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+    # (i) the corner block against the fp32 oracle on a crop (the crop's right / bottom borders are 128 input pixels from the block)
+    crop = frame[0, :256, :256].float().cpu().numpy()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    want = OSR.realesrganer_enhance(lambda x: OSR.rrdbnet_raw(p, x, 23), crop, tile=0, pre_pad=0)   # the far borders are not the frame's
+    got = big[0, :512, :512].cpu()
+    w = torch.from_numpy(want[:512, :512])
+    d = (got.int() - w.int()).abs()
+    assert psnr8(got, w) >= 35.0 and float((d > 2).float().mean()) <= 0.02, (psnr8(got, w), float((d > 2).float().mean()))
+    # (ii) tiled vs whole image at full size
+    tm = load_model("x4plus", dtype=torch.bfloat16, allow_random_init=True, tile=512)
+    tm.model.load_state_dict(p)
+    tm.model.set_channel_flip(True)
+    tiled = tm.enhance_frames(frame)
+    assert tuple(tiled.shape) == (1, 4096, 4096, 3) and psnr8(tiled, big) >= 35.0, psnr8(tiled, big)
