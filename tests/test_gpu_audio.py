@@ -139,7 +139,7 @@ def test_bench_latent_schedule_matches_oracle_on_a_frame_subset():
     T, fps, num_ws, w_dim = 3600, 30, 18, 512
     lat, _ = pipeline.synthetic_clip_latents(T, fps, num_ws, w_dim)
     assert tuple(lat.shape) == (T, num_ws, w_dim)
-    wav = pipeline.synthetic_audio(T * 1024, 1024 * fps)
+    wav = pipeline.synthetic_audio(T * 1024, 1024 * fps, fast=True)      # the benchmark clip's waveform
     env = OA.onsets(wav, 1024 * fps).squeeze(-1)
     mp = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0)).state_dict()
     pal = OSG.mapping_network(mp, get_z_latents("0-60", w_dim).float(), num_ws_=num_ws)
