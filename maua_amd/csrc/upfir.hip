@@ -15,7 +15,7 @@ namespace maua {
 // down UPFIR_ROWS output rows.  Per t row it loads 5 pieces and forms the two horizontal sums
 // (g = [1,3,3,1]/4 symmetric: .25*(c0+c3) + .75*(c1+c2)); the last four horizontal rows live in registers and
 // every output row is their vertical combination.  2.5 loads and ~13 VALU ops per output value (a 2 x 2 block per
-// thread costs 6.25 loads / 26 ops; measured 0.43 ms -> see DESIGN.md at 512^2 x 64 ch, B = 16).
+// thread costs 6.25 loads / 26 ops; measured 0.43 ms -> see DESIGN_LOG.md 4.2 at 512^2 x 64 ch, B = 16).
 constexpr int UPFIR_ROWS = 32;
 
 // channel pairs as float2 so the sums map to packed-f32 instructions (v_pk_add/mul/fma_f32)

@@ -1,5 +1,5 @@
 # Lists, per kernel of one .hip file, the global loads that are waited for immediately (s_waitcnt vmcnt(0) within three
-# instructions of a non-LDS global_load): each is a full memory round trip on the critical path of the wave.  DESIGN.md 10.8.
+# instructions of a non-LDS global_load): each is a full memory round trip on the critical path of the wave.  DESIGN_LOG.md 10.8.
 #   usage: bash scripts/isa_wait_audit.sh maua_amd/csrc/modconv_dma.hip
 set -e
 src=$1
