@@ -390,7 +390,7 @@ def main():
 
     def step(k, u8):
         i = lo + (k * B) % max(1, (hi - lo) - B + 1)  # batches walk this rank's frame range
-        nz = loop_batch(noise, i, B)  # 17 Loop modules, two launches
+        nz = loop_batch(noise, i, B, raw=True)  # 17 Loop modules: the maps in one pass + per-sample factors (two launches)
         net(latents[i:i + B], noise=nz, rgb8_out=u8)
 
     def fence():
@@ -535,7 +535,7 @@ def main():
         tc = time.perf_counter()
         for off, b in sg.chunks():
             i = lo + off
-            net(latents[i:i + b], noise=loop_batch(noise, i, b), rgb8_out=sg.local[off:off + b])
+            net(latents[i:i + b], noise=loop_batch(noise, i, b, raw=True), rgb8_out=sg.local[off:off + b])
             sg.chunk_done()
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(device))

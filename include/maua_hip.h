@@ -161,6 +161,9 @@ int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const*
  * then pack_rgb8 if requested.  Synchronises on the last event;
  * a call with ms_out != NULL resets the recording (ms_out == NULL only returns the count). */
 int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* count);
+/* Per-sample factors on the noise inputs of the NEXT forward calls: scales = device [num_layers][layer_stride >= B] f32, row l for
+ * synthesis layer l (maua_noise_loop_batch_raw's output), or NULL to go back to plain noise (x + noise * strength, ops.py:184-185). */
+int maua_synth_set_noise_scale(maua_synth* net, const float* scales, long layer_stride);
 /* debug/parity (what a torch forward hook on SynthesisLayer would capture): copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
 int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
 
@@ -345,6 +348,13 @@ int maua_noise_loop_batch(maua_ctx* ctx, int n, const float* const* planes, cons
                           const int* w, const float* sigma, int i0, int B, float* const* out);
 /* replaces noise.py:11-24 Blend.forward (noise2 != NULL: sum_m noise[m]*mod[b,m] + sum_m noise2[m]*(1-mod[b,m]))
  * and :27-39 Multiply.forward (noise2 == NULL).  noise/noise2 [M,h,w], mod [B,M] (rows i..i+B of the modulator). */
+/* The same maps UN-NORMALISED in one pass + the per-(layer, sample) factor 1 / (rms + eps) that noise.py:52 divides by:
+ * scales [n][B] f32 (device).  Hand the maps to the synthesis call as usual and the factors through maua_synth_set_noise_scale:
+ * the consuming convolution epilogues multiply them into their noise strength, so the maps are written once and sin(cos(.)) is
+ * evaluated once per value (the normalised form needs two passes).  Same reference lines as maua_noise_loop_batch. */
+int maua_noise_loop_batch_raw(maua_ctx* ctx, int n, const float* const* planes, const float* const* idx, const int* h,
+                              const int* w, const float* sigma, int i0, int B, float* const* out, float* scales);
+
 int maua_noise_mix(maua_ctx* ctx, const float* noise, const float* noise2, const float* mod, int M, int B, int h,
                    int w, float* out);
 /* replaces noise.py:56-63 Average (mode 0: (x+y)/2), :66-75 Modulate (mode 1: x*mod[b] + y*(1-mod[b]), mod [B]),

@@ -22,6 +22,7 @@ struct ConvArgs {
   const float* noise;   // [B|1][Ho][Wo] or NULL
   long noise_bstride;   // elements (0: broadcast)
   float noise_strength;
+  const float* noise_scale;  // [B] or NULL: per-sample factor on the noise (un-normalised Loop maps: 1 / (rms + eps), noise.hip raw mode)
   const float* bias;    // [Co] or NULL
   void* y;              // NHWC [B][Ho][Wo][Co] (T)
   int B, H, W, Ci, Co, up;
@@ -83,6 +84,7 @@ struct HiresArgs {
   const float* noise;   // [B|1][H*up][W*up] or NULL
   long noise_bstride;
   float noise_strength;
+  const float* noise_scale;  // [B] or NULL: per-sample factor on the noise (as in ConvArgs)
   const float* bias;    // [Co] or NULL
   void* y;              // NHWC bf16 [B][H*up][W*up][Co]; NULL with rgb_out: features are not stored
   int B, H, W, Ci, Co, up, act;
@@ -134,6 +136,7 @@ struct UpfirArgs {
   const float* noise;  // [B|1][2H][2W] or NULL
   long noise_bstride;
   float noise_strength;
+  const float* noise_scale;  // [B] or NULL: per-sample factor on the noise (as in ConvArgs)
   const float* bias;   // [Co] or NULL
   const float* out_scale;  // [B][Co] or NULL: the output is multiplied by the NEXT layer's styles (modconv_dma.hip)
   int B, H, W, Co;     // H, W = INPUT grid of the layer (output is 2H x 2W)

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
         if (gy < a.H && gx < a.W) nzr[i] = nb[(long)(gy * a.up + pa) * Wo + gx * a.up + pb];
       }
 #pragma unroll
-      for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength;
+      for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength * (a.noise_scale ? a.noise_scale[b] : 1.f);
     }
 #pragma unroll
     for (int q0 = 0; q0 < 4; q0 += 2) {   // two register groups (8 channels) per round trip

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #pragma unroll
     for (int i = 0; i < WM; i++) nzr[i] = nb[(long)(ty0 + wm * WM + i) * a.W + tx0 + r];
 #pragma unroll
-    for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength;
+    for (int i = 0; i < WM; i++) nzr[i] *= a.noise_strength * (a.noise_scale ? a.noise_scale[b] : 1.f);
   }
   constexpr int QG = KB == 64 ? 2 : 4;   // register groups per round trip (the 128-register variants take them in halves)
 #pragma unroll

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
     dv[qd * 4] = d4.x * a.gain; dv[qd * 4 + 1] = d4.y * a.gain; dv[qd * 4 + 2] = d4.z * a.gain; dv[qd * 4 + 3] = d4.w * a.gain;
   }
   }
-  const float nz_scale = a.noise_strength * a.gain;
+  const float nz_scale = a.noise_strength * a.gain * (a.noise_scale ? a.noise_scale[b] : 1.f);
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
   // fused toRGB as one more MFMA: B rows 0..2 = bf16(hi) part of the pre-modulated RGB weights, rows 8..10 = the
   // bf16 remainder (w = hi + lo to ~2^-17), everything else zero; rgb[c] = acc[row c] + acc[row 8+c], both of

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void lowres_epilogue_kernel(ConvArgs a, const 
   const int Ho = a.H * a.up, Wo = a.W * a.up;
   const long opix = (long)(gy * a.up + pa) * Wo + gx * a.up + pb;
   float nz = 0.f;
-  if (a.noise) nz = a.noise[(long)b * a.noise_bstride + opix] * a.noise_strength;
+  if (a.noise) nz = a.noise[(long)b * a.noise_bstride + opix] * a.noise_strength * (a.noise_scale ? a.noise_scale[b] : 1.f);
   float4 dv = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.d) dv = *reinterpret_cast<const float4*>(a.d + (long)b * a.Co + co);
   if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + co);

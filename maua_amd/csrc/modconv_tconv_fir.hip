@@ -276,7 +276,7 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
     if (fir_on) {
 #pragma unroll
       for (int e = 0; e < 4; e++) { dv[e] *= 0.0625f * u.gain; bv[e] *= u.gain; }
-      const float nzs = u.noise_strength * u.gain;
+      const float nzs = u.noise_strength * u.gain * (u.noise_scale ? u.noise_scale[b] : 1.f);
       const float cl = u.clamp >= 0.f ? u.clamp : 3.0e38f;
       char* yb = reinterpret_cast<char*>(u.y) + (long)b * Ho * Wo * a.Co * 2;
       const int cho2 = pc * 16;

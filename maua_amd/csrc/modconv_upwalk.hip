@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_row
         }
   }
   if (tid < CO) bias_s[tid] = (a.bias ? a.bias[tid] : 0.f) * a.gain;
-  const float nz_scale = a.noise_strength * a.gain;
+  const float nz_scale = a.noise_strength * a.gain * (a.noise_scale ? a.noise_scale[b] : 1.f);
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
 
   // ---- input rows: piece e = tid + 256 i of the 66-pixel row -> (pixel, 16-byte piece); rows / columns outside the
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       }
       __syncthreads();
       // ============================================================ conv0: half-folded walk (see upwalk_kernel) + staging
-      const float nz_scale = a.noise_strength * a.gain;
+      const float nz_scale = a.noise_strength * a.gain * (a.noise_scale ? a.noise_scale[b] : 1.f);
       const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
       const char* nbase = a.noise ? reinterpret_cast<const char*>(a.noise + (long)b * a.noise_bstride) : nullptr;
       const char* xbase = reinterpret_cast<const char*>(a.x) + (long)b * a.H * a.W * CI * 2;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       __syncthreads();
       // ============================================================ conv1 + toRGB + skip on the ring rows
       const float rgb_b0 = c.rgb_bias[0], rgb_b1 = c.rgb_bias[1], rgb_b2 = c.rgb_bias[2];
-      const float nz_scale = c.noise_strength * c.gain;
+      const float nz_scale = c.noise_strength * c.gain * (c.noise_scale ? c.noise_scale[b] : 1.f);
       const float cl = c.clamp >= 0.f ? c.clamp : 3.0e38f;
       const char* nbase = c.noise ? reinterpret_cast<const char*>(c.noise + (long)b * c.noise_bstride) : nullptr;
       const int pcol = widx * 32 + r;                     // column inside the strip; ring pixel of tap dx: pcol + dx

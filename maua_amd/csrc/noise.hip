@@ -161,6 +161,55 @@ __global__ __launch_bounds__(256) void noise_loop_batch_write_kernel(NoiseBatch 
                    nb.out[l] + (long)b * hw);
 }
 
+// RAW mode (round 4): ONE pass over every map - the un-normalised values are written and the squares summed per block in the same
+// sweep (the two-pass form evaluates sin(cos(.)) twice per value: 0.31 + 0.50 ms per 128 frames, both passes bound by those
+// instructions); a tiny second kernel turns the partial sums into the per-(layer, sample) factor 1 / (rms + eps) that the
+// consuming convolution epilogues multiply into their noise strength (ConvArgs / HiresArgs / UpfirArgs.noise_scale).
+// Same per-thread sweep as loop_write_slice; partial sums in a fixed order: deterministic.
+constexpr int NZ_RAW_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void noise_loop_batch_raw_kernel(NoiseBatch nb, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  const int l = blockIdx.z, b = blockIdx.y;
+  const int nblk = nb.wblk[l];
+  if ((int)blockIdx.x >= nblk) return;
+  const int hw = nb.hw[l];
+  const float* __restrict__ planes = nb.planes[l];
+  const float id = nb.idx[l][nb.i0 + b], inv_s = nb.inv_s[l];
+  float* __restrict__ out = nb.out[l] + (long)b * hw;
+  float acc = 0.f;
+  if ((hw & 3) == 0) {
+    const float4* p0 = reinterpret_cast<const float4*>(planes);
+    const float4* p1 = reinterpret_cast<const float4*>(planes + hw);
+    const float4* p2 = reinterpret_cast<const float4*>(planes + 2 * (long)hw);
+    float4* o = reinterpret_cast<float4*>(out);
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < (hw >> 2); v += nblk * 256) {
+      const float4 a = p0[v], bb = p1[v], c = p2[v];
+      const float x = loop_value(id, a.x, bb.x, c.x, inv_s), y = loop_value(id, a.y, bb.y, c.y, inv_s);
+      const float z = loop_value(id, a.z, bb.z, c.z, inv_s), w = loop_value(id, a.w, bb.w, c.w, inv_s);
+      o[v] = make_float4(x, y, z, w);
+      acc += x * x; acc += y * y; acc += z * z; acc += w * w;
+    }
+  } else {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += nblk * 256) {
+      const float v = loop_value(id, planes[p], planes[hw + p], planes[2 * (long)hw + p], inv_s);
+      out[p] = v;
+      acc += v * v;
+    }
+  }
+  const float t = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[((long)l * nb.B + b) * NZ_RAW_BLOCKS + blockIdx.x] = t;
+}
+
+// scales[l * B + b] = 1 / (sqrt(mean v^2) + eps) from the blocks' partial sums (fixed order)
+__global__ __launch_bounds__(256) void noise_loop_batch_scale_kernel(NoiseBatch nb, int n, const float* __restrict__ partial,
+                                                                     float* __restrict__ scales) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * nb.B) return;
+  const int l = i / nb.B;
+  scales[i] = loop_inv_denom(partial + (long)i * NZ_RAW_BLOCKS, nb.wblk[l], nb.hw[l]);
+}
+
 __global__ __launch_bounds__(256) void noise_mix_kernel(const float* __restrict__ noise, const float* __restrict__ noise2,
                                                         const float* __restrict__ mod, int M, int hw,
                                                         float* __restrict__ out) {
@@ -244,6 +293,33 @@ int maua_noise_loop_batch(maua_ctx* ctx, int n, const float* const* planes, cons
   hipLaunchKernelGGL(noise_loop_batch_sumsq_kernel, dim3(NZ_BLOCKS, B, n), dim3(256), 0, ctx->stream, nb, partial);
   hipLaunchKernelGGL(noise_loop_batch_write_kernel, dim3(max_wblk, B, n), dim3(256), 0,
                      ctx->stream, nb, partial);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+int maua_noise_loop_batch_raw(maua_ctx* ctx, int n, const float* const* planes, const float* const* idx, const int* h,
+                              const int* w, const float* sigma, int i0, int B, float* const* out, float* scales) {
+  MAUA_REQUIRE(ctx, "maua_noise_loop_batch_raw: ctx is NULL");
+  if (B == 0 || n == 0) return MAUA_OK;
+  MAUA_REQUIRE(planes && idx && h && w && sigma && out && scales, "maua_noise_loop_batch_raw: NULL argument");
+  MAUA_REQUIRE(n <= NZ_MAX_LAYERS, "maua_noise_loop_batch_raw: at most 24 layers per call");
+  NoiseBatch nb{};
+  int max_wblk = 1;
+  for (int l = 0; l < n; l++) {
+    MAUA_REQUIRE(planes[l] && idx[l] && out[l] && sigma[l] != 0.f, "maua_noise_loop_batch_raw: NULL layer argument");
+    nb.planes[l] = planes[l]; nb.idx[l] = idx[l]; nb.out[l] = out[l];
+    nb.hw[l] = h[l] * w[l];
+    nb.inv_s[l] = (float)(50.0 / (double)sigma[l]);
+    nb.wblk[l] = noise_wblk(nb.hw[l]);
+    max_wblk = std::max(max_wblk, nb.wblk[l]);
+  }
+  static_assert(NZ_RAW_BLOCKS >= 256, "noise_wblk() returns at most 256 blocks");
+  nb.i0 = i0; nb.B = B;
+  if (int rc = scratch_reserve(ctx, (size_t)n * B * NZ_RAW_BLOCKS * sizeof(float))) return rc;
+  float* partial = (float*)ctx->scratch;
+  hipLaunchKernelGGL(noise_loop_batch_raw_kernel, dim3(max_wblk, B, n), dim3(256), 0, ctx->stream, nb, partial);
+  hipLaunchKernelGGL(noise_loop_batch_scale_kernel, dim3((unsigned)((n * B + 255) / 256)), dim3(256), 0, ctx->stream, nb, n,
+                     partial, scales);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

@@ -72,6 +72,8 @@ struct maua_synth {
   int tconv_fir = 256; // up-layers with inputs of at least this size: transposed conv + FIR + epilogue in ONE kernel, t stays in
                        // LDS (modconv_tconv_fir.hip); 0 = never.  Measured at B = 128 (pair -> fused): 256^2 inputs 3.61 -> 3.48 ms,
                        // 128^2 2.33 -> 2.62, 64^2 1.89 -> 2.65: the 1.42x MACs pay only where the t round trip was HBM-bound.
+  const float* nz_scales = nullptr;   // [num_layers][nz_scale_stride] per-sample noise factors (maua_synth_set_noise_scale) or NULL
+  long nz_scale_stride = 0;
   int tconv_min = 32;  // ... from this input size up (below: the phase kernels / the batch-wide low-resolution GEMM)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
   int tconv_dma = 2;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
@@ -614,6 +616,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       const float* nz = (noise && noise[li]) ? noise[li] : c.noise_const;
       const long nz_stride = (noise && noise[li]) ? (noise_bstride ? noise_bstride[li] : (long)c.oh * c.ow) : 0;
       const float nz_strength = (n->nv_compat & 2) ? c.noise_strength : 1.f;
+      // (un-normalised Loop maps: the factor 1 / (rms + eps) of each sample rides on the noise strength; only with caller-supplied maps)
+      const float* nz_scale = (n->nz_scales && noise && noise[li]) ? n->nz_scales + (long)li * n->nz_scale_stride : nullptr;
       const bool hooked = n->rs_layer == (int)li + 1;  // this layer's output is resized before anything reads it
       void* y = hooked ? n->act[cur] : n->keep_features ? c.feat : n->act[cur];
       const int hin = std::min(c.ih, c.iw), hin_max = std::max(c.ih, c.iw);
@@ -647,7 +651,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       if (premod_in) {
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = nullptr; a.d = c.d;
-        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength;
+        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength; a.noise_scale = nz_scale;
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = 1;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
@@ -669,7 +673,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       } else if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};
         a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
-        a.noise_strength = nz_strength; a.bias = c.bias; a.y = y;
+        a.noise_strength = nz_strength; a.noise_scale = nz_scale; a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
         if (fuse_rgb_ok) {  // conv1: the block's toRGB + skip rides on the epilogue tile
@@ -707,6 +711,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
               f.x = nullptr; f.w = c1.wt; f.s = c1.s; f.d = c1.d; f.noise = nz1;
               f.noise_bstride = (noise && noise[li + 1]) ? (noise_bstride ? noise_bstride[li + 1] : (long)c1.oh * c1.ow) : 0;
               f.noise_strength = (n->nv_compat & 2) ? c1.noise_strength : 1.f;
+              f.noise_scale = (n->nz_scales && noise && noise[li + 1]) ? n->nz_scales + (long)(li + 1) * n->nz_scale_stride : nullptr;
               f.bias = c1.bias; f.y = nullptr;
               f.B = B; f.H = c1.ih; f.W = c1.iw; f.Ci = c1.Ci; f.Co = c1.Co; f.up = 1;
               f.act = MAUA_ACT_LRELU; f.alpha = 0.2f; f.gain = std::sqrt(2.0f); f.clamp = 256.f;
@@ -747,7 +752,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           if (n->tconv_fir > 0 && hin >= n->tconv_fir && tconv_fir_supported(n->dtype, c.Ci, c.Co, c.ih, c.iw)) {
             // the whole layer in one kernel: t never leaves LDS (bit-identical output)
             UpfirArgs u{};
-            u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
+            u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength; u.noise_scale = nz_scale;
             u.bias = c.bias; u.B = B; u.H = c.ih; u.W = c.iw; u.Co = c.Co;
             if (premod_out) {
               u.out_scale = n->convs[li + 1].s;
@@ -777,7 +782,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         if (!up_fused) {
         prof_mark(n, "conv0_tconv");  // (profile mode: this up-layer occupies two slots)
         UpfirArgs u{};
-        u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength;
+        u.t = n->tbuf; u.y = y; u.d = c.d; u.noise = nz; u.noise_bstride = nz_stride; u.noise_strength = nz_strength; u.noise_scale = nz_scale;
         u.bias = c.bias; u.B = B; u.H = c.ih; u.W = c.iw; u.Co = c.Co;
         if (premod_out) {
           u.out_scale = n->convs[li + 1].s;
@@ -789,7 +794,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       } else {
         ConvArgs a{};
         a.x = x; a.x_bstride = x_bstride; a.w = c.wt; a.s = c.s; a.d = c.d;
-        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength;
+        a.noise = nz; a.noise_bstride = nz_stride; a.noise_strength = nz_strength; a.noise_scale = nz_scale;
         a.bias = c.bias; a.y = y;
         a.B = B; a.H = c.ih; a.W = c.iw; a.Ci = c.Ci; a.Co = c.Co; a.up = c.up;
         a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = std::sqrt(2.0f); a.clamp = 256.f;
@@ -876,6 +881,14 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       if (int rc = launch_pack_rgb8(st, prev_img, rgb8_out, B, n->out_h, n->out_w)) return rc;
     prof_mark(n, "pack_rgb8");  // zero-length when the last block's epilogue packed the frame
   }
+  return MAUA_OK;
+}
+
+int maua_synth_set_noise_scale(maua_synth* n, const float* scales, long layer_stride) {
+  MAUA_REQUIRE(n, "maua_synth_set_noise_scale: NULL argument");
+  MAUA_REQUIRE(!scales || layer_stride > 0, "maua_synth_set_noise_scale: layer_stride must be positive");
+  n->nz_scales = scales;
+  n->nz_scale_stride = layer_stride;
   return MAUA_OK;
 }
 

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
   const float gfold = LRELU ? a.gain : 1.f;
 #pragma unroll
   for (int e = 0; e < EP2; e++) { dv[e] *= 0.0625f * gfold; bv[e] *= gfold; }
-  const float nzs = a.noise_strength * gfold;
+  const float nzs = a.noise_strength * gfold * (a.noise_scale ? a.noise_scale[b] : 1.f);
   const float cl = a.clamp >= 0.f ? a.clamp : 3.0e38f;
 
   // out row yo needs the horizontal sums of t rows yo-1 .. yo+2 (rows outside [0, Ht) are zero)

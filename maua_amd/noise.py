@@ -52,11 +52,36 @@ class Loop(Noise):
         return out
 
 
-def loop_batch(modules, i, b):
-    """forward(i, b) of a list of Loop modules in one C call (two launches for all layers) -> list of [b,h,w]."""
+class RawNoise(list):
+    """Un-normalised Loop maps of one batch ([b, h, w] per layer) + ``scales`` [n_layers, b]: the factor 1 / (rms + eps) of every
+    (layer, sample) that noise.py:52 divides by.  ``SynthesisNetwork.forward(noise=...)`` hands both to the library, whose
+    convolution epilogues apply the factor; ``normalised()`` gives the tensors the reference's modules return."""
+    scales = None
+
+    def normalised(self):
+        return [m * self.scales[l, : m.shape[0], None, None] for l, m in enumerate(self)]
+
+
+def loop_batch(modules, i, b, raw=False):
+    """forward(i, b) of a list of Loop modules in one C call (two launches for all layers) -> list of [b,h,w].
+    ``raw=True``: the maps un-normalised, written in ONE pass, as a ``RawNoise`` carrying the per-sample factors (what the
+    render loops use: the normalised form evaluates sin(cos(.)) twice per value)."""
     n = len(modules)
     if not all(isinstance(m, Loop) for m in modules):
         return [m.forward(i, b) for m in modules]
+    if raw:
+        res = [m._resident() for m in modules]
+        outs = RawNoise(m._out(max(0, min(b, m.length - i))) for m in modules)
+        nb = int(outs[0].shape[0])
+        outs.scales = torch.empty((n, max(nb, 1)), dtype=torch.float32, device=outs[0].device)
+        P = (C.c_void_p * n)(*[r[0].data_ptr() for r in res])
+        I = (C.c_void_p * n)(*[r[1].data_ptr() for r in res])
+        O = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        H = (C.c_int * n)(*[m.size[0] for m in modules])
+        W = (C.c_int * n)(*[m.size[1] for m in modules])
+        S = (C.c_float * n)(*[float(m.sigma) for m in modules])
+        L.check(L.lib().maua_noise_loop_batch_raw(L.ctx(), n, P, I, H, W, S, int(i), nb, O, L.ptr(outs.scales)))
+        return outs
     res = [m._resident() for m in modules]
     outs = [m._out(max(0, min(b, m.length - i))) for m in modules]
     P = (C.c_void_p * n)(*[r[0].data_ptr() for r in res])

@@ -81,5 +81,5 @@ def warm_up(device="cuda"):
     rng = torch.Generator().manual_seed(1)
     noise = [Loop(rng, n, (s[3], s[3]), n_loops=2, sigma=5) for s in net.layer_shapes()]
     u8 = torch.empty((n, res, res, 3), dtype=torch.uint8, device=device)
-    net(lat.contiguous(), noise=loop_batch(noise, 0, n), rgb8_out=u8)
+    net(lat.contiguous(), noise=loop_batch(noise, 0, n, raw=True), rgb8_out=u8)
     return u8

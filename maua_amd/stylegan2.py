@@ -327,7 +327,17 @@ class SynthesisNetwork(torch.nn.Module):
             oh, ow = self.output_hw
             out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=ws.device)
         ptrs, strides, keep = self._noise_args(noise, B)
-        L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
+        # un-normalised Loop maps (noise.loop_batch(..., raw=True)) bring their per-(layer, sample) factors 1 / (rms + eps) along:
+        # the convolution epilogues multiply them into the noise strength (the maps are written once instead of twice)
+        sc = getattr(noise, "scales", None)
+        if sc is not None and (sc.shape[0] != self.num_layers or sc.shape[1] < B):
+            raise ValueError(f"noise scales must be [{self.num_layers}, >= {B}], got {tuple(sc.shape)}")
+        L.check(L.lib().maua_synth_set_noise_scale(net, L.ptr(sc), C.c_long(0 if sc is None else sc.stride(0))))
+        try:
+            L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
+        finally:
+            if sc is not None:
+                L.check(L.lib().maua_synth_set_noise_scale(net, None, C.c_long(0)))
         del keep
         return out if out is not None else rgb8_out
 

@@ -523,3 +523,40 @@ def test_fused_up_layer_is_bit_identical_to_the_two_launch_path():
     assert tuple(res[0].shape) == (B, 3, 320, 768) and torch.equal(res[0], res[32])
     net.set_resize(None)
     L.check(L.lib().maua_synth_set_option(h, b"tconv_fir", 256))
+
+
+def test_raw_noise_maps_with_per_sample_factors_equal_the_normalised_maps():
+    """noise.loop_batch(raw=True): the Loop maps un-normalised in ONE pass + the factor 1 / (rms + eps) per (layer, sample), applied by
+    the convolution epilogues (every kernel that takes a noise operand: low-resolution GEMM, generic, LDS-direct, tconv + FIR pair,
+    fused up-layer, register-stationary, both halves of the fused walk).  Against the two-pass normalised maps (noise.py:42-53):
+    maps x factor == normalised maps to f32 rounding; the f32-mode image of a 256^2 network (all kernel families but the walk)
+    within 2e-6 of its range (u8 frames equal on >= 99.9 % of the bytes) and the bf16 1024^2 frames (the walk) at PSNR >= 70 dB; partial batches; a batch
+    whose factors are handed over equals the same frames rendered one by one."""
+    from maua_amd.noise import Loop, loop_batch
+    from maua_amd.stylegan2 import SynthesisNetwork
+    for res, dt, cbase, cmax, wd in ((256, torch.float32, 8192, 128, 64), (1024, torch.bfloat16, 32768, 512, 512)):
+        net = SynthesisNetwork(wd, res, 3, channel_base=cbase, channel_max=cmax, dtype=dt, generator=torch.Generator().manual_seed(0))
+        T, B = 11, 5
+        mods = [Loop(torch.Generator().manual_seed(43), T, (s[3], s[3]), n_loops=2, sigma=5) for s in net.layer_shapes()]
+        ws = torch.randn(T, net.num_ws, wd, generator=torch.Generator().manual_seed(1)).cuda()
+        for i0, b in ((2, B), (8, B)):                       # (8, 5): only 3 frames are left
+            raw, nrm = loop_batch(mods, i0, b, raw=True), loop_batch(mods, i0, b)
+            nb = raw[0].shape[0]
+            assert nb == min(b, T - i0) and tuple(raw.scales.shape) == (len(mods), nb)
+            for a, c in zip(raw.normalised(), nrm):
+                assert float((a - c).abs().max()) <= 4e-6 * float(c.abs().max())
+            u_raw = torch.empty((nb, res, res, 3), dtype=torch.uint8, device="cuda")
+            u_nrm = torch.empty_like(u_raw)
+            img_raw = net(ws[i0:i0 + nb], noise=raw, rgb8_out=u_raw, out=torch.empty((nb, 3, res, res), device="cuda"))
+            img_nrm = net(ws[i0:i0 + nb], noise=nrm, rgb8_out=u_nrm, out=torch.empty((nb, 3, res, res), device="cuda"))
+            rng = float(img_nrm.max() - img_nrm.min())
+            if dt == torch.float32:
+                assert float((img_raw - img_nrm).abs().max()) <= 2e-6 * rng
+            else:
+                assert psnr(img_raw.cpu(), img_nrm.cpu()) >= 70.0
+            # (bf16: every layer's output is rounded, a last-bit difference in the noise term flips some of those roundings)
+            assert float((u_raw == u_nrm).float().mean()) >= (0.999 if dt == torch.float32 else 0.95)
+            one = loop_batch(mods, i0 + 1, 1, raw=True)
+            u_one = torch.empty((1, res, res, 3), dtype=torch.uint8, device="cuda")
+            net(ws[i0 + 1:i0 + 2], noise=one, rgb8_out=u_one)
+            assert torch.equal(u_one[0], u_raw[1])          # position in the batch does not matter
