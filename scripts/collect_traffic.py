@@ -61,7 +61,7 @@ def bench_name(k):
     if m:
         return "modconv_hires_kernel<%s,%s,%s>" % m.groups()
     for n in ("torgb_kernel", "pack_rgb8_kernel", "styles_affine_kernel", "styles_demod_kernel",
-              "noise_loop_batch_sumsq_kernel", "noise_loop_batch_write_kernel"):
+              "noise_loop_batch_sumsq_kernel", "noise_loop_batch_write_kernel", "noise_loop_batch_raw_kernel"):
         if n in k:
             return n
     return None
