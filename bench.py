@@ -243,6 +243,17 @@ def cpu_baseline(seconds):
                       f"(B=1, fp32 oracle: noise + synthesis + u8), {dt:.1f} s"}
 
 
+def leg_traffic(leg):
+    """HBM bytes per unit of work of an extra leg (profiles/r04_<leg>_traffic.json, scripts/collect_leg_traffic.py: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the leg's own script, all kernels summed) -> (bytes, note) or (None, why)."""
+    p = Path(__file__).resolve().parent / "profiles" / f"r04_{leg}_traffic.json"
+    try:
+        v = json.loads(p.read_text())
+        return float(v["bytes_per_unit"]), f"replayed from profiles/{p.name}: {v['unit']} ({v['units_in_run']} units in the profiled run)"
+    except Exception as e:
+        return None, f"unmeasured ({type(e).__name__}: no PMC file for this leg)"
+
+
 def measured_traffic(kernel_name, batch=None):
     """HBM bytes per launch measured with rocprofv3 --pmc in an EARLIER run of this same command: profiles/traffic.json,
     written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the corrections of
@@ -288,12 +299,14 @@ def extra_diffusion(batch=16, steps=100, size=256):
         best = dt if best is None else min(best, dt)
     gf = unet_gflop(model, size, size)
     tf = gf * batch * steps / best / 1e3
+    tr, tr_note = leg_traffic("diffusion")
     return {"metric": "samples/sec, guided-diffusion 256x256, 100-step DDIM (configs[3])", "value": batch / best, "unit": "samples/s",
             "batch": batch, "steps": steps, "seconds_per_batch": best, "ms_per_step": best / steps * 1e3, "dtype": "bf16",
             "data": "synthetic (random-init UNet of the reference's configuration, 552.8 M parameters)",
             "hipgraph": model.graph_active(), "finite": bool(torch.isfinite(pred).all()),
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
-                         "gflop_per_forward_per_sample": gf, "traffic": None, "traffic_note": "unmeasured (no PMC pass for this leg)"}}
+                         "gflop_per_forward_per_sample": gf, "traffic": tr,
+                         "traffic_note": tr_note + " - collected at batch 8, this leg runs batch %d (weights, 1.1 GB per forward, do not scale)" % batch}}
 
 
 def extra_upscale(steps=3, frames=8, upscale_batch=4):
@@ -325,12 +338,14 @@ def extra_upscale(steps=3, frames=8, upscale_batch=4):
     rdb = 9 * sum((f + k * g) * (f if k == 4 else g) for k in range(5))
     macs_px = 23 * 3 * rdb + 9 * (3 * f + f * f) + 9 * f * f * 4 + 9 * f * f * 16 + 9 * f * f * 16 + 9 * f * 3 * 16
     tf = 2 * macs_px * RES * RES / 1e12 / dt     # algorithmic: the 1024^2 frame (the pre_pad border's 2 % extra pixels are not counted)
+    tr, tr_note = leg_traffic("upscale")
     return {"metric": "frames/sec per GPU, 1024^2 StyleGAN2 render -> RealESRGAN x4 -> 4096^2 u8 (configs[4], one GPU's slice)",
             "value": 1.0 / dt, "unit": "frames/s", "ms_per_frame": dt * 1e3, "dtype": "bf16", "data": "synthetic",
             "frames_per_render_call": frames, "frames_per_upscaler_call": upscale_batch,
             "path": "SynthesisNetwork(rgb8_out) -> RealESRGANer.enhance_frames (pre_pad 10), what generate(upscale='x4plus') runs per batch",
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
-                         "traffic": None, "traffic_note": "unmeasured (no PMC pass for this leg)"}}
+                         "traffic": tr, "traffic_note": tr_note,
+                         "frac_hbm_of_measured_traffic": None if tr is None else tr / dt / 1e9 / HBM_PEAK_GBS}}
 
 
 def main():
