@@ -203,6 +203,11 @@ def test_enhance_frames_equals_enhance_per_frame_on_ragged_sizes():
             for i in range(3):
                 want = torch.from_numpy(model.enhance(frames[i].float().numpy())[0])
                 close8(got[i], want, 1e-3 if dt == torch.float32 else None)
+    # the compact network (SRVGGNetCompact, "xsx4-animevideo") through the same entry
+    vgg = load_model("xsx4-animevideo", dtype=torch.float32, allow_random_init=True)
+    got = vgg.enhance_frames(frames.cuda()).cpu()
+    for i in range(3):
+        close8(got[i], torch.from_numpy(vgg.enhance(frames[i].float().numpy())[0]), 1e-3)
     model = load_model("x4plus-anime", dtype=torch.bfloat16, allow_random_init=True)
     a = model.enhance_frames(frames.cuda()).cpu()
     os.environ["MAUA_RRDB_DMA"] = "0"
