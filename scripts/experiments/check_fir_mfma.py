@@ -1,4 +1,5 @@
-"""GPU box: the fused up-layer's kernels against each other on SEPARATE network objects (own workspaces: no stale data can pass):
+"""(Needs modconv_tconv_pc.hip wired into the build: synth options `tconv_pc` / `fir_mfma`, see README.md here.)
+GPU box: the fused up-layer's kernels against each other on SEPARATE network objects (own workspaces: no stale data can pass):
 arm 0 = tconv_fir_kernel, FIR on the vector ALUs (bit-identical to the two-launch path); arm 1 = the form named on the command
 line: "fir" = tconv_fir_kernel's MFMA-FIR form, "pc" (default) = the persistent producer / consumer kernel.  Prints max
 difference / PSNR / u8 agreement on a 256^2 network whose 32^2..128^2 up-layers all take the fused kernel (overhanging tiles,
