@@ -190,6 +190,7 @@ def test_enhance_frames_equals_enhance_per_frame_on_ragged_sizes():
             assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= frac, (int(d.max()), float((d > 0).float().mean()))
         else:
             ps = 10 * np.log10(255.0 ** 2 / max(float((d.float() ** 2).mean()), 1e-12))
+            print("bf16 u8 PSNR between two summation orders:", ps)
             assert ps >= 35.0, ps
     import os
     from maua_amd.super import load_model
@@ -224,9 +225,10 @@ def test_full_size_upscale_1024_to_4096_u8():
     through the product call (enhance_frames: pre_pad 10 -> 1034^2 input, overhanging tiles).  Checked (i) against oracle/super.py
     on a 256 x 256 crop of the INPUT that contains the frame's top-left corner: the network is convolutional, so the crop's output
     equals the full frame's wherever the crop's other borders are further away than the information that reaches a pixel - compared
-    on the 512 x 512 output block at the corner, bf16 vs the fp32 oracle: PSNR >= 35 dB, <= 2 % of the u8 values off by more than 2;
+    on the 512 x 512 output block at the corner, bf16 vs the fp32 oracle: PSNR >= 45 dB (measured 51.4), <= 0.2 % of the u8 values off by
+    more than 2 (measured 0.014 %);
     (ii) tiling invariance at full size: enhance_frames with tile = 512 (tile_pad 10) agrees with the whole-image pass away from
-    tile seams the same way (PSNR >= 35 dB over the frame; identical where no seam is within reach is not guaranteed by the
+    tile seams the same way (PSNR >= 60 dB over the frame, measured 76.8; identical where no seam is within reach is not guaranteed by the
     published tiling either); (iii) the frame is not saturated or constant."""
     from maua_amd.stylegan2 import SynthesisNetwork
     from maua_amd.super import load_model
@@ -263,10 +265,12 @@ def test_full_size_upscale_1024_to_4096_u8():
     got = big[0, :512, :512].cpu()
     w = torch.from_numpy(want[:512, :512])
     d = (got.int() - w.int()).abs()
-    assert psnr8(got, w) >= 35.0 and float((d > 2).float().mean()) <= 0.02, (psnr8(got, w), float((d > 2).float().mean()))
+    print("4096^2 corner block vs fp32 oracle: PSNR", psnr8(got, w), "fraction off by > 2 LSB", float((d > 2).float().mean()))
+    assert psnr8(got, w) >= 45.0 and float((d > 2).float().mean()) <= 0.002, (psnr8(got, w), float((d > 2).float().mean()))
     # (ii) tiled vs whole image at full size
     tm = load_model("x4plus", dtype=torch.bfloat16, allow_random_init=True, tile=512)
     tm.model.load_state_dict(p)
     tm.model.set_channel_flip(True)
     tiled = tm.enhance_frames(frame)
-    assert tuple(tiled.shape) == (1, 4096, 4096, 3) and psnr8(tiled, big) >= 35.0, psnr8(tiled, big)
+    print("tiled vs whole image at 4096^2: PSNR", psnr8(tiled, big))
+    assert tuple(tiled.shape) == (1, 4096, 4096, 3) and psnr8(tiled, big) >= 60.0, psnr8(tiled, big)
