@@ -16,9 +16,10 @@ def frame_range(n_frames, rank, world):
 def synthetic_audio(n_samples, sr, seed=1234, fast=False):
     """SURVEY 8(d) synthetic clip: 220 Hz tone + 2 Hz click train + noise, float32 mono.
     Default: everything from ONE generator in float64 (the waveform the committed fixtures were made from - do not change).
-    ``fast=True`` (the benchmark clip): the click amplitudes from one generator (``seed``), the noise floor from a second one
-    (``seed + 1``) on a helper thread, both float32 draws - torch's CPU samplers are single-threaded, and the float64 normal draws
-    alone were 0.05 s of the 3600-frame clip's 0.09 s of set-up.  Same signal model, different random numbers."""
+    ``fast=True`` (the benchmark clip): the click amplitudes from one generator (``seed``), drawn only where a click sounds, the
+    noise floor from two more (``seed + 1``, ``seed + 2``: one half of the clip each, on helper threads), all float32 draws -
+    torch's CPU samplers are single-threaded, and the float64 normal draws alone were 0.05 s of the 3600-frame clip's 0.09 s of
+    set-up.  Same signal model (tone + 2 Hz clicks of 5 % duty + noise floor), different random numbers."""
     t = torch.arange(n_samples, dtype=torch.float64).div_(sr)
     if not fast:
         g = torch.Generator().manual_seed(seed)
@@ -30,17 +31,33 @@ def synthetic_audio(n_samples, sr, seed=1234, fast=False):
         t.mul_(2 * math.pi * 220).sin_().mul_(0.3).add_(u).add_(nz.mul_(0.01))
         return t.float()
     import threading
+    half = n_samples // 2
     box = {}
 
-    def noise():
-        box["nz"] = torch.randn(n_samples, generator=torch.Generator().manual_seed(seed + 1), dtype=torch.float32)
-    th = threading.Thread(target=noise)
-    th.start()
-    u = torch.rand(n_samples, generator=torch.Generator().manual_seed(seed), dtype=torch.float32)
-    u.sub_(0.5).mul_(0.2).mul_(t.mul(2).remainder_(1).lt_(0.05))
-    out = t.mul_(2 * math.pi * 220).sin_().mul_(0.3).float().add_(u)     # (the phase in float64)
-    th.join()
-    return out.add_(box["nz"], alpha=0.01)
+    def noise(k, lo, hi):   # the noise floor in two halves, each from its own generator (seed + 1, seed + 2), each on its own thread
+        box[k] = torch.randn(hi - lo, generator=torch.Generator().manual_seed(seed + 1 + k), dtype=torch.float32)
+    ths = [threading.Thread(target=noise, args=(0, 0, half)), threading.Thread(target=noise, args=(1, half, n_samples))]
+    for th in ths:
+        th.start()
+    out = t.mul_(2 * math.pi * 220).sin_().mul_(0.3).float()              # (the phase in float64)
+    # click train: 2 Hz, each click = the first 5 % of its half-second, amplitudes 0.2 (u - 0.5) drawn only where a click sounds
+    period = sr / 2.0
+    n_clicks = int(math.ceil(n_samples / period))
+    width = int(math.floor(0.05 * period))
+    u = torch.rand((n_clicks, max(width, 1)), generator=torch.Generator().manual_seed(seed), dtype=torch.float32).sub_(0.5).mul_(0.2)
+    if period == int(period) and n_samples % int(period) == 0 and width > 0:
+        out.view(n_clicks, int(period))[:, :width].add_(u[:, :width])
+    else:
+        for k in range(n_clicks):
+            lo = int(math.ceil(k * period))
+            hi = min(n_samples, lo + width)
+            if hi > lo:
+                out[lo:hi].add_(u[k, : hi - lo])
+    for th in ths:
+        th.join()
+    out[:half].add_(box[0], alpha=0.01)
+    out[half:].add_(box[1], alpha=0.01)
+    return out
 
 
 def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4, fast_audio=True):
