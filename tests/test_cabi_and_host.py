@@ -333,3 +333,29 @@ def test_host_layer_signatures_match_the_reference():
             elif torch.is_tensor(want):
                 want, got = float(want), float(got)
             assert got == want, (e["name"], e["reference"], n, d, p.default)
+
+
+def test_benchmark_setup_helpers_are_deterministic():
+    """The set-up shortcuts of bench.py (round 4): per-tensor parallel weight draws and the fast benchmark waveform depend on their
+    seed only (not on thread timing), keep the parameter set / the signal model, and leave the fixture waveform untouched."""
+    import torch
+    from maua_amd.pipeline import synthetic_audio
+    from maua_amd.stylegan2 import init_synthesis_params, init_synthesis_params_parallel
+    a = init_synthesis_params_parallel(64, 64, channel_base=2048, channel_max=64, seed=3, workers=4)
+    b = init_synthesis_params_parallel(64, 64, channel_base=2048, channel_max=64, seed=3, workers=2)
+    c = init_synthesis_params(64, 64, channel_base=2048, channel_max=64, generator=torch.Generator().manual_seed(3))
+    assert set(a) == set(c) and all(a[k].shape == c[k].shape for k in a)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(a["bs.2.conv0.bias"], c["bs.2.conv0.bias"]) and not torch.equal(a["bs.2.conv0.weight"], c["bs.2.conv0.weight"])
+    assert abs(float(a["bs.3.conv1.weight"].std()) - 1.0) < 0.02
+    d = init_synthesis_params_parallel(64, 64, channel_base=2048, channel_max=64, seed=4, workers=4)
+    assert not torch.equal(a["bs.1.conv1.weight"], d["bs.1.conv1.weight"])
+    n, sr = 5 * 15360 + 77, 30720     # not a whole number of click periods: the slow placement path
+    w1, w2 = synthetic_audio(n, sr, seed=9, fast=True), synthetic_audio(n, sr, seed=9, fast=True)
+    assert w1.dtype == torch.float32 and tuple(w1.shape) == (n,) and torch.equal(w1, w2)
+    whole = synthetic_audio(4 * 15360, sr, seed=9, fast=True)             # whole periods: the reshaped placement path
+    tone = 0.3 * torch.sin(2 * torch.pi * 220 * torch.arange(4 * 15360, dtype=torch.float64) / sr).float()
+    dev = (whole - tone).abs().reshape(4, 15360)
+    assert float(dev[:, :768].mean()) > 3 * float(dev[:, 768:].mean())    # clicks sit in the first 5 % of every half second
+    ref = synthetic_audio(4 * 15360, sr, seed=9)                          # the fixture waveform: same model, same level
+    assert abs(float(ref.std()) - float(whole.std())) < 5e-3 and not torch.equal(ref, whole)
