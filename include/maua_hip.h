@@ -63,6 +63,10 @@ int maua_ctx_clock_stamp(maua_ctx* ctx, unsigned long long* stamp_dev);
 void maua_ctx_destroy(maua_ctx* ctx);
 
 /* ---- B1: operator layer (NCHW contiguous, like the reference tensors) --------------------------- */
+/* replaces the tensor additions of SynthesisBlock.forward, inference/stylegan2.py:360 (`x = y + x`, "resnet") and :373
+ * (`img = img + y`) for callers that run the network one layer at a time: out = a + b over n elements, summed in f32 and
+ * rounded to dtype (F32 / BF16); out may alias a or b. */
+int maua_add(maua_ctx* ctx, const void* a, const void* b, void* out, long n, int dtype);
 /* replaces ops.py:65-84 bias_act (upstream plugin nv/torch_utils/ops/bias_act).
  * y = clamp(act(x + b[c]) * gain); b may be NULL; clamp < 0 disables clamping. */
 int maua_bias_act(maua_ctx* ctx, const void* x, const float* b, void* y, int N, int C, int H, int W, int dtype,

@@ -65,6 +65,48 @@ static int launch_bias_act(maua_ctx* ctx, const void* x, const float* b, void* y
   return MAUA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ residual add
+// out = a + b (summed in f32): the "resnet" blocks' x = y + x and the skip images' img + y (stylegan2.py:360, :373) for callers
+// that run the network a layer at a time.  HBM-bound: 16 bytes per lane per operand.
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long n,
+                                                  int vec) {
+  constexpr int V = 16 / sizeof(T);
+  const long stride = (long)gridDim.x * blockDim.x;
+  if (vec) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / V; i += stride) {
+      if constexpr (sizeof(T) == 4) {
+        float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      } else {
+        uint4 x = reinterpret_cast<const uint4*>(a)[i], y = reinterpret_cast<const uint4*>(b)[i];
+        const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+        unsigned r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          r[k] = pack2bf(__uint_as_float(xs[k] << 16) + __uint_as_float(ys[k] << 16),
+                         __uint_as_float(xs[k] & 0xffff0000u) + __uint_as_float(ys[k] & 0xffff0000u));
+        reinterpret_cast<uint4*>(o)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+      }
+    }
+    for (long i = (n / V) * V + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      Elem<T>::store(o + i, Elem<T>::load(a + i) + Elem<T>::load(b + i));
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      Elem<T>::store(o + i, Elem<T>::load(a + i) + Elem<T>::load(b + i));
+  }
+}
+
+template <typename T>
+static int launch_add(maua_ctx* ctx, const void* a, const void* b, void* o, long n) {
+  const int vec = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && ((uintptr_t)o % 16 == 0);
+  const long work = vec ? (n * (long)sizeof(T) + 15) / 16 : n;
+  const int grid = (int)std::min<long>((work + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL((add_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)a, (const T*)b, (T*)o, n, vec);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ upfirdn2d
 // reference ops.py:87-114.  One workgroup = one 16x64 output tile of one (n,c) plane.  The input footprint of
 // the tile (after zero-insertion only every up-th sample is non-zero, so the footprint is stored compacted at
@@ -285,6 +327,16 @@ int maua_bias_act(maua_ctx* ctx, const void* x, const float* b, void* y, int N, 
   if (dtype == MAUA_F32) return maua::launch_bias_act<float>(ctx, x, b, y, N, C, H, W, act, alpha, gain, clamp);
   if (dtype == MAUA_BF16) return maua::launch_bias_act<maua::bf16_t>(ctx, x, b, y, N, C, H, W, act, alpha, gain, clamp);
   return maua::fail("maua_bias_act: unsupported dtype");
+}
+
+int maua_add(maua_ctx* ctx, const void* a, const void* b, void* out, long n, int dtype) {
+  MAUA_REQUIRE(ctx, "maua_add: ctx is NULL");
+  MAUA_REQUIRE(n >= 0, "maua_add: negative size");
+  if (n == 0) return MAUA_OK;
+  MAUA_REQUIRE(a && b && out, "maua_add: NULL argument");
+  if (dtype == MAUA_F32) return maua::launch_add<float>(ctx, a, b, out, n);
+  if (dtype == MAUA_BF16) return maua::launch_add<maua::bf16_t>(ctx, a, b, out, n);
+  return maua::fail("maua_add: unsupported dtype");
 }
 
 int maua_upfirdn2d(maua_ctx* ctx, const void* x, const float* f, int fh, int fw, void* y, int N, int C, int H, int W,

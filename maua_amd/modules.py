@@ -164,7 +164,7 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv0(x, ws[:, w_idx], noise_mode, gain=1.0)
             x = self.conv1(x, ws[:, w_idx + 1], noise_mode, gain=sqrt(0.5))
             w_idx += 2
-            x = y + x
+            x = ops.add(y, x)
         else:
             x = self.conv0(x, ws[:, w_idx], noise_mode, gain=1.0)
             x = self.conv1(x, ws[:, w_idx + 1], noise_mode, gain=1.0)
@@ -173,5 +173,5 @@ class SynthesisBlock(torch.nn.Module):
             img = ops.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == "skip":
             y = self.torgb(x, ws[:, w_idx]).float()
-            img = (img + y) if img is not None else y
+            img = ops.add(img, y) if img is not None else y
         return x, img

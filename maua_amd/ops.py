@@ -130,6 +130,18 @@ def matmul_nt(a, b):
     return c
 
 
+def add(a, b, out=None):
+    """a + b on the HIP path (maua_add; f32 or bf16, summed in f32): the tensor additions of SynthesisBlock.forward
+    (inference/stylegan2.py:360 "resnet" residual, :373 skip image)."""
+    a = L.dev_tensor(a).contiguous()
+    b = L.dev_tensor(b, a.dtype).contiguous()
+    if a.shape != b.shape:
+        raise ValueError(f"add: shapes differ, {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().maua_add(L.ctx(a.device), L.ptr(a), L.ptr(b), L.ptr(out), C.c_long(a.numel()), L.dtype_id(a)))
+    return out
+
+
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     """ops.py:142-143 - the [P, D] prologue of the mapper (maua_normalize_2nd_moment: one wave per row)."""
     if x.dim() != 2 or dim not in (1, -1):

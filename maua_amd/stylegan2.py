@@ -39,8 +39,9 @@ def _randn(shape, generator):
 
 
 def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_base=32768, channel_max=512,
-                          generator=None) -> Dict[str, torch.Tensor]:
-    """Same tensors, same draw order as the reference constructors (stylegan2.py:296-337, :221-227, :263-265)."""
+                          generator=None, architecture="skip") -> Dict[str, torch.Tensor]:
+    """Same tensors, same draw order as the reference constructors (stylegan2.py:296-337, :221-227, :263-265; "orig" /
+    "resnet": a toRGB layer in the last block only, "resnet": the blocks' 1 x 1 skip convolution :331-337 drawn last)."""
     ch = channels_dict(img_resolution, channel_base, channel_max)
     f = ops.setup_filter([1, 3, 3, 1])
     p = {}
@@ -62,10 +63,14 @@ def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_bas
         else:
             layer(f"bs.{i}.conv0", cin, cout, r)
         layer(f"bs.{i}.conv1", cout, cout, r)
-        p[f"bs.{i}.torgb.affine.weight"] = _randn([cout, w_dim], generator)
-        p[f"bs.{i}.torgb.affine.bias"] = torch.ones([cout])
-        p[f"bs.{i}.torgb.weight"] = _randn([img_channels, cout, 1, 1], generator)
-        p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+        if architecture == "skip" or r == img_resolution:
+            p[f"bs.{i}.torgb.affine.weight"] = _randn([cout, w_dim], generator)
+            p[f"bs.{i}.torgb.affine.bias"] = torch.ones([cout])
+            p[f"bs.{i}.torgb.weight"] = _randn([img_channels, cout, 1, 1], generator)
+            p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+        if architecture == "resnet" and cin != 0:
+            p[f"bs.{i}.skip.resample_filter"] = f.clone()
+            p[f"bs.{i}.skip.weight"] = _randn([cout, cin, 1, 1], generator)
     return p
 
 
@@ -119,8 +124,9 @@ class SynthesisNetwork(torch.nn.Module):
         super().__init__()
         if img_channels != 3:
             raise NotImplementedError("img_channels must be 3")
-        if block_kwargs.get("architecture", "skip") != "skip":
-            raise NotImplementedError("only the 'skip' architecture (the reference default) is implemented")
+        self.architecture = block_kwargs.pop("architecture", "skip")
+        if self.architecture not in ("orig", "skip", "resnet"):
+            raise ValueError(f"architecture must be 'orig', 'skip' or 'resnet', got {self.architecture!r}")
         self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.channel_base, self.channel_max = channel_base, channel_max
@@ -130,7 +136,9 @@ class SynthesisNetwork(torch.nn.Module):
         self.dtype, self.nv_compat = dtype, bool(nv_compat)
         # (_params: clone() hands over an existing parameter dict - no random init, the RNG is not touched)
         self._params = dict(_params) if _params is not None else \
-            init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max, generator)
+            init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max, generator,
+                                  architecture=self.architecture)
+        self._dev_params = None  # "orig" / "resnet": device copies of the parameters for the layer-at-a-time forward
         self._net = None  # device handle, created on first use
         self._net_device = None
         self._keep_features = False
@@ -159,6 +167,7 @@ class SynthesisNetwork(torch.nn.Module):
                 self._params[k] = v.detach().float().cpu().contiguous()
             elif k.endswith("noise_strength"):
                 self._params[k] = v.detach().float().cpu().reshape(1)
+        self._dev_params = None
         self._destroy()
 
     def layer_shapes(self):
@@ -188,6 +197,9 @@ class SynthesisNetwork(torch.nn.Module):
         the one noise upload itself with the caller's generator (a draw here would come from the global RNG and be
         cached, so the caller's seed would never be used)."""
         L.require_device()
+        if self.architecture != "skip":
+            raise NotImplementedError(f"architecture {self.architecture!r} runs a layer at a time (forward only): the one-call "
+                                      "device network, feature capture and the resize / warp hooks are the 'skip' networks'")
         dev = torch.cuda.current_device()
         if self._net is None or self._net_device != dev:
             self._destroy()
@@ -259,7 +271,8 @@ class SynthesisNetwork(torch.nn.Module):
         """An independent network with the same parameters (own device object, own resize state): what every wrapper
         built from one cached checkpoint gets."""
         return SynthesisNetwork(self.w_dim, self.img_resolution, self.img_channels, self.channel_base, self.channel_max,
-                                dtype=self.dtype, nv_compat=self.nv_compat, _params=self._params)
+                                dtype=self.dtype, nv_compat=self.nv_compat, _params=self._params,
+                                architecture=self.architecture)
 
     def _apply_resize(self):
         r = self._resize
@@ -318,6 +331,8 @@ class SynthesisNetwork(torch.nn.Module):
         receives the packed frame (render/ffmpeg.py:72 + ops/io.py:47-70) in the same call."""
         if noise_mode != "const":
             raise NotImplementedError("noise_mode must be 'const' (the render path never uses 'random')")
+        if self.architecture != "skip":
+            return self._forward_layerwise(ws, noise, out, rgb8_out)
         net = self._handle()
         ws = L.dev_tensor(ws, torch.float32)
         B = ws.shape[0]
@@ -340,6 +355,67 @@ class SynthesisNetwork(torch.nn.Module):
                 L.check(L.lib().maua_synth_set_noise_scale(net, None, C.c_long(0)))
         del keep
         return out if out is not None else rgb8_out
+
+    def _forward_layerwise(self, ws, noise, out, rgb8_out):
+        """SynthesisBlock.forward, inference/stylegan2.py:340-382, for the "orig" and "resnet" architectures: one library call
+        per layer (maua_modconv2d with its fused bias_act, maua_upfirdn2d, maua_add) instead of the one-call network - these
+        architectures are not the reference's default and none of its shipped networks uses them, so they get the operator
+        path, not fused kernels.  "orig": no skip images, the last block's toRGB is the image; "resnet": y = skip(x) * sqrt(.5)
+        (1 x 1, up-sampled), x = conv1(conv0(x), gain sqrt(.5)), x = y + x."""
+        L.require_device()
+        ws = L.dev_tensor(ws, torch.float32)
+        B = ws.shape[0]
+        if tuple(ws.shape[1:]) != (self.num_ws, self.w_dim):
+            raise ValueError(f"ws must be [B, {self.num_ws}, {self.w_dim}], got {tuple(ws.shape)}")
+        if getattr(noise, "scales", None) is not None:
+            noise = noise.normalised()
+        if self._dev_params is None or next(iter(self._dev_params.values())).device != ws.device:
+            self._dev_params = {k: v.to(ws.device) for k, v in self._params.items()}
+        p = self._dev_params
+        resnet = self.architecture == "resnet"
+
+        def affine(prefix, w):    # FullyConnectedLayer (linear, bias_init 1): F.linear(w, W / sqrt(fan_in), b)
+            W = p[prefix + ".affine.weight"]
+            y = ops.matmul_nt(w.contiguous(), W * (1.0 / sqrt(W.shape[1])))
+            return ops.bias_act(y[:, :, None, None], p[prefix + ".affine.bias"])[:, :, 0, 0]
+
+        def layer(prefix, x, w, up, li, gain):
+            nz = noise[li] if noise is not None and li < len(noise) and noise[li] is not None else p[prefix + ".noise_const"]
+            strength = float(p[prefix + ".noise_strength"][0]) if self.nv_compat and (prefix + ".noise_strength") in p else 1.0
+            return ops.modulated_conv2d(x, p[prefix + ".weight"], affine(prefix, w), noise=nz, up=up, padding=1,
+                                        resample_filter=p[prefix + ".resample_filter"], flip_weight=self.nv_compat,
+                                        bias=p[prefix + ".bias"], act="lrelu", gain=sqrt(2.0) * gain, clamp=256.0 * gain,
+                                        noise_strength=strength)
+        x = None
+        w_idx = li = 0
+        for i, r in enumerate(self.block_resolutions):
+            g1 = 1.0
+            if i == 0:
+                x = p["bs.0.const"].to(self.dtype).unsqueeze(0).expand(B, -1, -1, -1).contiguous()
+            else:
+                y = None
+                if resnet:   # Conv2dLayer(1 x 1, bias=False, up=2), gain sqrt(.5): the 1 x 1 kernel commutes with the up-sampling
+                    wk = p[f"bs.{i}.skip.weight"]
+                    y = ops.conv2d_resample(x, wk * (sqrt(0.5) / sqrt(wk.shape[1])), padding=0)
+                    y = ops.upsample2d(y, p[f"bs.{i}.skip.resample_filter"], up=2)
+                    g1 = sqrt(0.5)
+                x = layer(f"bs.{i}.conv0", x, ws[:, w_idx], 2, li, 1.0)
+                w_idx, li = w_idx + 1, li + 1
+            x = layer(f"bs.{i}.conv1", x, ws[:, w_idx], 1, li, g1)
+            w_idx, li = w_idx + 1, li + 1
+            if i > 0 and resnet:
+                x = ops.add(y, x)
+        last = f"bs.{len(self.block_resolutions) - 1}.torgb"
+        cin = p[last + ".weight"].shape[1]
+        img = ops.modulated_conv2d(x, p[last + ".weight"], affine(last, ws[:, w_idx]) * (1.0 / sqrt(cin)), demodulate=False,
+                                   padding=0, bias=p[last + ".bias"], clamp=256.0).float()
+        if rgb8_out is not None:
+            # (render/ffmpeg.py:72 + ops/io.py:47-70: (img + 1) / 2 -> clamp -> * 255 -> round half even -> u8 HWC)
+            L.check(L.lib().maua_pack_rgb8(L.ctx(img.device), L.ptr(img), L.ptr(rgb8_out), B, img.shape[2], img.shape[3]))
+        if out is not None:
+            out.copy_(img)
+            return out
+        return img if rgb8_out is None else rgb8_out
 
     def get_feature(self, layer, B):
         shp = self.layer_shapes()[layer]

@@ -49,9 +49,10 @@ def layer_list(img_resolution, channel_base=32768, channel_max=512):
 
 # ----------------------------------------------------------------------------- random init
 def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_base=32768, channel_max=512,
-                          generator=None):
+                          generator=None, architecture="skip"):
     """Draw parameters in the order the reference constructors draw them
-    (stylegan2.py:296-337 block, :221-227 layer, :263-265 toRGB, :43-44 FC), so that
+    (stylegan2.py:296-337 block - toRGB only in the last block unless "skip", the 1 x 1 skip convolution only for
+    "resnet" -, :221-227 layer, :263-265 toRGB, :43-44 FC, :87-88 Conv2dLayer), so that
     ``torch.manual_seed(s); SynthesisNetwork(...)`` and this function with
     ``torch.Generator().manual_seed(s)`` produce the same tensors."""
     g = generator
@@ -79,9 +80,13 @@ def init_synthesis_params(img_resolution, w_dim=512, img_channels=3, channel_bas
         else:
             layer(f"bs.{i}.conv0", cin, cout, r)
         layer(f"bs.{i}.conv1", cout, cout, r)
-        fc(f"bs.{i}.torgb.affine", w_dim, cout, 1.0)
-        p[f"bs.{i}.torgb.weight"] = torch.randn([img_channels, cout, 1, 1], generator=g)
-        p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+        if architecture == "skip" or r == img_resolution:
+            fc(f"bs.{i}.torgb.affine", w_dim, cout, 1.0)
+            p[f"bs.{i}.torgb.weight"] = torch.randn([img_channels, cout, 1, 1], generator=g)
+            p[f"bs.{i}.torgb.bias"] = torch.zeros([img_channels])
+        if architecture == "resnet" and cin != 0:
+            p[f"bs.{i}.skip.resample_filter"] = f.clone()
+            p[f"bs.{i}.skip.weight"] = torch.randn([cout, cin, 1, 1], generator=g)
     return p
 
 
@@ -149,6 +154,16 @@ def torgb_layer(p, prefix, x, w, conv_clamp=256.0):
     return ops.bias_act(x, p[prefix + ".bias"], clamp=conv_clamp)
 
 
+def conv2d_layer(p, prefix, x, up=1, gain=1.0, act="linear", conv_clamp=None):
+    """Conv2dLayer.forward, stylegan2.py:100-113 (the "resnet" blocks' 1 x 1 up-sampling skip convolution: bias=False,
+    activation "linear" whose def_gain is 1)."""
+    w = p[prefix + ".weight"]
+    w = w * (1 / sqrt(w.shape[1] * w.shape[2] * w.shape[3]))
+    x = ops.conv2d_resample(x, w, f=p[prefix + ".resample_filter"], up=up, padding=w.shape[-1] // 2)
+    return ops.bias_act(x, p.get(prefix + ".bias"), act=act, gain=(sqrt(2) if act == "lrelu" else 1.0) * gain,
+                        clamp=None if conv_clamp is None else conv_clamp * gain)
+
+
 def _hook_resize(x, rs, feat):
     """get_hook's resize (wrappers/stylegan2.py:223-250 "stretch", :284-313 "pad-*"): the torch ops the hooks call."""
     if rs["mode"] == "stretch":
@@ -182,8 +197,9 @@ def warp_affine(x, M):
 
 
 def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, return_features=False, resize=None,
-                      warps=()):
-    """stylegan2.py:429-436 + SynthesisBlock.forward :340-382 ('skip' architecture).
+                      warps=(), architecture="skip"):
+    """stylegan2.py:429-436 + SynthesisBlock.forward :340-382 ("skip" - the reference default - here; "orig" and "resnet"
+    in _synthesis_network_plain below).
 
     ``noise``: optional list, one [B|1,1,h,w] tensor per synthesis layer in
     execution order (what StyleGAN2Synthesizer.forward installs, wrappers/stylegan2.py:85-100).
@@ -193,6 +209,11 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
     gets the rgb (inverse) and img (resize) hooks.  ``warps``: sequence of (layer, M [B,2,3]) forward hooks applied in
     order after the resize hook of their layer (the translate / zoom / rotate hooks, :153-194).
     """
+    if architecture != "skip":
+        if resize is not None or warps or return_features:
+            raise NotImplementedError("hooks and feature capture are restated for the 'skip' architecture only")
+        return _synthesis_network_plain(p, ws, noise, noise_strength, nv_compat, architecture)
+
     def hooks(x_, l1):
         for wl, M in warps:
             if wl == l1:
@@ -241,4 +262,38 @@ def synthesis_network(p, ws, noise=None, noise_strength=1.0, nv_compat=False, re
             img = _hook_resize(img, resize, False)
     if return_features:
         return img, feats
+    return img
+
+
+def _synthesis_network_plain(p, ws, noise, noise_strength, nv_compat, architecture):
+    """SynthesisBlock.forward :340-382 for architecture "orig" (no skip images: only the last block has a toRGB layer) and
+    "resnet" (y = skip(x, gain sqrt(.5)); x = conv1(conv0(x), gain sqrt(.5)); x = y + x).  The reference cannot execute its own
+    up = 2 layers, so this restatement is pinned on the op / layer goldens only."""
+    if architecture not in ("orig", "resnet"):
+        raise ValueError(architecture)
+    nblocks = 0
+    while f"bs.{nblocks}.conv1.weight" in p:
+        nblocks += 1
+    x = img = None
+    w_idx = li = 0
+
+    def nz():
+        return None if noise is None or li >= len(noise) else noise[li]
+    for i in range(nblocks):
+        g1 = 1.0
+        if i == 0:
+            x = p["bs.0.const"].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+        else:
+            y = conv2d_layer(p, f"bs.{i}.skip", x, up=2, gain=sqrt(0.5)) if architecture == "resnet" else None
+            x = synthesis_layer(p, f"bs.{i}.conv0", x, ws[:, w_idx], up=2, noise=nz(), noise_strength=noise_strength,
+                                nv_compat=nv_compat)
+            w_idx, li = w_idx + 1, li + 1
+            g1 = sqrt(0.5) if architecture == "resnet" else 1.0
+        x = synthesis_layer(p, f"bs.{i}.conv1", x, ws[:, w_idx], up=1, noise=nz(), noise_strength=noise_strength,
+                            gain=g1, nv_compat=nv_compat)
+        w_idx, li = w_idx + 1, li + 1
+        if i > 0 and architecture == "resnet":
+            x = y + x
+        if i == nblocks - 1:
+            img = torgb_layer(p, f"bs.{i}.torgb", x, ws[:, w_idx])
     return img

@@ -914,6 +914,58 @@ def golden_secondary():
     print("  strict load:", missing)
 
 
+def golden_architectures():
+    """g29: the "orig" / "resnet" block architectures (inference/stylegan2.py:275-382).  The reference's constructors run, its
+    up = 2 forwards do not, so this pins: (i) the constructors' key set, shapes, draw order and num_ws; (ii) the
+    reference Conv2dLayer (1 x 1, bias=False: the resnet skip) at up = 1 through its own forward with a gain; (iii) one resnet
+    block composed from the reference's own pieces the way SynthesisBlock.forward :354-360 composes them - the up = 2 layers
+    as conv_transpose2d + the reference upfirdn2d with the padding conv2d_resample :199-225 computes (3 x 3: (1,1,1,1),
+    1 x 1: (2,2,2,2)), conv1 through the reference SynthesisLayer with gain sqrt(.5)."""
+    from math import sqrt
+    from maua.GAN.wrappers.inference import ops as R
+    from maua.GAN.wrappers.inference import stylegan2 as S
+    out = {}
+    for arch, seed in (("orig", 31), ("resnet", 32)):
+        torch.manual_seed(seed)
+        net = S.SynthesisNetwork(w_dim=16, img_resolution=32, img_channels=3, channel_base=256, channel_max=16, architecture=arch)
+        out[f"{arch}__num_ws"] = np.int64(net.num_ws)
+        out[f"{arch}__keys"] = np.array(list(net.state_dict().keys()))
+        for k, v in net.state_dict().items():
+            out[f"{arch}__" + k.replace(".", "__")] = v
+    g = torch.Generator().manual_seed(33)
+    B, ci, co, h, wd = 2, 8, 6, 8, 16
+    torch.manual_seed(34)
+    blk = S.SynthesisBlock(ci, co, w_dim=wd, resolution=2 * h, img_channels=3, is_last=False, architecture="resnet")
+    blk.conv0.bias.data.copy_(torch.randn(co, generator=g))
+    blk.conv1.bias.data.copy_(torch.randn(co, generator=g))
+    x = torch.randn(B, ci, h, h, generator=g)
+    ws = torch.randn(B, 2, wd, generator=g)
+    f = blk.resample_filter
+    # (ii) the skip layer's class at up = 1 (tensor-typed attributes: Q1)
+    sk1 = S.Conv2dLayer(ci, co, kernel_size=1, bias=False, up=1)
+    sk1.weight.data.copy_(blk.skip.weight.data)
+    sk1.padding, sk1.up, sk1.down = T(0), T(1), T(1)
+    y_up1 = sk1(x, gain=sqrt(0.5))
+    # (iii) y = skip(x, gain sqrt(.5)), up = 2, 1 x 1
+    wsk = blk.skip.weight * blk.skip.weight_gain
+    t = torch.nn.functional.conv_transpose2d(x, wsk.permute(1, 0, 2, 3), stride=2, padding=0)
+    y = R.bias_act(R.upfirdn2d(t, f, padding=T([2, 2, 2, 2]), gain=T(4)), None, act="linear", gain=sqrt(0.5))
+    # conv0: styles = affine(w); modulate + demodulate; transposed convolution + FIR; + noise_const; bias_act(lrelu, sqrt 2, 256)
+    s = blk.conv0.affine(ws[:, 0])
+    w = blk.conv0.weight.unsqueeze(0) * s[:, None, :, None, None]
+    w = w / ((w * w).sum((2, 3, 4)) + 1e-8).sqrt()[..., None, None, None]
+    wg = w.permute(0, 2, 1, 3, 4).reshape(B * ci, co, 3, 3)
+    t = torch.nn.functional.conv_transpose2d(x.reshape(1, B * ci, h, h), wg, stride=2, padding=0, groups=B)
+    x0 = R.upfirdn2d(t, f, padding=T([1, 1, 1, 1]), gain=T(4)).reshape(B, co, 2 * h, 2 * h) + blk.conv0.noise_const
+    x0 = R.bias_act(x0, blk.conv0.bias, act="lrelu", gain=sqrt(2.0), clamp=256.0)
+    blk.conv1.padding, blk.conv1.up = T(1), T(1)
+    x1 = blk.conv1(x0, ws[:, 1], "const", gain=sqrt(0.5))
+    out.update(blk__x=x, blk__ws=ws, blk__skip_up1=y_up1, blk__skip=y, blk__conv0=x0, blk__conv1=x1, blk__out=y + x1)
+    for k, v in blk.state_dict().items():
+        out["blk__p__" + k.replace(".", "__")] = v
+    save("g29_architectures", **out)
+
+
 if __name__ == "__main__":
     import_reference()
     which = sys.argv[1:] or ["ops", "modules", "audio", "latents", "noise", "io"]

@@ -560,3 +560,66 @@ def test_raw_noise_maps_with_per_sample_factors_equal_the_normalised_maps():
             u_one = torch.empty((1, res, res, 3), dtype=torch.uint8, device="cuda")
             net(ws[i0 + 1:i0 + 2], noise=one, rgb8_out=u_one)
             assert torch.equal(u_one[0], u_raw[1])          # position in the batch does not matter
+
+
+@pytest.mark.parametrize("arch", ["orig", "resnet"])
+def test_orig_and_resnet_architectures_match_the_oracle(arch):
+    """inference/stylegan2.py:340-382 for the two non-default block architectures (layer-at-a-time on the operator kernels:
+    maua_modconv2d, maua_upfirdn2d, maua_add) against the oracle restatement that g29 pins on the reference's own pieces."""
+    from maua_amd.stylegan2 import SynthesisNetwork
+    g = torch.Generator().manual_seed(17)
+    B = 3
+    for dtype in (torch.float32, torch.bfloat16):
+        net = SynthesisNetwork(64, 64, 3, channel_base=2048, channel_max=128, dtype=dtype, architecture=arch,
+                               generator=torch.Generator().manual_seed(5))
+        p = net.state_dict()
+        assert (sum(k.endswith("torgb.weight") for k in p) == 1) and (any(".skip." in k for k in p) == (arch == "resnet"))
+        for k in p:
+            if k.endswith(".bias") and "affine" not in k:
+                p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+        net.load_state_dict(p)
+        ws = torch.randn(B, net.num_ws, 64, generator=g)
+        noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+        u8 = torch.empty((B, 64, 64, 3), dtype=torch.uint8, device="cuda")
+        img = net(ws, noise=noise).cpu()
+        assert torch.equal(net(ws, noise=noise, rgb8_out=u8).cpu(), u8.cpu())
+        ref = OS.synthesis_network(p, ws, noise=noise, architecture=arch)
+        if dtype == torch.float32:
+            assert float((img - ref).abs().max()) / float(ref.abs().max()) <= 2e-5
+        else:
+            assert psnr(img, ref) >= 50.0, psnr(img, ref)
+        # the layers' own noise_const when no noise is handed in; clone() keeps the architecture
+        img2 = net.clone()(ws).cpu()
+        ref2 = OS.synthesis_network(p, ws, architecture=arch)
+        assert (float((img2 - ref2).abs().max()) / float(ref2.abs().max()) <= 2e-5) if dtype == torch.float32 else psnr(img2, ref2) >= 50.0
+        # frames: the same packing as the one-call network's (ops/io.py:47-70)
+        want = ((img.clamp(-1, 1) + 1) / 2 * 255).round().to(torch.uint8).permute(0, 2, 3, 1)
+        assert float((u8.cpu().int() - want.int()).abs().max()) <= 1
+        with pytest.raises(NotImplementedError):
+            net.keep_features(True)
+            net.get_feature(0, B)
+
+
+def test_resnet_block_module_matches_the_reference_composition(golden):
+    """g29's resnet block (composed from the reference's own ops: Conv2dLayer skip, transposed convolution + upfirdn2d, conv1
+    through the reference SynthesisLayer, `y + x`) through maua_amd.modules.SynthesisBlock on the device."""
+    from maua_amd import modules as M, ops
+    g = golden("g29_architectures")
+    blk = M.SynthesisBlock(8, 6, w_dim=16, resolution=16, img_channels=3, is_last=False, architecture="resnet")
+    sd = {k[len("blk__p__"):].replace("__", "."): v for k, v in g.items() if k.startswith("blk__p__")}
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    x, img = blk(g["blk__x"].cuda(), None, g["blk__ws"].cuda())
+    assert img is None
+    ref = g["blk__out"]
+    assert float((x.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    y = blk.skip(g["blk__x"].cuda(), gain=2 ** -0.5).cpu()
+    assert float((y - g["blk__skip"]).abs().max()) <= 1e-5 * float(g["blk__skip"].abs().max())
+    # maua_add itself: both dtypes, a length that is not a multiple of the vector width, unaligned views, in place
+    gen = torch.Generator().manual_seed(1)
+    for dt in (torch.float32, torch.bfloat16):
+        a, b = torch.randn(100003, generator=gen).to(dt).cuda(), torch.randn(100003, generator=gen).to(dt).cuda()
+        want = (a.float() + b.float()).to(dt)
+        assert torch.equal(ops.add(a, b), want)
+        assert torch.equal(ops.add(a[1:], b[1:]), want[1:])
+        assert torch.equal(ops.add(a, b, out=a), want)

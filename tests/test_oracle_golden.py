@@ -624,3 +624,30 @@ def test_secondary_diffusion_model_and_fast_conditioning_match_the_reference(gol
     grad = OD.fast_conditioning(p, sch, lambda img, tt: (2.0 * scale / img[0].numel()) * (img - target), g["xt"], g["t_model"])
     want = g["cond_grad"]
     assert float((grad - want).abs().max()) <= 2e-5 * float(want.abs().max()) and float(want.abs().max()) > 0
+
+
+def test_orig_and_resnet_architectures_match_the_reference_pieces(golden):
+    """g29 (inference/stylegan2.py:275-382): constructor key set / shapes / draw order / num_ws of the "orig" and "resnet"
+    networks, the reference Conv2dLayer's own forward (the resnet skip at up = 1), and one resnet block composed from the
+    reference's ops the way SynthesisBlock.forward composes it."""
+    from math import sqrt
+    g = golden("g29_architectures")
+    for arch, seed in (("orig", 31), ("resnet", 32)):
+        p = S.init_synthesis_params(32, w_dim=16, channel_base=256, channel_max=16, generator=torch.Generator().manual_seed(seed),
+                                    architecture=arch)
+        keys = [str(k) for k in g[f"{arch}__keys"]]
+        assert set(p.keys()) == set(keys) and int(g[f"{arch}__num_ws"]) == S.num_ws(32)
+        for k in keys:
+            assert torch.equal(g[f"{arch}__" + k.replace(".", "__")], p[k]), (arch, k)
+    assert not any(".skip." in str(k) for k in g["orig__keys"]) and sum(".torgb.weight" in str(k) for k in g["orig__keys"]) == 1
+    p = {"bs.1." + k[len("blk__p__"):].replace("__", "."): v for k, v in g.items() if k.startswith("blk__p__")}
+    x, ws = g["blk__x"], g["blk__ws"]
+    up1 = S.conv2d_layer(p, "bs.1.skip", x, up=1, gain=sqrt(0.5))
+    assert torch.allclose(up1, g["blk__skip_up1"], rtol=1e-5, atol=1e-6)
+    y = S.conv2d_layer(p, "bs.1.skip", x, up=2, gain=sqrt(0.5))
+    assert torch.allclose(y, g["blk__skip"], rtol=1e-5, atol=1e-6)
+    x0 = S.synthesis_layer(p, "bs.1.conv0", x, ws[:, 0], up=2)
+    assert torch.allclose(x0, g["blk__conv0"], rtol=1e-4, atol=1e-5)
+    x1 = S.synthesis_layer(p, "bs.1.conv1", x0, ws[:, 1], up=1, gain=sqrt(0.5))
+    assert torch.allclose(x1, g["blk__conv1"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(y + x1, g["blk__out"], rtol=1e-4, atol=1e-5)
