@@ -2,7 +2,12 @@
 torchaudio.functional.resample (sample.py:16-32, audioreactive/audio.py:15-48) — un-vendored, so "parity unpinned" (SURVEY A1).
 Here: PCM/float WAV via scipy, ``.npy`` / ``.pt`` float arrays, mono mean, slice on the host; the resampler is torchaudio's
 published windowed-sinc polyphase algorithm as one GEMM on the HIP device (``audio.resample_sinc``; no host fallback).  MP3 /
-other compressed formats need a decoder the image does not have."""
+other compressed formats are decoded by the ``ffmpeg`` executable when one is on PATH (the decoder behind torchaudio.load
+too, and the program the reference's VideoWriter already requires, ops/video.py:15-63); the build image has none, so that
+route is exercised with a stand-in executable only."""
+import json
+import shutil
+import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -28,7 +33,34 @@ def read_audio(path):
             a = (a.astype(np.float32) - 128.0) / 128.0
         a = torch.from_numpy(np.asarray(a, dtype=np.float32))
         return (a.T if a.ndim == 2 else a), int(sr)
-    raise NotImplementedError(f"{p.suffix}: only .wav / .npy / .pt audio can be decoded without ffmpeg/torchaudio")
+    return _read_with_ffmpeg(p)
+
+
+def _read_with_ffmpeg(p):
+    """Compressed audio (configs[0] names an .mp3; sample.py:17 `torchaudio.load`): ffprobe for rate / channel count, ffmpeg
+    for interleaved f32 PCM on a pipe.  -> ([channels, n] float32, sr)."""
+    ffmpeg, ffprobe = shutil.which("ffmpeg"), shutil.which("ffprobe")
+    if ffmpeg is None or ffprobe is None:
+        raise NotImplementedError(f"{p.suffix}: .wav / .npy / .pt are read directly; any other format needs the ffmpeg and "
+                                  "ffprobe executables on PATH (none found)")
+    if not p.is_file():
+        raise FileNotFoundError(str(p))
+    probe = subprocess.run([ffprobe, "-v", "error", "-select_streams", "a:0", "-show_entries", "stream=sample_rate,channels",
+                            "-of", "json", str(p)], capture_output=True, check=False)
+    if probe.returncode != 0:
+        raise RuntimeError(f"ffprobe failed on {p}: {probe.stderr.decode(errors='replace').strip()}")
+    st = json.loads(probe.stdout.decode())["streams"]
+    if not st:
+        raise RuntimeError(f"{p}: no audio stream")
+    sr, ch = int(st[0]["sample_rate"]), int(st[0]["channels"])
+    dec = subprocess.run([ffmpeg, "-v", "error", "-nostdin", "-i", str(p), "-map", "a:0", "-f", "f32le", "-acodec", "pcm_f32le",
+                          "-ac", str(ch), "-ar", str(sr), "-"], capture_output=True, check=False)
+    if dec.returncode != 0:
+        raise RuntimeError(f"ffmpeg failed on {p}: {dec.stderr.decode(errors='replace').strip()}")
+    a = np.frombuffer(dec.stdout, dtype="<f4")
+    if a.size % ch:
+        raise RuntimeError(f"{p}: {a.size} samples do not divide into {ch} channels")
+    return torch.from_numpy(a.reshape(-1, ch).T.copy()), sr
 
 
 def load_audio(audio_file, offset=0, duration=None, fps=None, sr=None):

@@ -147,6 +147,42 @@ def test_patch_loading_and_audio_io(tmp_path):
     assert p.n_frames == round(2.0 * 24) and p.sr == sr
 
 
+def test_compressed_audio_goes_through_ffmpeg(tmp_path, monkeypatch):
+    """sample.py:17 (`torchaudio.load` of the .mp3 configs[0] names): formats scipy cannot read are piped through the ffmpeg /
+    ffprobe executables.  The image has neither, so stand-ins on PATH play them: this pins the plumbing (argument order,
+    channel de-interleave, mono mean, slice) and the error paths, not a decoder."""
+    import os
+    import stat
+    from maua_amd.audio_io import load_audio, read_audio
+    mp3 = tmp_path / "clip.mp3"
+    mp3.write_bytes(b"not really an mp3")
+    monkeypatch.setenv("PATH", str(tmp_path / "nobin"))
+    with pytest.raises(NotImplementedError, match="ffmpeg"):
+        read_audio(mp3)
+    sr, n = 22050, 4410
+    pcm = np.stack([np.linspace(-1, 1, n), np.linspace(1, -1, n) * 0.5], 1).astype("<f4")    # interleaved stereo
+    (tmp_path / "pcm.bin").write_bytes(pcm.tobytes())
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "ffprobe").write_text(f"#!/bin/sh\necho '{{\"streams\": [{{\"sample_rate\": \"{sr}\", \"channels\": 2}}]}}'\n")
+    (bindir / "ffmpeg").write_text(f"#!/bin/sh\necho \"$@\" > {tmp_path}/args.txt\ncat {tmp_path}/pcm.bin\n")
+    for f in ("ffprobe", "ffmpeg"):
+        os.chmod(bindir / f, os.stat(bindir / f).st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{bindir}:/usr/bin:/bin")
+    a, got_sr = read_audio(mp3)
+    assert got_sr == sr and tuple(a.shape) == (2, n) and np.array_equal(a.numpy(), pcm.T)
+    args = (tmp_path / "args.txt").read_text().split()
+    assert args[args.index("-i") + 1] == str(mp3) and args[args.index("-f") + 1] == "f32le" and args[args.index("-ac") + 1] == "2"
+    mono, s2 = load_audio(str(mp3), offset=0.05, duration=0.1)
+    lo = int(0.05 * sr)
+    assert s2 == sr and np.allclose(mono.numpy(), pcm.mean(1)[lo: lo + int(0.1 * sr)])
+    with pytest.raises(FileNotFoundError):
+        read_audio(tmp_path / "missing.mp3")
+    (bindir / "ffmpeg").write_text("#!/bin/sh\necho 'Invalid data found' >&2\nexit 1\n")
+    with pytest.raises(RuntimeError, match="Invalid data"):
+        read_audio(mp3)
+
+
 def test_video_writer_raw_fallback(tmp_path):
     import shutil
     if shutil.which("ffmpeg"):
