@@ -45,6 +45,15 @@ struct ConvArgs {
   const void* res;        // optional residual added after activation / gain / clamp: NHWC, res_pstride elements per pixel
   int res_pstride;
   long res_bstride;
+  // optional second residual applied to the value as it would have been stored (rounded to the network dtype):
+  // y = res_gain * y + res2 - the RRDB-level "out * 0.2 + x" folded into the last dense block's conv5 (super.hip)
+  const void* res2;
+  int res2_pstride;
+  long res2_bstride;
+  float res_gain;
+  // modconv_dma: input channels actually read (0 = Ci).  A K dimension padded with zero weights up to the kernel's chunk pair
+  // (Ci = 128 for a 96-channel layer) need not fetch the padding: only ceil(Ci_read / 32) chunks are loaded, at least 2.
+  int Ci_read;
   const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
   // modconv_dma (wide tiles) only: optional side output for a GroupNorm that follows (unet.hip) - per (sample, 8 x 32-pixel tile)
   // row and 8-channel piece the sum and the sum of squares of the STORED values: psum[b][tile][Co / 8][16] floats

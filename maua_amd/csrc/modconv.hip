@@ -365,6 +365,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
                           ((long)gy * a.W + gx) * a.res_pstride + co;
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] += Elem<T>::load(rp + k);
+            if (a.res2) {  // second residual on the value as stored (rounded to T): y = res_gain * y + res2
+              const T* rp2 = reinterpret_cast<const T*>(a.res2) + (long)b * a.res2_bstride +
+                             ((long)gy * a.W + gx) * a.res2_pstride + co;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                float t = v[k];
+                if constexpr (sizeof(T) == 2) t = bf2f(f2bf(t));
+                v[k] = a.res_gain * t + Elem<T>::load(rp2 + k);
+              }
+            }
           }
           char* dst = epi + m * ES + nl * (int)sizeof(T);
           if constexpr (sizeof(T) == 2)

@@ -153,6 +153,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const long tap_stride = (long)a.Co * a.Ci * 2;  // bytes between taps ([tap][Co][Ci])
   const char* wtile = wp + (long)n0 * a.Ci * 2;
   const int n_chunks = a.Ci / KC;
+  // chunks that are read from memory: a layer whose K was padded with zero weights (Ci_read < Ci) skips the halo loads of the
+  // padding - those MFMAs multiply whatever finite values an earlier chunk left in the halo buffer by zero
+  const int n_hchunks = a.Ci_read ? (a.Ci_read + KC - 1) / KC : n_chunks;
 
   // one tap (chunk C_, tap T_) into slice J_ of weight stage buffer BUF_
 #define MAUA_ISSUE_WTAP(C_, T_, BUF_, J_)                                                                \
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   }
 #define MAUA_ISSUE_H(J_, C_)                                                                             \
   {                                                                                                      \
-    if ((C_) < n_chunks && hoff[J_] != 0xffffffffu)                                                      \
+    if ((C_) < n_hchunks && hoff[J_] != 0xffffffffu)                                                     \
       dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (wave + NW * (J_)) * 1024); \
   }
 
@@ -446,7 +449,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   // the residual pieces of all of this thread's copy-out steps are requested up front (one round trip instead of one per step)
   static_assert((BM * PPP) % NT == 0, "whole copy-out steps");
   constexpr int NIT = BM * PPP / NT;
-  u32x4 rvs[NIT];
+  u32x4 rvs[NIT], rvs2[NIT];
+  const char* rb2 = (rb && a.res2) ? reinterpret_cast<const char*>(a.res2) + (long)b * a.res2_bstride * 2 : nullptr;
   if (rb) {
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       const int yy = min(ty0 + (m >> 5), a.H - 1), xx = min(tx0 + (m & 31), a.W - 1);   // (overhanging pixels read a valid one)
       const long pix = (long)yy * a.W + xx;
       rvs[it] = *reinterpret_cast<const u32x4*>(rb + (pix * a.res_pstride + n0 + pc * 8) * 2);
+      if (rb2) rvs2[it] = *reinterpret_cast<const u32x4*>(rb2 + (pix * a.res2_pstride + n0 + pc * 8) * 2);
     }
   }
 #pragma unroll
@@ -472,6 +477,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #pragma unroll
       for (int k = 0; k < 4; k++)
         v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
+      if (rb2) {   // second residual on the rounded sum (RRDB: (conv5 * 0.2 + x) * 0.2 + block input): what a separate pass would compute
+        const u32x4 r2 = rvs2[it];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          v[k] = pack2bf(a.res_gain * bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(r2[k] & 0xffff)),
+                         a.res_gain * bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(r2[k] >> 16)));
+      }
     }
     if (ty0 + (m >> 5) < a.H && tx0 + (m & 31) < a.W) *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
     if constexpr (PSUM) {

@@ -107,7 +107,7 @@ struct maua_rrdbnet {
   int ones_b = 0;
   // workspace (grow-only)
   size_t cap_px = 0;           // B * H * W the buffers were sized for
-  void *in32 = nullptr, *feat0 = nullptr, *dense[2] = {nullptr, nullptr}, *rsave = nullptr, *f1 = nullptr, *up1 = nullptr,
+  void *in32 = nullptr, *feat0 = nullptr, *dense[3] = {nullptr, nullptr, nullptr}, *f1 = nullptr, *up1 = nullptr,
        *f2 = nullptr, *up2 = nullptr, *f3 = nullptr, *f4 = nullptr, *f5 = nullptr;
 };
 
@@ -124,7 +124,7 @@ static int alloc_conv(PlainConv& c, int Ci, int Co, size_t esize) {
 }
 
 static void free_ws(maua_rrdbnet* n) {
-  void** ps[] = {&n->in32, &n->feat0, &n->dense[0], &n->dense[1], &n->rsave, &n->f1, &n->up1, &n->f2, &n->up2, &n->f3,
+  void** ps[] = {&n->in32, &n->feat0, &n->dense[0], &n->dense[1], &n->dense[2], &n->f1, &n->up1, &n->f2, &n->up2, &n->f3,
                  &n->f4, &n->f5};
   for (void** p : ps) {
     if (*p) hipFree(*p);
@@ -234,11 +234,10 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
     free_ws(n);
     MAUA_HIP_CHECK(hipMalloc(&n->in32, px * 32 * es));
     MAUA_HIP_CHECK(hipMalloc(&n->feat0, px * F * es));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
       MAUA_HIP_CHECK(hipMalloc(&n->dense[i], px * D * es));
       MAUA_HIP_CHECK(hipMemsetAsync(n->dense[i], 0, px * D * es, st));
     }
-    MAUA_HIP_CHECK(hipMalloc(&n->rsave, px * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f1, px * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->up1, px * 4 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f2, px * 4 * F * es));
@@ -259,13 +258,15 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
   // a plain 3x3 convolution on channel slices: x = first c.Cip channels of a buffer with xps channels per pixel,
   // y = c.Cop channels at channel offset ycoff of a buffer with yps per pixel (+ optional residual, yps-strided source)
   auto conv = [&](const PlainConv& c, const void* x, int xps, void* y, int yps, int ycoff, int h, int w, bool lrelu,
-                  float gain, const void* res, int rps) -> int {
+                  float gain, const void* res, int rps, const void* res2 = nullptr, int r2ps = 0, float res_gain = 1.f) -> int {
     ConvArgs a{};
     a.x = x; a.x_bstride = (long)h * w * xps; a.x_pstride = xps; a.w = c.wt; a.s = n->ones; a.d = nullptr;
     a.noise = nullptr; a.bias = c.bias; a.y = y; a.y_pstride = yps; a.y_coff = ycoff; a.y_bstride = (long)h * w * yps;
     a.B = B; a.H = h; a.W = w; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
     a.act = lrelu ? MAUA_ACT_LRELU : MAUA_ACT_LINEAR; a.alpha = 0.2f; a.gain = gain; a.clamp = -1.f;
     a.res = res; a.res_pstride = rps; a.res_bstride = (long)h * w * rps;
+    a.res2 = res2; a.res2_pstride = r2ps; a.res2_bstride = (long)h * w * r2ps; a.res_gain = res_gain;
+    a.Ci_read = std::max(c.Ci, 64);   // (the zero-weight padding of K is not fetched; at least one chunk pair)
     // 32 / 64 output channels with K in 64-channel chunks: both operands by LDS-direct loads (modconv_dma.hip narrow tiles)
     if (n->use_dma && dma_conv_narrow_supported(n->dtype, c.Cip, c.Cop, h, w)) return launch_modconv_dma(st, a);
     return launch_modconv3x3(st, n->dtype, a);
@@ -289,25 +290,30 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
   int rc = launch_nchw_to_nhwc<float, T>(st, img, n->in32, B, 3, H * W, 32);
   if (rc) return rc;
   if ((rc = conv(n->conv_first, n->in32, 32, n->feat0, F, 0, H, W, false, 1.f, nullptr, 0))) return rc;
-  // the trunk: block input in channels [0, F) of dense[0]
-  if ((rc = lincomb(n->dense[0], D, 1.f, n->feat0, F, 0.f, nullptr, 0, (long)px, F))) return rc;
+  // the trunk: block input in channels [0, F) of dense[ia].  Three dense-block buffers rotate: a block's input stays untouched in
+  // [0, F) of its buffer (the dense blocks only write the growth slices there) until the block's last conv5 adds it back, so
+  // neither a saved copy of the input nor a separate "out * 0.2 + x" pass is needed - both ride on that conv5's epilogue.
+  int ia = 0, ib = 1, ic = 2;
+  if ((rc = lincomb(n->dense[ia], D, 1.f, n->feat0, F, 0.f, nullptr, 0, (long)px, F))) return rc;
   for (int blk = 0; blk < n->num_block; blk++) {
-    if ((rc = lincomb(n->rsave, F, 1.f, n->dense[0], D, 0.f, nullptr, 0, (long)px, F))) return rc;
-    int cur = 0;
+    const int src[3] = {ia, ib, ic}, dst[3] = {ib, ic, ib};
     for (int r = 0; r < 3; r++) {
       const PlainConv* cs = &n->rdb[((size_t)blk * 3 + r) * 5];
-      char* db = (char*)n->dense[cur];
+      char* db = (char*)n->dense[src[r]];
       for (int k = 0; k < 4; k++)  // x_{k+1} = lrelu(conv_{k+1}(prefix)) -> its own channel slice of the same buffer
         if ((rc = conv(cs[k], db, D, db, D, F + k * G, H, W, true, 1.f, nullptr, 0))) return rc;
-      // out = conv5(all) * 0.2 + x  -> the next dense block's input slice
-      if ((rc = conv(cs[4], db, D, n->dense[cur ^ 1], D, 0, H, W, false, 0.2f, db, D))) return rc;
-      cur ^= 1;
+      // out = conv5(all) * 0.2 + x  -> the next dense block's input slice; the third one also: RRDB out = out * 0.2 + block input
+      if (r < 2) {
+        if ((rc = conv(cs[4], db, D, n->dense[dst[r]], D, 0, H, W, false, 0.2f, db, D))) return rc;
+      } else if ((rc = conv(cs[4], db, D, n->dense[dst[r]], D, 0, H, W, false, 0.2f, db, D, n->dense[ia], D, 0.2f))) {
+        return rc;
+      }
     }
-    // RRDB: out * 0.2 + x (three blocks later the data sit in dense[1]); result back into dense[0]
-    if ((rc = lincomb(n->dense[0], D, 0.2f, n->dense[1], D, 1.f, n->rsave, F, (long)px, F))) return rc;
+    const int t = ia;   // the next block's input sits in [0, F) of dense[ib]
+    ia = ib; ib = ic; ic = t;
   }
   // feat = feat0 + conv_body(trunk)
-  if ((rc = conv(n->conv_body, n->dense[0], D, n->f1, F, 0, H, W, false, 1.f, n->feat0, F))) return rc;
+  if ((rc = conv(n->conv_body, n->dense[ia], D, n->f1, F, 0, H, W, false, 1.f, n->feat0, F))) return rc;
   if ((rc = up2(n->f1, n->up1, H, W))) return rc;
   if ((rc = conv(n->conv_up1, n->up1, F, n->f2, F, 0, 2 * H, 2 * W, true, 1.f, nullptr, 0))) return rc;
   if ((rc = up2(n->f2, n->up2, 2 * H, 2 * W))) return rc;
