@@ -84,7 +84,7 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
 
 // PSUM: also emit ConvArgs.psum (its own instantiation: the 16 accumulators of the copy-out loop cost the 128-register
 // variants a few spilled registers, which the StyleGAN2 path's launches do not pay)
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
@@ -165,6 +165,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
         if (WPIECES >= NW || wave + NW * jj < WPIECES)                                                   \
           dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024);              \
   }
+  // ODDK (two taps per stage, an ODD number of chunks: plain convolutions on the 96 / 160-channel prefixes of a dense-block
+  // buffer, super.hip): the last period has one chunk.  Its stage 4 pairs the chunk's last tap with a tap that does not exist:
+  // that weight slice is zeroed in LDS instead of loaded (the halo buffer it multiplies still holds an earlier chunk - finite
+  // values x 0), and the period ends there instead of running four more stages of padding.
+#define MAUA_ZERO_WTAP(BUF_, J_)                                                                         \
+  {                                                                                                      \
+    _Pragma("unroll") for (int jj = 0; jj < WJ; jj++)                                                   \
+        if (WPIECES >= NW || wave + NW * jj < WPIECES)                                                   \
+          *reinterpret_cast<u32x4*>(smem + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u}; \
+  }
   // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
 #define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
   {                                                                                                      \
@@ -172,6 +182,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       const int lp_ = ((K_) % 9) * TPS + j_;                                                             \
       const int c_ = (CC_) + ((K_) / 9) * TPS + lp_ / 9;                                                 \
       if (c_ < n_chunks) MAUA_ISSUE_WTAP(c_, lp_ % 9, BUF_, j_)                                          \
+      else if (ODDK && c_ == n_chunks && lp_ == 9) MAUA_ZERO_WTAP(BUF_, j_)                              \
     }                                                                                                    \
   }
 #define MAUA_ISSUE_H(J_, C_)                                                                             \
@@ -228,6 +239,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   for (int cc = 0; cc < n_chunks; cc += TPS, pp ^= 1) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
+      if (ODDK && k == 5 && cc + 1 == n_chunks) break;   // (the single chunk of the last period ends inside stage 4)
       const int wbuf = pp ^ (k & 1);
       // (opaque copy per stage: keeps the tap x row fragment addresses from being hoisted out of the loop into
       //  registers the accumulators need)
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     }
   }
 #undef MAUA_ISSUE_WTAP
+#undef MAUA_ZERO_WTAP
 #undef MAUA_ISSUE_WSTAGE
 #undef MAUA_ISSUE_H
 #undef MAUA_LOAD_FRAGS
@@ -534,17 +547,19 @@ bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
 // (any H, W >= one tile: tiles that overhang the image read zeros - the convolution's own padding - and mask their stores;
 //  RealESRGANer's pre_pad makes a 1024^2 frame 1034 x 1034)
 bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W) {
-  return dtype == MAUA_BF16 && Ci % 64 == 0 && (Co == 32 || Co == 64) && H >= TH && W >= TW;
+  // (K in 32-channel chunks, two per period: 32 output channels also take an odd chunk count >= 3, ending the last period early)
+  return dtype == MAUA_BF16 && (Ci % 64 == 0 || (Co == 32 && Ci % 32 == 0 && Ci >= 96)) && (Co == 32 || Co == 64) && H >= TH &&
+         W >= TW;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
   const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KB + 2 * HALO_PX * KB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
-  MAUA_REQUIRE((a.Ci / (KB / 2)) % TPS == 0, "modconv_dma: chunk count must be a multiple of the taps per stage");
+  MAUA_REQUIRE(((a.Ci / (KB / 2)) % TPS == 0) != ODDK, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM, ODDK>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid(((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -564,7 +579,8 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   if (narrow) {
     MAUA_REQUIRE(!a.rgb_out && !a.out_scale && !a.psum, "modconv_dma: the narrow tiles carry no toRGB / style scaling / piece sums");
     MAUA_REQUIRE((a.H % TH == 0 && a.W % TW == 0) || !a.noise, "modconv_dma: overhanging tiles take no noise operand");
-    return a.Co == 64 ? launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
+    if (a.Co == 64) return launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a);
+    return (a.Ci / 32) % 2 ? launch_dma_variant<4, 1, 2, 1, 2, 64, false, true>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);
   }
   // (channel-sliced operands and the residual are honoured by every tile shape: the kernel's address arithmetic is shared)
   // 256-channel N tile: 128-byte K rows, one tap per stage, 149 KB of LDS, one workgroup per CU.

@@ -115,7 +115,8 @@ static int alloc_conv(PlainConv& c, int Ci, int Co, size_t esize) {
   c.Ci = Ci; c.Co = Co; c.Cip = (Ci + 31) / 32 * 32; c.Cop = (Co + 31) / 32 * 32;
   // bf16: K in whole 64-channel chunks (zero weights beyond Ci) so that the trunk runs on the LDS-direct kernel; the
   // channels read beyond Ci belong to the same dense-block buffer (zero-initialised, only ever finite)
-  if (esize == 2 && Ci >= 64) c.Cip = (Ci + 63) / 64 * 64;
+  // (32 output channels: the narrow tile also takes an odd number of 32-channel chunks, so 96 / 160-channel layers are not padded)
+  if (esize == 2 && Ci >= 64 && !(c.Cop == 32 && Ci >= 96)) c.Cip = (Ci + 63) / 64 * 64;
   MAUA_HIP_CHECK(hipMalloc(&c.wt, (size_t)9 * c.Cop * c.Cip * esize));
   MAUA_HIP_CHECK(hipMemset(c.wt, 0, (size_t)9 * c.Cop * c.Cip * esize));
   MAUA_HIP_CHECK(hipMalloc((void**)&c.bias, (size_t)c.Cop * 4));
