@@ -54,6 +54,10 @@ struct ConvArgs {
   // modconv_dma: input channels actually read (0 = Ci).  A K dimension padded with zero weights up to the kernel's chunk pair
   // (Ci = 128 for a 96-channel layer) need not fetch the padding: only ceil(Ci_read / 32) chunks are loaded, at least 2.
   int Ci_read;
+  // modconv_dma: x is a half-size tensor [B][H/2][W/2] that the layer sees up-sampled x2 by pixel repetition
+  // (F.interpolate(scale_factor=2, mode="nearest") in front of RRDBNet's conv_up1 / conv_up2): the up-sampled tensor is never
+  // written, the halo loads address the source pixel.  x_bstride is the SOURCE's sample stride.
+  int x_up2;
   const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
   // modconv_dma (wide tiles) only: optional side output for a GroupNorm that follows (unet.hip) - per (sample, 8 x 32-pixel tile)
   // row and 8-channel piece the sum and the sum of squares of the STORED values: psum[b][tile][Co / 8][16] floats

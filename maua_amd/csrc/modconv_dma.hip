@@ -135,7 +135,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     hoff[j] = 0xffffffffu;
     if (P < HALO_PX * PPR) {
       if (in) {
-        hoff[j] = (unsigned)(((gy * a.W + gx) * xps + q * 8) * 2);
+        // (x_up2: the input is the nearest-neighbour x2 up-sampling of a half-size tensor - read the source pixel directly)
+        hoff[j] = a.x_up2 ? (unsigned)((((gy >> 1) * (a.W >> 1) + (gx >> 1)) * xps + q * 8) * 2)
+                          : (unsigned)(((gy * a.W + gx) * xps + q * 8) * 2);
       } else {
         *reinterpret_cast<u32x4*>(smem + OFF_H + P * 16) = u32x4{0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(smem + OFF_H + HB + P * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -573,6 +575,7 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   MAUA_REQUIRE(narrow || dma_conv_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_dma: unsupported shape");
   MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");
   if (a.B == 0) return MAUA_OK;
+  MAUA_REQUIRE(!a.x_up2 || (a.H % 2 == 0 && a.W % 2 == 0 && a.up == 1), "modconv_dma: x_up2 needs even output sizes");
   MAUA_REQUIRE((long)a.H * a.W * (a.x_pstride ? a.x_pstride : a.Ci) * 2 < (1L << 32),
                "modconv_dma: a sample must stay below 4 GiB (32-bit offsets)");
   // narrow N tiles (4 waves, 64-byte K rows, two taps per stage): 64 channels = 2 x 2 blocks per wave, 32 = 2 x 1

@@ -240,9 +240,7 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
       MAUA_HIP_CHECK(hipMemsetAsync(n->dense[i], 0, px * D * es, st));
     }
     MAUA_HIP_CHECK(hipMalloc(&n->f1, px * F * es));
-    MAUA_HIP_CHECK(hipMalloc(&n->up1, px * 4 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f2, px * 4 * F * es));
-    MAUA_HIP_CHECK(hipMalloc(&n->up2, px * 16 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f3, px * 16 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f4, px * 16 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f5, px * 16 * 32 * es));
@@ -315,10 +313,24 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
   }
   // feat = feat0 + conv_body(trunk)
   if ((rc = conv(n->conv_body, n->dense[ia], D, n->f1, F, 0, H, W, false, 1.f, n->feat0, F))) return rc;
-  if ((rc = up2(n->f1, n->up1, H, W))) return rc;
-  if ((rc = conv(n->conv_up1, n->up1, F, n->f2, F, 0, 2 * H, 2 * W, true, 1.f, nullptr, 0))) return rc;
-  if ((rc = up2(n->f2, n->up2, 2 * H, 2 * W))) return rc;
-  if ((rc = conv(n->conv_up2, n->up2, F, n->f3, F, 0, 4 * H, 4 * W, true, 1.f, nullptr, 0))) return rc;
+  // conv_up(interpolate(x, 2, "nearest")): on the LDS-direct kernel the up-sampled tensor is never materialised (its halo loads
+  // address the half-size source); otherwise one repetition pass in front of the generic kernel
+  auto conv_up = [&](const PlainConv& c, const void* src, void** tmp, void* dst, int h, int w) -> int {   // h, w: source size
+    if (n->use_dma && dma_conv_narrow_supported(n->dtype, c.Cip, c.Cop, 2 * h, 2 * w)) {
+      ConvArgs a{};
+      a.x = src; a.x_bstride = (long)h * w * F; a.x_pstride = F; a.x_up2 = 1; a.w = c.wt; a.s = n->ones; a.bias = c.bias;
+      a.y = dst; a.y_pstride = F; a.y_bstride = (long)4 * h * w * F;
+      a.B = B; a.H = 2 * h; a.W = 2 * w; a.Ci = c.Cip; a.Co = c.Cop; a.up = 1;
+      a.act = MAUA_ACT_LRELU; a.alpha = 0.2f; a.gain = 1.f; a.clamp = -1.f;
+      return launch_modconv_dma(st, a);
+    }
+    // (only this path needs the up-sampled tensor; sized like every other buffer, for the capacity in pixels)
+    if (!*tmp) MAUA_HIP_CHECK(hipMalloc(tmp, n->cap_px * (size_t)(4 * h * w / (H * W)) * F * es));
+    if (int r2 = up2(src, *tmp, h, w)) return r2;
+    return conv(c, *tmp, F, dst, F, 0, 2 * h, 2 * w, true, 1.f, nullptr, 0);
+  };
+  if ((rc = conv_up(n->conv_up1, n->f1, &n->up1, n->f2, H, W))) return rc;
+  if ((rc = conv_up(n->conv_up2, n->f2, &n->up2, n->f3, 2 * H, 2 * W))) return rc;
   if ((rc = conv(n->conv_hr, n->f3, F, n->f4, F, 0, 4 * H, 4 * W, true, 1.f, nullptr, 0))) return rc;
   if ((rc = conv(n->conv_last, n->f4, F, n->f5, 32, 0, 4 * H, 4 * W, false, 1.f, nullptr, 0))) return rc;
   const long opx = (long)B * 16 * H * W;
