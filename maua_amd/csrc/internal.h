@@ -58,6 +58,11 @@ struct ConvArgs {
   // (F.interpolate(scale_factor=2, mode="nearest") in front of RRDBNet's conv_up1 / conv_up2): the up-sampled tensor is never
   // written, the halo loads address the source pixel.  x_bstride is the SOURCE's sample stride.
   int x_up2;
+  // modconv_dma (32-channel tile): write channels 0..2 of the output as an image instead of storing y - planar f32
+  // [B][3][H][W] (clamped to [0, 1] when img_clamp) and / or u8 HWC = round_half_even(clamp(v, 0, 1) * 255); y is not written
+  float* img_f32;
+  uint8_t* img_u8;
+  int img_clamp;
   const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
   // modconv_dma (wide tiles) only: optional side output for a GroupNorm that follows (unet.hip) - per (sample, 8 x 32-pixel tile)
   // row and 8-channel piece the sum and the sum of squares of the STORED values: psum[b][tile][Co / 8][16] floats

@@ -446,6 +446,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       ob[0] = o3[0]; ob[HWl] = o3[1]; ob[2 * HWl] = o3[2];
     }
   }
+  // ---- image output (the last convolution of an up-scaler: 3 real channels of a 32-channel tile): the tile's pixels go out as
+  // planar f32 [B][3][H][W] and / or u8 HWC, clamped to [0, 1], instead of as an NHWC feature tensor that a second pass would
+  // only read back.  Values are the tile's (rounded to the network dtype), i.e. what that pass would have seen.
+  if (BN == 32 && (a.img_f32 || a.img_u8)) {
+    static_assert(BN != 32 || NT == BM, "one pixel per thread");
+    const int m = tid, yy = ty0 + (m >> 5), xx = tx0 + (m & 31);
+    if (yy < a.H && xx < a.W) {
+      const long HWl = (long)a.H * a.W, pix = (long)yy * a.W + xx;
+      const uint2 t2 = *reinterpret_cast<const uint2*>(epi + m * ES);
+      const float v3[3] = {bf2f((bf16_t)(t2.x & 0xffff)), bf2f((bf16_t)(t2.x >> 16)), bf2f((bf16_t)(t2.y & 0xffff))};
+#pragma unroll
+      for (int cch = 0; cch < 3; cch++) {
+        const float cv = fminf(fmaxf(v3[cch], 0.f), 1.f);
+        if (a.img_f32) a.img_f32[((long)b * 3 + cch) * HWl + pix] = a.img_clamp ? cv : v3[cch];
+        if (a.img_u8) a.img_u8[((long)b * HWl + pix) * 3 + cch] = (uint8_t)__float2int_rn(cv * 255.0f);
+      }
+    }
+    return;
+  }
   const int yps = a.y_pstride ? a.y_pstride : a.Co;   // channel-sliced outputs: Co channels at offset y_coff of a wider pixel
   char* yb = reinterpret_cast<char*>(a.y) + ((long)b * (a.y_bstride ? a.y_bstride : (long)a.H * a.W * yps) + a.y_coff) * 2;
   const char* rb = a.res ? reinterpret_cast<const char*>(a.res) + (long)b * a.res_bstride * 2 : nullptr;
@@ -581,6 +600,7 @@ int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
   // narrow N tiles (4 waves, 64-byte K rows, two taps per stage): 64 channels = 2 x 2 blocks per wave, 32 = 2 x 1
   if (narrow) {
     MAUA_REQUIRE(!a.rgb_out && !a.out_scale && !a.psum, "modconv_dma: the narrow tiles carry no toRGB / style scaling / piece sums");
+    MAUA_REQUIRE(!(a.img_f32 || a.img_u8) || (a.Co == 32 && !a.res), "modconv_dma: image output is the 32-channel tile's, without a residual");
     MAUA_REQUIRE((a.H % TH == 0 && a.W % TW == 0) || !a.noise, "modconv_dma: overhanging tiles take no noise operand");
     if (a.Co == 64) return launch_dma_variant<4, 1, 2, 2, 2, 64>(stream, a);
     return (a.Ci / 32) % 2 ? launch_dma_variant<4, 1, 2, 1, 2, 64, false, true>(stream, a) : launch_dma_variant<4, 1, 2, 1, 2, 64>(stream, a);

@@ -243,7 +243,6 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
     MAUA_HIP_CHECK(hipMalloc(&n->f2, px * 4 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f3, px * 16 * F * es));
     MAUA_HIP_CHECK(hipMalloc(&n->f4, px * 16 * F * es));
-    MAUA_HIP_CHECK(hipMalloc(&n->f5, px * 16 * 32 * es));
     n->cap_px = px;
   }
   if (B > n->ones_b) {  // unit styles: [B][D] floats of 1
@@ -332,6 +331,17 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
   if ((rc = conv_up(n->conv_up1, n->f1, &n->up1, n->f2, H, W))) return rc;
   if ((rc = conv_up(n->conv_up2, n->f2, &n->up2, n->f3, 2 * H, 2 * W))) return rc;
   if ((rc = conv(n->conv_hr, n->f3, F, n->f4, F, 0, 4 * H, 4 * W, true, 1.f, nullptr, 0))) return rc;
+  if (n->use_dma && n->conv_last.Cop == 32 && dma_conv_narrow_supported(n->dtype, n->conv_last.Cip, 32, 4 * H, 4 * W)) {
+    // conv_last writes the image itself (clamp, f32 planes / u8 frame in its epilogue): no 32-channel tensor, no output pass
+    const PlainConv& c = n->conv_last;
+    ConvArgs a{};
+    a.x = n->f4; a.x_bstride = (long)16 * H * W * F; a.x_pstride = F; a.w = c.wt; a.s = n->ones; a.bias = c.bias;
+    a.B = B; a.H = 4 * H; a.W = 4 * W; a.Ci = c.Cip; a.Co = 32; a.up = 1;
+    a.act = MAUA_ACT_LINEAR; a.alpha = 0.2f; a.gain = 1.f; a.clamp = -1.f;
+    a.img_f32 = out_f32; a.img_u8 = out_u8; a.img_clamp = do_clamp;
+    return launch_modconv_dma(st, a);
+  }
+  if (!n->f5) MAUA_HIP_CHECK(hipMalloc(&n->f5, n->cap_px * 16 * 32 * es));
   if ((rc = conv(n->conv_last, n->f4, F, n->f5, 32, 0, 4 * H, 4 * W, false, 1.f, nullptr, 0))) return rc;
   const long opx = (long)B * 16 * H * W;
   hipLaunchKernelGGL(rrdb_output_kernel<T>, dim3((unsigned)((opx + 255) / 256)), dim3(256), 0, st, (const T*)n->f5, 32,
