@@ -26,7 +26,7 @@ else:
     FR, UB = 4, 4
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_upscale_quick.py"), str(FR), str(UB)]
     units, unit = None, "one 1024^2 frame rendered and up-scaled x4 to 4096^2 u8 (SynthesisNetwork + RealESRGANer.enhance_frames)"
-    COUNT, PER = "rrdb_output_kernel", UB            # one output pass per up-scaler call of UB frames
+    COUNT, PER = "upwalk_fused_kernel", FR           # one fused last-block walk per synthesis call of FR frames (every frame is up-scaled)
 OUT = os.path.join(ROOT, "gpurun_out", f"{leg}_traffic")
 
 
