@@ -46,7 +46,7 @@ def bench_name(k):
         return "tconv_dma_kernel (+edges, +premod)"
     if "tconv_edges_kernel" in k:
         return "tconv_edges_kernel"
-    m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+)(?:, (?:true|false))?>", k)
+    m = re.search(r"modconv_dma_kernel<(\d), (\d), (\d), (\d), (\d), (\d+)(?:, (?:true|false))*>", k)
     if m:
         return "modconv_dma_kernel<%s,%s,%s,%s,%s,%s>" % m.groups()
     if "tconv2_kernel<unsigned short>" in k:
