@@ -24,6 +24,14 @@
 #include "common.h"
 #include "internal.h"
 
+// K-loop schedule experiments (bit mask; results do not depend on it - scripts/experiments/README.md, round 5):
+//   1  static priority for the second-dispatched half of the workgroup (waves >= NW / 2: the younger wave of every SIMD)
+//   2  the first half issues its share of the stage's LDS-direct loads half a stage later (between the k-steps of the NEXT stage
+//      instead of right behind the barrier), so that the two waves of a SIMD do not both sit in their load-issue block at once
+#ifndef MAUA_DMA_SCHED
+#define MAUA_DMA_SCHED 0
+#endif
+
 namespace maua {
 
 namespace {
@@ -236,6 +244,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   int hpv = hp00;
   MAUA_LOAD_FRAGS(af, bf, 0, 0, 0, 0)
 
+  if constexpr ((MAUA_DMA_SCHED & 1) != 0) {
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   // A period = 9 stages = 9 TPS taps = TPS chunks; inside it every tap offset is a compile-time constant.
   int pp = 0;  // parity of the period index (odd number of stages per period: the weight ring flips with it)
   for (int cc = 0; cc < n_chunks; cc += TPS, pp ^= 1) {
@@ -255,7 +266,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
         MAUA_MMA(af1, bf1)                                                                               \
       }
       MAUA_STEP2(0)
-      if constexpr (Q == 8) { MAUA_STEP2(2) MAUA_STEP2(4) }
+      if constexpr (Q == 8) { MAUA_STEP2(2) }
+      if constexpr ((MAUA_DMA_SCHED & 2) != 0) {
+        // (schedule 2) the first half's weight loads of the PREVIOUS stage's refill: that stage's slot (the other one) has been
+        // free since its barrier; what lands here is first read behind this stage's barrier, after this wave's vmcnt(0)
+        if (wave < NW / 2) {
+          if (k >= 1) MAUA_ISSUE_WSTAGE(cc, k + 1, wbuf ^ 1)
+          else if (cc > 0) MAUA_ISSUE_WSTAGE(cc - TPS, 10, wbuf ^ 1)
+        }
+      }
+      if constexpr (Q == 8) { MAUA_STEP2(4) }
       MAUA_STEP2(Q - 2)
 #undef MAUA_STEP2
       // here: MFMAs of k-steps 0 .. Q-2 issued, fragments of k-step Q-1 in af1 / bf1.
@@ -269,7 +289,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       } else if (cc + TPS < n_chunks) {
         MAUA_LOAD_FRAGS(af, bf, cc + TPS, 0, 0, wbuf ^ 1)
       }
-      MAUA_ISSUE_WSTAGE(cc, k + 2, wbuf)  // stage s+2 into the slot stage s has just finished with
+      if ((MAUA_DMA_SCHED & 2) == 0 || wave >= NW / 2)
+        MAUA_ISSUE_WSTAGE(cc, k + 2, wbuf)  // stage s+2 into the slot stage s has just finished with
       if constexpr (TPS == 1) {
         if (k < HJ) MAUA_ISSUE_H(k, cc + 1)
       } else {
@@ -297,6 +318,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #undef MAUA_MMA
 #undef MAUA_SWZ
 
+  if constexpr ((MAUA_DMA_SCHED & 1) != 0) __builtin_amdgcn_s_setprio(0);
   // ---- epilogue: demod, noise, bias, activation, gain, clamp -> LDS tile [pixel][channel] -> coalesced NHWC rows
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
   __syncthreads();  // main-loop LDS is dead from here on

@@ -30,7 +30,7 @@ constexpr int KB = 64;                             // bytes of K per LDS row (32
 constexpr int WROWS = 9 * 32;
 constexpr int WBUF = WROWS * KB;
 constexpr int OFF_H = 2 * WBUF;
-constexpr int ES = 128 * 2 + 16;                   // t tile: [position][class * 32 + ch] bf16, row stride
+constexpr int ES = 128 * 2;                        // t tile: [position][class * 32 + ch] bf16, row stride (unpadded: XOR-swizzled)
 
 __device__ __constant__ const int kSlotF[9] = {0, 1, 1, 2, 2, 3, 3, 3, 3};  // as modconv_tconv.hip
 __device__ __constant__ const int kClsF[9] = {0, 0, 1, 0, 2, 0, 1, 2, 3};
@@ -47,17 +47,25 @@ __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x)
 }
 __device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
 
-// byte offset of t[local row tr][local column tc] (channel 0 of the block) inside the LDS tile
-__device__ __forceinline__ int t_off(int tr, int tc) {
-  return (((tr >> 1) * PTW + (tc >> 1)) * ES) + ((((tr & 1) << 1) | (tc & 1)) << 6);
+// The t tile, [position p = (tr >> 1) * 32 + (tc >> 1)][class (tr & 1) * 2 + (tc & 1)][32 channels] bf16, rows of 256 bytes
+// swizzled on two levels (round 5; the padded 272-byte rows of rounds 3-4 had 35 % of this kernel's LDS cycles in conflicts):
+//   the 64-byte class block sits at slot  cls ^ (p & 3)        - the four 2-column strips of a ds_read_b128 lane group differ in p & 3
+//   its 16-byte piece pc at               pc ^ ((p >> 2) & 3)  - 16 consecutive positions of a ds_write_b64 lane group take the 16
+//                                                                 (slot, piece) combinations: both sides conflict-free
+// column part of the byte offset of piece pc of t[.][tc]; the row part is (tr >> 1) * 32 * ES and XOR ((tr & 1) << 7)
+__device__ __forceinline__ int t_col(int tc, int pc) {
+  const int p = tc >> 1;
+  return p * ES + ((((tc & 1) ^ (p & 3)) << 6) | ((pc ^ ((p >> 2) & 3)) << 4));
 }
 
-// the two horizontal [1,3,3,1] sums of one t row for the output columns xl, xl + 1 (upfir_hrow's arithmetic)
-__device__ __forceinline__ void fir_hrow(const char* tile, int tr, int xl, int cho2, f32x2_t (&h)[2][4]) {
+// the two horizontal [1,3,3,1] sums of one t row for the output columns xl, xl + 1 (upfir_hrow's arithmetic); tcol[rx] =
+// t_col(xl - 1 + rx, pc)
+__device__ __forceinline__ void fir_hrow(const char* tile, int tr, const int (&tcol)[5], f32x2_t (&h)[2][4]) {
   f32x2_t c[5][4];
+  const int rowb = (tr >> 1) * (PTW * ES), rsw = (tr & 1) << 7;
 #pragma unroll
   for (int rx = 0; rx < 5; rx++) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(tile + t_off(tr, xl - 1 + rx) + cho2);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(tile + rowb + (tcol[rx] ^ rsw));
 #pragma unroll
     for (int k = 0; k < 4; k++) c[rx][k] = f32x2_t{__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
   }
@@ -262,12 +270,12 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
   char* tt = smem;
 #pragma unroll
   for (int R = 0; R < 2; R++) {
-    const int m = (2 * wave + R) * 32 + r;
+    const int m = (2 * wave + R) * 32 + r;   // (m & 3 = r & 3, (m >> 2) & 3 = (r >> 2) & 3: the swizzle terms are per-lane constants)
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
       for (int qd = 0; qd < 4; qd++)
-        *reinterpret_cast<uint2*>(tt + m * ES + (c * 32 + 8 * qd + 4 * h) * 2) =
+        *reinterpret_cast<uint2*>(tt + m * ES + (((c ^ (r & 3)) << 6) | ((qd ^ ((r >> 2) & 3)) << 4) | (h << 3))) =
             make_uint2(pack2bf(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), pack2bf(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
   }
   __syncthreads();
@@ -279,14 +287,16 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
       const float nzs = u.noise_strength * u.gain * (u.noise_scale ? u.noise_scale[b] : 1.f);
       const float cl = u.clamp >= 0.f ? u.clamp : 3.0e38f;
       char* yb = reinterpret_cast<char*>(u.y) + (long)b * Ho * Wo * a.Co * 2;
-      const int cho2 = pc * 16;
+      int tcol[5];
+#pragma unroll
+      for (int rx = 0; rx < 5; rx++) tcol[rx] = t_col(xl - 1 + rx, pc);
       f32x2_t hr[4][2][4];
-      fir_hrow(tt, yl0 - 1, xl, cho2, hr[0]);
-      fir_hrow(tt, yl0, xl, cho2, hr[1]);
-      fir_hrow(tt, yl0 + 1, xl, cho2, hr[2]);
+      fir_hrow(tt, yl0 - 1, tcol, hr[0]);
+      fir_hrow(tt, yl0, tcol, hr[1]);
+      fir_hrow(tt, yl0 + 1, tcol, hr[2]);
 #pragma unroll
       for (int k = 0; k < FROWS; k++) {
-        fir_hrow(tt, yl0 + k + 2, xl, cho2, hr[(k + 3) & 3]);
+        fir_hrow(tt, yl0 + k + 2, tcol, hr[(k + 3) & 3]);
         const int Y = 2 * ty0 + yl0 + k;
         if (Y < Ho) {
           const float nz[2] = {nzv[k].x * nzs, nzv[k].y * nzs};

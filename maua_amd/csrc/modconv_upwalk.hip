@@ -247,7 +247,7 @@ __device__ __forceinline__ void lds_dma_b32(const void* sbase, unsigned voff_byt
 
 template <int CI, int CM, bool DBG>
 __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, int seg_rows, int nseg, int strips,
-                                                             int n_items, int items_per_wg, long long* dbg) {
+                                                             int n_items, int items_per_wg, int narrow_last, long long* dbg) {
   constexpr int KS = CI / 16, KS1 = CM / 16;
   constexpr int PITCH = 126, XPX = 67, RPX = 132;
   constexpr int XG = (XPX + 7) / 8;         // 1 KB DMA pieces (8 positions) per staged input row
@@ -285,9 +285,19 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       const int b = item / (nseg * strips);
       const int rem = item - b * (nseg * strips);
       const int seg = rem / strips, strip = rem - seg * strips;
-      const int X0 = strip * PITCH, J0 = strip * (PITCH / 2);
-      const int r0 = seg * seg_rows, r1 = min(r0 + seg_rows, a.H);
-      const int nsteps = r1 - r0 + 5;
+      const int X0i = strip * PITCH, J0 = strip * (PITCH / 2);
+      const int r0i = seg * seg_rows, r1i = min(r0i + seg_rows, a.H);
+      // A NARROW last strip (<= 32 output columns: 1024 = 8 x 126 + 16) is walked as two sub-items at once - the upper and the
+      // lower half of the item's rows - in half the steps: sub-item A lives where the strip's first 32 positions / 64 ring pixels
+      // live (producer waves 0, 1 and consumer wave 0), sub-item B in the coordinates of positions 32.. / ring pixels 64..
+      // (producer waves 2, 3 and consumer wave 2: the same columns of the image, `drow` rows further down).  Every wave sees an
+      // ordinary strip whose origin is X0 (and whose rows are r0 .. r1); only the cooperative staging knows about the halves.
+      const bool narrow = narrow_last && strip == strips - 1;
+      const int hrows = narrow ? (r1i - r0i + 1) >> 1 : r1i - r0i, drow = narrow ? hrows : 0;
+      const int sub = narrow ? (widx >> 1) : 0;
+      const int X0 = X0i - 64 * sub;
+      const int r0 = r0i + sub * hrows, r1 = min(r0 + hrows, r1i);
+      const int nsteps = hrows + 5;
       __syncthreads();   // the previous item's LDS reads are done
       // ---- zero both staged-row buffers (positions outside the image stay zero: the DMA skips them)
       for (int i = tid; i < 2 * XROWB / 16; i += 256) reinterpret_cast<u32x4*>(xrow)[i] = u32x4{0u, 0u, 0u, 0u};
@@ -342,15 +352,19 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       unsigned xoff[3];
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const int grp = widx + 4 * j, q = grp * 8 + (lane >> 3), gx = J0 - 2 + q;
+        const int grp = widx + 4 * j, q = grp * 8 + (lane >> 3), gx = J0 - 2 + q - ((narrow && grp >= 4) ? 32 : 0);
         const bool ok = grp < XG && q < XPX && gx >= 0 && gx < a.W;
         xoff[j] = ok ? (unsigned)((gx * CI + (((lane & 7) ^ ((q >> 1) & 7)) * 8)) * 2) : 0xffffffffu;
       }
-      const int Jp0 = (X0 - 1) >> 1;               // first column of the previous image the strip's skip taps read
+      const int Jp0 = (X0i - 1) >> 1;              // first column of the previous image the strip's skip taps read
       unsigned pvoff;
+      int pvd;                                     // rows between this lane's staged pixel and sub-item A's row
       {
-        const int f = widx * 64 + lane, ch = f / PVP, pxi = f - ch * PVP, gx = Jp0 + pxi;
-        pvoff = (f < 3 * PVP) ? (unsigned)((ch * Hp + 0) * Wp + min(max(gx, 0), Wp - 1)) * 4u : 0xffffffffu;
+        const int f = widx * 64 + lane, ch = f / PVP, pxi = f - ch * PVP;
+        const bool lower = narrow && pxi >= 32;    // (staged pixels 32.. belong to sub-item B)
+        const int gx = Jp0 + pxi - (lower ? 32 : 0);
+        pvd = lower ? drow : 0;
+        pvoff = (f < 3 * PVP) ? (unsigned)((ch * Hp + pvd) * Wp + min(max(gx, 0), Wp - 1)) * 4u : 0xffffffffu;
       }
       // byte offsets of the x fragments inside a staged row: position q = (1 - pb) + t + kx, piece (2 cs + h) ^ swizzle
       int xfo[3 * KS];
@@ -361,19 +375,23 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
           const int q = (1 - pb) + t + kx;
           xfo[kx * KS + cs] = q * 128 + (((2 * cs + h) ^ ((q >> 1) & 7)) << 4);
         }
+      // (RHO: sub-item A's row; positions 32.. - pieces 4.. - hold the row `drow` further down, which is the same row unless narrow)
 #define MAUA_UWF_STAGE_X(RHO, BUF)                                                                      \
   {                                                                                                     \
-    const int gy_ = (RHO);                                                                              \
     char* dst_ = xrow + (BUF) * XROWB;                                                                  \
-    if (gy_ >= 0 && gy_ < a.H) {                                                                        \
-      const char* rb_ = xbase + (long)gy_ * a.W * CI * 2;                                               \
-      _Pragma("unroll") for (int j = 0; j < 3; j++)                                                    \
-        if (xoff[j] != 0xffffffffu) lds_dma_b128(rb_, xoff[j], dst_ + (widx + 4 * j) * 1024);           \
-    } else {                                                                                            \
-      for (int i = tid; i < XROWB / 16; i += 256) reinterpret_cast<u32x4*>(dst_)[i] = u32x4{0u, 0u, 0u, 0u}; \
+    _Pragma("unroll") for (int hs_ = 0; hs_ < 2; hs_++) {                                              \
+      const int gy_ = (RHO) + hs_ * drow;                                                               \
+      if (gy_ >= 0 && gy_ < a.H) {                                                                      \
+        const char* rb_ = xbase + (long)gy_ * a.W * CI * 2;                                             \
+        _Pragma("unroll") for (int j = hs_; j < 1 + 2 * hs_; j++)                                      \
+          if (xoff[j] != 0xffffffffu) lds_dma_b128(rb_, xoff[j], dst_ + (widx + 4 * j) * 1024);         \
+      } else {                                                                                          \
+        for (int i = tid + 256 * hs_; i < (hs_ ? XROWB / 16 : 256); i += 256)                           \
+          reinterpret_cast<u32x4*>(dst_)[i] = u32x4{0u, 0u, 0u, 0u};                                    \
+      }                                                                                                 \
     }                                                                                                   \
   }
-      MAUA_UWF_STAGE_X(r0 - 2, 0)
+      MAUA_UWF_STAGE_X(r0i - 2, 0)
       const f32x16* bhalf_p = reinterpret_cast<const f32x16*>(bias0_s + 16 * h);   // bias * gain / 2 of the lane's 16 channels
       f32x16 ecur = *bhalf_p, p0, p1, q0;
 #pragma unroll
@@ -391,11 +409,11 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         MAUA_TICK(dsum[3] += ta - tz)
         if (k == nsteps - 1) continue;   // (the consumers' last step; the loop ends right after)
         // ---- staging: input row rho + 1 and row rho - 1 of the previous image (slot k % 3) for the next step
-        MAUA_UWF_STAGE_X(rho + 1, (k + 1) & 1)
+        MAUA_UWF_STAGE_X(r0i - 2 + k + 1, (k + 1) & 1)
         if (pvbase) {
-          const int m = rho - 1;
+          const int m = r0i - 2 + k - 1;
           float* dst = pvs + (k % 3) * PVW;
-          if (m >= 0 && m < Hp) {
+          if (m + pvd >= 0 && m + pvd < Hp) {
             if (pvoff != 0xffffffffu) lds_dma_b32(pvbase + (long)m * Wp * 4, pvoff, dst + widx * 64);
           } else {
             dst[widx * 64 + lane] = 0.f;
@@ -491,9 +509,17 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
       const int b = item / (nseg * strips);
       const int rem = item - b * (nseg * strips);
       const int seg = rem / strips, strip = rem - seg * strips;
-      const int X0 = strip * PITCH, J0 = strip * (PITCH / 2);
-      const int r0 = seg * seg_rows, r1 = min(r0 + seg_rows, a.H);
-      const int nsteps = r1 - r0 + 5;
+      const int X0i = strip * PITCH;
+      const int r0i = seg * seg_rows, r1i = min(r0i + seg_rows, a.H);
+      // (narrow last strip: consumer wave 0 finishes sub-item A, wave 2 sub-item B, waves 1 and 3 only keep the barriers - see the
+      //  producers' item set-up)
+      const bool narrow = narrow_last && strip == strips - 1;
+      const int hrows = narrow ? (r1i - r0i + 1) >> 1 : r1i - r0i;
+      const int sub = narrow ? (widx >> 1) : 0;
+      const bool active = !narrow || (widx & 1) == 0;
+      const int X0 = X0i - 64 * sub;
+      const int r0 = r0i + sub * hrows, r1 = min(r0 + hrows, r1i);
+      const int nsteps = hrows + 5;
       __syncthreads();
       if (b != b_loaded) {
         b_loaded = b;
@@ -594,6 +620,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         __syncthreads();
         ta = MAUA_NOW();
         MAUA_TICK(dsum[0] += ta - tz)
+        if (!active) continue;
         f32x2_t nz = {0.f, 0.f};   // noise of the lane's column in rows arow - 1, arow (needed after the multiply)
         if (nbase) {               // (rows clamped into the image: the clamped ones are never stored)
           nz[0] = *reinterpret_cast<const float*>(nbase + (long)min(max(arow - 1, 0), Ho - 1) * Wo * 4 + nzoff);
@@ -709,7 +736,7 @@ bool upwalk_fused_supported(int dtype, int Ci, int Cm, int H, int W) {
   return dtype == MAUA_BF16 && Ci == 64 && Cm == 32 && H >= 2 && W >= 2 && (long)H * W * 4 * 3 < (1L << 31);
 }
 
-int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1) {
+int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs, int narrow_ok) {
   if (up.B == 0) return MAUA_OK;
   MAUA_REQUIRE(upwalk_fused_supported(MAUA_BF16, up.Ci, up.Co, up.H, up.W) && c1.Ci == up.Co && c1.Co == up.Co &&
                    c1.H == 2 * up.H && c1.W == 2 * up.W && up.up == 2 && c1.up == 1,
@@ -735,23 +762,37 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
   MAUA_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int Wo = up.W * 2;
   const int strips = (Wo + 125) / 126;
+  // a last strip of <= 32 columns is walked as two half-height sub-items at once (see the kernel): about half the steps
+  const int narrow_last = (narrow_ok && strips >= 2 && Wo - (strips - 1) * 126 <= 32) ? 1 : 0;
   // items = (sample, row segment, strip), about nine per CU (a segment costs five extra steps); one persistent workgroup
   // per CU takes a contiguous run of them
-  // the number of row segments that minimises a workgroup's step count: items per workgroup x (rows of a segment + 5)
+  // the number of row segments that minimises the LONGEST workgroup's step count (an item = rows of its segment + 5 steps, a
+  // narrow one half the rows + 5)
   int nseg = 1, seg_rows = up.H, n_items = strips * up.B, ipw = (n_items + cus - 1) / cus;
   {
     long best = -1;
     for (int cand = 1; cand <= std::max(1, up.H / 32); cand++) {
+      if (force_segs > 0 && cand != std::min(force_segs, std::max(1, up.H / 32))) continue;   // (tests: odd splits)
       const int rows = (up.H + cand - 1) / cand, segs = (up.H + rows - 1) / rows;
       const int items = strips * segs * up.B, per = (items + std::min(items, cus) - 1) / std::min(items, cus);
-      const long cost = (long)per * (rows + 5);
+      const int last_rows = up.H - (segs - 1) * rows;
+      long cost = 0;   // the worst contiguous run of `per` items (items ordered sample, segment, strip)
+      for (int i0 = 0; i0 < items; i0 += per) {
+        long c = 0;
+        for (int it = i0; it < std::min(i0 + per, items); it++) {
+          const int rem = it % (segs * strips), sg = rem / strips, st = rem % strips;
+          const int rr = sg == segs - 1 ? last_rows : rows;
+          c += ((narrow_last && st == strips - 1) ? (rr + 1) / 2 : rr) + 5;
+        }
+        cost = std::max(cost, c);
+      }
       if (best < 0 || cost < best) { best = cost; nseg = segs; seg_rows = rows; n_items = items; ipw = per; }
     }
   }
   static long long* dbg = nullptr;
   if (want_dbg && !dbg) { (void)hipMalloc((void**)&dbg, 16 * 8); (void)hipMemset(dbg, 0, 128); }
   hipLaunchKernelGGL(kern, dim3((n_items + ipw - 1) / ipw), dim3(512), smem, stream, A, seg_rows, nseg, strips, n_items,
-                     ipw, dbg);
+                     ipw, narrow_last, dbg);
   MAUA_HIP_CHECK(hipGetLastError());
   if (want_dbg) {
     long long hb[16];

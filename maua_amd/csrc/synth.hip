@@ -67,6 +67,8 @@ struct maua_synth {
   int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
   int upwalk = 2;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
                        // 2: the last block as one fused walk when nothing else reads its features
+  int walk_segs = 0;   // fused walk: force this many row segments (0: cost model); walk_narrow: a <= 32-column last strip as two
+  int walk_narrow = 1; // half-height sub-items walked at once (options "walk_segs" / "walk_narrow"; results do not depend on either)
   int fuse_torgb = 1;  // toRGB + skip fused into those conv1 epilogues
   int tconv_up = 1;    // up-layers: minimal transposed conv + separate FIR/epilogue pass (0 = 4 phase kernels)
   int tconv_fir = 256; // up-layers with inputs of at least this size: transposed conv + FIR + epilogue in ONE kernel, t stays in
@@ -442,6 +444,14 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->upwalk = value;
     return MAUA_OK;
   }
+  if (!strcmp(key, "walk_segs")) {
+    n->walk_segs = value;
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "walk_narrow")) {
+    n->walk_narrow = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "tconv_min")) {
     n->tconv_min = value;
     return MAUA_OK;
@@ -722,7 +732,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
                 f.rgb_skip_f32 = img_out == nullptr;
               }
               a.y = nullptr;
-              if (int rc = launch_upwalk_fused(st, a, f)) return rc;
+              if (int rc = launch_upwalk_fused(st, a, f, n->walk_segs, n->walk_narrow)) return rc;
               fused_walk = true;
               walk_skip = true;
             }

@@ -451,6 +451,41 @@ def test_upwalk_block_walks_match_phase_form_and_oracle(res, B):
         assert torch.equal(one[0].cpu(), imgs[2][B - 1])
 
 
+@pytest.mark.parametrize("res,B,segs", [(256, 3, 0), (256, 2, 3), (512, 2, 5), (512, 1, 7)])
+def test_fused_walk_narrow_last_strip_is_bit_identical(res, B, segs):
+    """Round 5: a last strip of <= 32 columns (256 = 2 x 126 + 4, 512 = 4 x 126 + 8, 1024 = 8 x 126 + 16) is walked as two
+    half-height sub-items at once (modconv_upwalk.hip, option "walk_narrow").  Same arithmetic per pixel, so frames must not
+    change by a bit - with the cost model's row segments and with forced odd splits (rows of a segment odd: the lower sub-item is
+    one row shorter; last segment shorter than the others)."""
+    from maua_amd import _lib as L
+    from maua_amd.stylegan2 import SynthesisNetwork
+    g = torch.Generator().manual_seed(res + segs)
+    net = SynthesisNetwork(64, res, 3, channel_base=32 * res, channel_max=64, dtype=torch.bfloat16, generator=g)
+    p = net.state_dict()
+    for k in p:
+        if k.endswith(".bias") and "affine" not in k:
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+    net.load_state_dict(p)
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    h = net._handle()
+    out = {}
+    for narrow in (0, 1):
+        L.check(L.lib().maua_synth_set_option(h, b"walk_narrow", narrow))
+        L.check(L.lib().maua_synth_set_option(h, b"walk_segs", segs))
+        img = torch.empty((B, 3, res, res), device="cuda")
+        u8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device="cuda")
+        net(ws, noise=noise, out=img, rgb8_out=u8)
+        out[narrow] = (img.cpu(), u8.cpu())
+    L.check(L.lib().maua_synth_set_option(h, b"walk_narrow", 1))
+    L.check(L.lib().maua_synth_set_option(h, b"walk_segs", 0))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    # ... and the cost model's segmentation gives the same frame as the forced one
+    img = torch.empty((B, 3, res, res), device="cuda")
+    net(ws, noise=noise, out=img)
+    assert torch.equal(img.cpu(), out[1][0])
+
+
 @pytest.mark.parametrize("target", [(40, 96), (33, 64), (7, 32)])
 def test_upwalk_block_walks_on_a_resized_non_square_grid(target):
     """The same three forms of the last block behind a feature-space resize (get_hook's resize: 64^2 -> target after
