@@ -14,7 +14,10 @@
  *  - launches are asynchronous on the ctx stream; the only synchronising calls are maua_ctx_sync(),
  *    maua_synth_load() (host->device upload) and the *_host helpers that say so.
  *  - a ctx is confined to one host thread at a time; different ctxs are independent.
- *  - dtype: MAUA_F32 (exact-f32 MFMA path, parity mode) or MAUA_BF16 (bf16 operands, f32 accumulate).
+ *  - dtype: MAUA_F32 (exact-f32 MFMA path, parity mode), MAUA_BF16 (bf16 operands, f32 accumulate: the bench dtype, every fast
+ *    kernel) or MAUA_F16 (IEEE half operands, f32 accumulate - the reference's own render dtype, render/ffmpeg.py:45 and
+ *    wrappers/__init__.py fp16=True; the operator layer and maua_synth_* take it on the generic MFMA kernels, with ops.py:161-165's
+ *    pre-normalisation of weights and styles; the diffusion / up-scaler networks do not).
  */
 #ifndef MAUA_HIP_H
 #define MAUA_HIP_H
@@ -28,7 +31,7 @@ extern "C" {
 #define MAUA_OK 0
 #define MAUA_ERR (-1)
 
-enum maua_dtype { MAUA_F32 = 0, MAUA_BF16 = 1 };
+enum maua_dtype { MAUA_F32 = 0, MAUA_BF16 = 1, MAUA_F16 = 2 };
 /* activation ids: reference ops.py:9-19 / :44-62 */
 enum maua_act {
   MAUA_ACT_LINEAR = 0, MAUA_ACT_RELU = 1, MAUA_ACT_LRELU = 2, MAUA_ACT_TANH = 3, MAUA_ACT_SIGMOID = 4,
@@ -482,6 +485,24 @@ int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const
  * model_t host f32 [n_steps], coef host f32 [n_steps][8]; use_graph: capture the loop in one hipGraph and replay it. */
 int maua_ddim_sample_loop(maua_unet* net, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,
                           int use_graph, float* pred_xstart);
+/* the GUIDED sampling loop - configs[3] as BASELINE states it - inside the library, one hipGraph per shape.  Replaces the per-step
+ * Python of maua/diffusion/processors/guided.py:302-311, 333-337 (diffusion.ddim_sample(..., cond_fn=self.conditioning)) with
+ * cond_fn = GradientGuidedConditioning.forward at the reference's default speed "fast" (:236-272: secondary model forward, img =
+ * pred * sigma + x * (1 - sigma), the grad modules' d loss / d img, torch.autograd.grad back through the secondary model) and an
+ * image-MSE grad module (d loss / d img = (img - target) * mse_k; a result holding a NaN counts as zeros, :262-265).  Per step:
+ * out = unet(x, t); pred = secondary(x, cos_t).pred; img; g; grad = c0 g + c1 (dv/dx)^T g; x, pred_xstart = ddim_step(x, out, grad).
+ * model_t / coef as maua_ddim_sample_loop; guide: host f32 [n_steps][5] = {cos_t, sigma, 1 - sigma, -(sigma a_c + 1 - sigma),
+ * sigma s_c} (the host evaluates them like :249-252, :266-268 do); target: device f32 [B][3][H][W] (target_bstride = 3 H W) or one
+ * image for every sample (target_bstride = 0).  Both networks must have been created on the same context. */
+int maua_ddim_guided_loop(maua_unet* net, maua_secondary* sec, float* x, int B, int H, int W, const float* model_t, const float* coef,
+                          const float* guide, int n_steps, const float* target, long target_bstride, float mse_k, int use_graph,
+                          float* pred_xstart);
+/* 1 when the last maua_ddim_guided_loop(use_graph = 1) replayed a captured hipGraph, 0 when it ran launch by launch */
+int maua_unet_guided_graph_active(maua_unet* net, int* active);
+/* that grad module as an operator: out = (img - target) * k over B rows of `row` floats, zeros if the result holds a NaN
+ * (guided.py:256-265 with an image-MSE loss); target_bstride = row or 0 */
+int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, long target_bstride, float k, int B, long row,
+                        float* out);
 
 /* ---- multi-GPU: the one exchange step of the frame-sharded render ------------------------------------
  * One process per GPU; frames are sharded by contiguous range (no data-path collective).  maua_gather_frames moves every

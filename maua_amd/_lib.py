@@ -15,7 +15,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MAUA_HIP_LIB", _HERE / "csrc" / "libmaua_hip.so"))
 HEADER = _HERE.parent / "include" / "maua_hip.h"
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACTS = {"linear": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "elu": 5, "selu": 6, "softplus": 7, "swish": 8}
 PAD_MODES = {"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}
 
@@ -123,7 +123,9 @@ def dtype_id(t):
         return F32
     if dt == torch.bfloat16:
         return BF16
-    raise MauaHipError(f"unsupported dtype {dt}: use float32 or bfloat16")
+    if dt == torch.float16:   # the reference's own render dtype (render/ffmpeg.py:45): operator layer + synthesis network
+        return F16
+    raise MauaHipError(f"unsupported dtype {dt}: use float32, bfloat16 or float16")
 
 
 def dev_tensor(t, dtype=None):

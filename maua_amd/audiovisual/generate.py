@@ -12,6 +12,7 @@ from uuid import uuid4
 
 import torch
 
+from ..video import muxable_audio
 from .patches.base import get_patch_from_file
 from .render import get_output_class
 
@@ -41,9 +42,9 @@ def generate_audiovisal_from_patch(audio_file: str, model_file: str, patch_file:
     postprocess.identity_at_native_size = po is None or po is getattr(StyleGAN2Patch, "process_outputs")
 
     kwargs = dict(renderer_kwargs)
-    if renderer == "ffmpeg":  # the writer muxes the clip's audio back in when it can read it (WAV)
+    if renderer == "ffmpeg":  # the writer muxes the clip's audio back in (anything the ffmpeg executable decodes)
         kwargs.update(fps=patch.fps,
-                      audio_file=patch.audio_file if str(patch.audio_file).lower().endswith(".wav") else None)
+                      audio_file=muxable_audio(patch.audio_file))
     video = get_output_class(renderer)(**kwargs)(patch.synthesizer, inputs, postprocess)
     return video, (patch.audio, patch.sr)
 

@@ -24,6 +24,10 @@ class FFMPEG(Renderer):
         with VideoWriter(self.output_file if world == 1 else f"{self.output_file}.part{rank}", (W, H), self.fps,
                          self.audio_file, self.audio_offset, self.audio_duration, self.ffmpeg_preset) as video:
             rh, rw = synthesizer.G_synth.output_hw if hasattr(synthesizer, "G_synth") else (H, W)
+            # fp16: 16-bit compute is a property of the synthesizer's dtype here (bf16 by default, torch.float16 = IEEE half); see
+            # MauaGenerator.render for what the flag does in the reference and why inputs are not rounded to float16
+            from ...stylegan2 import _warn_fp16_flag
+            _warn_fp16_flag(synthesizer, fp16)
             for i in range(lo, hi, self.batch_size):
                 b = min(self.batch_size, hi - i)
                 u8 = torch.empty((b, H, W, 3), dtype=torch.uint8, device="cuda")

@@ -25,7 +25,7 @@ from ..audio_io import load_audio
 from ..distributed import StreamingGather, world_info
 from ..pipeline import frame_range
 from ..stylegan2 import StyleGAN2
-from ..video import VideoWriter
+from ..video import VideoWriter, muxable_audio
 
 # selfsupervised/mir.py:9-11
 AFEATFNS = [A.chromagram, A.tonnetz, A.mfcc, A.spectral_contrast, A.spectral_flatness, A.rms, A.drop_strength, A.onsets]
@@ -205,7 +205,7 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
         sg.chunk_done()
     frames = sg.finish()
     if rank == 0:
-        wav = audio_file if str(audio_file).lower().endswith(".wav") else None
+        wav = muxable_audio(audio_file)
         with VideoWriter(out_file, out_size, fps, wav, audio_offset, audio_duration) as video:
             for i in range(0, T, 64):
                 chunk = frames[i:i + 64]
@@ -221,43 +221,28 @@ def generate(audio_file: str, stylegan2_checkpoint: Optional[str] = None, patch_
 def _generate_upscaled(G, latents, noise, T, lo, hi, rank, world, batch_size, model_name, upscale_batch, random_init, dtype,
                        out_file, fps, audio_file, audio_offset, audio_duration, patch, render_wh):
     """configs[4]: this rank's frames lo .. hi as render -> RealESRGAN x4 -> its own writer; rank 0 joins the parts."""
-    import shutil
-    import subprocess
-    import torch.distributed as dist
     from ..super import load_model
     up = load_model(model_name, dtype=dtype, allow_random_init=random_init)
     rw, rh = render_wh
     s = up.scale
     stem = out_file[: -len(".mp4")] + f"_{model_name}_{s * rw}x{s * rh}"
-    part = f"{stem}_part{rank:03d}.mp4"
     u8 = torch.empty((batch_size, rh, rw, 3), dtype=torch.uint8, device="cuda")
-    n_written = 0
-    with VideoWriter(part, (s * rw, s * rh), fps) as video:
-        for i in range(lo, hi, batch_size):
-            b = min(batch_size, hi - i)
-            nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
-            G.synthesizer(latents=latents[i:i + b], rgb8_out=u8[:b], **nz)
-            for k in range(0, b, upscale_batch):
-                video.write(up.enhance_frames(u8[k:min(b, k + upscale_batch)]))
-                n_written += min(b, k + upscale_batch) - k
-    assert n_written == hi - lo
-    if world > 1:
-        dist.barrier()
-    if rank != 0:
-        return None, None
-    parts = [f"{stem}_part{r:03d}.mp4" for r in range(world) if frame_range(T, r, world)[1] > frame_range(T, r, world)[0]]
-    lst = stem + "_parts.txt"
-    Path(lst).write_text("".join(f"file '{Path(p).name}'\n" for p in parts))
-    patch.save(stem + ".json")
-    joined = stem + ".mp4"
-    if shutil.which("ffmpeg") and all(Path(p).exists() for p in parts):
-        cmd = ["ffmpeg", "-y", "-loglevel", "error", "-f", "concat", "-safe", "0", "-i", lst]
-        wav = audio_file if str(audio_file).lower().endswith(".wav") else None
-        if wav:
-            cmd += ["-ss", str(audio_offset)] + (["-t", str(audio_duration)] if audio_duration else []) + ["-i", wav, "-c:a", "aac"]
-        subprocess.run(cmd + ["-c:v", "copy", joined], check=True)
-        return joined, None
-    return lst, None
+
+    def write_part(path, lo_, hi_):
+        n_written = 0
+        with VideoWriter(path, (s * rw, s * rh), fps) as video:
+            for i in range(lo_, hi_, batch_size):
+                b = min(batch_size, hi_ - i)
+                nz = {f"noise{j}": m.forward(i, b)[:, None] for j, m in enumerate(noise)}
+                G.synthesizer(latents=latents[i:i + b], rgb8_out=u8[:b], **nz)
+                for k in range(0, b, upscale_batch):
+                    video.write(up.enhance_frames(u8[k:min(b, k + upscale_batch)]))
+                    n_written += min(b, k + upscale_batch) - k
+        return n_written
+    from ..distributed import write_parts_and_join
+    out = write_parts_and_join(stem, T, rank, world, write_part, audio_file=muxable_audio(audio_file), audio_offset=audio_offset,
+                               audio_duration=audio_duration, on_rank0=lambda: patch.save(stem + ".json"))
+    return out, None
 
 
 def main(argv=None):

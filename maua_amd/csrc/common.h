@@ -32,6 +32,33 @@ __device__ __forceinline__ uint32_t to_u8(float x) {
   return (uint32_t)__float2int_rn(v * 255.0f);
 }
 
+// IEEE half (MAUA_F16, round 5: the reference's own render dtype - render/ffmpeg.py:45, wrappers/__init__.py fp16=True): raw
+// bits in a type of its own - bf16_t is a plain uint16_t - so that kernels templated on the element type can tell the two 16-bit
+// formats apart.  The fast bf16 kernels (LDS-direct convolutions, the walks) have no f16 form: an F16 network runs the generic
+// templated kernels on v_mfma_f32_32x32x16_f16.
+struct f16_t { uint16_t bits; };
+typedef _Float16 hw_f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {   // round to nearest even (v_cvt_f16_f32)
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_f16x2));
+}
+// the two 16-bit storage formats behind one interface: a packed pair <-> two floats, and the value a float has once stored
+template <typename T> struct Fmt16;
+template <> struct Fmt16<bf16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2bf(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t u) { return bf2f((bf16_t)(u & 0xffffu)); }
+  __device__ static __forceinline__ float hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+  __device__ static __forceinline__ float round(float f) { return bf2f(f2bf(f)); }
+};
+template <> struct Fmt16<f16_t> {
+  __device__ static __forceinline__ uint32_t pack2(float lo, float hi) { return pack2h(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t u) { return h2f((uint16_t)(u & 0xffffu)); }
+  __device__ static __forceinline__ float hi(uint32_t u) { return h2f((uint16_t)(u >> 16)); }
+  __device__ static __forceinline__ float round(float f) { return h2f((uint16_t)(pack2h(f, 0.f) & 0xffffu)); }
+};
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kDtype = MAUA_F32;
@@ -42,6 +69,12 @@ template <> struct Elem<bf16_t> {
   static constexpr int kDtype = MAUA_BF16;
   __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }
   __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+template <> struct Elem<f16_t> {
+  static constexpr int kDtype = MAUA_F16;
+  __device__ static __forceinline__ float load(const f16_t* p) { return h2f(p->bits); }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { p->bits = (uint16_t)(pack2h(v, 0.f) & 0xffffu); }
 };
 
 // activation ids follow maua_act in the header (reference ops.py:44-62)

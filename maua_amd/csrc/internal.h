@@ -129,7 +129,9 @@ int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int
 // block's features never reach HBM.  up = conv0's arguments (w from launch_prep_upwalk_weights, y unused), c1 = conv1's
 // (w from launch_prep_weights, rgb_* set, y unused)
 bool upwalk_fused_supported(int dtype, int Ci, int Cm, int H, int W);
-int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1);
+// force_segs > 0: that many row segments instead of the cost model's choice; narrow_ok: walk a last strip of <= 32 columns as two
+// half-height sub-items (both: results are identical by construction, tests compare them)
+int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs = 0, int narrow_ok = 1);
 
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
@@ -201,8 +203,13 @@ struct StyleLayer {
   int Cin, Co, Cs, Cd;
   float scale;            // 1 (conv) or 1/sqrt(Cin) (toRGB)
 };
+// f16_prenorm: the styles of the demodulating layers divided by their per-sample maximum before the demodulation coefficients
+// are formed (ops.py:161-165; MAUA_F16 networks)
 int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
-                  int w_dim, int B, int max_channels);
+                  int w_dim, int B, int max_channels, int f16_prenorm = 0);
+// ops.py:161-165 on plain tensors: out[co] = w[co] / (max |w[co]| * sqrt(Ci kk)); s[b][0 .. Cin) /= max |s[b]|
+int launch_f16_prenorm_weights(hipStream_t stream, const float* w, float* out, int Co, int Ci, int kk);
+int launch_f16_prenorm_styles(hipStream_t stream, float* s, int B, int Cs, int Cin);
 
 // toRGB (1x1 modconv, no demod, + bias, clamp) + FIR-upsampled skip + add -> f32 planar image
 struct RgbArgs {
@@ -246,5 +253,8 @@ struct AttnArgs {
 };
 bool attention_supported(int head_ch);
 int launch_attention(hipStream_t stream, int dtype, const AttnArgs& a);
+
+// secondary.hip: the context a secondary diffusion model was created on
+maua_ctx* secondary_ctx(maua_secondary* n);
 
 }  // namespace maua

@@ -44,6 +44,18 @@ template <> struct Mma<bf16_t> {
     return o;
   }
 };
+template <> struct Mma<f16_t> {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+  // scale 8 halves by 8 f32 styles, round to nearest even (the styles arrive pre-normalised, |s| <= 1: the product cannot overflow)
+  __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = pack2h(Fmt16<f16_t>::lo(v[k]) * sv[2 * k], Fmt16<f16_t>::hi(v[k]) * sv[2 * k + 1]);
+    return o;
+  }
+};
 template <> struct Mma<float> {
   // lane half h holds k = 8j+4h+e (e = 0..3): MFMA e consumes element e of both operands, so A and B see the
   // same K permutation and the sum is over the same set of products.
@@ -371,14 +383,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 #pragma unroll
               for (int k = 0; k < 4; k++) {
                 float t = v[k];
-                if constexpr (sizeof(T) == 2) t = bf2f(f2bf(t));
+                if constexpr (sizeof(T) == 2) t = Fmt16<T>::round(t);
                 v[k] = a.res_gain * t + Elem<T>::load(rp2 + k);
               }
             }
           }
           char* dst = epi + m * ES + nl * (int)sizeof(T);
           if constexpr (sizeof(T) == 2)
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3]));
           else
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -447,12 +459,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
         float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         u32x4 wf;
 #pragma unroll
-        for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * bf2f(f2bf(wv[k]))) * row_mask;  // hi rows: w, lo rows: w - bf16(w)
+        for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * Fmt16<T>::round(wv[k])) * row_mask;  // hi rows: w, lo rows: w - T(w)
 #pragma unroll
-        for (int k = 0; k < 4; k++) wf[k] = pack2bf(wv[2 * k], wv[2 * k + 1]);
+        for (int k = 0; k < 4; k++) wf[k] = Fmt16<T>::pack2(wv[2 * k], wv[2 * k + 1]);
         const u32x4 av = *reinterpret_cast<const u32x4*>(epi + mrow * ES + (ks * 16 + 8 * h) * 2);
-        racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, av),
-                                                       racc, 0, 0, 0);
+        Mma<T>::step(racc, wf, av);
       }
       if (px_ok) {
         float o3[3] = {racc[0] + racc[4] + rb0, racc[1] + racc[5] + rb1, racc[2] + racc[6] + rb2};
@@ -557,11 +568,12 @@ static int launch_modconv_t(hipStream_t stream, const ConvArgs& a) {
 
 // conv1 layers whose toRGB can ride on the epilogue tile: the variants with a 128-channel N tile (launch_modconv_t)
 bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W) {
-  return dtype == MAUA_BF16 && up == 1 && Co == 128 && Ci % 32 == 0 && H * W >= 4096 && (H % 2) == 0 && (W % 2) == 0;
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && up == 1 && Co == 128 && Ci % 32 == 0 && H * W >= 4096 && (H % 2) == 0 && (W % 2) == 0;
 }
 
 int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {
   if (dtype == MAUA_BF16) return launch_modconv_t<bf16_t>(stream, a);
+  if (dtype == MAUA_F16) return launch_modconv_t<f16_t>(stream, a);
   if (dtype == MAUA_F32) return launch_modconv_t<float>(stream, a);
   return fail("modconv3x3: unsupported dtype");
 }
@@ -630,6 +642,9 @@ int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt,
   dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, grid, dim3(256), 0, stream, w, (bf16_t*)wt, wsq, Co, Ci, k, up, flip,
+                       Cop, Cip);
+  else if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(prep_weights_kernel<f16_t>, grid, dim3(256), 0, stream, w, (f16_t*)wt, wsq, Co, Ci, k, up, flip,
                        Cop, Cip);
   else if (dtype == MAUA_F32)
     hipLaunchKernelGGL(prep_weights_kernel<float>, grid, dim3(256), 0, stream, w, (float*)wt, wsq, Co, Ci, k, up, flip,
@@ -736,12 +751,65 @@ __global__ __launch_bounds__(256) void styles_demod_kernel(const StyleLayer* __r
   }
 }
 
+// ---- ops.py:161-165, the FP16 pre-normalisation of a demodulated convolution ("Pre-normalize inputs to avoid FP16 overflow"):
+//   weight = weight / (amax |weight| over (ci, ky, kx) per output channel * sqrt(Ci k k));  styles = styles / amax |styles| per sample
+// Demodulation makes the layer's output invariant to both factors (up to its 1e-8); what they buy is range: with |s| <= 1 the
+// modulated activation x * s, which this library rounds to the network dtype, cannot leave the half range when x did not.
+// One workgroup per output channel
+__global__ __launch_bounds__(256) void f16_prenorm_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int row,
+                                                                  float rsqrt_fan) {
+  __shared__ float red[4];
+  const float* src = w + (long)blockIdx.x * row;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < row; i += 256) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float k = rsqrt_fan / m;   // (an all-zero channel divides by zero, as the reference does)
+  for (int i = threadIdx.x; i < row; i += 256) out[(long)blockIdx.x * row + i] = src[i] * k;
+}
+int launch_f16_prenorm_weights(hipStream_t stream, const float* w, float* out, int Co, int Ci, int kk) {
+  if (Co == 0) return MAUA_OK;
+  hipLaunchKernelGGL(f16_prenorm_weights_kernel, dim3(Co), dim3(256), 0, stream, w, out, Ci * kk, 1.f / sqrtf((float)(Ci * kk)));
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+// one wave per (layer, sample): s[b][0 .. Cin) /= max |s[b][.]|, for the layers that demodulate (L.d != NULL)
+__global__ __launch_bounds__(64) void f16_prenorm_styles_kernel(const StyleLayer* __restrict__ layers, int B) {
+  const StyleLayer L = layers[blockIdx.x];
+  if (!L.d) return;
+  float* sp = L.s + (long)blockIdx.y * L.Cs;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < L.Cin; i += 64) m = fmaxf(m, fabsf(sp[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  for (int i = threadIdx.x; i < L.Cin; i += 64) sp[i] = sp[i] / m;
+}
+// the same for one plain styles tensor [B][Cs] (operator-level entry point)
+__global__ __launch_bounds__(64) void f16_prenorm_styles_plain_kernel(float* __restrict__ s, int Cs, int Cin) {
+  float* sp = s + (long)blockIdx.x * Cs;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < Cin; i += 64) m = fmaxf(m, fabsf(sp[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  for (int i = threadIdx.x; i < Cin; i += 64) sp[i] = sp[i] / m;
+}
+int launch_f16_prenorm_styles(hipStream_t stream, float* s, int B, int Cs, int Cin) {
+  if (B == 0) return MAUA_OK;
+  hipLaunchKernelGGL(f16_prenorm_styles_plain_kernel, dim3(B), dim3(64), 0, stream, s, Cs, Cin);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
 int launch_styles(hipStream_t stream, const StyleLayer* layers_dev, int n_layers, const float* ws, int num_ws,
-                  int w_dim, int B, int max_channels) {
+                  int w_dim, int B, int max_channels, int f16_prenorm) {
   if (B == 0 || n_layers == 0) return MAUA_OK;
   MAUA_REQUIRE(w_dim % 4 == 0 && max_channels % 4 == 0, "styles: w_dim and channel counts must be multiples of 4");
   const int ny = cdiv(std::max(max_channels, 32), 32);
   hipLaunchKernelGGL(styles_affine_kernel, dim3(n_layers, ny), dim3(256), 0, stream, layers_dev, ws, num_ws, w_dim, B);
+  if (f16_prenorm) hipLaunchKernelGGL(f16_prenorm_styles_kernel, dim3(n_layers, B), dim3(64), 0, stream, layers_dev, B);
   hipLaunchKernelGGL(styles_demod_kernel, dim3(n_layers, ny), dim3(256), 0, stream, layers_dev, B);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
@@ -811,10 +879,10 @@ __global__ __launch_bounds__(256) void torgb_kernel(RgbArgs a, int lp_log2) {
       uint4 v = *reinterpret_cast<const uint4*>(xb + p * a.C + pc * EPC);
       float xv[EPC];
       if constexpr (sizeof(T) == 2) {
-        xv[0] = bf2f((bf16_t)(v.x & 0xffff)); xv[1] = bf2f((bf16_t)(v.x >> 16));
-        xv[2] = bf2f((bf16_t)(v.y & 0xffff)); xv[3] = bf2f((bf16_t)(v.y >> 16));
-        xv[4] = bf2f((bf16_t)(v.z & 0xffff)); xv[5] = bf2f((bf16_t)(v.z >> 16));
-        xv[6] = bf2f((bf16_t)(v.w & 0xffff)); xv[7] = bf2f((bf16_t)(v.w >> 16));
+        xv[0] = Fmt16<T>::lo(v.x); xv[1] = Fmt16<T>::hi(v.x);
+        xv[2] = Fmt16<T>::lo(v.y); xv[3] = Fmt16<T>::hi(v.y);
+        xv[4] = Fmt16<T>::lo(v.z); xv[5] = Fmt16<T>::hi(v.z);
+        xv[6] = Fmt16<T>::lo(v.w); xv[7] = Fmt16<T>::hi(v.w);
       } else {
         xv[0] = __uint_as_float(v.x); xv[1] = __uint_as_float(v.y);
         xv[2] = __uint_as_float(v.z); xv[3] = __uint_as_float(v.w);
@@ -890,7 +958,7 @@ __global__ __launch_bounds__(256) void torgb_mfma_kernel(RgbArgs a) {
 
 int launch_torgb(hipStream_t stream, int dtype, const RgbArgs& a) {
   if (a.B == 0) return MAUA_OK;
-  const int epc = dtype == MAUA_BF16 ? 8 : 4;
+  const int epc = dtype == MAUA_F32 ? 4 : 8;
   MAUA_REQUIRE(a.C % epc == 0, "torgb: C must be a multiple of the 16-byte piece");
   // (C = 512 layers are <= 64^2: the fragment set-up of 32 k-steps costs more than it saves there)
   if (dtype == MAUA_BF16 && (a.C == 32 || a.C == 64 || a.C == 128 || a.C == 256) && ((uintptr_t)a.wmod % 16) == 0) {
@@ -914,6 +982,8 @@ int launch_torgb(hipStream_t stream, int dtype, const RgbArgs& a) {
   size_t smem = (size_t)3 * a.C * sizeof(float);
   if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(torgb_kernel<bf16_t>, dim3(gx, a.B), dim3(256), smem, stream, a, lp_log2);
+  else if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(torgb_kernel<f16_t>, dim3(gx, a.B), dim3(256), smem, stream, a, lp_log2);
   else if (dtype == MAUA_F32)
     hipLaunchKernelGGL(torgb_kernel<float>, dim3(gx, a.B), dim3(256), smem, stream, a, lp_log2);
   else

@@ -31,6 +31,17 @@ template <> struct TMma<bf16_t> {
     return o;
   }
 };
+template <> struct TMma<f16_t> {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = pack2h(Fmt16<f16_t>::lo(v[k]) * sv[2 * k], Fmt16<f16_t>::hi(v[k]) * sv[2 * k + 1]);
+    return o;
+  }
+};
 template <> struct TMma<float> {
   __device__ static __forceinline__ void step(f32x16& acc, const u32x4& w, const u32x4& x) {
     f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
@@ -210,8 +221,8 @@ __global__ __launch_bounds__(512, 4) void tconv2_kernel(ConvArgs a, TconvRegions
     for (int qd = 0; qd < 4; qd++) {
       char* dst = epi + m * ES + (c * 32 + 8 * qd + 4 * h) * (int)sizeof(T);
       if constexpr (sizeof(T) == 2)
-        *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(acc[c][qd * 4 + 0], acc[c][qd * 4 + 1]),
-                                                    pack2bf(acc[c][qd * 4 + 2], acc[c][qd * 4 + 3]));
+        *reinterpret_cast<uint2*>(dst) = make_uint2(Fmt16<T>::pack2(acc[c][qd * 4 + 0], acc[c][qd * 4 + 1]),
+                                                    Fmt16<T>::pack2(acc[c][qd * 4 + 2], acc[c][qd * 4 + 3]));
       else
         *reinterpret_cast<float4*>(dst) =
             make_float4(acc[c][qd * 4 + 0], acc[c][qd * 4 + 1], acc[c][qd * 4 + 2], acc[c][qd * 4 + 3]);
@@ -269,6 +280,7 @@ static int launch_tconv_t(hipStream_t stream, const ConvArgs& a) {
 
 int launch_tconv2(hipStream_t stream, int dtype, const ConvArgs& a) {
   if (dtype == MAUA_BF16) return launch_tconv_t<bf16_t>(stream, a);
+  if (dtype == MAUA_F16) return launch_tconv_t<f16_t>(stream, a);
   if (dtype == MAUA_F32) return launch_tconv_t<float>(stream, a);
   return fail("tconv2: unsupported dtype");
 }
@@ -302,6 +314,8 @@ int launch_prep_tconv_weights(hipStream_t stream, int dtype, const float* w, voi
   dim3 grid((unsigned)((n + 255) / 256));
   if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(prep_tconv_weights_kernel<bf16_t>, grid, dim3(256), 0, stream, w, (bf16_t*)wt, Co, Ci, flip);
+  else if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(prep_tconv_weights_kernel<f16_t>, grid, dim3(256), 0, stream, w, (f16_t*)wt, Co, Ci, flip);
   else if (dtype == MAUA_F32)
     hipLaunchKernelGGL(prep_tconv_weights_kernel<float>, grid, dim3(256), 0, stream, w, (float*)wt, Co, Ci, flip);
   else

@@ -43,12 +43,12 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   MAUA_REQUIRE(ctx, "maua_modconv2d: ctx is NULL");
   if (N == 0) return MAUA_OK;
   MAUA_REQUIRE(x && weight && styles && y, "maua_modconv2d: NULL argument");
-  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_modconv2d: unsupported dtype");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16 || dtype == MAUA_F16, "maua_modconv2d: unsupported dtype");
   MAUA_REQUIRE(k == 1 || k == 3, "maua_modconv2d: kernel size must be 1 or 3");
   MAUA_REQUIRE(up == 1 || (up == 2 && k == 3), "maua_modconv2d: up must be 1, or 2 with a 3x3 kernel");
   MAUA_REQUIRE(N >= 0 && Ci > 0 && Co > 0 && H > 0 && W > 0, "maua_modconv2d: bad shape");
   if (N == 0) return MAUA_OK;
-  const size_t es = dtype == MAUA_BF16 ? 2 : 4;
+  const size_t es = dtype == MAUA_F32 ? 4 : 2;
   const int Cip = (Ci + 31) / 32 * 32, Cop = (Co + 31) / 32 * 32;
   const int Ho = H * up, Wo = W * up;
   const size_t wt_elems = prepped_weight_elems(3, up, Cop, Cip);
@@ -62,6 +62,9 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   size_t o_x = carve((size_t)N * H * W * Cip * es), o_y = carve((size_t)N * Ho * Wo * Cop * es);
   size_t o_w = carve(wt_elems * es), o_wsq = carve((size_t)Co * Ci * 4), o_s = carve((size_t)N * Cip * 4);
   size_t o_d = carve((size_t)N * Cop * 4), o_b = carve((size_t)Cop * 4);
+  // ops.py:161-165: "if x.dtype == torch.float16 and demodulate" the weight and the styles are pre-normalised
+  const bool prenorm = dtype == MAUA_F16 && demodulate;
+  size_t o_wn = prenorm ? carve((size_t)Co * Ci * k * k * 4) : 0;
   const bool dma = ctx->dma_conv && k == 3 && dma_conv_supported(dtype, Cip, Cop, up, H, W);
   size_t o_xm = dma ? carve((size_t)N * H * W * Cip * es) : 0;
   if (int rc = scratch_reserve(ctx, off)) return rc;
@@ -75,9 +78,15 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   float* dp = (float*)(base + o_d);
   float* bp = (float*)(base + o_b);
 
-  int rc = dtype == MAUA_BF16 ? launch_nchw_to_nhwc<bf16_t, bf16_t>(st, x, xn, N, Ci, H * W, Cip)
-                              : launch_nchw_to_nhwc<float, float>(st, x, xn, N, Ci, H * W, Cip);
+  int rc = dtype == MAUA_BF16   ? launch_nchw_to_nhwc<bf16_t, bf16_t>(st, x, xn, N, Ci, H * W, Cip)
+           : dtype == MAUA_F16 ? launch_nchw_to_nhwc<f16_t, f16_t>(st, x, xn, N, Ci, H * W, Cip)
+                               : launch_nchw_to_nhwc<float, float>(st, x, xn, N, Ci, H * W, Cip);
   if (rc) return rc;
+  if (prenorm) {
+    float* wn = (float*)(base + o_wn);
+    if ((rc = launch_f16_prenorm_weights(st, weight, wn, Co, Ci, k * k))) return rc;
+    weight = wn;
+  }
   MAUA_HIP_CHECK(hipMemsetAsync(wt, 0, wt_elems * es, st));
   // a 1x1 kernel is executed as the centre tap of a zero 3x3 kernel
   void* wt_dst = (k == 1) ? (void*)((char*)wt + (size_t)4 * Cop * Cip * es) : wt;
@@ -86,6 +95,8 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   MAUA_HIP_CHECK(hipMemsetAsync(sp, 0, (size_t)N * Cip * 4, st));
   MAUA_HIP_CHECK(hipMemcpy2DAsync(sp, (size_t)Cip * 4, styles, (size_t)Ci * 4, (size_t)Ci * 4, N,
                                   hipMemcpyDeviceToDevice, st));
+  if (prenorm)
+    if ((rc = launch_f16_prenorm_styles(st, sp, N, Cip, Ci))) return rc;
   if (demodulate) {
     hipLaunchKernelGGL(demod_kernel, dim3(cdiv(Cop, 4), N), dim3(256), 0, st, sp, wsq, dp, Ci, Co, Cip, Cop);
     MAUA_HIP_CHECK(hipGetLastError());
@@ -105,6 +116,7 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   } else if ((rc = launch_modconv3x3(st, dtype, a))) {
     return rc;
   }
-  return dtype == MAUA_BF16 ? launch_nhwc_to_nchw<bf16_t, bf16_t>(st, yn, y, N, Co, Ho * Wo, Cop)
-                            : launch_nhwc_to_nchw<float, float>(st, yn, y, N, Co, Ho * Wo, Cop);
+  return dtype == MAUA_BF16   ? launch_nhwc_to_nchw<bf16_t, bf16_t>(st, yn, y, N, Co, Ho * Wo, Cop)
+         : dtype == MAUA_F16 ? launch_nhwc_to_nchw<f16_t, f16_t>(st, yn, y, N, Co, Ho * Wo, Cop)
+                             : launch_nhwc_to_nchw<float, float>(st, yn, y, N, Co, Ho * Wo, Cop);
 }

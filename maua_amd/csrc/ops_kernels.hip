@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T* __restrict__ x, 
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else if constexpr (VEC == 4 && sizeof(T) == 2) {
       uint2 t = *reinterpret_cast<const uint2*>(x + e);
-      v[0] = bf2f((bf16_t)(t.x & 0xffff)); v[1] = bf2f((bf16_t)(t.x >> 16));
-      v[2] = bf2f((bf16_t)(t.y & 0xffff)); v[3] = bf2f((bf16_t)(t.y >> 16));
+      v[0] = Fmt16<T>::lo(t.x); v[1] = Fmt16<T>::hi(t.x);
+      v[2] = Fmt16<T>::lo(t.y); v[3] = Fmt16<T>::hi(t.y);
     } else {
       v[0] = Elem<T>::load(x + e);
     }
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T* __restrict__ x, 
     if constexpr (VEC == 4 && sizeof(T) == 4) {
       *reinterpret_cast<float4*>(y + e) = make_float4(v[0], v[1], v[2], v[3]);
     } else if constexpr (VEC == 4 && sizeof(T) == 2) {
-      *reinterpret_cast<uint2*>(y + e) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      *reinterpret_cast<uint2*>(y + e) = make_uint2(Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3]));
     } else {
       Elem<T>::store(y + e, v[0]);
     }
@@ -84,8 +84,7 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
         unsigned r[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          r[k] = pack2bf(__uint_as_float(xs[k] << 16) + __uint_as_float(ys[k] << 16),
-                         __uint_as_float(xs[k] & 0xffff0000u) + __uint_as_float(ys[k] & 0xffff0000u));
+          r[k] = Fmt16<T>::pack2(Fmt16<T>::lo(xs[k]) + Fmt16<T>::lo(ys[k]), Fmt16<T>::hi(xs[k]) + Fmt16<T>::hi(ys[k]));
         reinterpret_cast<uint4*>(o)[i] = make_uint4(r[0], r[1], r[2], r[3]);
       }
     }
@@ -311,6 +310,10 @@ template int launch_nchw_to_nhwc<bf16_t, bf16_t>(hipStream_t, const void*, void*
 template int launch_nhwc_to_nchw<float, float>(hipStream_t, const void*, void*, int, int, int, int);
 template int launch_nhwc_to_nchw<bf16_t, float>(hipStream_t, const void*, void*, int, int, int, int);
 template int launch_nhwc_to_nchw<bf16_t, bf16_t>(hipStream_t, const void*, void*, int, int, int, int);
+template int launch_nchw_to_nhwc<float, f16_t>(hipStream_t, const void*, void*, int, int, int, int);
+template int launch_nchw_to_nhwc<f16_t, f16_t>(hipStream_t, const void*, void*, int, int, int, int);
+template int launch_nhwc_to_nchw<f16_t, float>(hipStream_t, const void*, void*, int, int, int, int);
+template int launch_nhwc_to_nchw<f16_t, f16_t>(hipStream_t, const void*, void*, int, int, int, int);
 
 }  // namespace maua
 
@@ -326,6 +329,7 @@ int maua_bias_act(maua_ctx* ctx, const void* x, const float* b, void* y, int N, 
   MAUA_REQUIRE(x && y, "maua_bias_act: NULL argument");
   if (dtype == MAUA_F32) return maua::launch_bias_act<float>(ctx, x, b, y, N, C, H, W, act, alpha, gain, clamp);
   if (dtype == MAUA_BF16) return maua::launch_bias_act<maua::bf16_t>(ctx, x, b, y, N, C, H, W, act, alpha, gain, clamp);
+  if (dtype == MAUA_F16) return maua::launch_bias_act<maua::f16_t>(ctx, x, b, y, N, C, H, W, act, alpha, gain, clamp);
   return maua::fail("maua_bias_act: unsupported dtype");
 }
 
@@ -336,6 +340,7 @@ int maua_add(maua_ctx* ctx, const void* a, const void* b, void* out, long n, int
   MAUA_REQUIRE(a && b && out, "maua_add: NULL argument");
   if (dtype == MAUA_F32) return maua::launch_add<float>(ctx, a, b, out, n);
   if (dtype == MAUA_BF16) return maua::launch_add<maua::bf16_t>(ctx, a, b, out, n);
+  if (dtype == MAUA_F16) return maua::launch_add<maua::f16_t>(ctx, a, b, out, n);
   return maua::fail("maua_add: unsupported dtype");
 }
 
@@ -351,6 +356,8 @@ int maua_upfirdn2d(maua_ctx* ctx, const void* x, const float* f, int fh, int fw,
     return maua::launch_upfirdn2d<float>(ctx, x, f, fh, fw, y, N, C, H, W, up, down, px0, px1, py0, py1, gain);
   if (dtype == MAUA_BF16)
     return maua::launch_upfirdn2d<maua::bf16_t>(ctx, x, f, fh, fw, y, N, C, H, W, up, down, px0, px1, py0, py1, gain);
+  if (dtype == MAUA_F16)
+    return maua::launch_upfirdn2d<maua::f16_t>(ctx, x, f, fh, fw, y, N, C, H, W, up, down, px0, px1, py0, py1, gain);
   return maua::fail("maua_upfirdn2d: unsupported dtype");
 }
 

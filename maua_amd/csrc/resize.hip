@@ -116,6 +116,9 @@ int launch_resize2d(hipStream_t stream, int dtype, bool nhwc, const ResizeArgs& 
   } else if (dtype == MAUA_BF16) {
     if (nhwc) hipLaunchKernelGGL((resize2d_kernel<bf16_t, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((resize2d_kernel<bf16_t, false>), grid, dim3(256), 0, stream, a);
+  } else if (dtype == MAUA_F16) {
+    if (nhwc) hipLaunchKernelGGL((resize2d_kernel<f16_t, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((resize2d_kernel<f16_t, false>), grid, dim3(256), 0, stream, a);
   } else {
     return fail("resize2d: unsupported dtype");
   }
@@ -194,6 +197,8 @@ int launch_warp_affine_nhwc(hipStream_t stream, int dtype, const void* x, void* 
     hipLaunchKernelGGL(warp_affine_nhwc_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, (float*)y, minv, H, W, C, total);
   else if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(warp_affine_nhwc_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, minv, H, W, C, total);
+  else if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(warp_affine_nhwc_kernel<f16_t>, grid, dim3(256), 0, stream, (const f16_t*)x, (f16_t*)y, minv, H, W, C, total);
   else
     return fail("warp_affine: unsupported dtype");
   MAUA_HIP_CHECK(hipGetLastError());

@@ -487,6 +487,10 @@ int vjp_t(maua_secondary* n, const float* g_v, float* g_x) {
 
 }  // namespace
 
+namespace maua {
+maua_ctx* secondary_ctx(maua_secondary* n) { return n ? n->ctx : nullptr; }
+}
+
 extern "C" {
 
 int maua_secondary_create(maua_ctx* ctx, int dtype, maua_secondary** out) {

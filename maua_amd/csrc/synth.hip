@@ -265,13 +265,14 @@ int maua_synth_create(maua_ctx* ctx, int img_resolution, int w_dim, int channel_
   MAUA_REQUIRE(ctx && out, "maua_synth_create: NULL argument");
   MAUA_REQUIRE(img_resolution >= 4 && (img_resolution & (img_resolution - 1)) == 0,
                "maua_synth_create: img_resolution must be a power of two >= 4");
-  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_synth_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16 || dtype == MAUA_F16,
+               "maua_synth_create: dtype must be MAUA_F32, MAUA_BF16 or MAUA_F16");
   MAUA_REQUIRE(w_dim > 0 && w_dim <= 4096, "maua_synth_create: bad w_dim");
-  const int kc = dtype == MAUA_BF16 ? 32 : 16;
+  const int kc = dtype == MAUA_F32 ? 16 : 32;
   maua_synth* n = new maua_synth();
   n->ctx = ctx; n->res = img_resolution; n->w_dim = w_dim; n->channel_base = channel_base;
   n->channel_max = channel_max; n->dtype = dtype; n->nv_compat = nv_compat;
-  n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  n->esize = dtype == MAUA_F32 ? 4 : 2;
   int nb = 0;
   for (int r = 4; r <= img_resolution; r *= 2) nb++;
   n->nblocks = nb;
@@ -520,8 +521,9 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
     float* tmp;
     MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
     MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
-    int rc = n->dtype == MAUA_BF16 ? launch_nchw_to_nhwc<float, bf16_t>(st, tmp, n->const_x, 1, C, 16, C)
-                                   : launch_nchw_to_nhwc<float, float>(st, tmp, n->const_x, 1, C, 16, C);
+    int rc = n->dtype == MAUA_BF16   ? launch_nchw_to_nhwc<float, bf16_t>(st, tmp, n->const_x, 1, C, 16, C)
+             : n->dtype == MAUA_F16 ? launch_nchw_to_nhwc<float, f16_t>(st, tmp, n->const_x, 1, C, 16, C)
+                                    : launch_nchw_to_nhwc<float, float>(st, tmp, n->const_x, 1, C, 16, C);
     hipStreamSynchronize(st);
     hipFree(tmp);
     return rc;
@@ -557,6 +559,10 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
     float* tmp;
     MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
     MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+    // F16 networks: the reference's FP16 pre-normalisation of the weight (ops.py:161-163; every convolution of the synthesis
+    // network demodulates) - the styles' half is applied per batch (launch_styles)
+    if (n->dtype == MAUA_F16)
+      if (int rc0 = launch_f16_prenorm_weights(st, tmp, tmp, c->Co, c->Ci, 9)) { hipFree(tmp); return rc0; }
     int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, c->wsq, c->Co, c->Ci, 3, c->up,
                                  (c->up == 2) ? (n->nv_compat & 1) : 0, c->Co, c->Ci);
     if (!rc && c->up == 2)
@@ -591,7 +597,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   // events accumulate across forwards until maua_synth_get_profile() reads and resets them
   if (n->profile) n->ev_fwd_start.push_back(n->ev_used);
   prof_mark(n, "begin");
-  if (int rc = launch_styles(st, n->style_table_dev, ntab, ws, n->num_ws, n->w_dim, B, max_c)) return rc;
+  if (int rc = launch_styles(st, n->style_table_dev, ntab, ws, n->num_ws, n->w_dim, B, max_c, n->dtype == MAUA_F16)) return rc;
 
   prof_mark(n, "styles");
   const void* x = n->const_x;
@@ -935,6 +941,7 @@ int maua_synth_get_feature(maua_synth* n, int layer, int B, float* out_nchw) {
   ConvLayer& c = n->convs[layer];
   hipStream_t st = n->ctx->stream;
   if (n->dtype == MAUA_BF16) return launch_nhwc_to_nchw<bf16_t, float>(st, c.feat, out_nchw, B, c.Co, c.fh * c.fw, c.Co);
+  if (n->dtype == MAUA_F16) return launch_nhwc_to_nchw<f16_t, float>(st, c.feat, out_nchw, B, c.Co, c.fh * c.fw, c.Co);
   return launch_nhwc_to_nchw<float, float>(st, c.feat, out_nchw, B, c.Co, c.fh * c.fw, c.Co);
 }
 

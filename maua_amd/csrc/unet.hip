@@ -351,6 +351,9 @@ __global__ __launch_bounds__(256) void gn_finalize_psum_kernel(const float* __re
   }
 }
 
+// A thread owns one 16-byte channel piece and walks GN_PX output pixels of its row with it (round 5: one pixel per thread spent
+// 136 bytes of parameter loads - gamma, beta, scale, shift, statistics - on 16 bytes of data and ran at 1.7 TB/s).
+constexpr int GN_PX = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_group_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -360,8 +363,9 @@ __global__ __launch_bounds__(256) void gn_apply_group_kernel(const T* __restrict
   constexpr int EPC = 16 / (int)sizeof(T);
   const unsigned C = C0 + C1, PPP = C / EPC, cpg = C / 32;
   const unsigned li = blockIdx.x * 256u + threadIdx.x;
-  if (li >= (unsigned)Wo * PPP) return;
-  const unsigned ox = li / PPP, pc = li - ox * PPP;
+  const unsigned nxg = ((unsigned)Wo + GN_PX - 1) / GN_PX;
+  if (li >= nxg * PPP) return;
+  const unsigned oxg = li / PPP, pc = li - oxg * PPP;
   const unsigned b = blockIdx.y / (unsigned)Ho, oy = blockIdx.y - b * (unsigned)Ho;
   const unsigned c = pc * EPC;
   const T* src;
@@ -392,46 +396,59 @@ __global__ __launch_bounds__(256) void gn_apply_group_kernel(const T* __restrict
       sh[e] = hv[k];
     }
   }
-  float acc[EPC], raw[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; e++) acc[e] = raw[e] = 0.f;
   const int taps = mode == 1 ? 4 : 1;
-  for (int t = 0; t < taps; t++) {
-    unsigned iy, ix;
-    if (mode == 1) { iy = 2 * oy + (t >> 1); ix = 2 * ox + (t & 1); }
-    else if (mode == 2) { iy = oy >> 1; ix = ox >> 1; }
-    else { iy = oy; ix = ox; }
-    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)(iy * (unsigned)W + ix) * stride);
-#pragma unroll
-    for (int e = 0; e < EPC; e++) {
-      float f;
-      if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
-      else f = __uint_as_float(v[e]);
-      raw[e] += f;
-      float u = fmaf(f, ca[e], cb[e]);
-      if (ss) u = fmaf(u, sc[e], sh[e]);
-      if (silu) {
-        if constexpr (sizeof(T) == 2) u = __fdividef(u, 1.f + __expf(-u));
-        else u = u / (1.f + expf(-u));
-      }
-      acc[e] += u;
-    }
-  }
   const float norm = mode == 1 ? 0.25f : 1.f;
-  u32x4 o, ro;
-  if constexpr (sizeof(T) == 2) {
+  // the pixel group's loads are requested together (mode 0 / 2: one per pixel; the 4-tap average pool walks pixel by pixel)
+  u32x4 vin[GN_PX];
+  if (taps == 1) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      o[k] = pack2bf(acc[2 * k] * norm, acc[2 * k + 1] * norm);
-      ro[k] = pack2bf(raw[2 * k] * norm, raw[2 * k + 1] * norm);
+    for (int k = 0; k < GN_PX; k++) {
+      const unsigned ox = min(oxg * GN_PX + k, (unsigned)Wo - 1);
+      const unsigned iy = mode == 2 ? oy >> 1 : oy, ix = mode == 2 ? ox >> 1 : ox;
+      vin[k] = *reinterpret_cast<const u32x4*>(src + (long)(iy * (unsigned)W + ix) * stride);
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 4; k++) { o[k] = __float_as_uint(acc[k] * norm); ro[k] = __float_as_uint(raw[k] * norm); }
   }
-  const long opix = ((long)b * Ho + oy) * Wo + ox;
-  *reinterpret_cast<u32x4*>(y + opix * C + c) = o;
-  if (xr) *reinterpret_cast<u32x4*>(xr + opix * C + c) = ro;
+#pragma unroll
+  for (int k = 0; k < GN_PX; k++) {
+    const unsigned ox = oxg * GN_PX + k;
+    if (ox >= (unsigned)Wo) break;
+    float acc[EPC], raw[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e++) acc[e] = raw[e] = 0.f;
+    for (int t = 0; t < taps; t++) {
+      u32x4 v;
+      if (taps == 1) v = vin[k];
+      else v = *reinterpret_cast<const u32x4*>(src + (long)((2 * oy + (t >> 1)) * (unsigned)W + 2 * ox + (t & 1)) * stride);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        float f;
+        if constexpr (sizeof(T) == 2) f = bf2f((bf16_t)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu));
+        else f = __uint_as_float(v[e]);
+        raw[e] += f;
+        float u = fmaf(f, ca[e], cb[e]);
+        if (ss) u = fmaf(u, sc[e], sh[e]);
+        if (silu) {
+          if constexpr (sizeof(T) == 2) u = __fdividef(u, 1.f + __expf(-u));
+          else u = u / (1.f + expf(-u));
+        }
+        acc[e] += u;
+      }
+    }
+    u32x4 o, ro;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        o[q] = pack2bf(acc[2 * q] * norm, acc[2 * q + 1] * norm);
+        ro[q] = pack2bf(raw[2 * q] * norm, raw[2 * q + 1] * norm);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { o[q] = __float_as_uint(acc[q] * norm); ro[q] = __float_as_uint(raw[q] * norm); }
+    }
+    const long opix = ((long)b * Ho + oy) * Wo + ox;
+    *reinterpret_cast<u32x4*>(y + opix * C + c) = o;
+    if (xr) *reinterpret_cast<u32x4*>(xr + opix * C + c) = ro;
+  }
 }
 
 // workspace (bytes) of one GroupNorm over [B][HW][C]: partial sums + the [B][32][2] statistics
@@ -472,8 +489,8 @@ static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, i
       hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(B), dim3(256), 0, st, part, (int)p.nchunk, (double)HW * (C / 32), 1e-5f,
                          stats);
     }
-    hipLaunchKernelGGL(gn_apply_group_kernel<T>, dim3((unsigned)(((long)Wo * PPP + 255) / 256), (unsigned)(B * Ho)), dim3(256),
-                       0, st, x0, C0, x1, C1, stats, gamma, beta, ss, ss_ld, silu, mode, y, xr, H, W, Ho, Wo);
+    hipLaunchKernelGGL(gn_apply_group_kernel<T>, dim3((unsigned)(((long)((Wo + GN_PX - 1) / GN_PX) * PPP + 255) / 256), (unsigned)(B * Ho)),
+                       dim3(256), 0, st, x0, C0, x1, C1, stats, gamma, beta, ss, ss_ld, silu, mode, y, xr, H, W, Ho, Wo);
   } else {
     const GnPlan q = p.fast ? GnPlan{0, p.RY, p.ppc, p.nchunk, 0} : p;
     hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)q.nchunk, B), dim3(PPP * q.RY), 0, st, x0, C0, x1, C1, HW, q.ppc,
@@ -605,6 +622,28 @@ __global__ __launch_bounds__(256) void axpby_rows_kernel(const float* __restrict
   out[idx] = ab[2 * b] * x[idx] + ab[2 * b + 1] * y[idx];
 }
 
+// the image-MSE grad module of the guided sampler: g = (img - target) * k[b] (k = 2 scale / numel, one per sample; read from device
+// memory so that a captured loop serves every scale), one target per sample or one for all (tstride 0); any NaN raises *flag
+__global__ __launch_bounds__(256) void mse_guide_grad_kernel(const float* __restrict__ img, const float* __restrict__ target,
+                                                             long tstride, const float* __restrict__ kdev, long row, long total,
+                                                             float* __restrict__ out, int* __restrict__ flag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (idx < total) {
+    const long b = idx / row, i = idx - b * row;
+    const float v = (img[idx] - target[b * tstride + i]) * kdev[b];
+    out[idx] = v;
+    bad = v != v;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+// GradientGuidedConditioning.forward (guided.py:262-265): a grad module whose output holds a NaN contributes zeros
+__global__ __launch_bounds__(256) void zero_if_flag_kernel(float* __restrict__ g, long total, const int* __restrict__ flag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // (an agent-scope load: served by L2, where the previous launch's atomicOr landed - not by the scalar / vector L1)
+  if (idx < total && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) g[idx] = 0.f;
+}
+
 // ----------------------------------------------------------------------------------------------------- parameters
 struct UGN { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
 struct UConv { int Ci = 0, Co = 0, Cip = 0, Cop = 0; void* wt = nullptr; float* bias = nullptr; };
@@ -670,6 +709,17 @@ struct maua_unet {
   int graph_failed = 0;              // capture / instantiation failed once: the loop runs eagerly from then on
   float *g_x = nullptr, *g_out = nullptr, *g_pred = nullptr, *g_t = nullptr, *g_cf = nullptr;
   int g_steps = 0;
+  // guided sampler graph (maua_ddim_guided_loop): its own executable; the sample, the target and every per-step constant live in
+  // library buffers, so one capture serves every call of a shape
+  hipGraphExec_t gd_exec = nullptr;
+  size_t gd_key = 0;
+  int gd_failed = 0;
+  float* gd_buf = nullptr;           // x | v | pred | eps | img | g | jv | grad | target, B * C * H * W floats each
+  size_t gd_cap = 0;
+  float* gd_tab = nullptr;           // cos_t [S][B] | (sigma, 1 - sigma) [S][B][2] | grad coefficients [S][B][2] | k [B]
+  size_t gd_tab_cap = 0;
+  int* gd_flag = nullptr;            // [gd_flags] one NaN flag per step, zeroed before every loop (outside the graph)
+  int gd_flags = 0;
 };
 
 namespace {
@@ -1067,6 +1117,12 @@ struct Runner {
 
 size_t shape_key(int B, int H, int W) { return ((size_t)B << 40) ^ ((size_t)H << 20) ^ (size_t)W; }
 
+// the captured sampler loops hold pointers into the arena / the per-step tables: whatever moves those drops both executables
+void drop_sampler_graphs(maua_unet* n) {
+  if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+  if (n->gd_exec) { hipGraphExecDestroy(n->gd_exec); n->gd_exec = nullptr; n->gd_key = 0; }
+}
+
 template <typename T>
 int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int W, float* out) {
   hipStream_t st = n->ctx->stream;
@@ -1086,7 +1142,7 @@ int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int 
     }
     n->gather_bytes = pr.gather_ws_bytes;
     n->planned_key = key;
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
   }
   if (B > n->ones_b) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
@@ -1140,7 +1196,10 @@ void maua_unet_destroy(maua_unet* n) {
   if (!n) return;
   hipStreamSynchronize(n->ctx->stream);
   if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
+  if (n->gd_exec) hipGraphExecDestroy(n->gd_exec);
   if (n->cap_stream) hipStreamDestroy(n->cap_stream);
+  for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
+    if (p) hipFree(p);
   for (void* p : n->owned) hipFree(p);
   if (n->arena.base) hipFree(n->arena.base);
   if (n->ones) hipFree(n->ones);
@@ -1156,12 +1215,12 @@ int maua_unet_set_option(maua_unet* n, const char* key, int value) {
   if (!strcmp(key, "psum_off")) {
     n->psum_off = value;
     n->planned_key = 0;   // (the arena layout changes)
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
     return MAUA_OK;
   }
   if (!strcmp(key, "route")) {
     n->route = value;
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
     return MAUA_OK;
   }
   return fail(std::string("maua_unet_set_option: unknown option ") + key);
@@ -1374,13 +1433,11 @@ int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const
 // [n_steps][8] (maua_ddim_step's coefficients).  use_graph: capture the whole loop in ONE hipGraph on first use for a
 // (B, H, W, n_steps) and replay it afterwards (a forward is ~400 short launches: the graph removes the launch gaps).
 // pred_xstart (optional) receives the last step's prediction.
-int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,
-                          int use_graph, float* pred_xstart) {
-  MAUA_REQUIRE(n && x && model_t && coef && n_steps > 0, "maua_ddim_sample_loop: NULL argument");
-  if (B == 0) return MAUA_OK;
+// what both sampler loops need on the device before their first step: the timesteps [n_steps][B], the DDIM coefficients
+// [n_steps][B][8], the model-output / pred_xstart buffers and every step's timestep projections (emb_table)
+static int prepare_sampler(maua_unet* n, int B, int H, int W, const float* model_t, const float* coef, int n_steps) {
   hipStream_t st = n->ctx->stream;
   const long chw = (long)n->in_ch * H * W;
-  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52);
   // per-step constants on the device: timesteps [n_steps][B], coefficients [n_steps][B][8]
   if (n->g_steps < n_steps * B || !n->g_t) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
@@ -1388,7 +1445,7 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
     MAUA_HIP_CHECK(hipMalloc((void**)&n->g_t, (size_t)n_steps * B * 4));
     MAUA_HIP_CHECK(hipMalloc((void**)&n->g_cf, (size_t)n_steps * B * 8 * 4));
     n->g_steps = n_steps * B;
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
   }
   {
     std::vector<float> ht((size_t)n_steps * B), hc((size_t)n_steps * B * 8);
@@ -1408,7 +1465,7 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
     MAUA_HIP_CHECK(hipMalloc((void**)&n->g_out, out_bytes));
     MAUA_HIP_CHECK(hipMalloc((void**)&n->g_pred, pred_bytes));
     n->out_cap = out_bytes + pred_bytes;
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
   }
   // every step's timestep projections at once: the timesteps are known up front and shared by the samples, so the stacked
   // emb_layers GEMV (51 k x 1024 f32 weights at the 256^2 configuration) runs once per loop with n_steps rows instead of
@@ -1419,7 +1476,7 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
     n->emb_table = nullptr; n->emb_table_rows = 0;
     MAUA_HIP_CHECK(hipMalloc((void**)&n->emb_table, (size_t)n_steps * n->emb_total * 4));
     n->emb_table_rows = n_steps;
-    if (n->graph_exec) { hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; n->graph_key = 0; }
+    drop_sampler_graphs(n);
   }
   {
     const int E = n->emb_dim, mc = n->mc, half = mc / 2;
@@ -1437,6 +1494,18 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     hipFree(tt);
   }
+  return MAUA_OK;
+}
+
+int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,
+                          int use_graph, float* pred_xstart) {
+  MAUA_REQUIRE(n && x && model_t && coef && n_steps > 0, "maua_ddim_sample_loop: NULL argument");
+  if (B == 0) return MAUA_OK;
+  hipStream_t st = n->ctx->stream;
+  const long chw = (long)n->in_ch * H * W;
+  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52);
+  if (int rc = prepare_sampler(n, B, H, W, model_t, coef, n_steps)) return rc;
+  const size_t pred_bytes = (size_t)B * chw * 4;
   auto body = [&](int s) -> int {
     n->emb_row = n->emb_table + (size_t)s * n->emb_total;
     int rc = maua_unet_forward(n, x, n->g_t + (size_t)s * B, B, H, W, n->g_out);
@@ -1492,6 +1561,159 @@ int maua_ddim_sample_loop(maua_unet* n, float* x, int B, int H, int W, const flo
       if (int rc = body(s)) return rc;
   }
   if (pred_xstart) MAUA_HIP_CHECK(hipMemcpyAsync(pred_xstart, n->g_pred, pred_bytes, hipMemcpyDeviceToDevice, st));
+  return MAUA_OK;
+}
+
+// g = (img - target) * k over rows, zeros when any element is NaN (MSEGuide + the NaN rule of guided.py:262-265); k: device scalar
+// (reset_flag = false: *flag was zeroed by the caller - the captured sampler loop keeps memset nodes out of its graph: replays of a
+//  graph holding a 4-byte memset node were seen reading a non-zero flag after an eager run of the same calls, on ROCm 7.0.2)
+static int mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, long tstride, const float* kdev, int B, long row,
+                          float* out, int* flag, bool reset_flag = true) {
+  const long total = (long)B * row;
+  if (reset_flag) MAUA_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(mse_guide_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, img, target, tstride,
+                     kdev, row, total, out, flag);
+  hipLaunchKernelGGL(zero_if_flag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, out, total, flag);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// The image-MSE grad module as an operator: out = (img - target) * k, zeros if that holds a NaN.  img, out [B][row]; target [B][row]
+// (target_bstride = row) or one row for all samples (0).
+int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, long target_bstride, float k, int B, long row, float* out) {
+  MAUA_REQUIRE(ctx, "maua_mse_guide_grad: ctx is NULL");
+  if (B == 0 || row == 0) return MAUA_OK;
+  MAUA_REQUIRE(img && target && out, "maua_mse_guide_grad: NULL argument");
+  if (int rc = scratch_reserve(ctx, 256 + (size_t)B * 4)) return rc;
+  int* flag = reinterpret_cast<int*>(ctx->scratch);
+  float* kd = reinterpret_cast<float*>(reinterpret_cast<char*>(ctx->scratch) + 256);
+  std::vector<float> hk((size_t)B, k);
+  MAUA_HIP_CHECK(hipMemcpyAsync(kd, hk.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  MAUA_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (hk lives on this call's stack)
+  return mse_guide_grad(ctx, img, target, target_bstride, kd, B, row, out, flag);
+}
+
+// configs[3] as BASELINE states it: the GUIDED DDIM loop inside the library, one hipGraph per shape.  Per step s (guided.py:302-311,
+// 333-337 with cond_fn = GradientGuidedConditioning, speed "fast", :236-272, and the image-MSE grad module):
+//   out  = unet(x, t_s)                                      pred = secondary(x, cos_t_s).pred          (:252-253)
+//   img  = sigma_s pred + (1 - sigma_s) x                    g    = (img - target) k, zeros if NaN      (:254, :256-265)
+//   grad = c0_s g + c1_s (dv/dx)^T g                         x, pred_xstart = ddim_step(x, out, grad)   (:266-268, ddim_sample)
+// guide: host f32 [n_steps][5] = {cos_t, sigma, 1 - sigma, -(sigma a_c + 1 - sigma), sigma s_c} as GradientGuidedConditioning.forward
+// evaluates them.  target: device [B][C][H][W] (target_bstride = C H W) or one image for all samples (0).  x is updated in place.
+int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, int H, int W, const float* model_t, const float* coef,
+                          const float* guide, int n_steps, const float* target, long target_bstride, float mse_k, int use_graph,
+                          float* pred_xstart) {
+  MAUA_REQUIRE(n && sec && x && model_t && coef && guide && target && n_steps > 0, "maua_ddim_guided_loop: NULL argument");
+  MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: the secondary model guides 3-channel images");
+  MAUA_REQUIRE(secondary_ctx(sec) == n->ctx, "maua_ddim_guided_loop: both networks must live on one context (one stream)");
+  const long chw = (long)n->in_ch * H * W;
+  MAUA_REQUIRE(target_bstride == 0 || target_bstride == chw, "maua_ddim_guided_loop: target_bstride is 0 or C * H * W");
+  if (B == 0) return MAUA_OK;
+  hipStream_t st = n->ctx->stream;
+  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52) ^ ((size_t)(uintptr_t)sec << 1) ^ (target_bstride ? 1u : 0u);
+  if (int rc = prepare_sampler(n, B, H, W, model_t, coef, n_steps)) return rc;
+  const size_t tb = (size_t)B * chw, tab = (size_t)n_steps * B * 5 + B;
+  if (n->gd_cap < 9 * tb || n->gd_tab_cap < tab || !n->gd_flag || n->gd_flags < n_steps) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
+      if (p) hipFree(p);
+    n->gd_buf = nullptr; n->gd_tab = nullptr; n->gd_flag = nullptr; n->gd_cap = n->gd_tab_cap = 0;
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_buf, 9 * tb * 4));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_tab, tab * 4));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_flag, (size_t)n_steps * 4));
+    n->gd_cap = 9 * tb; n->gd_tab_cap = tab; n->gd_flags = n_steps;
+    drop_sampler_graphs(n);
+  }
+  float *bx = n->gd_buf, *bv = bx + tb, *bp = bv + tb, *be = bp + tb, *bimg = be + tb, *bg = bimg + tb, *bjv = bg + tb,
+        *bgrad = bjv + tb, *btgt = bgrad + tb;
+  float *t_ct = n->gd_tab, *t_img = t_ct + (size_t)n_steps * B, *t_grad = t_img + (size_t)n_steps * B * 2,
+        *t_k = t_grad + (size_t)n_steps * B * 2;
+  {
+    std::vector<float> h(tab);
+    for (int s = 0; s < n_steps; s++)
+      for (int b = 0; b < B; b++) {
+        const float* gs = guide + (size_t)s * 5;
+        h[(size_t)s * B + b] = gs[0];
+        h[(size_t)n_steps * B + ((size_t)s * B + b) * 2] = gs[1];
+        h[(size_t)n_steps * B + ((size_t)s * B + b) * 2 + 1] = gs[2];
+        h[(size_t)n_steps * B * 3 + ((size_t)s * B + b) * 2] = gs[3];
+        h[(size_t)n_steps * B * 3 + ((size_t)s * B + b) * 2 + 1] = gs[4];
+      }
+    for (int b = 0; b < B; b++) h[(size_t)n_steps * B * 5 + b] = mse_k;
+    MAUA_HIP_CHECK(hipMemcpyAsync(n->gd_tab, h.data(), tab * 4, hipMemcpyHostToDevice, st));
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  MAUA_HIP_CHECK(hipMemsetAsync(n->gd_flag, 0, (size_t)n_steps * 4, st));
+  MAUA_HIP_CHECK(hipMemcpyAsync(bx, x, tb * 4, hipMemcpyDeviceToDevice, st));
+  MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
+  const long tstride = target_bstride ? chw : 0;
+  auto body = [&](int s) -> int {
+    n->emb_row = n->emb_table + (size_t)s * n->emb_total;
+    int rc = maua_unet_forward(n, bx, n->g_t + (size_t)s * B, B, H, W, n->g_out);
+    n->emb_row = nullptr;
+    if (rc) return rc;
+    if ((rc = maua_secondary_forward(sec, bx, t_ct + (size_t)s * B, B, H, W, bv, bp, be))) return rc;
+    if ((rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg))) return rc;
+    if ((rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false))) return rc;
+    if ((rc = maua_secondary_vjp(sec, bg, B, H, W, bjv))) return rc;
+    if ((rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad))) return rc;
+    return maua_ddim_step(n->ctx, bx, n->g_out, bgrad, nullptr, n->g_cf + (size_t)s * B * 8, B, n->in_ch, n->out_ch, (long)H * W, bx,
+                          n->g_pred);
+  };
+  if (use_graph && !n->gd_failed) {
+    if (!n->gd_exec || n->gd_key != key) {
+      // one eager step on scratch copies first: it plans both networks' workspaces and sets the kernels' attributes (none of that
+      // can be captured); bx is restored afterwards
+      {
+        int rc = body(0);
+        if (rc) return rc;
+        MAUA_HIP_CHECK(hipMemcpyAsync(bx, x, tb * 4, hipMemcpyDeviceToDevice, st));
+        MAUA_HIP_CHECK(hipMemsetAsync(n->gd_flag, 0, (size_t)n_steps * 4, st));
+      }
+      if (n->gd_exec) { hipGraphExecDestroy(n->gd_exec); n->gd_exec = nullptr; }
+      if (!n->cap_stream) MAUA_HIP_CHECK(hipStreamCreateWithFlags(&n->cap_stream, hipStreamNonBlocking));
+      MAUA_HIP_CHECK(hipStreamSynchronize(st));
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipStreamBeginCapture(n->cap_stream, hipStreamCaptureModeThreadLocal);
+      int rc = MAUA_OK;
+      if (e == hipSuccess) {
+        n->ctx->stream = n->cap_stream;   // the launchers of both networks read the context's stream
+        for (int s = 0; s < n_steps && !rc; s++) rc = body(s);
+        n->ctx->stream = st;
+        e = hipStreamEndCapture(n->cap_stream, &graph);
+      }
+      if (!rc && e == hipSuccess) e = hipGraphInstantiate(&n->gd_exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc || e != hipSuccess) {
+        (void)hipGetLastError();
+        n->gd_exec = nullptr;
+        n->gd_failed = 1;
+        if (getenv("MAUA_VERBOSE"))
+          fprintf(stderr, "[maua] ddim_guided_loop: graph capture unavailable (%s), running launch by launch\n",
+                  rc ? maua_last_error() : hipGetErrorString(e));
+      } else {
+        n->gd_key = key;
+      }
+    }
+  }
+  if (use_graph && n->gd_exec && !n->gd_failed) {
+    // (the copies / memset above are stream-ordered before the graph anyway; one host wait per 100-step loop costs nothing and keeps
+    //  the replay independent of how the runtime orders copy engines against graph launches)
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    MAUA_HIP_CHECK(hipGraphLaunch(n->gd_exec, st));
+  } else {
+    for (int s = 0; s < n_steps; s++)
+      if (int rc = body(s)) return rc;
+  }
+  MAUA_HIP_CHECK(hipMemcpyAsync(x, bx, tb * 4, hipMemcpyDeviceToDevice, st));
+  if (pred_xstart) MAUA_HIP_CHECK(hipMemcpyAsync(pred_xstart, n->g_pred, tb * 4, hipMemcpyDeviceToDevice, st));
+  return MAUA_OK;
+}
+
+// 1 when the last maua_ddim_guided_loop(use_graph = 1) replayed a captured hipGraph
+int maua_unet_guided_graph_active(maua_unet* n, int* active) {
+  MAUA_REQUIRE(n && active, "maua_unet_guided_graph_active: NULL argument");
+  *active = n->gd_exec && !n->gd_failed ? 1 : 0;
   return MAUA_OK;
 }
 

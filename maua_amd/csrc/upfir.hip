@@ -36,7 +36,7 @@ __device__ __forceinline__ void upfir_hrow(const char* __restrict__ tb, uint32_t
     }
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) c[rx][k] = f32x2_t{__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+      for (int k = 0; k < 4; k++) c[rx][k] = f32x2_t{Fmt16<T>::lo(v[k]), Fmt16<T>::hi(v[k])};
     } else {
       c[rx][0] = f32x2_t{__uint_as_float(v[0]), __uint_as_float(v[1])};
       c[rx][1] = f32x2_t{__uint_as_float(v[2]), __uint_as_float(v[3])};
@@ -82,8 +82,8 @@ __device__ __forceinline__ void upfir_emit(const UpfirArgs& a, char* __restrict_
     }
     char* dst = yb + yoff + j * pxb;
     if constexpr (sizeof(T) == 2)
-      *reinterpret_cast<u32x4*>(dst) = u32x4{pack2bf(o[0][0], o[0][1]), pack2bf(o[1][0], o[1][1]),
-                                             pack2bf(o[2][0], o[2][1]), pack2bf(o[3][0], o[3][1])};
+      *reinterpret_cast<u32x4*>(dst) = u32x4{Fmt16<T>::pack2(o[0][0], o[0][1]), Fmt16<T>::pack2(o[1][0], o[1][1]),
+                                             Fmt16<T>::pack2(o[2][0], o[2][1]), Fmt16<T>::pack2(o[3][0], o[3][1])};
     else
       *reinterpret_cast<f32x4*>(dst) = f32x4{o[0][0], o[0][1], o[1][0], o[1][1]};
   }
@@ -159,14 +159,14 @@ __global__ __launch_bounds__(256) void upfir_epilogue_kernel(UpfirArgs a) {
 
 int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a) {
   if (a.B == 0) return MAUA_OK;
-  const int epc = dtype == MAUA_BF16 ? 8 : 4;
+  const int epc = dtype == MAUA_F32 ? 4 : 8;
   MAUA_REQUIRE(a.Co % epc == 0, "upfir_epilogue: Co must be a multiple of the 16-byte piece");
   MAUA_REQUIRE(!a.out_scale || ((uintptr_t)a.out_scale % 16) == 0, "upfir_epilogue: out_scale must be 16-byte aligned");
   MAUA_REQUIRE((!a.d || ((uintptr_t)a.d % 16) == 0) && (!a.bias || ((uintptr_t)a.bias % 16) == 0),
                "upfir_epilogue: d and bias must be 16-byte aligned");
   MAUA_REQUIRE(!a.noise || (((uintptr_t)a.noise % 8) == 0 && a.noise_bstride % 2 == 0),
                "upfir_epilogue: noise must be 8-byte aligned");
-  MAUA_REQUIRE((long)(2 * a.H + 1) * (2 * a.W + 1) * a.Co * (dtype == MAUA_BF16 ? 2 : 4) < (1L << 31),
+  MAUA_REQUIRE((long)(2 * a.H + 1) * (2 * a.W + 1) * a.Co * (dtype == MAUA_F32 ? 4 : 2) < (1L << 31),
                "upfir_epilogue: a sample of t must stay below 2 GiB (32-bit offsets)");
   const long total = (long)((2 * a.H + UPFIR_ROWS - 1) / UPFIR_ROWS) * a.W * (a.Co / epc);
   const dim3 grid((unsigned)((total + 255) / 256), a.B);
@@ -174,6 +174,9 @@ int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a) {
   if (dtype == MAUA_BF16) {
     if (lr) hipLaunchKernelGGL((upfir_epilogue_kernel<bf16_t, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((upfir_epilogue_kernel<bf16_t, false>), grid, dim3(256), 0, stream, a);
+  } else if (dtype == MAUA_F16) {
+    if (lr) hipLaunchKernelGGL((upfir_epilogue_kernel<f16_t, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((upfir_epilogue_kernel<f16_t, false>), grid, dim3(256), 0, stream, a);
   } else if (dtype == MAUA_F32) {
     if (lr) hipLaunchKernelGGL((upfir_epilogue_kernel<float, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((upfir_epilogue_kernel<float, false>), grid, dim3(256), 0, stream, a);

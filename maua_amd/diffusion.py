@@ -211,6 +211,12 @@ class UNetModel(torch.nn.Module):
         L.check(L.lib().maua_unet_graph_active(self._handle(), C.byref(a)))
         return bool(a.value)
 
+    def guided_graph_active(self):
+        """... the same for the guided loop (maua_ddim_guided_loop)."""
+        a = C.c_int()
+        L.check(L.lib().maua_unet_guided_graph_active(self._handle(), C.byref(a)))
+        return bool(a.value)
+
     def set_option(self, key, value):
         """Library options of the network object ("route", "psum_off": see maua_unet_set_option)."""
         L.check(L.lib().maua_unet_set_option(self._handle(), key.encode(), int(value)))
@@ -459,6 +465,37 @@ class SpacedDiffusion:
                                               cf.ctypes.data_as(C.c_void_p), n_steps, int(bool(use_graph)), L.ptr(pred)))
         return x, pred
 
+    def ddim_guided_loop(self, model, conditioning, x, start_step=None, n_steps=None, use_graph=True):
+        """The GUIDED loop inside the library (guided.py:302-311, 333-337 with cond_fn = ``conditioning``: speed "fast", one
+        image-MSE grad module whose target is set): UNet forward, secondary forward, grad module, secondary VJP and the DDIM
+        update of all steps as one hipGraph.  Same arithmetic, same kernels and the same host-evaluated coefficients as the
+        step-by-step path (``ddim_sample`` + ``GradientGuidedConditioning.forward``), so the results are identical.
+        -> (x after the last step, its pred_xstart); x is updated in place."""
+        start = self.num_timesteps - 1 if start_step is None else int(start_step)
+        n_steps = start + 1 if n_steps is None else int(n_steps)
+        ts = torch.arange(start, start - n_steps, -1)
+        ts = torch.where(ts < 0, ts + self.num_timesteps, ts)
+        mtt = self.model_timesteps(ts)
+        mt = np.ascontiguousarray(mtt.numpy(), dtype=np.float32)
+        cf = np.ascontiguousarray(self.step_coefficients(ts).numpy(), dtype=np.float32)
+        gc = np.ascontiguousarray(conditioning.guide_coefficients(mtt).numpy(), dtype=np.float32)
+        gm = conditioning.grad_modules[0]
+        x = L.dev_tensor(x, torch.float32)
+        tgt = L.dev_tensor(gm.target, torch.float32)
+        B, _, H, W = x.shape
+        if tuple(tgt.shape) == tuple(x.shape[1:]):
+            tstride = 0
+        elif tuple(tgt.shape) == tuple(x.shape):
+            tstride = x[0].numel()
+        else:
+            raise ValueError(f"ddim_guided_loop: target shape {tuple(tgt.shape)} fits neither {tuple(x.shape[1:])} nor {tuple(x.shape)}")
+        pred = torch.empty_like(x)
+        L.check(L.lib().maua_ddim_guided_loop(model._handle(), conditioning.model._handle(), L.ptr(x), B, H, W,
+                                              mt.ctypes.data_as(C.c_void_p), cf.ctypes.data_as(C.c_void_p),
+                                              gc.ctypes.data_as(C.c_void_p), n_steps, L.ptr(tgt), C.c_long(tstride),
+                                              C.c_float(gm.factor(x[0].numel())), int(bool(use_graph)), L.ptr(pred)))
+        return x, pred
+
 
 def model_and_diffusion_defaults():
     """script_util.model_and_diffusion_defaults (the keys guided.py:171-190 reads or overrides)."""
@@ -497,7 +534,7 @@ CHECKPOINTS = {"uncondImageNet512": ("modelzoo/512x512_diffusion_uncond_finetune
 
 
 def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diffusion_steps=1000, use_secondary=False,
-                  allow_random_init=False, dtype=torch.bfloat16, generator=None, **overrides):
+                  allow_random_init=False, dtype=torch.bfloat16, generator=None, secondary_dtype=torch.float32, **overrides):
     """guided.py:164-209.  The checkpoint file is loaded when it exists (upstream state-dict keys); there is no network
     access to download it: without the file this raises unless ``allow_random_init`` (seeded random weights of the same
     architecture - what the bench and the tests run).  ``overrides``: model_config entries (tests build small networks)."""
@@ -518,7 +555,9 @@ def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diff
     secondary = None
     if use_secondary:   # guided.py:198-205
         spath = "modelzoo/secondary_model_imagenet_2.pth"
-        secondary = SecondaryDiffusionImageNet2(dtype=dtype, generator=generator)
+        # (the reference keeps this 13.9 M-parameter model in fp32, guided.py:198-205, whatever the UNet runs in: exact-f32 MFMA mode by
+        #  default - the guidance gradient lands within 4e-4 of the reference's; bf16 is an opt-in, 3.5 % off in L2 norm)
+        secondary = SecondaryDiffusionImageNet2(dtype=secondary_dtype, generator=generator)
         if os.path.exists(spath):
             secondary.load_state_dict(torch.load(spath, map_location="cpu"))
         elif not allow_random_init:
@@ -567,6 +606,7 @@ class SecondaryDiffusionImageNet2(torch.nn.Module):
             self._params[k + ".weight"] = torch.randn(co.value, ci.value, 3, 3, generator=g) / math.sqrt(3.0 * 9 * ci.value)
             self._params[k + ".bias"] = torch.randn(co.value, generator=g) / math.sqrt(3.0 * 9 * ci.value)
         self._net = None
+        self._last = None   # (B, H, W) of the last forward: what vjp differentiates
 
     def state_dict(self, *a, **k):
         return dict(self._params)
@@ -583,6 +623,8 @@ class SecondaryDiffusionImageNet2(torch.nn.Module):
                     raise RuntimeError(f"{k}: shape {tuple(v.shape)} != {tuple(self._params[k].shape)}")
                 self._params[k] = v.contiguous()
         self._destroy()
+        self._last = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, extra)
 
     def eval(self):
         return self
@@ -635,6 +677,8 @@ class SecondaryDiffusionImageNet2(torch.nn.Module):
 
     def vjp(self, g_v):
         """(d v / d input)^T g_v for the input of the last ``forward``."""
+        if self._last is None:
+            raise RuntimeError("SecondaryDiffusionImageNet2.vjp: call forward first (the product is taken at the last forward's input)")
         g = L.dev_tensor(g_v, torch.float32)
         B, H, W = self._last
         if tuple(g.shape) != (B, 3, H, W):
@@ -664,10 +708,16 @@ class GradientGuidedConditioning(torch.nn.Module):
         self.sqrt_one_minus_alphas_cumprod = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod).float()
         self.noise = None
 
-    def set_targets(self, prompts, noise):
+    def set_targets(self, prompts, noise, per_sample=False):
         self.noise = noise
         for gm in self.grad_modules:
-            gm.set_targets(prompts)
+            if per_sample:
+                gm.set_targets_per_sample(prompts)   # (only modules that declare it: GuidedDiffusion.run checks)
+            else:
+                gm.set_targets(prompts)
+
+    def per_sample_prompts(self):
+        return all(hasattr(gm, "set_targets_per_sample") for gm in self.grad_modules)
 
     def _sum_grads(self, img, ot):
         img_grad = torch.zeros_like(img)
@@ -677,6 +727,22 @@ class GradientGuidedConditioning(torch.nn.Module):
                 sub = torch.zeros_like(img)
             img_grad += sub
         return img_grad
+
+    def guide_coefficients(self, t):
+        """[len(t), 5] float32 = {cos_t, sigma, 1 - sigma, -(sigma a_c + 1 - sigma), sigma s_c} of the "fast" conditioning at the
+        model timesteps ``t``, evaluated exactly like ``forward`` evaluates them (host float32 tensor arithmetic, :249-252 / :266-268);
+        what maua_ddim_guided_loop takes per step."""
+        idx = torch.tensor([self.timestep_map.index(int(v)) for v in torch.as_tensor(t).long().cpu().reshape(-1)])
+        alpha, sigma = self.sqrt_alphas_cumprod[idx], self.sqrt_one_minus_alphas_cumprod[idx]
+        cosine_t = torch.atan2(sigma, alpha) * 2 / math.pi
+        a_c, s_c = torch.cos(cosine_t * math.pi / 2), torch.sin(cosine_t * math.pi / 2)
+        return torch.stack([cosine_t, sigma, 1 - sigma, -(sigma * a_c + 1 - sigma), sigma * s_c], 1).float().contiguous()
+
+    def graphable(self):
+        """True when the whole guided step is library work (speed "fast", exactly one image-MSE grad module with a target): the
+        sampler loop then runs as one hipGraph (SpacedDiffusion.ddim_guided_loop)."""
+        return (self.speed == "fast" and len(self.grad_modules) == 1 and isinstance(self.grad_modules[0], MSEGuide)
+                and self.grad_modules[0].target is not None)
 
     def forward(self, x, t, kw={}):
         ot = t.clone()
@@ -715,10 +781,27 @@ class MSEGuide:
         ts = [p.target if hasattr(p, "target") else p for p in prompts]
         self.target = None if not ts else torch.stack([torch.as_tensor(t).float() for t in ts]).mean(0).cuda()
 
+    def set_targets_per_sample(self, prompts):
+        """One prompt per SAMPLE of the batch (the audio-switched schedule: frames either side of a prompt switch travel through
+        the sampler together): target [B, C, H, W]."""
+        ts = [p.target if hasattr(p, "target") else p for p in prompts]
+        self.target = None if not ts else torch.stack([torch.as_tensor(t).float() for t in ts]).cuda()
+
+    def factor(self, numel):
+        return 2.0 * self.scale / numel
+
     def __call__(self, img, t):
         if self.target is None:
             return torch.zeros_like(img)
-        return (2.0 * self.scale / img[0].numel()) * (img - self.target.to(img.device))
+        img = L.dev_tensor(img, torch.float32)
+        tgt = L.dev_tensor(self.target, torch.float32)
+        if tuple(tgt.shape) not in (tuple(img.shape[1:]), tuple(img.shape)):
+            raise ValueError(f"MSEGuide: target shape {tuple(tgt.shape)} does not fit images of shape {tuple(img.shape)}")
+        row = img[0].numel()
+        out = torch.empty_like(img)
+        L.check(L.lib().maua_mse_guide_grad(L.ctx(img.device), L.ptr(img), L.ptr(tgt), C.c_long(row if tgt.dim() == img.dim() else 0),
+                                            C.c_float(self.factor(row)), img.shape[0], C.c_long(row), L.ptr(out)))
+        return out
 
 
 class ImageTarget:
@@ -738,7 +821,7 @@ class GuidedDiffusion(torch.nn.Module):
 
     def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
                  ddim_eta=0, plms_order=2, speed="fast", model=None, diffusion=None, secondary_model=None, allow_random_init=False,
-                 dtype=torch.bfloat16):
+                 dtype=torch.bfloat16, secondary_dtype=torch.float32):
         super().__init__()
         if sampler not in ("ddim", "p", "plms"):
             raise NotImplementedError()
@@ -746,9 +829,9 @@ class GuidedDiffusion(torch.nn.Module):
         if model is None:
             model, diffusion, secondary_model = create_models(            # (:292: "ddimN" spacing only for DDIM)
                 checkpoint=model_checkpoint, timestep_respacing=f"ddim{timesteps}" if sampler == "ddim" else str(timesteps),
-                use_secondary=speed == "fast", allow_random_init=allow_random_init, dtype=dtype)
+                use_secondary=speed == "fast", allow_random_init=allow_random_init, dtype=dtype, secondary_dtype=secondary_dtype)
         elif speed == "fast" and secondary_model is None and mods:
-            secondary_model = SecondaryDiffusionImageNet2(dtype=dtype) if allow_random_init else None
+            secondary_model = SecondaryDiffusionImageNet2(dtype=secondary_dtype) if allow_random_init else None
             if secondary_model is None:
                 raise ValueError('speed="fast" with ready objects needs secondary_model= (or allow_random_init=True)')
         self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
@@ -757,14 +840,16 @@ class GuidedDiffusion(torch.nn.Module):
         self.conditioning = GradientGuidedConditioning(diffusion, secondary_model if speed == "fast" else model, mods,   # :297-302
                                                        speed=speed) if mods else None
         self.device = device
+        self.use_graph = True   # guided loops whose every step is library work run as one hipGraph (False: step by step)
         self.original_num_steps = diffusion.original_num_steps
         self.timestep_map = diffusion.timestep_map
         self.image_size = model.image_size
 
     @torch.no_grad()
-    def run(self, img, prompts, start_step, n_steps, noise=None):
+    def run(self, img, prompts, start_step, n_steps, noise=None, per_sample=False):
         """q_sample(img, start_step, noise), then n_steps DDIM updates with t = start_step, start_step - 1, ...
-        -> the last step's pred_xstart.  Without grad modules the loop runs inside the library as one hipGraph."""
+        -> the last step's pred_xstart.  Without grad modules, and with guidance that is all library work (speed "fast", one image-MSE
+        module), the loop runs inside the library as one hipGraph.  ``per_sample``: ``prompts`` holds one prompt per sample."""
         img = L.dev_tensor(img, torch.float32)
         t = torch.tensor([start_step] * img.shape[0], dtype=torch.long)
         noise = torch.randn_like(img) if noise is None else L.dev_tensor(noise, torch.float32)
@@ -774,7 +859,11 @@ class GuidedDiffusion(torch.nn.Module):
         if self.sampler == "ddim" and self.conditioning is None and self.ddim_eta == 0:
             return self.diffusion.ddim_sample_loop(self.model, x, start_step, n_steps)[1]
         if self.conditioning is not None:
-            self.conditioning.set_targets([p.to(img) for p in prompts], noise)
+            if per_sample and (len(prompts) != img.shape[0] or not self.conditioning.per_sample_prompts()):
+                raise ValueError("per_sample needs one prompt per sample and grad modules with set_targets_per_sample")
+            self.conditioning.set_targets([p.to(img) for p in prompts], noise, per_sample)
+            if self.sampler == "ddim" and self.ddim_eta == 0 and self.use_graph and self.conditioning.graphable():
+                return self.diffusion.ddim_guided_loop(self.model, self.conditioning, x, start_step, n_steps)[1]
         out = None
         for _ in range(n_steps):   # guided.py:302-311, :333-337
             if self.sampler == "ddim":
@@ -838,13 +927,19 @@ def sample(prompts: List, audio=None, sr=None, fps=30, n_frames=None, size=(256,
     frames = torch.empty((n_frames, 3, H, W), dtype=torch.float32, device="cuda")
     n = len(gd.timestep_map)
     f = 0
+    per_sample = bool(prompts) and gd.conditioning is not None and gd.conditioning.per_sample_prompts() and t_start is None
     while f < n_frames:
-        # frames that share a prompt go through the sampler together (up to `batch`)
+        # frames that share a prompt go through the sampler together (up to `batch`); grad modules that take one prompt per sample
+        # (MSEGuide) let a batch run across the switches, so every batch is full
         e = f + 1
-        while e < n_frames and e - f < batch and idx[e] == idx[f]:
+        while e < n_frames and e - f < batch and (per_sample or idx[e] == idx[f]):
             e += 1
         x0 = torch.randn((e - f, 3, H, W), generator=g) if init is None else torch.as_tensor(init).expand(e - f, 3, H, W)
         nz = torch.randn((e - f, 3, H, W), generator=g)
+        if per_sample:
+            frames[f:e] = gd.run(x0, [prompts[int(idx[j])] for j in range(f, e)], n - 1, n, noise=nz, per_sample=True)
+            f = e
+            continue
         active = [prompts[int(idx[f])]] if prompts else []
         if t_start is None:   # the whole respaced schedule: t = n - 1 ... 0 (`timesteps` DDIM steps)
             frames[f:e] = gd.run(x0, active, n - 1, n, noise=nz)

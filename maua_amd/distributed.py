@@ -48,42 +48,63 @@ def _want_cabi(transport=None):
 def _cabi_comm(rank, world, device):
     """RCCL communicator of the C-ABI (maua_comm_*), one per process - COLLECTIVE, and it returns the same answer on every
     rank: the communicator, or ``(None, reason)`` everywhere if ANY rank could not build its part (then the callers take
-    torch.distributed's point-to-point path together).  Every rank executes the same two collectives in the same order
-    whatever fails where: (1) a broadcast of [status byte | 128-byte id] from rank 0 - rank 0 broadcasts status 0 if
-    ``maua_comm_unique_id`` itself failed (RCCL not loadable, ``ncclGetUniqueId`` error) instead of skipping the broadcast -,
-    (2) a MIN all-reduce of "my maua_comm_init succeeded"."""
+    torch.distributed's point-to-point path together).  ``ncclCommInitRank`` inside ``maua_comm_init`` is itself a collective,
+    so nobody enters it before everybody can: every rank executes, in this order and whatever fails where,
+      (1) a MIN all-reduce of a PRE-FLIGHT flag - library loaded, context created, RCCL resolved (``maua_comm_unique_id`` on a
+          throw-away buffer: it is what dlopens RCCL) - a rank that cannot get that far takes everyone to the fallback here;
+      (2) a broadcast of [status byte | 128-byte id] from rank 0 (status 0 if drawing the real id failed);
+      (3) ``maua_comm_init``, entered by all or by none;
+      (4) a MIN all-reduce of "my maua_comm_init succeeded".
+    The outcome - also a negative one - is cached per (rank, world, device): a failed build is not retried (and not warned
+    about) at every later gather; ``reset_cabi_comm()`` forgets it.  What this cannot cover: a rank that dies INSIDE
+    ncclCommInitRank leaves its peers to RCCL's own time-out."""
     import ctypes as C
     from . import _lib as L
     key = (rank, world, torch.device(device).index)
     if key in _comm:
         return _comm[key]
-    lib = L.lib()
+    cdev = device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    err, lib, ctx = None, None, None
+    try:   # (1) pre-flight: everything maua_comm_init needs that can fail on ONE rank only
+        lib = L.lib()
+        ctx = L.ctx(device)
+        L.check(lib.maua_comm_unique_id((C.c_char * 128)()))
+    except Exception as e:   # noqa: BLE001 - reported after the ranks have agreed
+        err = e
+    if world > 1:
+        flag = torch.tensor([0 if err is not None else 1], device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            _comm[key] = (None, err or RuntimeError("a peer rank could not load the library / RCCL or create its context"))
+            return _comm[key]
+    elif err is not None:
+        _comm[key] = (None, err)
+        return _comm[key]
     idbuf = (C.c_char * 128)()
-    status, err = 1, None
+    status = 1
     if rank == 0:
         try:
             L.check(lib.maua_comm_unique_id(idbuf))
-        except Exception as e:   # noqa: BLE001 - reported below, after every rank has left the broadcast
+        except Exception as e:   # noqa: BLE001
             status, err = 0, e
     t = torch.tensor([status] + list(bytes(idbuf.raw)), dtype=torch.uint8)
-    cdev = device if (world > 1 and dist.get_backend() == "nccl") else "cpu"
-    if world > 1:
+    if world > 1:   # (2)
         t = t.to(cdev)
         dist.broadcast(t, src=0)
         t = t.cpu()
     status = int(t[0])
     comm = None
-    if status:
+    if status:   # (3) every rank passed the pre-flight and holds the id: all enter
         idbuf.raw = bytes(t[1:].tolist())
         c = C.c_void_p()
         try:
-            L.check(lib.maua_comm_init(L.ctx(device), idbuf, rank, world, C.byref(c)))
+            L.check(lib.maua_comm_init(ctx, idbuf, rank, world, C.byref(c)))
             comm = c
         except Exception as e:   # noqa: BLE001
             err = e
     elif err is None:
         err = RuntimeError("rank 0 could not create the RCCL unique id")
-    if world > 1:
+    if world > 1:   # (4)
         flag = torch.tensor([0 if comm is None else 1], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
@@ -92,10 +113,13 @@ def _cabi_comm(rank, world, device):
                 comm = None
             if err is None:
                 err = RuntimeError("a peer rank could not build its RCCL communicator")
-    if comm is None:
-        return None, err          # (not cached: a later call may try again, collectively)
-    _comm[key] = (comm, None)
+    _comm[key] = (comm, None) if comm is not None else (None, err)
     return _comm[key]
+
+
+def reset_cabi_comm():
+    """Forget cached communicator outcomes (tests; after the environment that made a build fail has changed)."""
+    _comm.clear()
 
 
 def gather_frames_cabi(local, n_frames, rank=None, world=None, dst=0):
@@ -306,3 +330,60 @@ class StreamingGather:
             if self._comm is not None:
                 L.check(L.lib().maua_comm_set_stream(self._comm, None, 1))   # the communicator is shared with gather_frames_cabi
         return self.clip if self.rank == self.dst else None
+
+
+# ---------------------------------------------------------------------------------------------- per-rank part files
+def part_path(stem, rank):
+    return f"{stem}_part{rank:03d}.mp4"
+
+
+def write_parts_and_join(stem, n_frames, rank, world, write_part, audio_file=None, audio_offset=0, audio_duration=None,
+                         on_rank0=None, run=None, which=None):
+    """configs[4]'s multi-rank writer (a 4096^2 frame is 48 MiB: no gather): every rank with a non-empty ``frame_range`` writes
+    ``<stem>_partRRR.mp4`` through ``write_part(path, lo, hi) -> frames written``; rank 0 then joins the parts in rank order by
+    stream copy (ffmpeg concat demuxer) and muxes the clip's audio in.  The reference's only multi-process writer has this
+    shape (super/image/bulk.py:31-109: one output per worker, ordered by index).
+    * an empty shard (more ranks than frames) writes nothing and is left out of the list;
+    * a rank whose ``write_part`` raises still reaches the rendezvous: a MIN all-reduce of "my part is complete" replaces the
+      barrier, and EVERY rank raises when any part is missing - nobody hangs, rank 0 never joins a clip with a hole;
+    * audio: any file the ``ffmpeg`` executable can read (it decodes mp3 / flac / ... itself), cut with -ss / -t and ``-shortest``
+      so that it cannot outlast the frames.
+    -> on rank 0: the joined file (or the concat list when no ``ffmpeg`` executable is on PATH); elsewhere None."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    lo, hi = frame_range(n_frames, rank, world)
+    err = None
+    try:
+        if hi > lo:
+            n = write_part(part_path(stem, rank), lo, hi)
+            if n != hi - lo:
+                raise RuntimeError(f"rank {rank} wrote {n} of {hi - lo} frames")
+    except Exception as e:   # noqa: BLE001 - re-raised below, after the ranks have met
+        err = e
+    if world > 1:
+        ok = torch.tensor([0 if err is not None else 1])
+        if dist.get_backend() == "nccl":
+            ok = ok.cuda()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"a rank failed to write its part of {stem}" + (f" (this one: {err})" if err is not None else "")) from err
+    elif err is not None:
+        raise err
+    if rank != 0:
+        return None
+    parts = [part_path(stem, r) for r in range(world) if frame_range(n_frames, r, world)[1] > frame_range(n_frames, r, world)[0]]
+    lst = stem + "_parts.txt"
+    Path(lst).write_text("".join(f"file '{Path(p).name}'\n" for p in parts))
+    if on_rank0 is not None:
+        on_rank0()
+    joined = stem + ".mp4"
+    which = which or shutil.which
+    if which("ffmpeg") and all(Path(p).exists() for p in parts):
+        cmd = ["ffmpeg", "-y", "-loglevel", "error", "-f", "concat", "-safe", "0", "-i", lst]
+        if audio_file:
+            cmd += ["-ss", str(audio_offset)] + (["-t", str(audio_duration)] if audio_duration else []) + ["-i", str(audio_file), "-c:a", "aac",
+                                                                                                           "-shortest"]
+        (run or subprocess.run)(cmd + ["-c:v", "copy", joined], check=True)
+        return joined
+    return lst

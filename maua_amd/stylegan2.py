@@ -116,8 +116,9 @@ def get_z_latents(seeds, z_dim=512):
 
 
 class SynthesisNetwork(torch.nn.Module):
-    """inference/stylegan2.py:385-436.  ``dtype``: torch.bfloat16 (default, MFMA bf16 operands / f32 accumulate)
-    or torch.float32 (exact-f32 MFMA, parity mode)."""
+    """inference/stylegan2.py:385-436.  ``dtype``: torch.bfloat16 (default, MFMA bf16 operands / f32 accumulate: every fast
+    kernel), torch.float32 (exact-f32 MFMA, parity mode) or torch.float16 (IEEE half operands / f32 accumulate with ops.py:161-165's
+    pre-normalisation of weights and styles - the reference's half type - on the generic MFMA kernels)."""
 
     def __init__(self, w_dim, img_resolution, img_channels=3, channel_base=32768, channel_max=512, num_fp16_res=0,
                  dtype=torch.bfloat16, nv_compat=False, generator=None, _params=None, **block_kwargs):
@@ -742,6 +743,19 @@ class StyleGAN2Synthesizer(MauaSynthesizer):
         return noises
 
 
+_fp16_warned = set()
+
+
+def _warn_fp16_flag(synthesizer, fp16):
+    """``fp16=False`` cannot turn a network whose weights were prepared in a 16-bit type into a float32 one: say so once."""
+    dt = getattr(getattr(synthesizer, "G_synth", synthesizer), "dtype", None)
+    if not fp16 and dt in (torch.bfloat16, torch.float16) and dt not in _fp16_warned:
+        import warnings
+        _fp16_warned.add(dt)
+        warnings.warn(f"fp16=False requested, but the synthesizer was built with dtype={dt}: it renders in that type "
+                      "(float32 accumulation); build it with dtype=torch.float32 for float32 compute")
+
+
 class MauaGenerator(torch.nn.Module):
     """maua/GAN/wrappers/__init__.py:41-99"""
     MapperCls = None
@@ -754,8 +768,14 @@ class MauaGenerator(torch.nn.Module):
 
     def render(self, inputs, batch_size=32, postprocess_fn=lambda x: x, device=None, fp16=True, batched=True,
                verbose=False):
-        """Generator over frame batches in [0,1] (wrappers/__init__.py:52-99).  ``fp16`` is accepted for drop-in
-        compatibility; the compute type is the synthesizer's dtype (bf16 by default)."""
+        """Generator over frame batches in [0,1] (wrappers/__init__.py:52-99).  ``fp16``: the reference (:62-82, render/ffmpeg.py:
+        41-60) casts the INPUTS to float16 and sets ``use_fp16`` on the synthesis blocks - a flag its in-tree inference network
+        stores (inference/stylegan2.py:297) and never reads, while F.linear / conv2d refuse the float16-input x float32-weight mix
+        that results.  What the flag asks for - 16-bit compute - is here a property of the synthesizer: built with the default
+        ``dtype=torch.bfloat16`` or with ``torch.float16`` (IEEE half operands, ops.py:161-165's pre-normalisation) it renders in
+        that type with float32 accumulation, inputs kept in float32; ``fp16=False`` on such a synthesizer warns once (build it with
+        ``dtype=torch.float32`` for the exact-f32 path) instead of silently computing in 16 bits."""
+        _warn_fp16_flag(self.synthesizer, fp16)
         keys = list(inputs.keys())
         T = len(inputs[keys[0]])
         for i in range(0, T, batch_size):

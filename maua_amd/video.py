@@ -43,6 +43,16 @@ def tensor2bytes(tensor, value_range=(0, 1)):
     return out[0].cpu().numpy().tobytes()
 
 
+def muxable_audio(audio_file):
+    """The clip's audio file if the ``ffmpeg`` executable can be handed it for muxing (it decodes wav / mp3 / flac / ... itself,
+    as the reference's writer relies on, ops/video.py:44-52), None for the tensor dumps this package also accepts as "audio"
+    (.npy / .npz / .pt) and for no file at all."""
+    if not audio_file:
+        return None
+    ext = Path(str(audio_file)).suffix.lower()
+    return None if ext in (".npy", ".npz", ".pt", ".pth") else str(audio_file)
+
+
 class VideoWriter:
     def __init__(self, output_file, output_size, fps, audio_file=None, audio_offset=0, audio_duration=None,
                  ffmpeg_preset="slow", debug=False, value_range=(0, 1), max_queue=64):

@@ -12,6 +12,19 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def secondary_gflop(H, W, vjp=True):
+    """algorithmic GFLOP per sample of SecondaryDiffusionImageNet2.forward (guided.py:77-134: 24 3x3 convolutions, two per level
+    of a 6-level U) and, with ``vjp``, of the input-gradient pass the "fast" conditioning needs (the same convolutions transposed)."""
+    c = [64, 128, 128, 256, 256, 512]
+    ci = [19, c[0], c[0], c[1], c[1], c[2], c[2], c[3], c[3], c[4], c[4], c[5], c[5], c[5], 2 * c[4], c[4], 2 * c[3], c[3], 2 * c[2],
+          c[2], 2 * c[1], c[1], 2 * c[0], c[0]]
+    co = [c[0], c[0], c[1], c[1], c[2], c[2], c[3], c[3], c[4], c[4], c[5], c[5], c[5], c[4], c[4], c[3], c[3], c[2], c[2], c[1], c[1],
+          c[0], c[0], 3]
+    lev = [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0]
+    total = sum(2.0 * 9 * a * b * (H >> l) * (W >> l) for a, b, l in zip(ci, co, lev))
+    return total * (2.0 if vjp else 1.0) / 1e9
+
+
 def unet_gflop(net, H, W):
     """algorithmic GFLOP of one forward per sample: 3x3 and 1x1 convolutions + attention products (2 * MACs)."""
     s = net._structure

@@ -966,6 +966,30 @@ def golden_architectures():
     save("g29_architectures", **out)
 
 
+def golden_fp16():
+    """g30: the reference's operator layer on float16 tensors (its own render dtype, render/ffmpeg.py:45): modulated_conv2d with
+    ops.py:161-165's pre-normalisation branch taken (x.dtype == float16 and demodulate; up = 1 - the up = 2 branch cannot execute
+    in-tree), with styles large enough that x * s would leave the half range without it; bias_act and upfirdn2d on
+    float16 inputs.  Everything float16 in, float16 out, computed by the reference's functions on the CPU."""
+    from maua.GAN.wrappers.inference import ops as R
+    g = torch.Generator().manual_seed(300)
+    h = torch.float16
+    x = (torch.randn(2, 32, 16, 16, generator=g) * 40).clamp(-256, 256).to(h)
+    w3 = torch.randn(32, 32, 3, 3, generator=g).to(h)
+    s = ((torch.randn(2, 32, generator=g) + 1) * 300).to(h)           # |x s| reaches 1e5 > 65504
+    nz = torch.randn(2, 1, 16, 16, generator=g).to(h)
+    y_demod = R.modulated_conv2d(x, w3, s, noise=nz, up=T(1), padding=T(1))
+    y_small = R.modulated_conv2d(x, w3, (s.float() / 300).to(h), up=T(1), padding=T(1))
+    assert y_demod.dtype == h and bool(torch.isfinite(y_demod.float()).all())
+    b = torch.randn(32, generator=g).to(h)
+    xb = (torch.randn(2, 32, 8, 8, generator=g) * 3).to(h)
+    y_ba = R.bias_act(xb, b, act="lrelu", gain=T(sqrt(2)), clamp=T(256.0))
+    f = R.setup_filter([1, 3, 3, 1])
+    xu = torch.randn(2, 4, 9, 9, generator=g).to(h)
+    y_up = R.upfirdn2d(xu, f.to(h), up=T(2), padding=T([2, 1, 2, 1]), gain=T(4))
+    save("g30_fp16_ops", x=x, w3=w3, s=s, noise=nz, y_demod=y_demod, y_small=y_small, b=b, xb=xb, y_ba=y_ba, f=f, xu=xu, y_up=y_up)
+
+
 if __name__ == "__main__":
     import_reference()
     which = sys.argv[1:] or ["ops", "modules", "audio", "latents", "noise", "io"]

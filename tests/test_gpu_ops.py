@@ -105,6 +105,52 @@ def test_modconv_golden(M, golden):
     assert relerr(y, g["y"]) <= F32_TOL
 
 
+F16_TOL = 4e-3   # IEEE half operands (11 significant bits), f32 accumulate
+
+
+def test_fp16_operator_layer_matches_the_reference_fixture(M, golden):
+    """Round 5: the boundary takes the reference's own half type.  g30 = the reference's modulated_conv2d /
+    bias_act / upfirdn2d on float16 tensors (CPU), with ops.py:161-165's pre-normalisation branch taken and styles so large that
+    x * s leaves the half range without it.  The HIP path (v_mfma_f32_32x32x16_f16, f32 accumulation, one rounding of the output)
+    is MORE precise than the reference's half arithmetic (per-sample weights, demodulation and the convolution's result each rounded
+    to half): compared against the float32 oracle on the same half inputs at the half tolerance, and against the reference's half
+    result at the tolerance its own roundings allow."""
+    g = golden("g30_fp16_ops")
+    h = torch.float16
+    f32 = lambda k: g[k].float()
+    y = M.modulated_conv2d(g["x"], g["w3"].float(), g["s"].float(), noise=g["noise"].float(), up=1, padding=1)
+    assert y.dtype == h and bool(torch.isfinite(y.float()).all())
+    exact = O.modulated_conv2d(f32("x"), f32("w3"), f32("s"), noise=f32("noise"), up=1, padding=1)
+    assert relerr(y, exact) <= F16_TOL
+    assert relerr(y, g["y_demod"]) <= 1.5e-2 and relerr(g["y_demod"], exact) <= 1.5e-2     # the reference's own half result
+    y = M.modulated_conv2d(g["x"], g["w3"].float(), f32("s") / 300, up=1, padding=1)
+    assert relerr(y, O.modulated_conv2d(f32("x"), f32("w3"), f32("s") / 300, up=1, padding=1)) <= F16_TOL
+    # elementwise operators: one rounding each, like the reference's
+    yb = M.bias_act(g["xb"], f32("b"), act="lrelu", gain=sqrt(2), clamp=256.0)
+    assert yb.dtype == h and relerr(yb, g["y_ba"]) <= 2e-3
+    yu = M.upfirdn2d(g["xu"], g["f"], up=2, padding=[2, 1, 2, 1], gain=4)
+    assert yu.dtype == h and relerr(yu, g["y_up"]) <= 2e-3
+    assert relerr(M.add(g["xb"], g["xb"]), 2 * f32("xb")) <= 1e-3
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 32, 32, 1), (1, 128, 64, 33, 17, 2), (3, 40, 24, 12, 20, 1), (2, 256, 128, 8, 8, 2)])
+def test_modconv_random_fp16(M, case):
+    """float16 through every generic route (up = 1 / 2, padded channel counts, odd sizes) against the oracle on the same half inputs;
+    styles of both signs and magnitudes up to ~100 (pre-normalised away: ops.py:161-165)."""
+    B, ci, co, hh, w, up = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = (torch.randn(B, ci, hh, w, generator=g) * 8).half()
+    wt = torch.randn(co, ci, 3, 3, generator=g)
+    s = (torch.randn(B, ci, generator=g) + 1) * 30
+    nz = torch.randn(B, 1, hh * up, w * up, generator=g)
+    bias = torch.randn(co, generator=g)
+    f = O.setup_filter([1, 3, 3, 1])
+    ref = O.modulated_conv2d(x.float(), wt, s, noise=nz, up=up, padding=1, resample_filter=f)
+    ref = O.bias_act(ref, bias, act="lrelu", gain=sqrt(2), clamp=256.0)
+    y = M.modulated_conv2d(x, wt, s, noise=nz, up=up, padding=1, resample_filter=f, bias=bias, act="lrelu", gain=sqrt(2), clamp=256.0)
+    assert y.dtype == torch.float16 and relerr(y, ref) <= F16_TOL
+
+
 CASES = [  # (B, Ci, Co, H, W, up)
     (1, 32, 32, 16, 16, 1), (2, 64, 64, 32, 32, 1), (1, 128, 128, 16, 16, 1), (2, 256, 128, 8, 8, 2),
     (1, 64, 32, 32, 32, 2), (3, 40, 24, 12, 20, 1), (1, 16, 96, 5, 7, 2), (2, 512, 512, 4, 4, 1),

@@ -65,6 +65,37 @@ def test_synth_bf16_vs_oracle():
     assert float((img - ref).abs().max()) <= 1e-2 * rng
 
 
+@pytest.mark.parametrize("res,cbase,cmax", [(64, 2048, 128), (256, 8192, 64)])
+def test_synth_fp16_vs_oracle(res, cbase, cmax):
+    """Round 5: SynthesisNetwork(dtype=torch.float16) - IEEE half activations and weights on v_mfma_f32_32x32x16_f16 with the
+    reference's FP16 pre-normalisation (ops.py:161-165: weights by their per-channel maximum and sqrt(fan-in) at load time, styles by
+    their per-sample maximum every batch) - against the fp32 oracle.  Half carries three more mantissa bits than bf16, so the bar
+    sits above the bf16 one (55 dB; measured here >= 75 dB); u8 frames, per-layer features and a latent scale that would overflow
+    x * s without the pre-normalisation."""
+    net, p = build(res, cbase, cmax, torch.float16)
+    net16, _ = build(res, cbase, cmax, torch.bfloat16)
+    net.keep_features(True)
+    g = torch.Generator().manual_seed(12)
+    B = 2
+    ws = torch.randn(B, net.num_ws, 64, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    img = torch.empty((B, 3, res, res), device="cuda")
+    u8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device="cuda")
+    net(ws, noise=noise, out=img, rgb8_out=u8)
+    ref, feats = OS.synthesis_network(p, ws, noise=noise, return_features=True)
+    for l, f in enumerate(feats):
+        got = net.get_feature(l, B).cpu()
+        assert float((got - f).abs().max()) / float(f.abs().max()) <= 8e-3, l
+    q = psnr(img.cpu(), ref)
+    assert q >= 65.0 and q >= psnr(net16(ws, noise=noise).cpu(), ref), q
+    assert torch.equal(u8, ((img + 1) / 2).clamp(0, 1).mul(255).round().byte().permute(0, 2, 3, 1))
+    # latents 40x larger: styles of several hundred, |x * s| far beyond 65504 - finite and as close to the oracle as before
+    big = ws * 40
+    img_b = net(big, noise=noise).cpu()
+    ref_b = OS.synthesis_network(p, big, noise=noise)
+    assert bool(torch.isfinite(img_b).all()) and psnr(img_b, ref_b) >= 60.0, psnr(img_b, ref_b)
+
+
 def test_synth_rgb8_and_determinism():
     net, p = build(32, 1024, 64, torch.float32)
     g = torch.Generator().manual_seed(11)

@@ -63,6 +63,22 @@ def test_modconv_up1(golden):
     close(O.modulated_conv2d(g["x"], g["w1"], g["s"], demodulate=False), g["y_1x1"], 2e-6)
 
 
+def test_fp16_ops(golden):
+    """g30: the reference's operator layer on float16 tensors, incl. the FP16 pre-normalisation branch (ops.py:161-165).  Same
+    functions, same dtype, same CPU kernels underneath: the oracle reproduces the reference to the bit."""
+    g = golden("g30_fp16_ops")
+    h = torch.float16
+    assert g["x"].dtype == h and g["y_demod"].dtype == h
+    y = O.modulated_conv2d(g["x"], g["w3"], g["s"], noise=g["noise"], up=1, padding=1)
+    assert y.dtype == h and torch.equal(y, g["y_demod"])
+    s_small = (g["s"].float() / 300).to(h)
+    assert torch.equal(O.modulated_conv2d(g["x"], g["w3"], s_small, up=1, padding=1), g["y_small"])
+    # the branch is what keeps this case finite: |x * s| exceeds the half range
+    assert float((g["x"].float().abs().amax() * g["s"].float().abs().amax())) > 65504.0
+    assert torch.equal(O.bias_act(g["xb"], g["b"], act="lrelu", gain=sqrt(2), clamp=256.0), g["y_ba"])
+    assert torch.equal(O.upfirdn2d(g["xu"], g["f"].to(h), up=2, padding=[2, 1, 2, 1], gain=4), g["y_up"])
+
+
 def test_modconv_up2(golden):
     g = golden("g06_modconv_up2")
     y = O.modulated_conv2d(g["x"], g["w3"], g["s"], noise=g["noise"], up=2, padding=1, resample_filter=g["f"])
