@@ -163,11 +163,12 @@ def layer_table(net):
     return rows
 
 
-def build_inputs(device, rank, world, seed=0):
-    """Everything that is resident in HBM before the render loop.  The three host-bound parts of the set-up - the network's
-    random init (23.6 M draws, one generator per tensor on a thread pool) + upload, the 17 noise modules' planes (8.4 M draws)
-    + upload, and the clip's chain (synthetic waveform -> onset pre-pass -> mapper -> latent schedule) - are independent and run
-    side by side (torch's CPU kernels release the GIL); the results do not depend on the interleaving (separate generators)."""
+def build_inputs(device, rank, world, seed=0, host_rng=False):
+    """Everything that is resident in HBM before the render loop.  Round 5: the network's random init (23.6 M values) and the 17
+    noise modules' planes (8.4 M) are drawn ON THE DEVICE from the build-owned counter RNG (maua_philox_normal, SURVEY 8(d):
+    identical on every rank / device, reproducible on the host through oracle/rng.py) - kernels instead of host draws + uploads.
+    The clip's chain (synthetic waveform -> onset pre-pass -> mapper -> latent schedule) stays as it was and runs beside it.
+    ``host_rng=True``: round 4's set-up (torch's host generators on helper threads), kept for A/B."""
     import threading
     from maua_amd.noise import Loop
     from maua_amd.stylegan2 import SynthesisNetwork
@@ -179,23 +180,37 @@ def build_inputs(device, rank, world, seed=0):
 
     def make_net():
         torch.cuda.set_device(device)
-        # every random tensor from its own seeded generator on a thread pool (torch's CPU sampler is serial: 23.6 M draws were
-        # the longest item of the set-up), then upload + weight preparation
-        from maua_amd.stylegan2 import init_synthesis_params_parallel
-        net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, _params=init_synthesis_params_parallel(RES, W_DIM, seed=seed))
+        from maua_amd.stylegan2 import init_synthesis_params_device, init_synthesis_params_parallel
+        p = init_synthesis_params_parallel(RES, W_DIM, seed=seed) if host_rng else init_synthesis_params_device(RES, W_DIM, seed=seed)
+        net = SynthesisNetwork(W_DIM, RES, 3, dtype=torch.bfloat16, _params=p)
         net._handle()
         box["net"] = net
-    def make_noise():   # 17 Loop modules: 8.4 M host draws from one generator (their draw order is the modules' order) + upload
+    def make_noise():   # 17 Loop modules: three planes each
         torch.cuda.set_device(device)
-        rng = torch.Generator().manual_seed(42)
-        box["noise"] = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
-    ths = [threading.Thread(target=make_net), threading.Thread(target=make_noise)]
-    for th in ths:
+        if host_rng:
+            rng = torch.Generator().manual_seed(42)
+            box["noise"] = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
+        else:   # module j's planes = Philox stream j of seed 42 + seed (streams 0 .. 16; the network's tensors use their own seed)
+            from maua_amd.rng import philox_normal
+            box["noise"] = [Loop(None, T_FRAMES, (s, s), n_loops=4, sigma=5, noise=philox_normal((3, s, s), 42 + seed, j, device=device))
+                            for j, s in enumerate(NOISE_SIZES)]
+    if host_rng:
+        ths = [threading.Thread(target=make_net), threading.Thread(target=make_noise)]
+        for th in ths:
+            th.start()
+        latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)
+        for th in ths:
+            th.join()
+    else:   # device draws are a few milliseconds of kernels: the clip's host chain first (its device work overlaps), then these
+        th = threading.Thread(target=lambda: box.__setitem__("clip", pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)))
         th.start()
-    latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)
-    for th in ths:
+        make_net()
+        make_noise()
         th.join()
+        latents, info = box["clip"]
     net, noise = box["net"], box["noise"]
+    info = dict(info, weights_and_noise_planes="torch host generators" if host_rng else
+                "device counter RNG (Philox4x32-10, maua_philox_normal): network = streams of seed %d, noise planes = streams of seed %d" % (seed, 42 + seed))
     assert net.num_ws == 18
     return net, latents.to(device), noise, info
 

@@ -155,6 +155,8 @@ int maua_synth_set_option(maua_synth* net, const char* key, int value);
  * "bs.1.conv1.noise_const", optional "bs.1.conv1.noise_strength").  host_data: HOST f32 array.
  * Synchronous.  Unknown names return MAUA_ERR ("resample_filter" buffers are accepted and checked). */
 int maua_synth_load(maua_synth* net, const char* name, const float* host_data, size_t count);
+/* the same with the values in DEVICE memory (e.g. drawn by maua_philox_normal): no host round trip for the large tensors */
+int maua_synth_load_device(maua_synth* net, const char* name, const float* dev_values, size_t count);
 /* replaces wrappers/stylegan2.py:65-102 StyleGAN2Synthesizer.forward + G_synth.forward(noise_mode="const").
  * ws [B,num_ws,w_dim] f32; noise: NULL or array of num_layers pointers, entry l = f32 [B|1, h_l, w_l] (or NULL
  * for that layer's noise_const), noise_batch_stride[l] in elements (0 = broadcast); img_out f32 [B,3,R,R]. */
@@ -168,8 +170,10 @@ int maua_synth_render_rgb8(maua_synth* net, const float* ws, const float* const*
  * then pack_rgb8 if requested.  Synchronises on the last event;
  * a call with ms_out != NULL resets the recording (ms_out == NULL only returns the count). */
 int maua_synth_get_profile(maua_synth* net, float* ms_out, int capacity, int* count);
-/* Per-sample factors on the noise inputs of the NEXT forward calls: scales = device [num_layers][layer_stride >= B] f32, row l for
- * synthesis layer l (maua_noise_loop_batch_raw's output), or NULL to go back to plain noise (x + noise * strength, ops.py:184-185). */
+/* Per-sample factors on the noise inputs of the NEXT maua_synth_render_rgb8 call - that one call only: it forgets them when it
+ * returns (also on an error), so one batch's factors cannot leak into a later forward.  scales = device [num_layers][layer_stride >=
+ * B] f32, row l for synthesis layer l (maua_noise_loop_batch_raw's output), or NULL for plain noise (x + noise * strength,
+ * ops.py:184-185). */
 int maua_synth_set_noise_scale(maua_synth* net, const float* scales, long layer_stride);
 /* debug/parity (what a torch forward hook on SynthesisLayer would capture): copy layer l's activation (NHWC, net dtype) converted to f32 NCHW [B,C,h,w] after a forward. */
 int maua_synth_get_feature(maua_synth* net, int layer, int B, float* out_nchw);
@@ -503,6 +507,16 @@ int maua_unet_guided_graph_active(maua_unet* net, int* active);
  * (guided.py:256-265 with an image-MSE loss); target_bstride = row or 0 */
 int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, long target_bstride, float k, int B, long row,
                         float* out);
+
+/* ---- build-owned counter RNG: Philox4x32-10, identical on every device / rank and in the oracle twin (oracle/rng.py,
+ * pinned to the published known-answer vectors).  No reference counterpart: the reference's random-init generator and noise planes
+ * come from torch's host generator (inference/stylegan2.py:216-227, selfsupervised/noise.py:42-53); the benchmark's synthetic
+ * network and planes are drawn on the device instead (a clip's set-up then costs kernels, not 32 M host draws + their upload).
+ * Element i of (seed, stream): counter {i / 4, stream}, key seed, word i % 4; offset = index of out[0] in the stream (any value:
+ * a tensor may be filled in pieces).  normal: Box-Muller on word pairs, u = ((x >> 9) + 0.5) 2^-23; out = mean + stdev z. */
+int maua_philox_u32(maua_ctx* ctx, unsigned long long seed, unsigned long long stream, unsigned long long offset, uint32_t* out, long n);
+int maua_philox_normal(maua_ctx* ctx, unsigned long long seed, unsigned long long stream, unsigned long long offset, float* out, long n,
+                       float mean, float stdev);
 
 /* ---- multi-GPU: the one exchange step of the frame-sharded render ------------------------------------
  * One process per GPU; frames are sharded by contiguous range (no data-path collective).  maua_gather_frames moves every

@@ -488,11 +488,14 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
   return fail(std::string("maua_synth_set_option: unknown option ") + key);
 }
 
+// where maua_synth_load's source lives: host memory (maua_synth_load) or this device (maua_synth_load_device, large tensors)
+static thread_local hipMemcpyKind g_load_kind = hipMemcpyHostToDevice;
+
 static int upload(float* dst, const float* host, size_t count, size_t expect, const char* name) {
   if (count != expect)
     return fail(std::string("maua_synth_load: ") + name + ": expected " + std::to_string(expect) + " values, got " +
                 std::to_string(count));
-  MAUA_HIP_CHECK(hipMemcpy(dst, host, count * sizeof(float), hipMemcpyHostToDevice));
+  MAUA_HIP_CHECK(hipMemcpy(dst, host, count * sizeof(float), g_load_kind));
   return MAUA_OK;
 }
 
@@ -520,7 +523,7 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
     if (count != (size_t)C * 16) return fail("maua_synth_load: bs.0.const: wrong size");
     float* tmp;
     MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
-    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, g_load_kind));
     int rc = n->dtype == MAUA_BF16   ? launch_nchw_to_nhwc<float, bf16_t>(st, tmp, n->const_x, 1, C, 16, C)
              : n->dtype == MAUA_F16 ? launch_nchw_to_nhwc<float, f16_t>(st, tmp, n->const_x, 1, C, 16, C)
                                     : launch_nchw_to_nhwc<float, float>(st, tmp, n->const_x, 1, C, 16, C);
@@ -558,7 +561,7 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
     if (count != expect) return fail("maua_synth_load: " + s + ": wrong size");
     float* tmp;
     MAUA_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
-    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
+    MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, g_load_kind));
     // F16 networks: the reference's FP16 pre-normalisation of the weight (ops.py:161-163; every convolution of the synthesis
     // network demodulates) - the styles' half is applied per batch (launch_styles)
     if (n->dtype == MAUA_F16)
@@ -575,6 +578,22 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
   return fail("maua_synth_load: unknown parameter name: " + s);
 }
 
+// The same from DEVICE memory (parameters drawn on the device: maua_philox_normal): large tensors are copied device to device,
+// small ones (filters, scalars, <= 4096 values: the loader inspects them on the host) take a detour through a host buffer.
+int maua_synth_load_device(maua_synth* n, const char* name, const float* dev, size_t count) {
+  MAUA_REQUIRE(n && name && dev, "maua_synth_load_device: NULL argument");
+  MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));   // (the producer of `dev` ran on the context's stream)
+  if (count <= 4096) {
+    std::vector<float> h(count);
+    MAUA_HIP_CHECK(hipMemcpy(h.data(), dev, count * 4, hipMemcpyDeviceToHost));
+    return maua_synth_load(n, name, h.data(), count);
+  }
+  g_load_kind = hipMemcpyDeviceToDevice;
+  const int rc = maua_synth_load(n, name, dev, count);
+  g_load_kind = hipMemcpyHostToDevice;
+  return rc;
+}
+
 // does this up-layer run the LDS-direct transposed-conv kernel?  (same routing conditions as in the forward below)
 static bool up_uses_tconv_dma(const maua_synth* n, const ConvLayer& c) {
   if (!n->tconv_dma || n->tconv_up != 1 || c.up != 2) return false;
@@ -587,6 +606,9 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
                            float* img_out, uint8_t* rgb8_out) {
   MAUA_REQUIRE(n && ws, "maua_synth_forward: NULL argument");
   MAUA_REQUIRE(B >= 0, "maua_synth_forward: negative batch");
+  // the per-sample noise factors (maua_synth_set_noise_scale) belong to THIS call: forgotten on every way out, so that a caller
+  // cannot leak one batch's factors into a later forward
+  struct ForgetScales { maua_synth* n; ~ForgetScales() { n->nz_scales = nullptr; n->nz_scale_stride = 0; } } forget{n};
   MAUA_REQUIRE(img_out || rgb8_out, "maua_synth_forward: no output buffer");
   if (B == 0) return MAUA_OK;
   if (int rc = ensure_workspace(n, B)) return rc;

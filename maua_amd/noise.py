@@ -52,14 +52,30 @@ class Loop(Noise):
         return out
 
 
-class RawNoise(list):
-    """Un-normalised Loop maps of one batch ([b, h, w] per layer) + ``scales`` [n_layers, b]: the factor 1 / (rms + eps) of every
-    (layer, sample) that noise.py:52 divides by.  ``SynthesisNetwork.forward(noise=...)`` hands both to the library, whose
-    convolution epilogues apply the factor; ``normalised()`` gives the tensors the reference's modules return."""
-    scales = None
+class RawNoise:
+    """Un-normalised Loop maps of one batch (``maps``: [b, h, w] per layer) + ``scales`` [n_layers, b]: the factor 1 / (rms + eps)
+    of every (layer, sample) that noise.py:52 divides by.  ``SynthesisNetwork.forward(noise=<RawNoise>)`` hands both to the
+    library, whose convolution epilogues apply the factor.  Deliberately NOT a list: whatever treats it as a sequence of tensors -
+    iteration, indexing, ``list(nz)``, ``[m[:, None] for m in nz]``, the wrappers' ``noise{j}=`` keywords - gets the NORMALISED
+    maps (the tensors the reference's modules return, one multiply per map, computed once), so the factors cannot be dropped
+    silently on the way to the network; only code that knows about them reads ``maps`` / ``scales``."""
+
+    def __init__(self, maps):
+        self.maps, self.scales, self._norm = list(maps), None, None
 
     def normalised(self):
-        return [m * self.scales[l, : m.shape[0], None, None] for l, m in enumerate(self)]
+        if self._norm is None:
+            self._norm = [m * self.scales[l, : m.shape[0], None, None] for l, m in enumerate(self.maps)]
+        return self._norm
+
+    def __len__(self):
+        return len(self.maps)
+
+    def __iter__(self):
+        return iter(self.normalised())
+
+    def __getitem__(self, k):
+        return self.normalised()[k]
 
 
 def loop_batch(modules, i, b, raw=False):
@@ -72,11 +88,11 @@ def loop_batch(modules, i, b, raw=False):
     if raw:
         res = [m._resident() for m in modules]
         outs = RawNoise(m._out(max(0, min(b, m.length - i))) for m in modules)
-        nb = int(outs[0].shape[0])
-        outs.scales = torch.empty((n, max(nb, 1)), dtype=torch.float32, device=outs[0].device)
+        nb = int(outs.maps[0].shape[0])
+        outs.scales = torch.empty((n, max(nb, 1)), dtype=torch.float32, device=outs.maps[0].device)
         P = (C.c_void_p * n)(*[r[0].data_ptr() for r in res])
         I = (C.c_void_p * n)(*[r[1].data_ptr() for r in res])
-        O = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        O = (C.c_void_p * n)(*[o.data_ptr() for o in outs.maps])
         H = (C.c_int * n)(*[m.size[0] for m in modules])
         W = (C.c_int * n)(*[m.size[1] for m in modules])
         S = (C.c_float * n)(*[float(m.sigma) for m in modules])

@@ -97,6 +97,17 @@ def init_synthesis_params_parallel(img_resolution, w_dim=512, img_channels=3, ch
     return p
 
 
+def init_synthesis_params_device(img_resolution, w_dim=512, img_channels=3, channel_base=32768, channel_max=512, seed=0,
+                                 device=None) -> Dict[str, torch.Tensor]:
+    """The same parameter set with every random tensor drawn ON THE DEVICE from the build-owned counter RNG (rng.PhiloxStreams:
+    the k-th random tensor of the construction order is Philox stream k of ``seed``) - no host draws, no upload: what the benchmark's
+    synthetic generator uses (SURVEY 8(d)).  Identical on every rank / device and reproducible on the host through oracle/rng.py;
+    NOT the values of torch's generator."""
+    from .rng import PhiloxStreams
+    return init_synthesis_params(img_resolution, w_dim, img_channels, channel_base, channel_max,
+                                 generator=PhiloxStreams(seed, device=device))
+
+
 def parse_seeds(seeds):
     """wrappers/stylegan.py:59-65: "a-b,c" -> ints (ranges end-exclusive)."""
     out = []
@@ -210,6 +221,10 @@ class SynthesisNetwork(torch.nn.Module):
             L.check(lib.maua_synth_create(L.ctx(dev), self.img_resolution, self.w_dim, self.channel_base,
                                           self.channel_max, L.dtype_id(self.dtype), flags, C.byref(net)))
             for k, v in self._params.items():
+                if v.is_cuda:   # drawn on the device (rng.PhiloxStreams): no host round trip
+                    v = v.to(device=dev, dtype=torch.float32).contiguous()
+                    L.check(lib.maua_synth_load_device(net, k.encode(), L.ptr(v), C.c_size_t(v.numel())))
+                    continue
                 a = np.ascontiguousarray(v.numpy(), dtype=np.float32)
                 L.check(lib.maua_synth_load(net, k.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
             L.check(lib.maua_synth_set_option(net, b"keep_features", int(self._keep_features)))
@@ -265,6 +280,10 @@ class SynthesisNetwork(torch.nn.Module):
                 if nz is None or tuple(nz.shape) != (h, w):
                     nz = torch.randn((h, w), generator=noise_generator)
                     self._resized_noise[key] = nz
+            if nz.is_cuda:
+                nz = nz.to(dtype=torch.float32).contiguous()
+                L.check(L.lib().maua_synth_load_device(self._net, key.encode(), L.ptr(nz), C.c_size_t(nz.numel())))
+                continue
             a = np.ascontiguousarray(nz.numpy(), dtype=np.float32)
             L.check(L.lib().maua_synth_load(self._net, key.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
 
@@ -342,18 +361,19 @@ class SynthesisNetwork(torch.nn.Module):
         if out is None and rgb8_out is None:
             oh, ow = self.output_hw
             out = torch.empty((B, 3, oh, ow), dtype=torch.float32, device=ws.device)
+        # un-normalised Loop maps (noise.loop_batch(..., raw=True) -> RawNoise) bring their per-(layer, sample) factors 1 / (rms + eps)
+        # along: the convolution epilogues multiply them into the noise strength (the maps are written once instead of twice).  Any
+        # other sequence - also a RawNoise somebody iterated or sliced - holds normalised maps
+        from .noise import RawNoise
+        sc = None
+        if isinstance(noise, RawNoise):
+            noise, sc = noise.maps, noise.scales
+            if sc is None or sc.shape[0] != self.num_layers or sc.shape[1] < B:
+                raise ValueError(f"noise scales must be [{self.num_layers}, >= {B}], got {None if sc is None else tuple(sc.shape)}")
         ptrs, strides, keep = self._noise_args(noise, B)
-        # un-normalised Loop maps (noise.loop_batch(..., raw=True)) bring their per-(layer, sample) factors 1 / (rms + eps) along:
-        # the convolution epilogues multiply them into the noise strength (the maps are written once instead of twice)
-        sc = getattr(noise, "scales", None)
-        if sc is not None and (sc.shape[0] != self.num_layers or sc.shape[1] < B):
-            raise ValueError(f"noise scales must be [{self.num_layers}, >= {B}], got {tuple(sc.shape)}")
+        # (the factors apply to the NEXT render call only: the library forgets them when that call returns)
         L.check(L.lib().maua_synth_set_noise_scale(net, L.ptr(sc), C.c_long(0 if sc is None else sc.stride(0))))
-        try:
-            L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
-        finally:
-            if sc is not None:
-                L.check(L.lib().maua_synth_set_noise_scale(net, None, C.c_long(0)))
+        L.check(L.lib().maua_synth_render_rgb8(net, L.ptr(ws), ptrs, strides, B, L.ptr(out), L.ptr(rgb8_out)))
         del keep
         return out if out is not None else rgb8_out
 
@@ -368,7 +388,8 @@ class SynthesisNetwork(torch.nn.Module):
         B = ws.shape[0]
         if tuple(ws.shape[1:]) != (self.num_ws, self.w_dim):
             raise ValueError(f"ws must be [B, {self.num_ws}, {self.w_dim}], got {tuple(ws.shape)}")
-        if getattr(noise, "scales", None) is not None:
+        from .noise import RawNoise
+        if isinstance(noise, RawNoise):
             noise = noise.normalised()
         if self._dev_params is None or next(iter(self._dev_params.values())).device != ws.device:
             self._dev_params = {k: v.to(ws.device) for k, v in self._params.items()}

@@ -36,8 +36,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for si, cs in enumerate(SETS):
     cs = [c for c in cs if c in avail]
     d = f"/tmp/pmcsum_{si}"
+    # PMC_TARGET: another workload than one synthesis forward, e.g. "scripts/bench_upscale_quick.py 4 4" (the configs[4] leg)
+    target = os.environ.get("PMC_TARGET", f"scripts/profile_layers.py {B}").split()
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *cs, "--output-format", "csv", "-d", d, "-o", "k", "--",
-           sys.executable, "scripts/profile_layers.py", B]
+           sys.executable, *target]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     f = glob.glob(d + "/**/k_counter_collection.csv", recursive=True)
     if not f:

@@ -395,3 +395,26 @@ def test_benchmark_setup_helpers_are_deterministic():
     assert float(dev[:, :768].mean()) > 3 * float(dev[:, 768:].mean())    # clicks sit in the first 5 % of every half second
     ref = synthetic_audio(4 * 15360, sr, seed=9)                          # the fixture waveform: same model, same level
     assert abs(float(ref.std()) - float(whole.std())) < 5e-3 and not torch.equal(ref, whole)
+
+
+def test_counter_rng_twin_matches_the_published_known_answer_vectors():
+    """oracle/rng.py (the CPU twin of csrc/rng.hip, the build-owned counter RNG of SURVEY 8(d)) against the Philox4x32-10
+    known-answer vectors of the Random123 distribution (Salmon et al., SC'11) - the pin of an oracle that has no reference file to
+    follow - and the stream addressing both sides share: element i = word i % 4 of counter i / 4, any offset, any length."""
+    import numpy as np
+    from oracle import rng
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = rng.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert [int(v) for v in got] == list(want)
+    whole = rng.u32(5, 7, 41)
+    assert all(np.array_equal(rng.u32(5, 7, n, offset=o), whole[o:o + n]) for o, n in ((0, 41), (3, 6), (4, 8), (17, 24), (40, 1)))
+    assert not np.array_equal(rng.u32(5, 8, 41), whole) and not np.array_equal(rng.u32(6, 7, 41), whole)
+    # stream 2^32 differs from stream 0 (the high counter words carry the stream), seeds use both key words
+    assert not np.array_equal(rng.u32(1, 1 << 32, 8), rng.u32(1, 0, 8)) and not np.array_equal(rng.u32(1 << 32, 0, 8), rng.u32(0, 0, 8))
+    z = rng.normal(1, 2, 400000)
+    assert z.dtype == np.float32 and abs(float(z.mean())) < 6e-3 and abs(float(z.std()) - 1.0) < 5e-3 and bool(np.isfinite(z).all())
+    assert np.array_equal(rng.normal(1, 2, 10, offset=6), z[6:16])
+    assert np.allclose(rng.normal(1, 2, 10, mean=3.0, std=0.5), 3.0 + 0.5 * z[:10], atol=1e-6)

@@ -204,3 +204,43 @@ def test_sample_generate_with_fused_upscale(wav_long, tmp_path):
         assert 10 * np.log10(255.0 ** 2 / max(float((d ** 2).mean()), 1e-12)) >= 35.0
     else:
         assert out.endswith(".mp4")
+
+
+def test_device_counter_rng_matches_its_oracle_twin_and_seeds_the_synthetic_network():
+    """Round 5: the build-owned counter RNG.  maua_philox_u32 is bit-exact against oracle/rng.py
+    (itself pinned to the published known-answer vectors, CPU suite) at every offset; normals agree to the last ulps of the float32
+    log / sin / cos (4e-6 absolute); a tensor filled in pieces equals the tensor filled at once.  The benchmark's synthetic
+    generator drawn on the device (init_synthesis_params_device) holds exactly the twin's numbers - so any rank, any device and
+    the host agree on the network without exchanging it - and renders the same frames as a network fed the same numbers from the
+    host."""
+    import numpy as np
+    from maua_amd.rng import philox_normal, philox_u32
+    from maua_amd.stylegan2 import SynthesisNetwork, init_synthesis_params_device
+    from oracle import rng as OR
+    for seed, stream, n, off in ((0, 0, 1, 0), (5, 7, 1000, 0), (5, 7, 999, 3), (2 ** 40 + 1, 2 ** 33 + 5, 4097, 2 ** 34 + 2), (9, 1, 6, 1)):
+        got = philox_u32(seed, stream, n, off).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, OR.u32(seed, stream, n, off)), (seed, stream, n, off)
+        z = philox_normal((n,), seed, stream, off, mean=0.25, std=2.0).cpu().numpy()
+        assert float(np.abs(z - OR.normal(seed, stream, n, off, mean=0.25, std=2.0)).max()) <= 8e-6
+    whole = philox_normal((3, 50, 7), 11, 4)
+    parts = torch.cat([philox_normal((k,), 11, 4, offset=o) for o, k in ((0, 13), (13, 500), (513, 537))])
+    assert torch.equal(whole.reshape(-1), parts)
+    assert abs(float(whole.mean())) < 0.1 and abs(float(whole.std()) - 1) < 0.1
+    # the synthetic generator: the k-th random tensor of the construction order = stream k of the seed
+    p = init_synthesis_params_device(64, 64, channel_base=2048, channel_max=64, seed=3)
+    rand_keys = [k for k, v in p.items() if v.is_cuda]
+    assert rand_keys[0] == "bs.0.const" and rand_keys[1] == "bs.0.conv1.affine.weight" and len(rand_keys) == 1 + 3 * 9 + 2 * 5
+    for j in (0, 1, 7, len(rand_keys) - 1):
+        k = rand_keys[j]
+        twin = torch.from_numpy(OR.normal(3, j, p[k].numel())).reshape(p[k].shape)
+        assert float((p[k].cpu() - twin).abs().max()) <= 4e-6, k
+    q = init_synthesis_params_device(64, 64, channel_base=2048, channel_max=64, seed=3)
+    assert all(torch.equal(p[k], q[k]) for k in p)
+    assert not torch.equal(p["bs.2.conv0.weight"], init_synthesis_params_device(64, 64, channel_base=2048, channel_max=64, seed=4)["bs.2.conv0.weight"])
+    net_dev = SynthesisNetwork(64, 64, 3, channel_base=2048, channel_max=64, dtype=torch.bfloat16, _params=p)
+    net_host = SynthesisNetwork(64, 64, 3, channel_base=2048, channel_max=64, dtype=torch.bfloat16, _params={k: v.cpu() for k, v in p.items()})
+    ws = torch.randn(3, net_dev.num_ws, 64, generator=torch.Generator().manual_seed(1))
+    a, b = (torch.empty((3, 64, 64, 3), dtype=torch.uint8, device="cuda") for _ in range(2))
+    net_dev(ws, rgb8_out=a)
+    net_host(ws, rgb8_out=b)
+    assert torch.equal(a, b)

@@ -626,6 +626,15 @@ def test_raw_noise_maps_with_per_sample_factors_equal_the_normalised_maps():
             u_one = torch.empty((1, res, res, 3), dtype=torch.uint8, device="cuda")
             net(ws[i0 + 1:i0 + 2], noise=one, rgb8_out=u_one)
             assert torch.equal(u_one[0], u_raw[1])          # position in the batch does not matter
+            # the factors cannot be dropped silently - whatever treats a RawNoise as a sequence gets NORMALISED maps
+            # (iteration, indexing, a comprehension), and the library forgets a batch's factors when its render call returns
+            assert not isinstance(raw, list) and len(raw) == len(mods)
+            as_list = [m[:, None] for m in raw]
+            assert all(float((a[:, 0] - c).abs().max()) <= 4e-6 * float(c.abs().max()) for a, c in zip(as_list, nrm))
+            u_lst = torch.empty_like(u_raw)
+            net(ws[i0:i0 + nb], noise=as_list, rgb8_out=u_lst)     # right after a raw call: no stale factors on the handle
+            assert float((u_lst == u_nrm).float().mean()) >= (0.999 if dt == torch.float32 else 0.95)
+            assert torch.equal(raw[3], raw.normalised()[3])
 
 
 @pytest.mark.parametrize("arch", ["orig", "resnet"])
