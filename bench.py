@@ -259,9 +259,10 @@ def cpu_baseline(seconds):
 
 
 def leg_traffic(leg):
-    """HBM bytes per unit of work of an extra leg (profiles/r04_<leg>_traffic.json, scripts/collect_leg_traffic.py: separate
+    """HBM bytes per unit of work of an extra leg (profiles/rNN_<leg>_traffic.json of the newest round, scripts/collect_leg_traffic.py: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the leg's own script, all kernels summed) -> (bytes, note) or (None, why)."""
-    p = Path(__file__).resolve().parent / "profiles" / f"r04_{leg}_traffic.json"
+    cands = sorted((Path(__file__).resolve().parent / "profiles").glob(f"r*_{leg}_traffic.json"))   # the newest round's file
+    p = cands[-1] if cands else Path(__file__).resolve().parent / "profiles" / f"{leg}_traffic.json"
     try:
         v = json.loads(p.read_text())
         return float(v["bytes_per_unit"]), f"replayed from profiles/{p.name}: {v['unit']} ({v['units_in_run']} units in the profiled run)"

@@ -42,6 +42,8 @@ struct ConvArgs {
   int x_pstride, y_pstride, y_coff;
   long y_bstride;         // elements between samples of y (0 = Ho * Wo * Co)
   const float* out_scale; // modconv_dma: [B][Co] or NULL - the stored features are multiplied by the NEXT layer's styles
+  void* y_scaled;         // modconv_dma, with out_scale: y keeps the plain features (a separate toRGB pass reads them) and the
+                          // scaled copy goes here, dense [B][H][W][Co] - instead of a premod pass over y afterwards
   const void* res;        // optional residual added after activation / gain / clamp: NHWC, res_pstride elements per pixel
   int res_pstride;
   long res_bstride;

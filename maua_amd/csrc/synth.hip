@@ -78,6 +78,7 @@ struct maua_synth {
   long nz_scale_stride = 0;
   int tconv_min = 32;  // ... from this input size up (below: the phase kernels / the batch-wide low-resolution GEMM)
   int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
+  int dual_store = 1;  // ... whose toRGB is a separate pass (512 channels): plain + style-scaled output in one epilogue (no premod pass)
   int tconv_dma = 2;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
   float* ones = nullptr;   // [Bcap][max channels] unit styles (kernels that take already-modulated input)
   void* xm = nullptr;      // [Bcap] pre-modulated copy of an up-layer's input when its producer could not scale it
@@ -445,6 +446,10 @@ int maua_synth_set_option(maua_synth* n, const char* key, int value) {
     n->upwalk = value;
     return MAUA_OK;
   }
+  if (!strcmp(key, "dual_store")) {
+    n->dual_store = value;
+    return MAUA_OK;
+  }
   if (!strcmp(key, "walk_segs")) {
     n->walk_segs = value;
     return MAUA_OK;
@@ -643,6 +648,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
   bool walk_skip = false;      // the previous up-layer ran the whole block (modconv_upwalk.hip): its conv1 is done
   bool x_premod = false;       // the current x already carries the styles of the conv1 that reads it (modconv_dma.hip)
   bool premod_for_up = false;  // ... of the up-layer that reads it (modconv_tconv_dma.hip)
+  bool premod_in_xm = false;   // ... or the premod buffer already holds x times that up-layer's styles (dual store of the conv1 before it)
   for (int blk = 0; blk < n->nblocks; blk++) {
     const int nconv = blk == 0 ? 1 : 2;
     RgbLayer& g = n->rgbs[blk];
@@ -677,6 +683,8 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
       x_premod = false;
       const bool premod_up_in = premod_for_up;   // x carries this up-layer's styles (set by the conv1 that produced it)
       premod_for_up = false;
+      const bool xm_ready = premod_in_xm;        // ... or that conv1 wrote the scaled copy into the premod buffer
+      premod_in_xm = false;
       bool premod_out = false;
       // (producers that can scale their output: the FIR pass of a tconv up-layer, the generic kernel's epilogue)
       const bool generic_up = c.up == 2 && !via_tconv && !hires_up &&
@@ -705,6 +713,17 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           if (nx.up == 2 && up_uses_tconv_dma(n, nx)) {
             a.out_scale = nx.s;
             premod_for_up = true;
+          }
+        } else if (!rgb_fused && n->dual_store && n->xm && !hooked && !warped && !n->keep_features && li + 1 < n->convs.size()) {
+          // (round 5) the 512-channel conv1 layers keep a separate toRGB pass, which reads the PLAIN features: they are stored
+          // twice - plain to y, multiplied by the next up-layer's styles into the premod buffer - instead of a pass over y later
+          const ConvLayer& nx = n->convs[li + 1];
+          bool warped_nx = n->rs_layer == (int)li + 2;
+          for (int wsl = 0; wsl < 3; wsl++) warped_nx = warped_nx || (n->warp_layer[wsl] == (int)li + 2 && n->warp_minv[wsl]);
+          if (nx.up == 2 && up_uses_tconv_dma(n, nx) && nx.ih == c.oh && nx.iw == c.ow && !warped_nx && n->rs_layer != (int)li + 1) {
+            a.out_scale = nx.s;
+            a.y_scaled = n->xm;
+            premod_in_xm = true;
           }
         }
         if (int rc = launch_modconv_dma(st, a)) return rc;
@@ -781,7 +800,10 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
         if (up_uses_tconv_dma(n, c)) {
           // main block on the LDS-direct kernel (input already multiplied by the styles: by the producing conv1, or by
           // a pass over the - small - input here), last row / column of positions on the register-staged kernel
-          if (!premod_up_in) {
+          if (xm_ready) {          // the producing conv1 left the scaled copy in the premod buffer
+            a.x = n->xm;
+            a.x_bstride = (long)c.ih * c.iw * c.Ci;
+          } else if (!premod_up_in) {
             if (int rc = launch_premod_nhwc(st, x, x_bstride, c.s, n->xm, B, (long)c.ih * c.iw, c.Ci)) return rc;
             a.x = n->xm;
             a.x_bstride = (long)c.ih * c.iw * c.Ci;

@@ -67,10 +67,19 @@ def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4
     from . import audio, latent
     from .stylegan2 import MappingNetwork, get_z_latents
     sr = 1024 * fps
+    # the mapper's random init (2.1 M host draws, its own generator) does not depend on the clip: drawn on a
+    # helper thread while the waveform is synthesised (torch's CPU samplers release the GIL)
+    import threading
+    box = {}
+
+    def make_mapper():
+        box["mapper"] = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0))
+    th = threading.Thread(target=make_mapper)
+    th.start()
     wav = synthetic_audio(n_frames * 1024, sr, fast=fast_audio)
     env = audio.onsets(wav, sr).squeeze(-1)                      # [T], on device
-    mapper = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0))
-    palette = mapper(get_z_latents(seeds, w_dim).float())        # [P, num_ws, w_dim]
+    th.join()
+    palette = box["mapper"](get_z_latents(seeds, w_dim).float())   # [P, num_ws, w_dim]
     half = palette.shape[0] // 2
     low = latent.spline_loops(palette[:half], n_frames, n_loops)
     high = latent.spline_loops(palette[half:2 * half], n_frames, n_loops)

@@ -93,7 +93,9 @@ int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const 
 // PSUM: also emit ConvArgs.psum (its own instantiation: the 16 accumulators of the copy-out loop cost the 128-register
 // variants a few spilled registers, which the StyleGAN2 path's launches do not pay)
 template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
+// (waves per SIMD the register allocation aims for = what LDS lets live on a CU anyway: 149 KB -> one 8-wave workgroup; 75 KB ->
+//  two 8-wave workgroups; the four-wave narrow tiles 52 KB (32 channels) -> three, 60 KB (64 channels) -> two)
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB != 64 ? 2 : WAVES_M * WAVES_N == 8 ? 4 : WN == 2 ? 2 : 3) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
   constexpr int BM = TH * TW, BN = WAVES_N * WN * 32;
@@ -103,12 +105,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   constexpr int TB = BN * KCB;                          // bytes of one tap's weight slice (BN rows)
   constexpr int WB = TPS * TB;                          // bytes of one weight stage (TPS taps)
   constexpr int WPIECES = TB / 1024;                    // 1 KB weight load instructions per tap (all waves together)
-  constexpr int WJ = (WPIECES + NW - 1) / NW;           // ... per wave (narrow N tiles: only the first WPIECES waves load)
-  constexpr int HJ = (HALO_PX * PPR + NT - 1) / NT;     // halo load instructions per wave per chunk
+  // SPLIT (round 5, the four-wave narrow tiles of the RRDB up-scaler): their stages are 8 MFMAs per wave long, and every stage's
+  // `s_waitcnt vmcnt(0)` also waited for the halo pieces of a chunk that is not read for four more stages - an HBM round trip
+  // exposed per stage (PMC: half of the wave cycles parked, matrix pipe 0.30 busy).  The loads are therefore split by wave: waves
+  // 0, 1 stream the weights (L2-resident; waited for every stage, as before), waves 2, 3 stream the halos and wait for them only
+  // at the two stages of a period whose barrier publishes a halo buffer.  Same loads, same LDS image, same arithmetic.
+#ifdef MAUA_DMA_NOSPLIT   // (timing-only A/B builds: scripts/mk_variant.sh nosplit modconv_dma.hip -DMAUA_DMA_NOSPLIT)
+  constexpr bool SPLIT = false;
+#else
+  constexpr bool SPLIT = NW == 4 && KB == 64 && TPS == 2;
+#endif
+  constexpr int HSTR = SPLIT ? 2 : NW, WSTR = SPLIT ? 2 : NW;   // loader waves per operand
+  constexpr int HJ = SPLIT ? ((HALO_PX * PPR + 63) / 64 + 1) / 2 : (HALO_PX * PPR + NT - 1) / NT;   // halo load instructions per loader wave per chunk
+  constexpr int WJ = (WPIECES + WSTR - 1) / WSTR;       // ... per loader wave (narrow N tiles: only the first WPIECES waves load)
   constexpr int KSPT = KB / 32;                         // 32-byte k-steps per tap
   constexpr int Q = KSPT * TPS;                         // k-steps per stage
-  static_assert(TB % 1024 == 0 && (WPIECES % NW == 0 || WPIECES < NW) && (HJ == 6 || HJ == 3) && (TPS == 1 || TPS == 2) &&
+  static_assert(TB % 1024 == 0 && (WPIECES % WSTR == 0 || WPIECES < WSTR) && (HJ == 6 || HJ == 3 || SPLIT) && (TPS == 1 || TPS == 2) &&
                     (Q == 4 || Q == 8), "stage split");
+  constexpr int HT1 = (HJ + 2) / 3, HT2 = 2 * ((HJ + 2) / 3) < HJ ? 2 * ((HJ + 2) / 3) : HJ;   // the thirds a chunk's halo is issued in (TPS == 2)
   constexpr int OFF_H = 2 * WB;
   // piece p of row n sits at piece index p ^ swz(n): 8 rows x 8 pieces or 16 rows x 4 pieces tile one 1 KB bank period
 #define MAUA_SWZ(N_) (KB == 128 ? (((N_) >> 1) & 7) : (((N_) >> 2) & 3))
@@ -120,6 +134,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int r = lane & 31, h = lane >> 5;
+  const bool w_loader = !SPLIT || wave < 2, h_loader = !SPLIT || wave >= 2;
+  const int wslot = wave, hslot = SPLIT ? (wave - 2) & 1 : wave;   // this wave's first load instruction of a tap / of a chunk's halo
   const int tiles_x = (a.W + TW - 1) >> 5;   // (narrow plain convolutions may overhang the image: their stores are masked)
   const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
   const int ty0 = tyi * TH, tx0 = txi * TW;
@@ -134,14 +150,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   unsigned hoff[HJ];
 #pragma unroll
   for (int j = 0; j < HJ; j++) {
-    const int P = (wave + NW * j) * 64 + lane;
+    const int P = (hslot + HSTR * j) * 64 + lane;
     const int hp = P >> PSH, q = (P & (PPR - 1)) ^ MAUA_SWZ(hp);
     const int py = (hp * 1928) >> 16;  // hp / 34 for hp < 340
     const int px = hp - py * HW2;
     const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
     const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     hoff[j] = 0xffffffffu;
-    if (P < HALO_PX * PPR) {
+    if (h_loader && P < HALO_PX * PPR) {
       if (in) {
         // (x_up2: the input is the nearest-neighbour x2 up-sampling of a half-size tensor - read the source pixel directly)
         hoff[j] = a.x_up2 ? (unsigned)((((gy >> 1) * (a.W >> 1) + (gx >> 1)) * xps + q * 8) * 2)
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   unsigned woff[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; j++) {
-    const int row = min((1024 / KB) * (wave + NW * j) + (lane >> PSH), BN - 1);
+    const int row = min((1024 / KB) * (wslot + WSTR * j) + (lane >> PSH), BN - 1);
     const int q = (lane & (PPR - 1)) ^ MAUA_SWZ(row);
     woff[j] = (unsigned)((row * a.Ci + q * 8) * 2);
   }
@@ -172,8 +188,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   {                                                                                                      \
     const char* ws_ = wtile + (long)(T_) * tap_stride + (long)(C_) * (KC * 2);                           \
     _Pragma("unroll") for (int jj = 0; jj < WJ; jj++)                                                   \
-        if (WPIECES >= NW || wave + NW * jj < WPIECES)                                                   \
-          dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024);              \
+        if (w_loader && (WPIECES >= WSTR * WJ || wslot + WSTR * jj < WPIECES))                           \
+          dma16_s(ws_, woff[jj], lds0 + (BUF_) * WB + (J_) * TB + (wslot + WSTR * jj) * 1024);           \
   }
   // ODDK (two taps per stage, an ODD number of chunks: plain convolutions on the 96 / 160-channel prefixes of a dense-block
   // buffer, super.hip): the last period has one chunk.  Its stage 4 pairs the chunk's last tap with a tap that does not exist:
@@ -182,8 +198,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #define MAUA_ZERO_WTAP(BUF_, J_)                                                                         \
   {                                                                                                      \
     _Pragma("unroll") for (int jj = 0; jj < WJ; jj++)                                                   \
-        if (WPIECES >= NW || wave + NW * jj < WPIECES)                                                   \
-          *reinterpret_cast<u32x4*>(smem + (BUF_) * WB + (J_) * TB + (wave + NW * jj) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u}; \
+        if (w_loader && (WPIECES >= WSTR * WJ || wslot + WSTR * jj < WPIECES))                           \
+          *reinterpret_cast<u32x4*>(smem + (BUF_) * WB + (J_) * TB + (wslot + WSTR * jj) * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u}; \
   }
   // the stage at position K_ of the period that starts at chunk CC_ (positions >= 9 belong to the next period)
 #define MAUA_ISSUE_WSTAGE(CC_, K_, BUF_)                                                                 \
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 #define MAUA_ISSUE_H(J_, C_)                                                                             \
   {                                                                                                      \
     if ((C_) < n_hchunks && hoff[J_] != 0xffffffffu)                                                     \
-      dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (wave + NW * (J_)) * 1024); \
+      dma16_s(xb + (long)(C_) * (KC * 2), hoff[J_], lds0 + OFF_H + ((C_) & 1) * HB + (hslot + HSTR * (J_)) * 1024); \
   }
 
   // ---- fragment addresses: A (pixels) from the halo, B (channels) from the weight stage
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   for (int j = 0; j < HJ; j++) MAUA_ISSUE_H(j, 0)
   if constexpr (TPS == 2) {
 #pragma unroll
-    for (int j = 0; j < HJ / 3; j++) MAUA_ISSUE_H(j, 1)
+    for (int j = 0; j < HT1; j++) MAUA_ISSUE_H(j, 1)
   }
   MAUA_ISSUE_WSTAGE(0, 0, 0)
   MAUA_ISSUE_WSTAGE(0, 1, 1)
@@ -282,7 +298,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       // Every load this wave issued behind the previous barrier (the next stage's weights, pieces of a coming halo)
       // has landed; the barrier publishes them and tells everybody that this stage's buffers have been read for the
       // last time.
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (SPLIT: the halo loaders wait only where the coming barrier publishes a halo buffer - chunk cc + 1's is first read inside
+      //  stage 4, chunk cc + 2's right behind the barrier of stage 8; their pieces were issued at least two stages earlier)
+      if (!SPLIT || w_loader || k == 3 || k == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (k + 1 < 9) {
         MAUA_LOAD_FRAGS(af, bf, cc, (k + 1) % 9, 0, wbuf ^ 1)
@@ -298,13 +316,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
         // third), first read by the second tap of stage 4; chunk cc+2 -> H[0]: free once stage 4 has read tap 8, first
         // read by the next period's stage 0.  HJ / 3 load instructions per wave at each of the six points.
 #pragma unroll
-        for (int j = 0; j < HJ / 3; j++) {
-          if (k == 0) MAUA_ISSUE_H(HJ / 3 + j, cc + 1)
-          if (k == 1) MAUA_ISSUE_H(2 * (HJ / 3) + j, cc + 1)
-          if (k == 4) MAUA_ISSUE_H(j, cc + 2)
-          if (k == 5) MAUA_ISSUE_H(HJ / 3 + j, cc + 2)
-          if (k == 6) MAUA_ISSUE_H(2 * (HJ / 3) + j, cc + 2)
-          if (k == 8) MAUA_ISSUE_H(j, cc + 3)
+        for (int j = 0; j < HJ; j++) {
+          const int third = j < HT1 ? 0 : j < HT2 ? 1 : 2;
+          if (k == 0 && third == 1) MAUA_ISSUE_H(j, cc + 1)
+          if (k == 1 && third == 2) MAUA_ISSUE_H(j, cc + 1)
+          if (k == 4 && third == 0) MAUA_ISSUE_H(j, cc + 2)
+          if (k == 5 && third == 1) MAUA_ISSUE_H(j, cc + 2)
+          if (k == 6 && third == 2) MAUA_ISSUE_H(j, cc + 2)
+          if (k == 8 && third == 0) MAUA_ISSUE_H(j, cc + 3)
         }
       }
       MAUA_MMA(af1, bf1)

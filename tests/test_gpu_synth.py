@@ -482,6 +482,31 @@ def test_upwalk_block_walks_match_phase_form_and_oracle(res, B):
         assert torch.equal(one[0].cpu(), imgs[2][B - 1])
 
 
+def test_dual_store_of_plain_and_style_scaled_features_is_bit_identical():
+    """Round 5: a conv1 layer whose toRGB stays a separate pass (512 channels: 32^2, 64^2) writes its features twice in one epilogue -
+    plain for that pass, multiplied by the next up-layer's styles into the premod buffer - instead of a premod pass over them
+    (option "dual_store").  Same products, same roundings: frames must not change by a bit."""
+    from maua_amd import _lib as L
+    from maua_amd.stylegan2 import SynthesisNetwork
+    net = SynthesisNetwork(512, 256, 3, dtype=torch.bfloat16, generator=torch.Generator().manual_seed(5))   # 512 channels up to 64^2
+    g = torch.Generator().manual_seed(6)
+    B = 3
+    ws = torch.randn(B, net.num_ws, 512, generator=g)
+    noise = [torch.randn(B, 1, s[3], s[3], generator=g) for s in net.layer_shapes()]
+    h = net._handle()
+    out = {}
+    for mode in (0, 1):
+        L.check(L.lib().maua_synth_set_option(h, b"dual_store", mode))
+        img = torch.empty((B, 3, 256, 256), device="cuda")
+        u8 = torch.empty((B, 256, 256, 3), dtype=torch.uint8, device="cuda")
+        net(ws, noise=noise, out=img, rgb8_out=u8)
+        out[mode] = (img.cpu(), u8.cpu())
+    L.check(L.lib().maua_synth_set_option(h, b"dual_store", 1))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    ref = OS.synthesis_network(net.state_dict(), ws, noise=noise)
+    assert psnr(out[1][0], ref) >= 55.0
+
+
 @pytest.mark.parametrize("res,B,segs", [(256, 3, 0), (256, 2, 3), (512, 2, 5), (512, 1, 7)])
 def test_fused_walk_narrow_last_strip_is_bit_identical(res, B, segs):
     """Round 5: a last strip of <= 32 columns (256 = 2 x 126 + 4, 512 = 4 x 126 + 8, 1024 = 8 x 126 + 16) is walked as two
