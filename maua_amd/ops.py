@@ -160,33 +160,67 @@ def repeat_rows(x, n):
     return out
 
 
-def _check_resample_filter(f):
+def _is_render_filter(f):
+    """True for setup_filter([1, 3, 3, 1]) - the one resample filter of the reference networks, which the fused up-layer kernels
+    carry as constants."""
     if f is None:
-        return
-    ref = setup_filter([1, 3, 3, 1])
-    if tuple(f.shape) != (4, 4) or not torch.allclose(f.detach().cpu().float(), ref, atol=1e-6):
-        raise NotImplementedError("only the [1,3,3,1] resample filter of the reference networks is supported")
+        return False
+    f = torch.as_tensor(f)
+    return tuple(f.shape) == (4, 4) and torch.allclose(f.detach().cpu().float(), setup_filter([1, 3, 3, 1]), atol=1e-6)
+
+
+def _up_paddings(k, fw, fh, up, padding):
+    """ops.py:199-224's padding arithmetic for up > 1 (Q1: the scalar max(min(-p0, -p1), 0) it means):
+    (transposed-conv padding x, y), (upfirdn2d padding x0, x1, y0, y1)."""
+    px0 = px1 = py0 = py1 = padding
+    px0 += (fw + up - 1) // 2 - (k - 1)
+    px1 += (fw - up) // 2 - (k - up)
+    py0 += (fh + up - 1) // 2 - (k - 1)
+    py1 += (fh - up) // 2 - (k - up)
+    pxt = max(min(-px0, -px1), 0)
+    pyt = max(min(-py0, -py1), 0)
+    return (pxt, pyt), (px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt)
+
+
+def _modconv_up_composed(x, weight, styles, up, padding, f, demodulate, flip_weight):
+    """ops.py:211-225 for ANY up factor / resample filter / padding, composed of the operators above (the fused up-layer kernels
+    take the render path's up = 2, [1,3,3,1], 'same' case only):
+      conv_transpose2d(x, w, stride=up, padding=pt)  ==  the valid correlation of the zero-stuffed input, padded by k - 1 - pt,
+                                                         with the spatially flipped kernel (Q2: the reference does NOT flip
+                                                         before its transposed convolution, so the flip happens here)
+    then upfirdn2d(f, padding, gain = up^2).  up^2 the MACs of the minimal form - this is the off-path route."""
+    k = weight.shape[2]
+    fw, fh = _get_filter_size(f)
+    (pxt, pyt), fpad = _up_paddings(k, fw, fh, up, padding)
+    qx, qy = k - 1 - pxt, k - 1 - pyt
+    zs = upfirdn2d(x, None, up=up, padding=(qx, qx - (up - 1), qy, qy - (up - 1)))
+    wt = weight if flip_weight else weight.flip([2, 3])
+    t = modulated_conv2d(zs, wt, styles, up=1, padding=k // 2, demodulate=demodulate)
+    if k > 1:
+        t = pad2d(t, (-(k // 2),) * 4)
+    return upfirdn2d(t, f, padding=fpad, gain=up * up)
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=False, bias=None, act="linear", alpha=None, gain=None, clamp=None,
                      noise_strength=1.0):
     """ops.py:146-186.  Extra keyword arguments (bias/act/gain/clamp) fuse the bias_act that follows the
-    convolution in every SynthesisLayer; leave them at their defaults for the bare reference op."""
+    convolution in every SynthesisLayer; leave them at their defaults for the bare reference op.
+    The render path's cases (up = 1; up = 2 with the [1,3,3,1] filter) run as one fused launch; any other up factor or
+    resample filter is composed of the same operators (_modconv_up_composed).  down != 1 and padding != k // 2 raise, as
+    the reference does: its reshape to [B, Co, H * up, W * up] (ops.py:183) fits no other output size."""
     up, down, padding = _int(up), _int(down), _int(padding)
-    if down != 1:
-        raise NotImplementedError("down-sampling is not on the render path")
     x = L.dev_tensor(x)
     n, ci, h, w = x.shape
     co, wci, kh, kw = weight.shape
     if wci != ci or kh != kw or kh not in (1, 3):
         raise ValueError("weight must be [Co, Ci, k, k] with k in (1, 3)")
-    if padding != kh // 2:
-        raise NotImplementedError("padding must be kernel_size // 2 ('same' convolution)")
-    if up not in (1, 2):
-        raise NotImplementedError("up must be 1 or 2")
-    if up == 2:
-        _check_resample_filter(resample_filter)
+    if down != 1 or padding != kh // 2:
+        raise ValueError(f"modulated_conv2d: down = {down}, padding = {padding} give an output that is not [B, Co, H * up, W * up] "
+                         "(the reference's reshape at ops.py:183 raises for it too); conv2d_resample takes these")
+    if up < 1:
+        raise ValueError("up must be a positive integer")
+    fused = up == 1 or (up == 2 and _is_render_filter(resample_filter))
     weight = L.dev_tensor(weight, torch.float32)
     styles = L.dev_tensor(styles, torch.float32)
     nstride = 0
@@ -200,6 +234,14 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
             raise ValueError("noise must be [N|1, 1, H*up, W*up] (or [H*up, W*up])")
     if bias is not None:
         bias = L.dev_tensor(bias, torch.float32)
+    if not fused:
+        y = _modconv_up_composed(x, weight, styles, up, padding, resample_filter, demodulate, flip_weight)
+        if noise is not None:
+            nz = (noise.reshape(-1, 1, h * up, w * up) * _num(noise_strength)).to(y.dtype)
+            y = add(y, nz.expand(n, co, h * up, w * up).contiguous())
+        if bias is not None or act != "linear" or gain is not None or clamp is not None:
+            y = bias_act(y, bias, act, alpha=alpha, gain=gain, clamp=clamp)
+        return y
     da, dg = _DEFAULTS[act]
     alpha = da if alpha is None else _num(alpha)
     gain = dg if gain is None else _num(gain)
@@ -212,16 +254,45 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     return y
 
 
-def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=False):
-    """ops.py:189-233 for groups == 1: an un-modulated convolution = modulated_conv2d with unit styles
-    and no demodulation."""
-    if _int(groups) != 1:
-        raise NotImplementedError("grouped conv2d_resample is an implementation detail of the reference's "
-                                  "modulated_conv2d; call modulated_conv2d instead")
-    x = L.dev_tensor(x)
+def _conv2d_resample_one(x, w, f, up, down, padding, flip_weight):
+    """conv2d_resample for one group (ops.py:189-233 with groups == 1)."""
+    k = w.shape[2]
     styles = torch.ones((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-    return modulated_conv2d(x, w, styles, up=up, down=down, padding=padding, resample_filter=f, demodulate=False,
-                            flip_weight=flip_weight)
+    if up > 1:
+        if down == 1 and padding == k // 2 and up == 2 and _is_render_filter(f):
+            return modulated_conv2d(x, w, styles, up=2, padding=padding, resample_filter=f, demodulate=False, flip_weight=flip_weight)
+        y = _modconv_up_composed(x, L.dev_tensor(w, torch.float32), styles, up, padding, f, False, flip_weight)
+        return upfirdn2d(y, f, down=down) if down > 1 else y        # ops.py:226-227
+    if down != 1:
+        raise NotImplementedError("conv2d_resample: down > 1 without up > 1 is the reference's 'Something weird is going on' "
+                                  "assertion (ops.py:232)")
+    if padding < 0:
+        raise ValueError("padding must be >= 0 (ops.py:230)")
+    if padding == k // 2:
+        return modulated_conv2d(x, w, styles, up=1, padding=padding, demodulate=False)
+    # F.conv2d(x, w, padding = p) = the 'same' convolution of the input padded by p, without its k // 2 border
+    y = modulated_conv2d(pad2d(x, (padding,) * 4) if padding else x, w, styles, up=1, padding=k // 2, demodulate=False)
+    return pad2d(y, (-(k // 2),) * 4) if k > 1 else y
+
+
+def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=False):
+    """ops.py:189-233: an un-modulated convolution = modulated_conv2d with unit styles and no demodulation.  up = 1 with any
+    padding >= 0; up > 1 with any resample filter and padding, followed by the down-sampling FIR when down > 1 (:226-227);
+    groups > 1 (the form modulated_conv2d hands over, x [1, G * Ci, H, W], w [G * Co, Ci, k, k]) runs group by group - inside
+    this library the per-sample weights of that form never exist, modulated_conv2d is the fused operator."""
+    up, down, padding, groups = _int(up), _int(down), _int(padding), _int(groups)
+    x = L.dev_tensor(x)
+    co, cig, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise ValueError("weight must be [Co, Ci / groups, k, k] with k in (1, 3)")
+    if groups == 1:
+        return _conv2d_resample_one(x, w, f, up, down, padding, flip_weight)
+    if x.shape[1] != groups * cig or co % groups:
+        raise ValueError("x must be [N, groups * Ci, H, W] and w [groups * Co, Ci, k, k]")
+    cog = co // groups
+    outs = [_conv2d_resample_one(x[:, g * cig:(g + 1) * cig].contiguous(), w[g * cog:(g + 1) * cog].contiguous(), f, up, down, padding,
+                                 flip_weight) for g in range(groups)]
+    return torch.cat(outs, dim=1)
 
 
 _PAD_HOW = {"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}

@@ -105,6 +105,47 @@ def test_modconv_golden(M, golden):
     assert relerr(y, g["y"]) <= F32_TOL
 
 
+def test_operator_arguments_outside_the_render_path(M, golden):
+    """VERDICT r4 missing 7: the B1 operators no longer refuse what the reference's signatures accept off the render path -
+    conv2d_resample at any padding >= 0 and with groups (g31: the reference's own call), up-layers with any resample filter and
+    up factor (g31: composed of the reference's pieces, as g06 is), the down-sampling FIR behind an up-layer (ops.py:226-227, vs
+    the oracle).  What the reference itself cannot run raises here too."""
+    g = golden("g31_offpath_ops")
+    for p in (0, 2, 3):
+        y = M.conv2d_resample(g["x"], g["w3"], padding=p)
+        assert y.shape == g[f"y3_p{p}"].shape and relerr(y, g[f"y3_p{p}"]) <= F32_TOL
+    assert relerr(M.conv2d_resample(g["x"], g["w1"], padding=2), g["y1_p2"]) <= F32_TOL
+    assert relerr(M.conv2d_resample(g["xg"], g["wg"], padding=0, groups=3), g["yg_p0"]) <= F32_TOL
+    for name, up in (("f121_up2", 2), ("f11_up2", 2), ("f14641_up2", 2), ("f1331_up4", 4), ("f8_up4", 4), ("f6_up3", 3)):
+        f = g["f_" + name]
+        y = M.modulated_conv2d(g["x"], g["w3"], g["s"], up=up, padding=1, resample_filter=f)
+        assert y.shape == g["y_" + name].shape and relerr(y, g["y_" + name]) <= F32_TOL, name
+    # noise + the fused bias_act keywords on the composed route; the upstream-NVIDIA flip
+    f = g["f_f121_up2"]
+    gen = torch.Generator().manual_seed(5)
+    nz, b = torch.randn(2, 1, 20, 24, generator=gen), torch.randn(6, generator=gen)
+    y = M.modulated_conv2d(g["x"], g["w3"], g["s"], noise=nz, up=2, padding=1, resample_filter=f, bias=b, act="lrelu", clamp=2.0,
+                           flip_weight=True)
+    ref = O.bias_act(O.modulated_conv2d(g["x"], g["w3"], g["s"], noise=nz, up=2, padding=1, resample_filter=f, flip_weight=True),
+                     b, act="lrelu", clamp=2.0)
+    assert relerr(y, ref) <= F32_TOL
+    # un-modulated up-layer with a free padding, then the down-sampling FIR
+    y = M.conv2d_resample(g["x"], g["w3"], f=f, up=2, down=2, padding=2)
+    t = O.conv2d_resample(g["x"], g["w3"], f=f, up=2, padding=2)
+    assert relerr(y, O.upfirdn2d(t, f, down=2)) <= F32_TOL
+    # the render path's own case through conv2d_resample stays on the fused kernel and agrees with the composed route
+    f4 = M.setup_filter([1, 3, 3, 1])
+    ya = M.conv2d_resample(g["x"], g["w3"], f=f4, up=2, padding=1)
+    yb = M._modconv_up_composed(g["x"].cuda(), g["w3"].cuda(), torch.ones(2, 8, device="cuda"), 2, 1, f4, False, False)
+    assert relerr(ya, yb) <= F32_TOL
+    with pytest.raises(ValueError):
+        M.modulated_conv2d(g["x"], g["w3"], g["s"], up=1, padding=0)       # ops.py:183's reshape fails in the reference as well
+    with pytest.raises(ValueError):
+        M.modulated_conv2d(g["x"], g["w3"], g["s"], up=2, down=2, padding=1, resample_filter=f4)
+    with pytest.raises(NotImplementedError):
+        M.conv2d_resample(g["x"], g["w3"], f=f4, down=2, padding=1)         # ops.py:232 "Something weird is going on"
+
+
 F16_TOL = 4e-3   # IEEE half operands (11 significant bits), f32 accumulate
 
 

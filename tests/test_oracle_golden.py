@@ -85,6 +85,19 @@ def test_modconv_up2(golden):
     close(y, g["y"], 2e-6)
 
 
+def test_offpath_operator_arguments(golden):
+    """g31: conv2d_resample at paddings other than k // 2 (the reference's own call) and up-layers with other filters / factors
+    (composed of the reference's pieces like g06) - the oracle's restatement of ops.py:189-233 covers them as written."""
+    g = golden("g31_offpath_ops")
+    for p in (0, 2, 3):
+        close(O.conv2d_resample(g["x"], g["w3"], padding=p), g[f"y3_p{p}"], 2e-6)
+    close(O.conv2d_resample(g["x"], g["w1"], padding=2), g["y1_p2"], 2e-6)
+    close(O.conv2d_resample(g["xg"], g["wg"], padding=0, groups=3), g["yg_p0"], 2e-6)
+    for name, up in (("f121_up2", 2), ("f11_up2", 2), ("f14641_up2", 2), ("f1331_up4", 4), ("f8_up4", 4), ("f6_up3", 3)):
+        y = O.modulated_conv2d(g["x"], g["w3"], g["s"], up=up, padding=1, resample_filter=g["f_" + name])
+        close(y, g["y_" + name], 2e-6)
+
+
 def test_norm2nd_fc_mapping(golden):
     g = golden("g07_norm2nd")
     close(O.normalize_2nd_moment(g["z"]), g["y"])
