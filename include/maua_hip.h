@@ -429,6 +429,15 @@ int maua_unet_set_option(maua_unet* net, const char* key, int value);
  * model of respace.py passes: original timestep index, rescaled to 0..1000), out device f32 [B][out_channels][H][W].
  * H, W: multiples of 2^(levels - 1). */
 int maua_unet_forward(maua_unet* net, const float* x, const float* timesteps, int B, int H, int W, float* out);
+/* Guidance speed "regular" (guided.py:214-218, 250-272): the loss gradient is taken THROUGH the diffusion UNet -
+ * `torch.autograd.grad(img, x, img_grad)` with img a function of p_mean_variance(model, x, t)["pred_xstart"].  The library's
+ * form of that autograd call: maua_unet_forward_keep = maua_unet_forward that leaves what the input gradient reads on the
+ * network's arena (GroupNorm inputs and statistics, qkv, the attention rows' log-sum-exp), then
+ * maua_unet_vjp: g_x [B][in_channels][H][W] = (d out / d x)^T g_out, g_out [B][out_channels][H][W] (device f32).
+ * Back to back on one network, same shape; option "vjp" = 1 (maua_unet_set_option) BEFORE maua_unet_load, which then also
+ * prepares every weight's transposed copy (3x3: transposed + spatially flipped - the gradient is the same MFMA convolution). */
+int maua_unet_forward_keep(maua_unet* net, const float* x, const float* timesteps, int B, int H, int W, float* out);
+int maua_unet_vjp(maua_unet* net, const float* g_out, int B, int H, int W, float* g_x);
 /* gaussian_diffusion.py ddim_sample for an epsilon model, clip_denoised False (guided.py:303-306): x [B][C][HW], model_out
  * [B][Cm][HW] (first C channels = eps), cond_grad = cond_fn(x, t) [B][C][HW] or NULL (condition_score), noise or NULL
  * (eta 0), coef device f32 [B][8] = {sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, sqrt(1 - alphas_cumprod),
@@ -477,6 +486,9 @@ int maua_secondary_vjp(maua_secondary* net, const float* g_v, int B, int H, int 
  * QKVAttentionLegacy.forward - qkv [B][T][3 * heads * head_ch] with channel = head * 3 ch + {q | k | v} * ch + c (what
  * `qkv.reshape(bs * n_heads, ch * 3, length).split(ch, dim=1)` sees) -> out [B][T][heads * head_ch]; head_ch 32 or 64 */
 int maua_attention_legacy(maua_ctx* ctx, const void* qkv, void* out, int B, int T, int heads, int head_ch, int dtype);
+/* its input gradient (autograd through QKVAttentionLegacy.forward): d_out [B][T][heads * head_ch] -> d_qkv like qkv */
+int maua_attention_legacy_vjp(maua_ctx* ctx, const void* qkv, const void* d_out, void* d_qkv, int B, int T, int heads, int head_ch,
+                              int dtype);
 /* conv_nd(1, K, N, 1) / a linear layer over rows (AttentionBlock.qkv / proj_out + residual, ResBlock.skip_connection):
  * c[M][N] = a[M][K] x w[N][K]^T + bias[N] (+ res[M][N]); K % 32 (bf16) / 16 (f32) == 0, N % 32 == 0 */
 int maua_linear_nt(maua_ctx* ctx, const void* a, const void* w, const float* bias, const void* res, void* c, long M, int N,
@@ -485,6 +497,11 @@ int maua_linear_nt(maua_ctx* ctx, const void* a, const void* w, const float* bia
  * statistics in float64, eps 1e-5.  x, y [B][H][W][C] */
 int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* scale_shift,
                          int silu, int B, int H, int W, int C, int dtype, void* y);
+/* its input gradient, with the ResBlocks' resampling behind the activation (resample 0 none, 1 avg_pool2d 2, 2 nearest x2:
+ * h_upd(in_rest(x)), unet.py ResBlock._forward): dy [B][Ho][Wo][C] -> dx [B][H][W][C]; dres (optional, shaped like dy): the
+ * gradient of x_upd(x), the same resampling of the raw input, added */
+int maua_group_norm_nhwc_vjp(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* scale_shift, int silu,
+                             int resample, const void* dy, const void* dres, int B, int H, int W, int C, int dtype, void* dx);
 /* the unconditioned sampling loop of guided.py:333-337 inside the library: n_steps x (forward + DDIM update) on x in place;
  * model_t host f32 [n_steps], coef host f32 [n_steps][8]; use_graph: capture the loop in one hipGraph and replay it. */
 int maua_ddim_sample_loop(maua_unet* net, float* x, int B, int H, int W, const float* model_t, const float* coef, int n_steps,

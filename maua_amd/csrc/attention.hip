@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
   }
   if (qrow >= T_) return;
+  if (a.lse && h == 0) a.lse[((long)b * a.heads + head) * T_ + qrow] = m_i + logf(l_i);
   const float inv = 1.f / l_i;
   T* orow = reinterpret_cast<T*>(a.out) + ((long)b * T_ + qrow) * a.ld_out + head * D;
 #pragma unroll

@@ -252,9 +252,49 @@ struct AttnArgs {
   int B, T, heads, D;
   long ld_qkv, ld_out;
   float scale;          // 1 / sqrt(D)
+  float* lse;           // optional [B][heads][T]: each row's log-sum-exp of the scaled scores (what the input gradient needs)
 };
 bool attention_supported(int head_ch);
 int launch_attention(hipStream_t stream, int dtype, const AttnArgs& a);
+
+// attention_vjp.hip: the input gradient of launch_attention.  d_out [B][T][ld_out] -> d_qkv [B][T][ld_qkv]; lse = what the
+// forward left in AttnArgs.lse, out = its result; workspace: B * heads * T floats (the rows' sum d_out . out)
+struct AttnVjpArgs {
+  const void* qkv;
+  const void* out;
+  const void* d_out;
+  const float* lse;
+  void* d_qkv;
+  float* delta;
+  int B, T, heads, D;
+  long ld_qkv, ld_out;
+  float scale;
+};
+int launch_attention_vjp(hipStream_t stream, int dtype, const AttnVjpArgs& a);
+
+// groupnorm_vjp.hip: the input gradient of the UNet's GroupNorm (+ scale-shift) (+ SiLU) (+ resample) pass over [x0 | x1]
+// ([B][H][W][C0 | C1], dense NHWC in the network dtype).  dy, dres: [B][Ho][Wo][C0 + C1] at the forward's output size (dres: the
+// gradient of the resampled raw input - the ResBlock's x_upd - or of an identity skip; optional); add0 / add1: optional gradients
+// already known for x0 / x1 (may alias dx0 / dx1); stats: the forward's [B][32][2] (mean, rstd).
+struct GnVjpArgs {
+  const void* x0; int C0;
+  const void* x1; int C1;
+  const float* stats;
+  const float* gamma;
+  const float* beta;
+  const float* ss;      // [B][ss_ld]: scale at [c], shift at [C + c]; or NULL
+  long ss_ld;
+  int silu, mode;
+  const void* dy;
+  const void* dres;
+  const void* add0;
+  const void* add1;
+  void* dx0;
+  void* dx1;
+  int B, H, W;
+};
+size_t group_norm_vjp_workspace(int B, int C, long HW, int esize);
+int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, void* workspace);
 
 // secondary.hip: the context a secondary diffusion model was created on
 maua_ctx* secondary_ctx(maua_secondary* n);

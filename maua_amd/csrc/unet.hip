@@ -91,6 +91,16 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restric
   }
 }
 
+// dst[i][o][k] = src[o][i][kk - 1 - k]: a convolution's (kk = 9) / linear layer's (kk = 1) weight for its input gradient
+__global__ __launch_bounds__(256) void transpose_flip_kernel(const float* __restrict__ src, float* __restrict__ dst, int Co, int Ci, int kk) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Co * Ci * kk) return;
+  const int k = (int)(idx % kk);
+  const long oi = idx / kk;
+  const int i = (int)(oi % Ci), o = (int)(oi / Ci);
+  dst[((long)i * Co + o) * kk + (kk - 1 - k)] = src[idx];
+}
+
 // ------------------------------------------------------------------------------------------------------ GroupNorm
 // Statistics in float64 (sum and sum of squares of exactly representable f32 products): no cancellation whatever the
 // mean / spread ratio; fixed summation order (bit-reproducible).  Pass 1: per (sample, pixel chunk, row slot) per-channel
@@ -503,6 +513,19 @@ static int launch_group_norm(hipStream_t st, const T* x0, int C0, const T* x1, i
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
+// the statistics passes alone (per-channel kernels: any C % 32 == 0)
+template <typename T>
+static int launch_group_norm_stats(hipStream_t st, const T* x, int C, int B, int H, int W, double* part, float* stats) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int PPP = C / EPC;
+  const long HW = (long)H * W;
+  MAUA_REQUIRE(C % 32 == 0 && PPP <= 1024, "group_norm: C % 32 == 0, at most 1024 16-byte pieces per pixel");
+  const GnPlan p = gn_plan(B, C, HW, (int)sizeof(T));
+  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3((unsigned)p.nchunk, B), dim3(PPP * p.RY), 0, st, x, C, (const T*)nullptr, 0, HW, p.ppc, part);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(32, B), dim3(256), 0, st, part, (int)(p.nchunk * p.RY), C, HW, 1e-5f, stats);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
 static size_t gn_part_bytes(int B, int C, long HW, int esize) {
   // (the per-channel layout is the larger one and also serves the fall-back of a fast-path shape with too many rows)
   const GnPlan p = gn_plan(B, C, HW, esize);
@@ -646,8 +669,8 @@ __global__ __launch_bounds__(256) void zero_if_flag_kernel(float* __restrict__ g
 
 // ----------------------------------------------------------------------------------------------------- parameters
 struct UGN { int C = 0; float* gamma = nullptr; float* beta = nullptr; };
-struct UConv { int Ci = 0, Co = 0, Cip = 0, Cop = 0; void* wt = nullptr; float* bias = nullptr; };
-struct ULin { int K = 0, N = 0; void* w = nullptr; float* bias = nullptr; };
+struct UConv { int Ci = 0, Co = 0, Cip = 0, Cop = 0; void* wt = nullptr; float* bias = nullptr; void* wt_t = nullptr; };   // wt_t: the input-gradient convolution (option "vjp")
+struct ULin { int K = 0, N = 0; void* w = nullptr; float* bias = nullptr; void* w_t = nullptr; };   // w_t [K][N]: the input-gradient GEMM
 struct URes { int Cin, Cout, updown; UGN n1; UConv c1; int emb_off; UGN n2; UConv c2; bool skip; ULin sk; };
 struct UAttn { int C, heads; UGN n; ULin qkv, proj; };
 struct ULayer { int kind; int idx; };  // 0 conv_in, 1 res, 2 attn
@@ -655,6 +678,20 @@ struct UBlock { std::vector<ULayer> layers; int out_ch = 0; };
 
 enum PKind { P_GN_G, P_GN_B, P_CONV_W, P_CONV_B, P_LIN_W, P_LIN_B, P_F32 };
 struct PRef { PKind kind; void* obj; float* f32 = nullptr; size_t count = 0; };
+
+// What a kept forward (maua_unet_forward_keep) leaves for maua_unet_vjp: per layer, the tensors its input gradient reads
+struct TapeOp {
+  int kind, idx;                  // 1 ResBlock, 2 AttentionBlock (index into res / attn)
+  const void* x0; int C0;         // the layer's input (virtually concatenated [x0 | x1])
+  const void* x1; int C1;
+  int H, W;                       // input size
+  void* out;                      // its output
+  void* h1;                       // ResBlock: conv1's output (the second GroupNorm's input); Attention: qkv
+  void* ao;                       // Attention: the attention result (proj_out's input)
+  float* st1;                     // statistics of the first / only GroupNorm
+  float* st2;                     // ... of the ResBlock's second
+  float* lse;                     // Attention: log-sum-exp rows
+};
 
 struct Arena {
   char* base = nullptr;
@@ -720,6 +757,20 @@ struct maua_unet {
   size_t gd_tab_cap = 0;
   int* gd_flag = nullptr;            // [gd_flags] one NaN flag per step, zeroed before every loop (outside the graph)
   int gd_flags = 0;
+  // input gradient (maua_unet_forward_keep + maua_unet_vjp; option "vjp" = 1 before the weights are loaded)
+  int vjp = 0;
+  float* zero_bias = nullptr;        // [max padded channels] zeros: the gradient convolutions have no bias
+  std::vector<TapeOp> tape;
+  bool tape_valid = false;           // the arena still holds the kept forward the tape describes
+  int tape_B = 0, tape_H = 0, tape_W = 0;
+  void* tape_h0 = nullptr;           // conv_in's output
+  void* tape_hf = nullptr;           // the last block's output (out_norm's input)
+  int tape_cf = 0;
+  float* tape_stf = nullptr;         // out_norm's statistics
+  float* tape_emb = nullptr;         // the emb_layers outputs of that forward
+  long tape_emb_ld = 0;
+  size_t tape_top = 0;               // arena top behind the kept forward
+  float* tape_gather_ws = nullptr;   // the split-K workspace of that forward (the gradient convolutions share it)
 };
 
 namespace {
@@ -895,8 +946,13 @@ struct Runner {
   std::unordered_map<const void*, std::pair<const float*, int>> psums;
   float* gather_ws = nullptr;
   size_t gather_ws_bytes = 0;
+  bool keep = false;         // record the tape and keep what the input gradient needs out of the per-layer scratch
+  std::vector<TapeOp>* tape = nullptr;
+  // gradients known so far, by forward tensor (backward pass)
+  std::unordered_map<const void*, T*> grads;
 
-  Runner(maua_unet* n_, hipStream_t s, int B_, bool plan_) : n(n_), st(s), B(B_), plan(plan_), ar(n_->arena) {}
+  Runner(maua_unet* n_, hipStream_t s, int B_, bool plan_, bool keep_ = false) : n(n_), st(s), B(B_), plan(plan_), ar(n_->arena), keep(keep_) {}
+  float* stats_alloc() { return keep ? (float*)ar.get((size_t)B * 32 * 2 * 4) : nullptr; }
 
   T* alloc(long px, int C) { return (T*)ar.get((size_t)px * C * sizeof(T)); }
   // room for the piece sums of a [B][H][W][C] tensor an LDS-direct convolution may produce (NULL where it cannot)
@@ -947,9 +1003,9 @@ struct Runner {
 
   // GroupNorm (+ scale-shift) (+ SiLU) (+ resample) of [x0 | x1] -> y (dense, C0 + C1 channels); xr: resampled raw x0
   int gn(const UGN& g, const T* x0, int C0, const T* x1, int C1, int H, int W, const float* ss, int silu, int mode, T* y,
-         T* xr) {
+         T* xr, float* stats_keep = nullptr) {
     const size_t mark = ar.top;
-    float* stats = (float*)ar.get((size_t)B * 32 * 2 * 4);
+    float* stats = stats_keep ? stats_keep : (float*)ar.get((size_t)B * 32 * 2 * 4);
     double* part = (double*)ar.get(gn_part_bytes(B, C0 + C1, (long)H * W, (int)sizeof(T)));
     int rc = MAUA_OK;
     if (!plan) {
@@ -970,18 +1026,27 @@ struct Runner {
 
   // ResBlock on [x0 | x1] (H x W) -> out (dense, Cout channels at the resampled size)
   int resblock(const URes& r, const T* x0, int C0, const T* x1, int C1, int H, int W, T* out, float* out_psum) {
-    const size_t mark = ar.top;
     const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
     const long opx = (long)B * Ho * Wo;
+    // (kept forward: conv1's output and both GroupNorms' statistics outlive the block's scratch)
+    T* h1_keep = keep ? alloc(opx, r.Cout) : nullptr;
+    float *st1 = stats_alloc(), *st2 = stats_alloc();
+    const size_t mark = ar.top;
     T* a1 = alloc(opx, r.Cin);
     T* xr = r.updown ? alloc(opx, r.Cin) : nullptr;
     int rc;
-    if ((rc = gn(r.n1, x0, C0, x1, C1, H, W, nullptr, 1, r.updown, a1, xr))) return rc;
-    T* h1 = alloc(opx, r.Cout);
+    if ((rc = gn(r.n1, x0, C0, x1, C1, H, W, nullptr, 1, r.updown, a1, xr, st1))) return rc;
+    T* h1 = keep ? h1_keep : alloc(opx, r.Cout);
     float* ps1 = psum_alloc(Ho, Wo, r.Cout);
     if ((rc = conv(r.c1, a1, h1, Ho, Wo, nullptr, ps1))) return rc;
     T* a2 = alloc(opx, r.Cout);
-    if ((rc = gn(r.n2, h1, r.Cout, nullptr, 0, Ho, Wo, emb_all + r.emb_off, 1, 0, a2, nullptr))) return rc;
+    if ((rc = gn(r.n2, h1, r.Cout, nullptr, 0, Ho, Wo, emb_all + r.emb_off, 1, 0, a2, nullptr, st2))) return rc;
+    if (keep) {
+      TapeOp op{};
+      op.kind = 1; op.idx = (int)(&r - n->res.data()); op.x0 = x0; op.C0 = C0; op.x1 = x1; op.C1 = C1; op.H = H; op.W = W; op.out = out;
+      op.h1 = h1; op.st1 = st1; op.st2 = st2;
+      tape->push_back(op);
+    }
     const T* resid;
     if (r.skip) {  // 1x1 skip_connection over the (virtually concatenated) input
       T* sk = alloc(opx, r.Cout);
@@ -1002,13 +1067,23 @@ struct Runner {
 
   // AttentionBlock, in place on x (dense [B][HW][C])
   int attention(const UAttn& at, T* x, int H, int W, T* out) {
-    const size_t mark = ar.top;
     const long px = (long)B * H * W;
+    T* qkv_keep = keep ? alloc(px, 3 * at.C) : nullptr;
+    T* ao_keep = keep ? alloc(px, at.C) : nullptr;
+    float* lse = keep ? (float*)ar.get((size_t)B * at.heads * H * W * 4) : nullptr;
+    float* st1 = stats_alloc();
+    const size_t mark = ar.top;
     T* a = alloc(px, at.C);
     int rc;
-    if ((rc = gn(at.n, x, at.C, nullptr, 0, H, W, nullptr, 0, 0, a, nullptr))) return rc;
-    T* qkv = alloc(px, 3 * at.C);
-    T* ao = alloc(px, at.C);
+    if ((rc = gn(at.n, x, at.C, nullptr, 0, H, W, nullptr, 0, 0, a, nullptr, st1))) return rc;
+    T* qkv = keep ? qkv_keep : alloc(px, 3 * at.C);
+    T* ao = keep ? ao_keep : alloc(px, at.C);
+    if (keep) {
+      TapeOp op{};
+      op.kind = 2; op.idx = (int)(&at - n->attn.data()); op.x0 = x; op.C0 = at.C; op.H = H; op.W = W; op.out = out; op.h1 = qkv; op.ao = ao;
+      op.st1 = st1; op.lse = lse;
+      tape->push_back(op);
+    }
     if (!plan) {
       GemmArgs g{};
       g.a0 = a; g.lda0 = at.C; g.K0 = at.C; g.w = at.qkv.w; g.bias = at.qkv.bias; g.c = qkv; g.ldc = 3 * at.C; g.M = px;
@@ -1016,7 +1091,7 @@ struct Runner {
       if ((rc = launch_gemm_nt(st, n->dtype, g))) return rc;
       AttnArgs aa{};
       aa.qkv = qkv; aa.out = ao; aa.B = B; aa.T = H * W; aa.heads = at.heads; aa.D = n->head_ch; aa.ld_qkv = 3 * at.C;
-      aa.ld_out = at.C; aa.scale = 1.f / sqrtf((float)n->head_ch);
+      aa.ld_out = at.C; aa.scale = 1.f / sqrtf((float)n->head_ch); aa.lse = lse;
       if ((rc = launch_attention(st, n->dtype, aa))) return rc;
       GemmArgs p{};
       p.a0 = ao; p.lda0 = at.C; p.K0 = at.C; p.w = at.proj.w; p.bias = at.proj.bias; p.res = x; p.ldr = at.C; p.c = out;
@@ -1076,6 +1151,7 @@ struct Runner {
     }
     // split-K workspace of the gather GEMM: sized in the planning pass, placed here in the real one
     gather_ws = (float*)ar.get(plan ? 0 : n_gather_bytes);
+    if (keep) n->tape_gather_ws = gather_ws;
     // ---- input: NCHW f32 -> NHWC T, channels padded to 32
     T* xin = alloc(px, n->conv_in.Cip);
     if (!plan && (rc = launch_nchw_to_nhwc<float, T>(st, x_nchw, xin, B, n->in_ch, H * W, n->conv_in.Cip))) return rc;
@@ -1084,6 +1160,7 @@ struct Runner {
     T* h = alloc(px, n->conv_in.Cop);
     if ((rc = conv(n->conv_in, xin, h, H, W, nullptr))) return rc;   // (3 -> C input convolution: generic kernel, no piece sums)
     int ch = n->conv_in.Co, hh = H, ww = W;
+    T* const h0_first = h;
     hs.push_back(h); hs_c.push_back(ch);
     for (size_t i = 1; i < n->input.size(); i++) {
       T* o;
@@ -1104,8 +1181,13 @@ struct Runner {
       h = o; ch = n->output[i].out_ch;
     }
     // ---- out: GroupNorm -> SiLU -> conv -> NCHW f32
+    float* stf = stats_alloc();
+    if (keep) {
+      n->tape_h0 = (void*)h0_first; n->tape_hf = h; n->tape_cf = ch; n->tape_stf = stf; n->tape_emb = emb_all;
+      n->tape_emb_ld = n->emb_row ? 0L : (long)n->emb_total;
+    }
     T* a = alloc(px, ch);
-    if ((rc = gn(n->out_norm, h, ch, nullptr, 0, hh, ww, nullptr, 1, 0, a, nullptr))) return rc;
+    if ((rc = gn(n->out_norm, h, ch, nullptr, 0, hh, ww, nullptr, 1, 0, a, nullptr, stf))) return rc;
     T* y = alloc(px, n->conv_out.Cop);
     if ((rc = conv(n->conv_out, a, y, hh, ww, nullptr))) return rc;
     if (!plan && (rc = launch_nhwc_to_nchw<T, float>(st, y, out_nchw, B, n->out_ch, H * W, n->conv_out.Cop))) return rc;
@@ -1113,6 +1195,132 @@ struct Runner {
   }
 
   size_t n_gather_bytes = 0;
+
+  // ------------------------------------------------------------------------------------------ input gradient (guided.py:250-272)
+  // dx = conv3x3(dy) with the transposed, spatially flipped kernel (UConv.wt_t), no bias, optional residual
+  int conv_t(const UConv& c, const T* dy, T* dx, int H, int W, const T* res) {
+    UConv v;
+    v.Ci = c.Co; v.Co = c.Ci; v.Cip = c.Cop; v.Cop = c.Cip; v.wt = c.wt_t; v.bias = n->zero_bias;
+    return conv(v, dy, dx, H, W, res);
+  }
+  // c [M][N] = a [M][K] w_t^T (+ res), w_t rows [n0, n0 + N) of a transposed linear weight [Kin][Nout]
+  int gemm_t(const ULin& l, int n0, int N, const T* a, T* c, long M, const T* res) {
+    if (plan) return MAUA_OK;
+    GemmArgs g{};
+    g.a0 = a; g.lda0 = l.N; g.K0 = l.N; g.w = (const char*)l.w_t + (size_t)n0 * l.N * sizeof(T); g.bias = nullptr;
+    g.res = res; g.ldr = N; g.c = c; g.ldc = N; g.M = M; g.N = N;
+    return launch_gemm_nt(st, n->dtype, g);
+  }
+  int gn_vjp(const UGN& g, const void* x0, int C0, const void* x1, int C1, int H, int W, const float* stats, const float* ss, int silu,
+             int mode, const T* dy, const T* dres, const T* add0, const T* add1, T* dx0, T* dx1) {
+    const size_t mark = ar.top;
+    void* ws = ar.get(group_norm_vjp_workspace(B, C0 + C1, (long)H * W, (int)sizeof(T)));
+    int rc = MAUA_OK;
+    if (!plan) {
+      GnVjpArgs a{};
+      a.x0 = x0; a.C0 = C0; a.x1 = x1; a.C1 = C1; a.stats = stats; a.gamma = g.gamma; a.beta = g.beta; a.ss = ss; a.ss_ld = n->tape_emb_ld;
+      a.silu = silu; a.mode = mode; a.dy = dy; a.dres = dres; a.add0 = add0; a.add1 = add1; a.dx0 = dx0; a.dx1 = dx1; a.B = B; a.H = H; a.W = W;
+      rc = launch_group_norm_vjp(st, n->dtype, a, ws);
+    }
+    ar.top = mark;
+    return rc;
+  }
+  // the gradient buffer of a forward tensor: the one already there (a second consumer adds to it) or a fresh one
+  T* grad_of(const void* t, long px, int C, bool* had) {
+    auto it = grads.find(t);
+    *had = it != grads.end();
+    if (*had) return it->second;
+    T* g = alloc(px, C);
+    grads[t] = g;
+    return g;
+  }
+
+  int resblock_vjp(const TapeOp& op) {
+    const URes& r = n->res[op.idx];
+    const int H = op.H, W = op.W;
+    const int Ho = r.updown == 1 ? H / 2 : (r.updown == 2 ? H * 2 : H), Wo = r.updown == 1 ? W / 2 : (r.updown == 2 ? W * 2 : W);
+    const long ipx = (long)B * H * W, opx = (long)B * Ho * Wo;
+    auto it = grads.find(op.out);
+    if (it == grads.end()) return fail("maua_unet_vjp: a block's output has no gradient (tape out of order)");
+    const T* dout = it->second;
+    bool had0 = false, had1 = false;
+    T* dx0 = grad_of(op.x0, ipx, op.C0, &had0);
+    T* dx1 = op.x1 ? grad_of(op.x1, ipx, op.C1, &had1) : nullptr;
+    const size_t mark = ar.top;
+    int rc;
+    T* d_a2 = alloc(opx, r.Cout);
+    if ((rc = conv_t(r.c2, dout, d_a2, Ho, Wo, nullptr))) return rc;
+    T* d_h1 = alloc(opx, r.Cout);
+    if ((rc = gn_vjp(r.n2, op.h1, r.Cout, nullptr, 0, Ho, Wo, op.st2, n->tape_emb + r.emb_off, 1, 0, d_a2, nullptr, nullptr, nullptr, d_h1,
+                     nullptr)))
+      return rc;
+    T* d_a1 = alloc(opx, r.Cin);
+    if ((rc = conv_t(r.c1, d_h1, d_a1, Ho, Wo, nullptr))) return rc;
+    if (r.skip) {
+      // out = skip_connection([x0 | x1]) + ...: the 1x1 convolution's input gradients land in dx0 / dx1 first
+      if ((rc = gemm_t(r.sk, 0, op.C0, dout, dx0, opx, had0 ? dx0 : nullptr))) return rc;
+      if (op.x1 && (rc = gemm_t(r.sk, op.C0, op.C1, dout, dx1, opx, had1 ? dx1 : nullptr))) return rc;
+      rc = gn_vjp(r.n1, op.x0, op.C0, op.x1, op.C1, H, W, op.st1, nullptr, 1, 0, d_a1, nullptr, dx0, dx1, dx0, dx1);
+    } else {
+      // identity (or resampled: x_upd) residual: through the same resampling's adjoint inside the pass
+      rc = gn_vjp(r.n1, op.x0, op.C0, nullptr, 0, H, W, op.st1, nullptr, 1, r.updown, d_a1, dout, had0 ? dx0 : nullptr, nullptr, dx0, nullptr);
+    }
+    ar.top = mark;
+    return rc;
+  }
+
+  int attention_vjp(const TapeOp& op) {
+    const UAttn& at = n->attn[op.idx];
+    const int H = op.H, W = op.W;
+    const long px = (long)B * H * W;
+    auto it = grads.find(op.out);
+    if (it == grads.end()) return fail("maua_unet_vjp: a block's output has no gradient (tape out of order)");
+    const T* dout = it->second;
+    bool had = false;
+    T* dx = grad_of(op.x0, px, at.C, &had);
+    const size_t mark = ar.top;
+    int rc;
+    T* d_ao = alloc(px, at.C);
+    if ((rc = gemm_t(at.proj, 0, at.C, dout, d_ao, px, nullptr))) return rc;
+    T* d_qkv = alloc(px, 3 * at.C);
+    float* delta = (float*)ar.get((size_t)B * at.heads * H * W * 4);
+    if (!plan) {
+      AttnVjpArgs a{};
+      a.qkv = op.h1; a.out = op.ao; a.d_out = d_ao; a.lse = op.lse; a.d_qkv = d_qkv; a.delta = delta; a.B = B; a.T = H * W; a.heads = at.heads;
+      a.D = n->head_ch; a.ld_qkv = 3 * at.C; a.ld_out = at.C; a.scale = 1.f / sqrtf((float)n->head_ch);
+      if ((rc = launch_attention_vjp(st, n->dtype, a))) return rc;
+    }
+    T* d_a = alloc(px, at.C);
+    if ((rc = gemm_t(at.qkv, 0, at.C, d_qkv, d_a, px, nullptr))) return rc;
+    rc = gn_vjp(at.n, op.x0, at.C, nullptr, 0, H, W, op.st1, nullptr, 0, 0, d_a, dout, had ? dx : nullptr, nullptr, dx, nullptr);
+    ar.top = mark;
+    return rc;
+  }
+
+  // g_out [B][out_ch][H][W] f32 -> g_x [B][in_ch][H][W] f32; walks n->tape (or, planning, `ops`) backwards
+  int backward(const std::vector<TapeOp>& ops, const float* g_out, int H, int W, float* g_x) {
+    int rc;
+    const long px = (long)B * H * W;
+    T* dy = alloc(px, n->conv_out.Cop);
+    if (!plan && (rc = launch_nchw_to_nhwc<float, T>(st, g_out, dy, B, n->out_ch, H * W, n->conv_out.Cop))) return rc;
+    T* d_a = alloc(px, n->tape_cf);
+    if ((rc = conv_t(n->conv_out, dy, d_a, H, W, nullptr))) return rc;
+    bool had = false;
+    T* d_hf = grad_of(n->tape_hf, px, n->tape_cf, &had);
+    if ((rc = gn_vjp(n->out_norm, n->tape_hf, n->tape_cf, nullptr, 0, H, W, n->tape_stf, nullptr, 1, 0, d_a, nullptr, nullptr, nullptr, d_hf,
+                     nullptr)))
+      return rc;
+    for (size_t i = ops.size(); i-- > 0;) {
+      const TapeOp& op = ops[i];
+      if ((rc = op.kind == 1 ? resblock_vjp(op) : attention_vjp(op))) return rc;
+    }
+    auto it = grads.find(n->tape_h0);
+    if (it == grads.end()) return fail("maua_unet_vjp: the input convolution's output has no gradient");
+    T* d_xin = alloc(px, n->conv_in.Cip);
+    if ((rc = conv_t(n->conv_in, it->second, d_xin, H, W, nullptr))) return rc;
+    if (!plan && (rc = launch_nhwc_to_nchw<T, float>(st, d_xin, g_x, B, n->in_ch, H * W, n->conv_in.Cip))) return rc;
+    return MAUA_OK;
+  }
 };
 
 size_t shape_key(int B, int H, int W) { return ((size_t)B << 40) ^ ((size_t)H << 20) ^ (size_t)W; }
@@ -1124,14 +1332,19 @@ void drop_sampler_graphs(maua_unet* n) {
 }
 
 template <typename T>
-int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int W, float* out) {
+int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int W, float* out, bool keep = false) {
   hipStream_t st = n->ctx->stream;
-  const size_t key = shape_key(B, H, W);
+  const size_t key = shape_key(B, H, W) ^ (keep ? (size_t)1 << 62 : 0);
+  n->tape_valid = false;
   if (key != n->planned_key) {
-    // planning pass: the same walk with a counting arena
+    // planning pass: the same walk with a counting arena (a kept forward: followed by the gradient's walk)
     n->arena.plan = true; n->arena.top = 0; n->arena.peak = 0;
-    Runner<T> pr(n, st, B, true);
+    Runner<T> pr(n, st, B, true, keep);
+    std::vector<TapeOp> ptape;
+    pr.tape = &ptape;
     if (int rc = pr.forward(x, t, H, W, out)) return rc;
+    if (keep)
+      if (int rc = pr.backward(ptape, nullptr, H, W, nullptr)) return rc;
     const size_t need = n->arena.peak + pr.gather_ws_bytes + (1 << 20);
     if (need > n->arena.cap) {
       MAUA_HIP_CHECK(hipStreamSynchronize(st));
@@ -1154,9 +1367,24 @@ int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int 
     n->ones = p; n->ones_b = B;
   }
   n->arena.plan = false; n->arena.top = 0;
-  Runner<T> r(n, st, B, false);
+  Runner<T> r(n, st, B, false, keep);
   r.n_gather_bytes = n->gather_bytes;
-  return r.forward(x, t, H, W, out);
+  n->tape.clear();
+  r.tape = &n->tape;
+  if (int rc = r.forward(x, t, H, W, out)) return rc;
+  if (keep) { n->tape_valid = true; n->tape_B = B; n->tape_H = H; n->tape_W = W; n->tape_top = n->arena.top; }
+  return MAUA_OK;
+}
+
+// the gradient's walk continues on the arena where the kept forward stopped (its tensors stay where they are)
+template <typename T>
+int run_vjp(maua_unet* n, const float* g_out, float* g_x) {
+  hipStream_t st = n->ctx->stream;
+  n->arena.plan = false; n->arena.top = n->tape_top;
+  Runner<T> r(n, st, n->tape_B, false, true);
+  r.n_gather_bytes = n->gather_bytes;
+  r.gather_ws = n->tape_gather_ws;
+  return r.backward(n->tape, g_out, n->tape_H, n->tape_W, g_x);
 }
 
 }  // namespace
@@ -1223,6 +1451,16 @@ int maua_unet_set_option(maua_unet* n, const char* key, int value) {
     drop_sampler_graphs(n);
     return MAUA_OK;
   }
+  if (!strcmp(key, "vjp")) {   // 1: maua_unet_load also prepares the transposed weights maua_unet_vjp convolves / multiplies with
+    MAUA_REQUIRE(value == 0 || value == 1, "maua_unet_set_option: vjp is 0 or 1");
+    if (value && !n->zero_bias) {
+      int mp = 32;
+      for (auto& r : n->res) mp = std::max(mp, std::max(r.c1.Cip, r.c1.Cop));
+      if (int rc = dev_alloc(n, &n->zero_bias, (size_t)mp * 4)) return rc;
+    }
+    n->vjp = value;
+    return MAUA_OK;
+  }
   return fail(std::string("maua_unet_set_option: unknown option ") + key);
 }
 
@@ -1281,6 +1519,19 @@ int maua_unet_load(maua_unet* n, const char* name, const float* host, size_t cou
       MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
       MAUA_HIP_CHECK(hipMemsetAsync(c->wt, 0, (size_t)9 * c->Cop * c->Cip * n->esize, st));
       int rc = launch_prep_weights(st, n->dtype, tmp, c->wt, nullptr, c->Co, c->Ci, 3, 1, 0, c->Cop, c->Cip);
+      if (!rc && n->vjp) {
+        // the input-gradient convolution: Wt[ci][co][ky][kx] = W[co][ci][2 - ky][2 - kx]
+        float* tt = nullptr;
+        if (hipMalloc((void**)&tt, count * 4) != hipSuccess) { hipFree(tmp); return fail("maua_unet_load: out of device memory"); }
+        if (!c->wt_t) rc = dev_alloc(n, &c->wt_t, (size_t)9 * c->Cop * c->Cip * n->esize);
+        if (!rc) {
+          hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, tmp, tt, c->Co, c->Ci, 9);
+          hipMemsetAsync(c->wt_t, 0, (size_t)9 * c->Cop * c->Cip * n->esize, st);
+          rc = launch_prep_weights(st, n->dtype, tt, c->wt_t, nullptr, c->Ci, c->Co, 3, 1, 0, c->Cip, c->Cop);
+        }
+        hipStreamSynchronize(st);
+        hipFree(tt);
+      }
       hipStreamSynchronize(st);
       hipFree(tmp);
       return rc;
@@ -1293,6 +1544,17 @@ int maua_unet_load(maua_unet* n, const char* name, const float* host, size_t cou
       MAUA_HIP_CHECK(hipMemcpy(tmp, host, count * 4, hipMemcpyHostToDevice));
       // a k = 1 "convolution": [N][K] rows, converted to the network dtype
       int rc = launch_prep_weights(st, n->dtype, tmp, l->w, nullptr, l->N, l->K, 1, 1, 0, l->N, l->K);
+      if (!rc && n->vjp) {
+        float* tt = nullptr;
+        if (hipMalloc((void**)&tt, count * 4) != hipSuccess) { hipFree(tmp); return fail("maua_unet_load: out of device memory"); }
+        if (!l->w_t) rc = dev_alloc(n, &l->w_t, (size_t)l->N * l->K * n->esize);
+        if (!rc) {
+          hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, tmp, tt, l->N, l->K, 1);
+          rc = launch_prep_weights(st, n->dtype, tt, l->w_t, nullptr, l->K, l->N, 1, 1, 0, l->K, l->N);
+        }
+        hipStreamSynchronize(st);
+        hipFree(tt);
+      }
       hipStreamSynchronize(st);
       hipFree(tmp);
       return rc;
@@ -1310,6 +1572,28 @@ int maua_unet_forward(maua_unet* n, const float* x, const float* timesteps, int 
   MAUA_REQUIRE(H % down == 0 && W % down == 0, "maua_unet_forward: H and W must be multiples of 2^(levels - 1)");
   if (B == 0) return MAUA_OK;
   return n->dtype == MAUA_BF16 ? run_forward<bf16_t>(n, x, timesteps, B, H, W, out) : run_forward<float>(n, x, timesteps, B, H, W, out);
+}
+
+// The forward again, keeping what its input gradient needs (GroupNorm inputs + statistics, qkv + the attention rows' log-sum-exp)
+// on the arena; then maua_unet_vjp(g_out [B][out_channels][H][W]) -> g_x [B][in_channels][H][W] = (d out / d x)^T g_out, the
+// vector-Jacobian product guided.py:258-272 asks autograd for (speed "regular": img = f(pred_xstart(UNet(x)))).  The pair must
+// run back to back on one network (any other forward in between invalidates the kept tensors); option "vjp" = 1 before the
+// weights are loaded.  Every 3x3 convolution's gradient is the same MFMA convolution with the transposed, flipped kernel.
+int maua_unet_forward_keep(maua_unet* n, const float* x, const float* timesteps, int B, int H, int W, float* out) {
+  MAUA_REQUIRE(n && x && timesteps && out, "maua_unet_forward_keep: NULL argument");
+  MAUA_REQUIRE(n->vjp, "maua_unet_forward_keep: set option \"vjp\" = 1 before loading the weights");
+  MAUA_REQUIRE(n->conv_in.wt_t && n->conv_out.wt_t, "maua_unet_forward_keep: the weights were loaded before option \"vjp\" was set");
+  MAUA_REQUIRE(B > 0 && H > 0 && W > 0, "maua_unet_forward_keep: bad shape");
+  const int down = 1 << (n->mult.size() - 1);
+  MAUA_REQUIRE(H % down == 0 && W % down == 0, "maua_unet_forward_keep: H and W must be multiples of 2^(levels - 1)");
+  return n->dtype == MAUA_BF16 ? run_forward<bf16_t>(n, x, timesteps, B, H, W, out, true) : run_forward<float>(n, x, timesteps, B, H, W, out, true);
+}
+
+int maua_unet_vjp(maua_unet* n, const float* g_out, int B, int H, int W, float* g_x) {
+  MAUA_REQUIRE(n && g_out && g_x, "maua_unet_vjp: NULL argument");
+  MAUA_REQUIRE(n->tape_valid && n->tape_B == B && n->tape_H == H && n->tape_W == W,
+               "maua_unet_vjp: no kept forward of this shape (call maua_unet_forward_keep first, nothing in between)");
+  return n->dtype == MAUA_BF16 ? run_vjp<bf16_t>(n, g_out, g_x) : run_vjp<float>(n, g_out, g_x);
 }
 
 // One DDIM update (gaussian_diffusion.py ddim_sample, epsilon model, clip_denoised False).  x [B][C][H][W], model_out
@@ -1426,6 +1710,51 @@ int maua_group_norm_nhwc(maua_ctx* ctx, const void* x, const float* gamma, const
                                      silu, 0, (bf16_t*)y, nullptr, part, stats);
   return launch_group_norm<float>(ctx->stream, (const float*)x, C, nullptr, 0, B, H, W, gamma, beta, scale_shift, 2L * C, silu,
                                   0, (float*)y, nullptr, part, stats);
+}
+
+// Input gradients of the two operator-level blocks above (what maua_unet_vjp walks a network with).  Attention: qkv as the
+// forward's, d_out [B][T][C] -> d_qkv [B][T][3C] (the forward is re-run here for the rows' log-sum-exp and the result).
+int maua_attention_legacy_vjp(maua_ctx* ctx, const void* qkv, const void* d_out, void* d_qkv, int B, int T, int heads, int head_ch,
+                              int dtype) {
+  MAUA_REQUIRE(ctx && qkv && d_out && d_qkv, "maua_attention_legacy_vjp: NULL argument");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_attention_legacy_vjp: f32 / bf16");
+  if (B == 0) return MAUA_OK;
+  const size_t esize = dtype == MAUA_BF16 ? 2 : 4;
+  const size_t out_bytes = ((size_t)B * T * heads * head_ch * esize + 255) & ~(size_t)255, row_bytes = ((size_t)B * heads * T * 4 + 255) & ~(size_t)255;
+  if (int rc = scratch_reserve(ctx, out_bytes + 2 * row_bytes + 512)) return rc;
+  char* ws = (char*)ctx->scratch;
+  AttnArgs f{};
+  f.qkv = qkv; f.out = ws; f.B = B; f.T = T; f.heads = heads; f.D = head_ch; f.ld_qkv = 3L * heads * head_ch;
+  f.ld_out = (long)heads * head_ch; f.scale = 1.f / sqrtf((float)head_ch); f.lse = (float*)(ws + out_bytes);
+  if (int rc = launch_attention(ctx->stream, dtype, f)) return rc;
+  AttnVjpArgs a{};
+  a.qkv = qkv; a.out = ws; a.d_out = d_out; a.lse = f.lse; a.d_qkv = d_qkv; a.delta = (float*)(ws + out_bytes + row_bytes); a.B = B; a.T = T;
+  a.heads = heads; a.D = head_ch; a.ld_qkv = f.ld_qkv; a.ld_out = f.ld_out; a.scale = f.scale;
+  return launch_attention_vjp(ctx->stream, dtype, a);
+}
+
+// GroupNorm32 (+ scale-shift) (+ SiLU) (+ resample: 0 none, 1 2x2 average, 2 nearest x2 - behind the activation, as the
+// ResBlocks' h_upd): dy [B][Ho][Wo][C] -> dx [B][H][W][C]; dres (optional, like dy): the gradient of the resampled raw x, added.
+int maua_group_norm_nhwc_vjp(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, const float* scale_shift, int silu,
+                             int resample, const void* dy, const void* dres, int B, int H, int W, int C, int dtype, void* dx) {
+  MAUA_REQUIRE(ctx && x && gamma && beta && dy && dx, "maua_group_norm_nhwc_vjp: NULL argument");
+  MAUA_REQUIRE(C % 32 == 0 && (dtype == MAUA_F32 || dtype == MAUA_BF16), "maua_group_norm_nhwc_vjp: C % 32, f32 / bf16");
+  if (B == 0) return MAUA_OK;
+  const int esize = dtype == MAUA_BF16 ? 2 : 4;
+  const size_t part_bytes = (gn_part_bytes(B, C, (long)H * W, esize) + 255) & ~(size_t)255;
+  const size_t vjp_bytes = group_norm_vjp_workspace(B, C, (long)H * W, esize);
+  if (int rc = scratch_reserve(ctx, part_bytes + (size_t)B * 64 * 4 + 512 + vjp_bytes)) return rc;
+  double* part = (double*)ctx->scratch;
+  float* stats = (float*)((char*)ctx->scratch + part_bytes);
+  void* ws = (char*)ctx->scratch + part_bytes + (size_t)B * 64 * 4 + 256;
+  // the forward's statistics (its output goes nowhere: the statistics passes only)
+  if (int rc = dtype == MAUA_BF16 ? launch_group_norm_stats<bf16_t>(ctx->stream, (const bf16_t*)x, C, B, H, W, part, stats)
+                                  : launch_group_norm_stats<float>(ctx->stream, (const float*)x, C, B, H, W, part, stats))
+    return rc;
+  GnVjpArgs a{};
+  a.x0 = x; a.C0 = C; a.stats = stats; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.ss_ld = 2L * C; a.silu = silu; a.mode = resample;
+  a.dy = dy; a.dres = dres; a.dx0 = dx; a.B = B; a.H = H; a.W = W;
+  return launch_group_norm_vjp(ctx->stream, dtype, a, ws);
 }
 
 // The unconditioned sampler loop inside the library: n_steps x (UNet forward + DDIM update), x updated in place.

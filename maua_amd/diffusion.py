@@ -13,8 +13,10 @@ The network runs behind the C ABI (``maua_unet_*``, csrc/unet.hip); the sampler'
 Conditioning speeds (guided.py:212-274): "fast" - the reference's DEFAULT (:287) - differentiates through the in-tree secondary
 model (``SecondaryDiffusionImageNet2``, :68-143): forward and vector-Jacobian product run behind ``maua_secondary_*``
 (csrc/secondary.hip evaluates the transposed network by hand; pinned by tests/golden/g28_secondary.npz, which the reference's own
-classes generated); "hyper" (:248-249: the x0 estimate from the known noise, Jacobian 1 / alpha) is exact; "regular"
-back-propagates through the 553 M-parameter UNet itself and is refused.  All three samplers of guided.py:302-311 exist ("ddim":
+classes generated); "hyper" (:248-249: the x0 estimate from the known noise, Jacobian 1 / alpha) is exact; "regular" (:250-252)
+back-propagates through the 553 M-parameter UNet itself: ``UNetModel.forward_keep`` + ``UNetModel.vjp`` (maua_unet_forward_keep /
+maua_unet_vjp - the network walked backwards in the library: every convolution's gradient is the same MFMA convolution with the
+transposed kernel, GroupNorm / SiLU / resampling and attention have hand-written input-gradient kernels).  All three samplers of guided.py:302-311 exist ("ddim":
 configs[3]; "p"; "plms": the fork's sampler restated from its published algorithm).
 
 What is NOT here, and why: the reference's text prompts go through CLIP / LPIPS perceptors (maua/grad.py:48-199: un-vendored
@@ -50,8 +52,9 @@ class UNetModel(torch.nn.Module):
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
                  use_fp16=False, num_heads=1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
-                 resblock_updown=False, use_new_attention_order=False, dtype=torch.bfloat16, generator=None):
+                 resblock_updown=False, use_new_attention_order=False, dtype=torch.bfloat16, generator=None, vjp=False):
         super().__init__()
+        self._vjp = bool(vjp)   # also prepare the transposed weights of the input gradient (forward_keep / vjp)
         if not (use_scale_shift_norm and resblock_updown) or use_new_attention_order or num_classes is not None or dims != 2 \
                 or dropout != 0 or num_head_channels not in (32, 64):
             raise NotImplementedError("only the configuration of maua's create_models is implemented: use_scale_shift_norm, "
@@ -193,6 +196,8 @@ class UNetModel(torch.nn.Module):
                                          self.num_res_blocks, cm, len(self.channel_mult), ads,
                                          len(self.attention_resolutions), self.num_head_channels, L.dtype_id(self.dtype),
                                          C.byref(net)))
+            if self._vjp:
+                L.check(lib.maua_unet_set_option(net, b"vjp", 1))
             for k, v in self._params.items():
                 a = np.ascontiguousarray(v.numpy(), dtype=np.float32)
                 L.check(lib.maua_unet_load(net, k.encode(), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.size)))
@@ -225,8 +230,8 @@ class UNetModel(torch.nn.Module):
         """0: per-shape kernel routing (default), 1: generic 3x3 kernel only, 2: no split-K gather GEMM."""
         L.check(L.lib().maua_unet_set_option(self._handle(), b"route", int(route)))
 
-    def forward(self, x, timesteps, y=None, out=None):
-        """x [N, C, H, W], timesteps [N] -> [N, out_channels, H, W] (float32)."""
+    def forward(self, x, timesteps, y=None, out=None, keep=False):
+        """x [N, C, H, W], timesteps [N] -> [N, out_channels, H, W] (float32).  ``keep``: leave what ``vjp`` reads on the device."""
         if y is not None:
             raise NotImplementedError("class conditioning is not on this path")
         x = L.dev_tensor(x, torch.float32)
@@ -236,8 +241,39 @@ class UNetModel(torch.nn.Module):
             raise ValueError("one timestep per sample")
         if out is None:
             out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        L.check(L.lib().maua_unet_forward(self._handle(), L.ptr(x), L.ptr(t), B, H, W, L.ptr(out)))
+        if keep:
+            self.enable_vjp()
+            L.check(L.lib().maua_unet_forward_keep(self._handle(), L.ptr(x), L.ptr(t), B, H, W, L.ptr(out)))
+            self._kept = (B, H, W)
+        else:
+            L.check(L.lib().maua_unet_forward(self._handle(), L.ptr(x), L.ptr(t), B, H, W, L.ptr(out)))
+            self._kept = None
         return out
+
+    def enable_vjp(self):
+        """Prepare the network for ``forward_keep`` / ``vjp`` (the library object is rebuilt once with the transposed weights)."""
+        if not self._vjp:
+            self._vjp = True
+            self._destroy()
+        return self
+
+    def forward_keep(self, x, timesteps, out=None):
+        """``forward`` that keeps the GroupNorm inputs / statistics and the attention operands for ``vjp`` (back to back)."""
+        return self.forward(x, timesteps, out=out, keep=True)
+
+    def vjp(self, g_out):
+        """(d out / d x)^T g_out of the last ``forward_keep``: what ``torch.autograd.grad(out, x, g_out)`` returns in the reference
+        (guided.py:268 for speed "regular").  g_out [N, out_channels, H, W] -> [N, in_channels, H, W] float32."""
+        kept = getattr(self, "_kept", None)
+        if kept is None:
+            raise RuntimeError("vjp: call forward_keep first (no other forward in between)")
+        g = L.dev_tensor(g_out, torch.float32).contiguous()
+        B, H, W = kept
+        if tuple(g.shape) != (B, self.out_channels, H, W):
+            raise ValueError(f"vjp: g_out must be {(B, self.out_channels, H, W)}, got {tuple(g.shape)}")
+        gx = torch.empty((B, self.in_channels, H, W), dtype=torch.float32, device=g.device)
+        L.check(L.lib().maua_unet_vjp(self._handle(), L.ptr(g), B, H, W, L.ptr(gx)))
+        return gx
 
 
 # ------------------------------------------------------------------------------------------------------ diffusion
@@ -698,11 +734,14 @@ class GradientGuidedConditioning(torch.nn.Module):
 
     def __init__(self, diffusion, model, grad_modules, speed="fast"):
         super().__init__()
-        if speed not in ("hyper", "fast"):
-            raise NotImplementedError('speed "regular" back-propagates through the UNet itself; use "fast" (default) or "hyper"')
-        if speed == "fast" and not hasattr(model, "vjp"):
+        if speed == "fast" and not isinstance(model, SecondaryDiffusionImageNet2):
             raise ValueError('speed="fast" needs the secondary model (create_models(use_secondary=True))')
+        if speed not in ("hyper", "fast"):      # guided.py:217-218: anything else is "regular", through the UNet itself
+            if not hasattr(model, "forward_keep"):
+                raise ValueError('speed="regular" needs the diffusion UNet (a UNetModel) as its model')
+            model.enable_vjp()
         self.speed, self.model, self.grad_modules = speed, model, list(grad_modules)
+        self.diffusion = diffusion
         self.timestep_map = list(diffusion.timestep_map)
         self.sqrt_alphas_cumprod = torch.from_numpy(diffusion.sqrt_alphas_cumprod).float()
         self.sqrt_one_minus_alphas_cumprod = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod).float()
@@ -756,6 +795,27 @@ class GradientGuidedConditioning(torch.nn.Module):
             ab = L.dev_tensor(torch.stack([1 / alpha, -sigma / alpha], 1).contiguous(), torch.float32)
             L.check(lib.maua_axpby_rows(ctx, L.ptr(x), L.ptr(self.noise), L.ptr(ab), B, row, L.ptr(img)))
             return -self._sum_grads(img, ot) / alpha.to(x.device).reshape(-1, 1, 1, 1)
+        if self.speed != "fast":
+            # "regular" (:250-252): img = pred_xstart * sigma + x * (1 - sigma), pred_xstart = ra * x - rm * eps(x, t) from
+            # p_mean_variance (gaussian_diffusion.py _predict_xstart_from_eps; eps = the first half of the learn_sigma output), so
+            #     -J^T g = -[(sigma * ra + 1 - sigma) * g - sigma * rm * (d eps / d x)^T g]
+            ra, rm = self.diffusion._f32(self.diffusion.sqrt_recip_alphas_cumprod, idx), self.diffusion._f32(self.diffusion.sqrt_recipm1_alphas_cumprod, idx)
+            nc = x.shape[1]
+            out = self.model.forward_keep(x, self.diffusion.model_timesteps(idx))
+            eps = out[:, :nc].contiguous()
+            pred = torch.empty_like(x)
+            ab = L.dev_tensor(torch.stack([ra, -rm], 1).contiguous(), torch.float32)
+            L.check(lib.maua_axpby_rows(ctx, L.ptr(x), L.ptr(eps), L.ptr(ab), B, row, L.ptr(pred)))
+            ab = L.dev_tensor(torch.stack([sigma, 1 - sigma], 1).contiguous(), torch.float32)
+            L.check(lib.maua_axpby_rows(ctx, L.ptr(pred), L.ptr(x), L.ptr(ab), B, row, L.ptr(img)))
+            g = self._sum_grads(img, ot)
+            g_out = torch.zeros_like(out)
+            g_out[:, :nc] = g
+            jv = self.model.vjp(g_out)
+            cf = L.dev_tensor(torch.stack([-(sigma * ra + 1 - sigma), sigma * rm], 1).contiguous(), torch.float32)
+            res = torch.empty_like(x)
+            L.check(lib.maua_axpby_rows(ctx, L.ptr(g), L.ptr(jv), L.ptr(cf), B, row, L.ptr(res)))
+            return res
         cosine_t = torch.atan2(sigma, alpha) * 2 / math.pi                           # :252
         pred = self.model(x, cosine_t).pred                                          # :253
         ab = L.dev_tensor(torch.stack([sigma, 1 - sigma], 1).contiguous(), torch.float32)

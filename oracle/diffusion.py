@@ -198,10 +198,7 @@ def _run(p, pfx, layers, h, emb, cfg):
     return h
 
 
-@torch.no_grad()
-def unet_forward(p, cfg, x, timesteps, capture=None):
-    """UNetModel.forward: x [N, C, H, W], timesteps [N] (already scaled) -> [N, out_channels, H, W].
-    ``capture``: optional dict that receives every block's output (for layer-by-layer parity)."""
+def _unet_forward(p, cfg, x, timesteps, capture=None):
     s = unet_structure(cfg)
     emb = timestep_embedding(timesteps, cfg["model_channels"])
     emb = F.linear(F.silu(F.linear(emb, p["time_embed.0.weight"], p["time_embed.0.bias"])),
@@ -223,6 +220,13 @@ def unet_forward(p, cfg, x, timesteps, capture=None):
             capture[f"output_blocks.{i}"] = h
     h = F.silu(_gn(p, "out.0", h))
     return F.conv2d(h, p["out.2.weight"], p["out.2.bias"], padding=1)
+
+
+@torch.no_grad()
+def unet_forward(p, cfg, x, timesteps, capture=None):
+    """UNetModel.forward: x [N, C, H, W], timesteps [N] (already scaled) -> [N, out_channels, H, W].
+    ``capture``: optional dict that receives every block's output (for layer-by-layer parity)."""
+    return _unet_forward(p, cfg, x, timesteps, capture)
 
 
 # ------------------------------------------------------------------------------------------------------ diffusion
@@ -490,5 +494,33 @@ def fast_conditioning(p, sch, grad_fn, x, t):
         pred = secondary_forward(p, xx, cosine_t)[1]
         s = sigma.reshape(-1, 1, 1, 1)
         img = pred * s + xx * (1 - s)
+        g = grad_fn(img.detach(), t)
+        return -torch.autograd.grad(img, xx, g)[0]
+
+
+def unet_input_vjp(p, cfg, x, timesteps, g_out):
+    """(d UNet(x, t) / d x)^T g_out by torch autograd on the restatement above - the checker of maua_unet_vjp (the product walks the
+    network backwards by hand; the reference asks autograd, guided.py:268)."""
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_()
+        out = _unet_forward(p, cfg, xx, timesteps)
+        return torch.autograd.grad(out, xx, g_out)[0]
+
+
+def regular_conditioning(p, cfg, sch, grad_fn, x, t):
+    """guided.py:236-272 with speed="regular" (any speed other than "hyper" / "fast", :214-218): the loss is differentiated through
+    the diffusion UNet itself.  self.model = partial(diffusion.p_mean_variance, model=model, clip_denoised=False) (:218);
+    out = self.model(x=x, t=t)["pred_xstart"] (:251) with t the RESPACED index (:238) - p_mean_variance of the respaced process maps
+    it back to the network's timestep and, for an epsilon model with learned variance, returns
+    pred_xstart = sqrt_recip_alphas_cumprod[t] * x - sqrt_recipm1_alphas_cumprod[t] * eps, eps = the first half of the output
+    (gaussian_diffusion.py p_mean_variance / _predict_xstart_from_eps); img = out * sigma + x * (1 - sigma) (:252)."""
+    idx = torch.tensor([list(sch.timestep_map).index(int(v)) for v in t.long()])
+    sigma = torch.from_numpy(sch.sqrt_one_minus_alphas_cumprod).float()[idx].reshape(-1, 1, 1, 1)
+    ra, rm = _ex(sch.sqrt_recip_alphas_cumprod, idx, x.shape), _ex(sch.sqrt_recipm1_alphas_cumprod, idx, x.shape)
+    with torch.enable_grad():
+        xx = x.detach().clone().requires_grad_()
+        out = _unet_forward(p, cfg, xx, sch.model_timesteps(idx))
+        pred = ra * xx - rm * out[:, :x.shape[1]]
+        img = pred * sigma + xx * (1 - sigma)
         g = grad_fn(img.detach(), t)
         return -torch.autograd.grad(img, xx, g)[0]

@@ -608,3 +608,136 @@ def test_full_size_100_step_ddim_bf16_drift_and_onset_switched_sampling():
     c, _ = sample(other, wav, 1024 * fps, fps, **kw)
     same = [bool(torch.equal(a[f], c[f])) for f in range(first_switch + 2)]
     assert all(same[:first_switch]) and not any(same[first_switch:]), same
+
+# ------------------------------------------------------------------------------------ speed "regular": the UNet's input gradient
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C_,H,W", [(2, 32, 8, 8), (1, 256, 16, 16), (2, 96, 6, 10), (1, 1024, 8, 8)])
+def test_group_norm_input_gradient_matches_autograd(dt, B, C_, H, W):
+    """maua_group_norm_nhwc_vjp against torch.autograd through GroupNorm32 -> [scale-shift] -> [SiLU] -> [avg_pool 2 | nearest x2]
+    (ResBlock.in_layers + h_upd, out_layers, AttentionBlock.norm), with and without the residual branch's gradient (x_upd / the
+    identity skip) joining at the input.  f32: <= 5e-5 of the gradient's maximum; bf16 (x, dy and dx rounded): <= 2e-2."""
+    from maua_amd import _lib as L
+    g = torch.Generator().manual_seed(C_ + H)
+    x = torch.randn(B, C_, H, W, generator=g) * 0.7 + 2.0 * torch.randn(1, C_, 1, 1, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    ss = 0.3 * torch.randn(B, 2 * C_, generator=g)
+    if dt == torch.bfloat16:
+        x = x.bfloat16().float()
+    xd = _nhwc(x, dt)
+    gd, bd, ssd = gamma.cuda(), beta.cuda(), ss.cuda()
+    resample = {0: (lambda t: t), 1: (lambda t: F.avg_pool2d(t, 2, 2)), 2: (lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))}
+    for use_ss, silu, mode, with_res in ((False, False, 0, True), (True, True, 0, False), (False, True, 1, True), (False, True, 2, True),
+                                         (True, False, 2, False)):
+        xx = x.clone().requires_grad_()
+        y = F.group_norm(xx, 32, gamma, beta, eps=1e-5)
+        if use_ss:
+            y = y * (1 + ss[:, :C_, None, None]) + ss[:, C_:, None, None]
+        if silu:
+            y = F.silu(y)
+        y = resample[mode](y)
+        dy = torch.randn(y.shape, generator=g)
+        dres = torch.randn(y.shape, generator=g) if with_res else None
+        if dt == torch.bfloat16:
+            dy = dy.bfloat16().float()
+            dres = dres.bfloat16().float() if with_res else None
+        total = (y * dy).sum() + ((resample[mode](xx) * dres).sum() if with_res else 0.0)
+        want = torch.autograd.grad(total, xx)[0]
+        dyd = _nhwc(dy, dt)
+        drd = _nhwc(dres, dt) if with_res else None
+        dx = torch.empty_like(xd)
+        L.check(L.lib().maua_group_norm_nhwc_vjp(L.ctx(), L.ptr(xd), L.ptr(gd), L.ptr(bd), L.ptr(ssd) if use_ss else None, int(silu), mode,
+                                                 L.ptr(dyd), L.ptr(drd) if with_res else None, B, H, W, C_, L.dtype_id(dt), L.ptr(dx)))
+        got = dx.float().cpu().permute(0, 3, 1, 2)
+        assert rel(got, want) <= (5e-5 if dt == torch.float32 else 2e-2), (use_ss, silu, mode, with_res, rel(got, want))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,heads,ch", [(2, 64, 2, 32), (1, 256, 4, 64), (2, 48, 1, 64), (1, 1024, 2, 64), (3, 16, 2, 32), (1, 200, 2, 64)])
+def test_attention_input_gradient_matches_autograd(dt, B, T, heads, ch):
+    """maua_attention_legacy_vjp against torch.autograd through QKVAttentionLegacy.forward (T not a multiple of 32 or of the
+    128-row tile, one and several blocks on both sides).  P and dS are rebuilt from the forward's log-sum-exp rows; in bf16 they are
+    rounded before the second products, like the forward rounds P."""
+    from maua_amd import _lib as L
+    g = torch.Generator().manual_seed(T + 3 * heads)
+    qkv = torch.randn(B, 3 * heads * ch, T, generator=g)
+    d_out = torch.randn(B, heads * ch, T, generator=g)
+    if dt == torch.bfloat16:
+        qkv, d_out = qkv.bfloat16().float(), d_out.bfloat16().float()
+    qq = qkv.clone().requires_grad_()
+    q, k, v = qq.reshape(B * heads, ch * 3, T).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v).reshape(B, -1, T)
+    want = torch.autograd.grad(a, qq, d_out)[0]                                   # [B, 3 * heads * ch, T]
+    x = qkv.permute(0, 2, 1).contiguous().to(device="cuda", dtype=dt)
+    dod = d_out.permute(0, 2, 1).contiguous().to(device="cuda", dtype=dt)
+    dq = torch.empty_like(x)
+    L.check(L.lib().maua_attention_legacy_vjp(L.ctx(), L.ptr(x), L.ptr(dod), L.ptr(dq), B, T, heads, ch, L.dtype_id(dt)))
+    got = dq.float().cpu().permute(0, 2, 1)
+    assert rel(got, want) <= (5e-5 if dt == torch.float32 else 3e-2), rel(got, want)
+
+
+@pytest.mark.parametrize("cfgkw,hw", [(SMALL, (64, 64)), (SMALL, (32, 96)), (WIDE, (64, 64))], ids=["small", "small-32x96", "wide"])
+def test_unet_input_gradient_matches_autograd_on_the_oracle(cfgkw, hw):
+    """UNetModel.forward_keep + vjp (maua_unet_forward_keep / maua_unet_vjp: the network walked backwards inside the library - transposed
+    MFMA convolutions and GEMMs, GroupNorm / SiLU / resampling and attention input-gradient kernels, the skip connections' two
+    consumers added up) against torch.autograd.grad through the oracle's UNet - what guided.py:268 computes for speed "regular".
+    f32: <= 2e-4 of the gradient's maximum over the whole 40-layer chain there and back; bf16: cosine >= 0.99, L2 <= 12 %.  The kept
+    forward returns what the plain forward returns; a vjp without its forward is refused."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, *hw, generator=g)
+    t = torch.tensor([870.0, 240.0])
+    cfg, p, net = _build(cfgkw, torch.float32)
+    g_out = torch.randn(2, cfg["out_channels"], *hw, generator=g)
+    want = OD.unet_input_vjp(p, cfg, x, t, g_out)
+    plain = net(x, t)
+    with pytest.raises(RuntimeError):
+        net.vjp(g_out)
+    kept = net.forward_keep(x, t)
+    assert torch.equal(kept, net(x, t)) and rel(kept, plain) <= 1e-6
+    net.forward_keep(x, t)
+    got = net.vjp(g_out)
+    assert rel(got, want) <= 2e-4, rel(got, want)
+    again = net.vjp(g_out)                             # the kept tensors are read, not consumed
+    assert torch.equal(got, again)
+    net.forward_keep(x[1:], t[1:])                     # a sample's gradient does not depend on its batch neighbours
+    assert rel(net.vjp(g_out[1:]), want[1:]) <= 2e-4
+    net.set_route(1)                                   # ... nor on the convolution route
+    net.forward_keep(x, t)
+    assert rel(net.vjp(g_out), want) <= 2e-4
+    _, _, net16 = _build(cfgkw, torch.bfloat16)
+    net16.forward_keep(x, t)
+    got16 = net16.vjp(g_out).cpu()
+    cos = float((got16 * want).sum() / (got16.norm() * want.norm()))
+    l2 = float((got16 - want).norm() / want.norm())
+    print("bf16 UNet input gradient vs f32 autograd: cosine", cos, "l2", l2)
+    assert cos >= 0.99 and l2 <= 0.12, (cos, l2)
+
+
+def test_regular_speed_conditioning_matches_the_oracle_and_guides_the_sampler():
+    """GradientGuidedConditioning(speed="regular") - guided.py:214-218, :250-252: the loss gradient through p_mean_variance's
+    pred_xstart, i.e. through the diffusion UNet - against oracle.diffusion.regular_conditioning (torch autograd on the restated
+    network and schedule); GuidedDiffusion(speed="regular") then runs the DDIM loop with it and moves the result towards the target."""
+    from maua_amd.diffusion import GradientGuidedConditioning, GuidedDiffusion, ImageTarget, MSEGuide, SpacedDiffusion, space_timesteps
+    cfg, p, net = _build(SMALL, torch.float32)
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim20"), OD.linear_betas(1000), rescale_timesteps=True)
+    sch = OD.Schedule(1000, "ddim20")
+    g = torch.Generator().manual_seed(9)
+    img, nz, target = (torch.randn(2, 3, 64, 64, generator=g) for _ in range(3))
+    xt = OD.q_sample(sch, img, torch.tensor([12, 5]), nz)
+    t_model = torch.tensor([float(sd.timestep_map[12]), float(sd.timestep_map[5])])
+    guide = MSEGuide(scale=500.0)
+    cond = GradientGuidedConditioning(sd, net, [guide], speed="regular")
+    cond.set_targets([ImageTarget(target)], torch.zeros_like(xt))
+    got = cond(xt, t_model).cpu()
+    k = guide.factor(target[0].numel())
+    want = OD.regular_conditioning(p, cfg, sch, lambda im, _t: k * (im - target), xt, t_model)
+    l2 = float((got - want).norm() / want.norm())
+    print("regular conditioning vs oracle autograd: l2", l2, "max", rel(got, want))
+    assert l2 <= 2e-4 and rel(got, want) <= 5e-4, (l2, rel(got, want))
+    gd = GuidedDiffusion([MSEGuide(scale=2000.0)], timesteps=20, model=net, diffusion=sd, speed="regular")
+    assert gd.conditioning.speed == "regular"
+    guided = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+    plain = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd).forward(img, [], 0.3, t_end=0.6, noise=nz).cpu()
+    assert torch.isfinite(guided).all()
+    assert float((guided - target).norm()) < float((plain - target).norm())
