@@ -355,6 +355,27 @@ def extra_diffusion(batch=16, steps=100, size=256):
     sec16 = SecondaryDiffusionImageNet2(dtype=torch.bfloat16)
     sec16.load_state_dict(secondary.state_dict())
     best16, finite16, graphed16 = guided_leg(sec16)
+    # ---- speed "regular" (guided.py:250-252): the loss gradient through the diffusion UNet itself - a kept forward + the network
+    # walked backwards every step (maua_unet_forward_keep / maua_unet_vjp); a Python loop of library calls, timed on a 10-step run
+    def regular_leg(n_timed=10):
+        gd = GuidedDiffusion([MSEGuide(1000.0)], timesteps=steps, model=model, diffusion=diffusion, speed="regular")
+        gr = torch.Generator().manual_seed(5)
+        x0, nz = (torch.randn(batch, 3, size, size, generator=gr).cuda() for _ in range(2))
+        pr = [prompts[int(idx[j])] for j in range(batch)]
+        gd.run(x0, pr, n - 1, 2, noise=nz, per_sample=True)       # weights' transposed copies + arena (untimed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = gd.run(x0, pr, n - 1, n_timed, noise=nz, per_sample=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_timed
+        return {"value": batch / (dt * steps), "unit": "samples/s", "ms_per_step": dt * 1e3, "steps_timed": n_timed,
+                "finite": bool(torch.isfinite(out).all()), "hipgraph": False,
+                "note": "speed 'regular': UNet forward (kept) + input gradient through the UNet + DDIM update per step; value = the "
+                        "%d-step rate extrapolated from %d timed steps of the same loop" % (steps, n_timed)}
+    try:
+        regular = regular_leg()
+    except Exception as e:   # (an extra of an extra: never takes the leg down)
+        regular = {"error": repr(e)[:300]}
     tf = (gf + gf_sec) * batch * steps / best / 1e3
     tr, tr_note = leg_traffic("diffusion")
     return {"metric": "samples/sec, guided-diffusion 256x256, 100-step DDIM, onset-switched prompts (configs[3])", "value": batch / best,
@@ -368,6 +389,7 @@ def extra_diffusion(batch=16, steps=100, size=256):
             "hipgraph": graphed, "finite": finite,
             "guided_bf16_secondary": {"value": batch / best16, "unit": "samples/s", "seconds_per_batch": best16, "hipgraph": graphed16,
                                       "finite": finite16, "note": "opt-in: secondary model in bf16 (guidance gradient 3.5 % off the reference's in L2 norm)"},
+            "guided_regular": regular,
             "unguided": unguided, "guided_over_unguided": best_u / best, "guided_bf16_secondary_over_unguided": best_u / best16,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                          "gflop_per_forward_per_sample": gf, "gflop_secondary_forward_and_vjp_per_sample": gf_sec,

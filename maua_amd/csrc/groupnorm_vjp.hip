@@ -71,51 +71,69 @@ __device__ __forceinline__ void adjoint_piece(const T* __restrict__ g, int b, in
   }
 }
 
-// dxh and xh of one piece at one input pixel
+// Per-thread constants of one 16-byte channel piece: xh = f * rs + nmr,  pre = xh * gs + bs,  dxh = da * silu'(pre) * gs
+//   rs = rstd, nmr = -mean * rstd, gs = gamma * (1 + scale), bs = beta * (1 + scale) + shift
 template <typename T>
-__device__ __forceinline__ void piece_grad(const GnVjpArgs& a, const T* src, long stride, int b, int iy, int ix, int C, int c,
-                                           const float* mean, const float* rstd, const float* gam, const float* bet, const float* sc,
-                                           const float* sh, float* dxh, float* xh) {
-  constexpr int EPC = 16 / (int)sizeof(T);
-  float f[EPC], d[EPC];
-  unpack_piece<T>(*reinterpret_cast<const u32x4*>(src + ((long)iy * a.W + ix) * stride), f);
-  adjoint_piece<T>(reinterpret_cast<const T*>(a.dy), b, iy, ix, a.H, a.W, a.mode, C, c, d);
+struct PieceCoef {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  float rs[EPC], nmr[EPC], gs[EPC], bs[EPC];
+  __device__ __forceinline__ void load(const GnVjpArgs& a, int b, int C, int c) {
+    const int cpg = C / 32;
 #pragma unroll
-  for (int e = 0; e < EPC; e++) {
-    xh[e] = (f[e] - mean[e]) * rstd[e];
-    const float u = fmaf(xh[e], gam[e], bet[e]);
-    const float pre = fmaf(u, sc[e], sh[e]);
-    float dd = d[e];
-    if (a.silu) {
-      const float sg = 1.f / (1.f + expf(-pre));
-      dd *= sg * (1.f + pre * (1.f - sg));
+    for (int q4 = 0; q4 < EPC / 4; q4++) {
+      const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c + 4 * q4);
+      const float4 bt = *reinterpret_cast<const float4*>(a.beta + c + 4 * q4);
+      const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+      float sv[4] = {1.f, 1.f, 1.f, 1.f}, hv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.ss) {
+        const float4 s4 = *reinterpret_cast<const float4*>(a.ss + (long)b * a.ss_ld + c + 4 * q4);
+        const float4 h4 = *reinterpret_cast<const float4*>(a.ss + (long)b * a.ss_ld + C + c + 4 * q4);
+        sv[0] = 1.f + s4.x; sv[1] = 1.f + s4.y; sv[2] = 1.f + s4.z; sv[3] = 1.f + s4.w;
+        hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int e = 4 * q4 + k;
+        gs[e] = gv[k] * sv[k];
+        bs[e] = fmaf(bv[k], sv[k], hv[k]);
+      }
     }
-    dxh[e] = dd * sc[e] * gam[e];
-  }
-}
-
-template <typename T>
-__device__ __forceinline__ void load_coefs(const GnVjpArgs& a, int b, int C, int c, float* mean, float* rstd, float* gam, float* bet,
-                                           float* sc, float* sh) {
-  constexpr int EPC = 16 / (int)sizeof(T);
-  const int cpg = C / 32;
+    if (cpg % EPC == 0) {   // the piece lies inside one group (every layer of the real network)
+      const float2 mr = *reinterpret_cast<const float2*>(a.stats + ((long)b * 32 + c / cpg) * 2);
 #pragma unroll
-  for (int e = 0; e < EPC; e++) {
-    const int g = (c + e) / cpg;
-    mean[e] = a.stats[((long)b * 32 + g) * 2];
-    rstd[e] = a.stats[((long)b * 32 + g) * 2 + 1];
-    gam[e] = a.gamma[c + e];
-    bet[e] = a.beta[c + e];
-    sc[e] = a.ss ? 1.f + a.ss[(long)b * a.ss_ld + c + e] : 1.f;
-    sh[e] = a.ss ? a.ss[(long)b * a.ss_ld + C + c + e] : 0.f;
+      for (int e = 0; e < EPC; e++) { rs[e] = mr.y; nmr[e] = -mr.x * mr.y; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPC; e++) {
+        const float2 mr = *reinterpret_cast<const float2*>(a.stats + ((long)b * 32 + (c + e) / cpg) * 2);
+        rs[e] = mr.y; nmr[e] = -mr.x * mr.y;
+      }
+    }
   }
-}
+  // x piece f, adjoint-resampled upstream gradient d -> dxh, xh (bf16 networks: hardware exp / reciprocal, like the forward)
+  __device__ __forceinline__ void grad(const float* f, const float* d, int silu, float* dxh, float* xh) const {
+#pragma unroll
+    for (int e = 0; e < EPC; e++) {
+      xh[e] = fmaf(f[e], rs[e], nmr[e]);
+      float dd = d[e];
+      if (silu) {
+        const float pre = fmaf(xh[e], gs[e], bs[e]);
+        float sg;
+        if constexpr (sizeof(T) == 2) sg = __fdividef(1.f, 1.f + __expf(-pre));
+        else sg = 1.f / (1.f + expf(-pre));
+        dd *= sg * fmaf(pre, 1.f - sg, 1.f);
+      }
+      dxh[e] = dd * gs[e];
+    }
+  }
+};
 
-// pass 1: per (sample, pixel chunk) and channel: sum dxh, sum dxh * xh (float64), rows of the workgroup added through LDS
+// pass 1: per (sample, pixel chunk) and channel: sum dxh, sum dxh * xh; a thread's own run in float32 (at most a few hundred
+// terms), everything across threads and chunks in float64 in a fixed order
 template <typename T>
 __global__ void gn_vjp_partial_kernel(GnVjpArgs a, int ppc, double* __restrict__ part) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  extern __shared__ double red[];   // [2][blockDim.x * EPC]
+  extern __shared__ float redf[];   // [2][blockDim.x * EPC]
   const int C = a.C0 + a.C1, PPP = C / EPC;
   const int pc = threadIdx.x % PPP, ry = threadIdx.x / PPP, RY = blockDim.x / PPP;
   const int chunk = blockIdx.x, b = blockIdx.y;
@@ -125,31 +143,31 @@ __global__ void gn_vjp_partial_kernel(GnVjpArgs a, int ppc, double* __restrict__
   long stride;
   if (c < a.C0) { src = reinterpret_cast<const T*>(a.x0) + (long)b * HW * a.C0 + c; stride = a.C0; }
   else { src = reinterpret_cast<const T*>(a.x1) + (long)b * HW * a.C1 + (c - a.C0); stride = a.C1; }
-  float mean[EPC], rstd[EPC], gam[EPC], bet[EPC], sc[EPC], sh[EPC];
-  load_coefs<T>(a, b, C, c, mean, rstd, gam, bet, sc, sh);
-  double s1[EPC], s2[EPC];
+  PieceCoef<T> k;
+  k.load(a, b, C, c);
+  float s1[EPC], s2[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; e++) s1[e] = s2[e] = 0.0;
+  for (int e = 0; e < EPC; e++) s1[e] = s2[e] = 0.f;
   const long p0 = (long)chunk * ppc, p1 = p0 + ppc < HW ? p0 + ppc : HW;
-  if (ry < RY) {
-    for (long p = p0 + ry; p < p1; p += RY) {
-      const int iy = (int)(p / a.W), ix = (int)(p - (long)iy * a.W);
-      float dxh[EPC], xh[EPC];
-      piece_grad<T>(a, src, stride, b, iy, ix, C, c, mean, rstd, gam, bet, sc, sh, dxh, xh);
+  for (long p = p0 + ry; p < p1; p += RY) {
+    const int iy = (int)(p / a.W), ix = (int)(p - (long)iy * a.W);
+    float f[EPC], d[EPC], dxh[EPC], xh[EPC];
+    unpack_piece<T>(*reinterpret_cast<const u32x4*>(src + p * stride), f);
+    adjoint_piece<T>(reinterpret_cast<const T*>(a.dy), b, iy, ix, a.H, a.W, a.mode, C, c, d);
+    k.grad(f, d, a.silu, dxh, xh);
 #pragma unroll
-      for (int e = 0; e < EPC; e++) { s1[e] += (double)dxh[e]; s2[e] += (double)dxh[e] * (double)xh[e]; }
-    }
+    for (int e = 0; e < EPC; e++) { s1[e] += dxh[e]; s2[e] = fmaf(dxh[e], xh[e], s2[e]); }
   }
   const int nt = blockDim.x;
 #pragma unroll
-  for (int e = 0; e < EPC; e++) { red[(long)threadIdx.x * EPC + e] = s1[e]; red[((long)nt + threadIdx.x) * EPC + e] = s2[e]; }
+  for (int e = 0; e < EPC; e++) { redf[(long)threadIdx.x * EPC + e] = s1[e]; redf[((long)nt + threadIdx.x) * EPC + e] = s2[e]; }
   __syncthreads();
   if (ry == 0) {
     double* dst = part + (((long)b * gridDim.x + chunk) * C + c) * 2;
 #pragma unroll
     for (int e = 0; e < EPC; e++) {
       double t1 = 0.0, t2 = 0.0;
-      for (int r = 0; r < RY; r++) { t1 += red[((long)r * PPP + pc) * EPC + e]; t2 += red[((long)nt + r * PPP + pc) * EPC + e]; }
+      for (int r = 0; r < RY; r++) { t1 += (double)redf[((long)r * PPP + pc) * EPC + e]; t2 += (double)redf[((long)nt + r * PPP + pc) * EPC + e]; }
       dst[2 * e] = t1;
       dst[2 * e + 1] = t2;
     }
@@ -188,51 +206,74 @@ __global__ __launch_bounds__(256) void gn_vjp_finalize_kernel(const double* __re
   }
 }
 
-// pass 2: dx = rstd * (dxh - m1 - xh * m2) + R^T dres + add
+// pass 2: dx = rstd * (dxh - m1 - xh * m2) + R^T dres + add.  A thread owns one 16-byte channel piece and walks VJP_PX pixels of
+// its input row with it (the per-piece constants are 100+ bytes of loads: amortised like the forward's gn_apply_group_kernel)
+constexpr int VJP_PX = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void gn_vjp_apply_kernel(GnVjpArgs a, const float* __restrict__ m) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  const int C = a.C0 + a.C1, PPP = C / EPC, cpg = C / 32;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)a.B * a.H * a.W * PPP) return;
-  const int pc = (int)(idx % PPP);
-  long p = idx / PPP;
-  const int ix = (int)(p % a.W); p /= a.W;
-  const int iy = (int)(p % a.H);
-  const int b = (int)(p / a.H);
-  const int c = pc * EPC;
+  const unsigned C = a.C0 + a.C1, PPP = C / EPC, cpg = C / 32;
+  const unsigned li = blockIdx.x * 256u + threadIdx.x;
+  const unsigned nxg = ((unsigned)a.W + VJP_PX - 1) / VJP_PX;
+  if (li >= nxg * PPP) return;
+  const unsigned xg = li / PPP, pc = li - xg * PPP;
+  const unsigned b = blockIdx.y / (unsigned)a.H, iy = blockIdx.y - b * (unsigned)a.H;
+  const unsigned c = pc * EPC;
   const long HW = (long)a.H * a.W;
-  const bool first = c < a.C0;
+  const bool first = c < (unsigned)a.C0;
   const T* src;
   long stride;
   if (first) { src = reinterpret_cast<const T*>(a.x0) + (long)b * HW * a.C0 + c; stride = a.C0; }
   else { src = reinterpret_cast<const T*>(a.x1) + (long)b * HW * a.C1 + (c - a.C0); stride = a.C1; }
-  float mean[EPC], rstd[EPC], gam[EPC], bet[EPC], sc[EPC], sh[EPC];
-  load_coefs<T>(a, b, C, c, mean, rstd, gam, bet, sc, sh);
-  float dxh[EPC], xh[EPC], out[EPC];
-  piece_grad<T>(a, src, stride, b, iy, ix, C, c, mean, rstd, gam, bet, sc, sh, dxh, xh);
+  PieceCoef<T> k;
+  k.load(a, (int)b, (int)C, (int)c);
+  float m1[EPC], m2[EPC];
+  if (cpg % EPC == 0) {
+    const float2 mm = *reinterpret_cast<const float2*>(m + ((long)b * 32 + c / cpg) * 2);
 #pragma unroll
-  for (int e = 0; e < EPC; e++) {
-    const int g = (c + e) / cpg;
-    const float m1 = m[((long)b * 32 + g) * 2], m2 = m[((long)b * 32 + g) * 2 + 1];
-    out[e] = rstd[e] * (dxh[e] - m1 - xh[e] * m2);
-  }
-  if (a.dres) {
-    float r[EPC];
-    adjoint_piece<T>(reinterpret_cast<const T*>(a.dres), b, iy, ix, a.H, a.W, a.mode, C, c, r);
+    for (int e = 0; e < EPC; e++) { m1[e] = mm.x; m2[e] = mm.y; }
+  } else {
 #pragma unroll
-    for (int e = 0; e < EPC; e++) out[e] += r[e];
+    for (int e = 0; e < EPC; e++) {
+      const float2 mm = *reinterpret_cast<const float2*>(m + ((long)b * 32 + (c + e) / cpg) * 2);
+      m1[e] = mm.x; m2[e] = mm.y;
+    }
   }
-  const long off = first ? (((long)b * HW + (long)iy * a.W + ix) * a.C0 + c) : (((long)b * HW + (long)iy * a.W + ix) * a.C1 + (c - a.C0));
   const T* add = reinterpret_cast<const T*>(first ? a.add0 : a.add1);
-  if (add) {
-    float r[EPC];
-    unpack_piece<T>(*reinterpret_cast<const u32x4*>(add + off), r);
-#pragma unroll
-    for (int e = 0; e < EPC; e++) out[e] += r[e];
-  }
   T* dst = reinterpret_cast<T*>(first ? a.dx0 : a.dx1);
-  *reinterpret_cast<u32x4*>(dst + off) = pack_piece<T>(out);
+  const unsigned cs = first ? c : c - a.C0;
+  // the pixel group's x pieces are requested together
+  u32x4 vin[VJP_PX];
+#pragma unroll
+  for (int q = 0; q < VJP_PX; q++) {
+    const unsigned ix = min(xg * VJP_PX + q, (unsigned)a.W - 1);
+    vin[q] = *reinterpret_cast<const u32x4*>(src + ((long)iy * a.W + ix) * stride);
+  }
+#pragma unroll
+  for (int q = 0; q < VJP_PX; q++) {
+    const unsigned ix = xg * VJP_PX + q;
+    if (ix >= (unsigned)a.W) break;
+    float f[EPC], d[EPC], dxh[EPC], xh[EPC], out[EPC];
+    unpack_piece<T>(vin[q], f);
+    adjoint_piece<T>(reinterpret_cast<const T*>(a.dy), (int)b, (int)iy, (int)ix, a.H, a.W, a.mode, (int)C, (int)c, d);
+    k.grad(f, d, a.silu, dxh, xh);
+#pragma unroll
+    for (int e = 0; e < EPC; e++) out[e] = k.rs[e] * (dxh[e] - m1[e] - xh[e] * m2[e]);
+    if (a.dres) {
+      float r[EPC];
+      adjoint_piece<T>(reinterpret_cast<const T*>(a.dres), (int)b, (int)iy, (int)ix, a.H, a.W, a.mode, (int)C, (int)c, r);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) out[e] += r[e];
+    }
+    const long off = ((long)b * HW + (long)iy * a.W + ix) * (first ? a.C0 : a.C1) + cs;
+    if (add) {
+      float r[EPC];
+      unpack_piece<T>(*reinterpret_cast<const u32x4*>(add + off), r);
+#pragma unroll
+      for (int e = 0; e < EPC; e++) out[e] += r[e];
+    }
+    *reinterpret_cast<u32x4*>(dst + off) = pack_piece<T>(out);
+  }
 }
 
 struct VjpPlan { int RY, ppc; long nchunk; };
@@ -256,10 +297,10 @@ int run(hipStream_t st, const GnVjpArgs& a, void* ws) {
   double* part = reinterpret_cast<double*>(ws);
   float* m = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)a.B * p.nchunk * C * 16);
   const int nt = PPP * p.RY;
-  hipLaunchKernelGGL(gn_vjp_partial_kernel<T>, dim3((unsigned)p.nchunk, a.B), dim3(nt), (size_t)nt * EPC * 16, st, a, p.ppc, part);
+  hipLaunchKernelGGL(gn_vjp_partial_kernel<T>, dim3((unsigned)p.nchunk, a.B), dim3(nt), (size_t)nt * EPC * 8, st, a, p.ppc, part);
   hipLaunchKernelGGL(gn_vjp_finalize_kernel, dim3(32, a.B), dim3(256), 0, st, part, (int)p.nchunk, C, HW, m);
-  const long total = (long)a.B * HW * PPP;
-  hipLaunchKernelGGL(gn_vjp_apply_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, m);
+  const unsigned nxg = (unsigned)((a.W + VJP_PX - 1) / VJP_PX);
+  hipLaunchKernelGGL(gn_vjp_apply_kernel<T>, dim3((nxg * (unsigned)PPP + 255) / 256, (unsigned)(a.B * a.H)), dim3(256), 0, st, a, m);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
@@ -278,6 +319,7 @@ int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, voi
   MAUA_REQUIRE(C % 32 == 0 && C / EPC <= 1024 && a.C0 % EPC == 0 && a.C1 % EPC == 0 && (a.C1 == 0 || (a.x1 && a.dx1)),
                "group_norm_vjp: C % 32 == 0, at most 1024 16-byte pieces per pixel");
   MAUA_REQUIRE(a.mode >= 0 && a.mode <= 2 && (a.mode != 1 || (a.H % 2 == 0 && a.W % 2 == 0)), "group_norm_vjp: bad resample mode");
+  MAUA_REQUIRE((long)a.B * a.H <= 65535, "group_norm_vjp: B * H must fit one grid dimension");
   if (a.B == 0) return MAUA_OK;
   return dtype == MAUA_BF16 ? run<bf16_t>(stream, a, workspace) : run<float>(stream, a, workspace);
 }

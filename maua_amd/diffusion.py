@@ -337,6 +337,18 @@ class SpacedDiffusion:
         ts = torch.tensor(self.timestep_map, device=t.device)[t.long()]
         return ts.float() * (1000.0 / self.original_num_steps) if self.rescale_timesteps else ts.float()
 
+    @staticmethod
+    def _model_output(model, x, mt, cond_fn):
+        """The step's model evaluation.  A conditioning that differentiates through this very network (speed "regular") evaluates
+        it again on the same (x, t) - guided.py:251 inside cond_fn, after the sampler's own call: here it runs ONCE, as a kept forward
+        whose result is offered to the conditioning (same kernels, same bits as two separate evaluations)."""
+        if cond_fn is not None and hasattr(cond_fn, "offer") and getattr(cond_fn, "model", None) is model \
+                and getattr(cond_fn, "speed", "fast") not in ("hyper", "fast"):
+            out = model.forward_keep(x, mt)
+            cond_fn.offer(x, mt, out)
+            return out
+        return model(x, mt)
+
     def _f32(self, arr, t):
         """_extract_into_tensor: the table values at t as float32 (host)."""
         return torch.from_numpy(arr)[torch.as_tensor(t).long().cpu()].float()
@@ -374,7 +386,7 @@ class SpacedDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn (the reference passes clip_denoised=False)")
         x = L.dev_tensor(x, torch.float32)
         mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
-        out = model(x, mt)
+        out = self._model_output(model, x, mt, cond_fn)
         grad = None
         if cond_fn is not None:
             grad = L.dev_tensor(cond_fn(x, mt), torch.float32)
@@ -399,7 +411,7 @@ class SpacedDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn (the reference passes clip_denoised=False)")
         x = L.dev_tensor(x, torch.float32)
         mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
-        out = model(x, mt)
+        out = self._model_output(model, x, mt, cond_fn)
         B, Cc = x.shape[0], x.shape[1]
         if out.shape[1] != 2 * Cc:
             raise NotImplementedError("p_sample needs the learned-range variance channels (learn_sigma)")
@@ -423,7 +435,7 @@ class SpacedDiffusion:
     def _plms_model_output(self, model, x, t, cond_fn):
         """plms_sample's get_model_output -> (eps, pred_xstart after condition_score, unconditioned pred_xstart)"""
         mt = self.model_timesteps(torch.as_tensor(t).to(x.device))
-        out = model(x, mt)
+        out = self._model_output(model, x, mt, cond_fn)
         grad = None if cond_fn is None else L.dev_tensor(cond_fn(x, mt), torch.float32)
         cf = L.dev_tensor(self.step_coefficients(t), torch.float32)
         eps, pred, pred_orig = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
@@ -742,6 +754,7 @@ class GradientGuidedConditioning(torch.nn.Module):
             model.enable_vjp()
         self.speed, self.model, self.grad_modules = speed, model, list(grad_modules)
         self.diffusion = diffusion
+        self._offer = None
         self.timestep_map = list(diffusion.timestep_map)
         self.sqrt_alphas_cumprod = torch.from_numpy(diffusion.sqrt_alphas_cumprod).float()
         self.sqrt_one_minus_alphas_cumprod = torch.from_numpy(diffusion.sqrt_one_minus_alphas_cumprod).float()
@@ -754,6 +767,11 @@ class GradientGuidedConditioning(torch.nn.Module):
                 gm.set_targets_per_sample(prompts)   # (only modules that declare it: GuidedDiffusion.run checks)
             else:
                 gm.set_targets(prompts)
+
+    def offer(self, x, t, out):
+        """The sampler's own kept evaluation of the network on (x, t) (SpacedDiffusion._model_output): the next ``forward`` on the same
+        sample tensor and timesteps differentiates through it instead of evaluating the network a second time."""
+        self._offer = (x, torch.as_tensor(t).detach().float().cpu().clone(), out)
 
     def per_sample_prompts(self):
         return all(hasattr(gm, "set_targets_per_sample") for gm in self.grad_modules)
@@ -801,7 +819,13 @@ class GradientGuidedConditioning(torch.nn.Module):
             #     -J^T g = -[(sigma * ra + 1 - sigma) * g - sigma * rm * (d eps / d x)^T g]
             ra, rm = self.diffusion._f32(self.diffusion.sqrt_recip_alphas_cumprod, idx), self.diffusion._f32(self.diffusion.sqrt_recipm1_alphas_cumprod, idx)
             nc = x.shape[1]
-            out = self.model.forward_keep(x, self.diffusion.model_timesteps(idx))
+            offer, self._offer = self._offer, None
+            mt = self.diffusion.model_timesteps(idx)
+            if offer is not None and offer[0].data_ptr() == x.data_ptr() and offer[0].shape == x.shape \
+                    and torch.equal(offer[1], mt.float().cpu()) and getattr(self.model, "_kept", None) == (B, x.shape[2], x.shape[3]):
+                out = offer[2]
+            else:
+                out = self.model.forward_keep(x, mt)
             eps = out[:, :nc].contiguous()
             pred = torch.empty_like(x)
             ab = L.dev_tensor(torch.stack([ra, -rm], 1).contiguous(), torch.float32)

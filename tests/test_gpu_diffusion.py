@@ -741,3 +741,9 @@ def test_regular_speed_conditioning_matches_the_oracle_and_guides_the_sampler():
     plain = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd).forward(img, [], 0.3, t_end=0.6, noise=nz).cpu()
     assert torch.isfinite(guided).all()
     assert float((guided - target).norm()) < float((plain - target).norm())
+    # the sampler hands its own (kept) evaluation of the network to the conditioning; the reference evaluates it twice per step
+    # (guided.py:251 inside cond_fn): the same bits either way
+    sd._model_output = lambda model, x, mt, cond_fn: model(x, mt)
+    twice = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+    del sd._model_output
+    assert torch.equal(twice, guided)
