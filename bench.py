@@ -167,7 +167,8 @@ def build_inputs(device, rank, world, seed=0, host_rng=False):
     """Everything that is resident in HBM before the render loop.  Round 5: the network's random init (23.6 M values) and the 17
     noise modules' planes (8.4 M) are drawn ON THE DEVICE from the build-owned counter RNG (maua_philox_normal, SURVEY 8(d):
     identical on every rank / device, reproducible on the host through oracle/rng.py) - kernels instead of host draws + uploads.
-    The clip's chain (synthetic waveform -> onset pre-pass -> mapper -> latent schedule) stays as it was and runs beside it.
+    So are the clip's waveform and the mapper's random init (pipeline.synthetic_clip_latents(device_rng=True)): the whole set-up is
+    device work behind a few milliseconds of host calls, on one thread.
     ``host_rng=True``: round 4's set-up (torch's host generators on helper threads), kept for A/B."""
     import threading
     from maua_amd.noise import Loop
@@ -201,13 +202,10 @@ def build_inputs(device, rank, world, seed=0, host_rng=False):
         latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)
         for th in ths:
             th.join()
-    else:   # device draws are a few milliseconds of kernels: the clip's host chain first (its device work overlaps), then these
-        th = threading.Thread(target=lambda: box.__setitem__("clip", pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM)))
-        th.start()
+    else:   # everything is device work behind a few milliseconds of host calls: one thread, one stream
         make_net()
         make_noise()
-        th.join()
-        latents, info = box["clip"]
+        latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM, device_rng=True)
     net, noise = box["net"], box["noise"]
     info = dict(info, weights_and_noise_planes="torch host generators" if host_rng else
                 "device counter RNG (Philox4x32-10, maua_philox_normal): network = streams of seed %d, noise planes = streams of seed %d" % (seed, 42 + seed))
@@ -227,7 +225,8 @@ def cpu_baseline(seconds):
     # the clip's audio pre-pass (once per clip - STFT, HPSS medians, iSTFT, mel, onset envelope of all
     # 3 686 400 samples), timed on its own: it belongs to the CPU path's whole-clip time, not to its per-frame rate
     ta = time.time()
-    wav = synthetic_audio(T_FRAMES * 1024, 1024 * FPS, fast=True)   # the clip the device leg rendered
+    from maua_amd.rng import clip_audio
+    wav = clip_audio(T_FRAMES * 1024, 1024 * FPS, seed=1234).cpu()   # the clip the device leg rendered (drawn on the device)
     env = OA.onsets(wav, 1024 * FPS)
     audio_s = time.time() - ta
     assert env.shape[0] == T_FRAMES

@@ -534,6 +534,9 @@ int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, lo
 int maua_philox_u32(maua_ctx* ctx, unsigned long long seed, unsigned long long stream, unsigned long long offset, uint32_t* out, long n);
 int maua_philox_normal(maua_ctx* ctx, unsigned long long seed, unsigned long long stream, unsigned long long offset, float* out, long n,
                        float mean, float stdev);
+/* The benchmark clip's waveform on the device (0.3 sin(2 pi 220 t) + 0.2 (u - 0.5) [(2t mod 1) < 0.05] + 0.01 n; u / n =
+ * streams 0 / 1 of `seed`): out device f32 [n].  No reference counterpart (synthetic input); host twin oracle/rng.py clip_audio. */
+int maua_philox_clip_audio(maua_ctx* ctx, unsigned long long seed, long n, double sample_rate, float* out);
 
 /* ---- multi-GPU: the one exchange step of the frame-sharded render ------------------------------------
  * One process per GPU; frames are sharded by contiguous range (no data-path collective).  maua_gather_frames moves every

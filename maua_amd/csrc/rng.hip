@@ -60,6 +60,30 @@ __global__ __launch_bounds__(256) void philox_kernel(uint32_t s0, uint32_t s1, u
   }
 }
 
+// SURVEY 8(d)'s synthetic clip, four samples per thread (counter c of both streams):
+//   y[i] = 0.3 sin(2 pi 220 t) + 0.2 (u - 0.5) [(2 t mod 1) < 0.05] + 0.01 n,   t = i / sr (float64 phase)
+//   u = unit23 of stream 0's word i, n = stream 1's normal i of `seed`
+__global__ __launch_bounds__(256) void clip_audio_kernel(uint32_t s0, uint32_t s1, long n, double sr, float* __restrict__ out) {
+  const unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long base = (long)(c << 2);
+  if (base >= n) return;
+  const U4 uw = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 0u, 0u, s0, s1);
+  const U4 nw = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), 1u, 0u, s0, s1);
+  float z[4];
+  box_muller(nw.x, nw.y, z[0], z[1]);
+  box_muller(nw.z, nw.w, z[2], z[3]);
+  const uint32_t w[4] = {uw.x, uw.y, uw.z, uw.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (base + k >= n) break;
+    const double t = (double)(base + k) / sr;
+    const double ph = 2.0 * t;
+    const bool click = ph - floor(ph) < 0.05;
+    const float tone = (float)(0.3 * sin(6.283185307179586 * 220.0 * t));
+    out[base + k] = tone + (click ? 0.2f * (unit23(w[k]) - 0.5f) : 0.f) + 0.01f * z[k];
+  }
+}
+
 int launch(maua_ctx* ctx, unsigned long long seed, unsigned long long stream, unsigned long long offset, long n, uint32_t* u, float* f,
            float mean, float stdev) {
   if (n == 0) return MAUA_OK;
@@ -90,6 +114,20 @@ int maua_philox_normal(maua_ctx* ctx, unsigned long long seed, unsigned long lon
   MAUA_REQUIRE(ctx, "maua_philox_normal: ctx is NULL");
   MAUA_REQUIRE(n >= 0 && (n == 0 || out), "maua_philox_normal: bad argument");
   return launch(ctx, seed, stream, offset, n, nullptr, out, mean, stdev);
+}
+
+// The benchmark's synthetic waveform ("220 Hz tone + 2 Hz click train + noise from a build-owned counter RNG") drawn on
+// the device: out [n] f32 at sample rate sr; streams 0 (click amplitudes) and 1 (noise floor) of `seed`.  oracle/rng.py clip_audio is
+// its host twin.
+int maua_philox_clip_audio(maua_ctx* ctx, unsigned long long seed, long n, double sample_rate, float* out) {
+  MAUA_REQUIRE(ctx, "maua_philox_clip_audio: ctx is NULL");
+  MAUA_REQUIRE(n >= 0 && (n == 0 || out) && sample_rate > 0, "maua_philox_clip_audio: bad argument");
+  if (n == 0) return MAUA_OK;
+  const long counters = (n + 3) >> 2;
+  hipLaunchKernelGGL(clip_audio_kernel, dim3((unsigned)((counters + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), n, sample_rate, out);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
 }
 
 }  // extern "C"

@@ -60,32 +60,46 @@ def synthetic_audio(n_samples, sr, seed=1234, fast=False):
     return out
 
 
-def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4, fast_audio=True):
+def synthetic_clip_latents(n_frames, fps, num_ws, w_dim, seeds="0-60", n_loops=4, fast_audio=True, device_rng=False, keep=None):
     """Audio-reactive latent schedule of the BASELINE clip: onset envelope of the synthetic audio blends two
     spline-loop schedules (latent.py:12-18 single_weighted over latent.py:83-92 spline_loops), sigma=2 smoothing.
-    Returns ([T, num_ws, w_dim] f32 on the HIP device, description)."""
+    Returns ([T, num_ws, w_dim] f32 on the HIP device, description).
+    ``device_rng`` (round 5, what bench.py times): the waveform and the mapper's random init come from the build-owned counter RNG
+    ON THE DEVICE (rng.clip_audio: streams 0 / 1 of seed 1234; the mapper's matrices: streams 2^20 .. of seed 0) - two kernels and
+    no upload instead of 5.8 M host draws; same signal model and initialisation law, other numbers.  ``keep``: a dict that receives
+    the waveform and the mapper (tests rebuild the schedule from them with the oracle)."""
     from . import audio, latent
     from .stylegan2 import MappingNetwork, get_z_latents
     sr = 1024 * fps
-    # the mapper's random init (2.1 M host draws, its own generator) does not depend on the clip: drawn on a
-    # helper thread while the waveform is synthesised (torch's CPU samplers release the GIL)
-    import threading
-    box = {}
+    if device_rng:
+        from .rng import PhiloxStreams, clip_audio
+        wav = clip_audio(n_frames * 1024, sr, seed=1234)
+        env = audio.onsets(wav, sr).squeeze(-1)                      # [T], on device
+        mapper = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=PhiloxStreams(0, first_stream=1 << 20))
+    else:
+        # the mapper's random init (2.1 M host draws, its own generator) does not depend on the clip: drawn on a
+        # helper thread while the waveform is synthesised (torch's CPU samplers release the GIL)
+        import threading
+        box = {}
 
-    def make_mapper():
-        box["mapper"] = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0))
-    th = threading.Thread(target=make_mapper)
-    th.start()
-    wav = synthetic_audio(n_frames * 1024, sr, fast=fast_audio)
-    env = audio.onsets(wav, sr).squeeze(-1)                      # [T], on device
-    th.join()
-    palette = box["mapper"](get_z_latents(seeds, w_dim).float())   # [P, num_ws, w_dim]
+        def make_mapper():
+            box["mapper"] = MappingNetwork(w_dim, 0, w_dim, num_ws, generator=torch.Generator().manual_seed(0))
+        th = threading.Thread(target=make_mapper)
+        th.start()
+        wav = synthetic_audio(n_frames * 1024, sr, fast=fast_audio)
+        env = audio.onsets(wav, sr).squeeze(-1)                      # [T], on device
+        th.join()
+        mapper = box["mapper"]
+    if keep is not None:
+        keep.update(wav=wav, mapper=mapper)
+    palette = mapper(get_z_latents(seeds, w_dim).float())   # [P, num_ws, w_dim]
     half = palette.shape[0] // 2
     low = latent.spline_loops(palette[:half], n_frames, n_loops)
     high = latent.spline_loops(palette[half:2 * half], n_frames, n_loops)
     lat = latent.sequence_weighted(low, high, env)
     lat = audio.gaussian_filter(lat, 2)
-    return lat.contiguous(), {"seeds": seeds, "schedule": f"spline_loops(n_loops={n_loops}) x2 blended by onsets, gaussian sigma=2"}
+    return lat.contiguous(), {"seeds": seeds, "schedule": f"spline_loops(n_loops={n_loops}) x2 blended by onsets, gaussian sigma=2",
+                              "audio_and_mapper": "device counter RNG" if device_rng else "torch host generators"}
 
 
 def warm_up(device="cuda"):
@@ -97,11 +111,13 @@ def warm_up(device="cuda"):
     from .noise import Loop, loop_batch
     from .stylegan2 import MappingNetwork, SynthesisNetwork, get_z_latents
     n, fps, w_dim, res = 16, 30, 64, 64
-    wav = synthetic_audio(n * 1024, 1024 * fps, seed=7)
+    from .rng import PhiloxStreams, clip_audio
+    wav = clip_audio(n * 1024, 1024 * fps, seed=7, device=device)
     env = audio.onsets(wav, 1024 * fps).squeeze(-1)
     net = SynthesisNetwork(w_dim, res, 3, channel_base=4096, channel_max=64, dtype=torch.bfloat16,
                            generator=torch.Generator().manual_seed(0))
-    mapper = MappingNetwork(w_dim, 0, w_dim, net.num_ws, generator=torch.Generator().manual_seed(0))
+    # (device-resident mapper weights: the scale / transpose of its matrices are PyTorch device kernels - loaded here once)
+    mapper = MappingNetwork(w_dim, 0, w_dim, net.num_ws, generator=PhiloxStreams(0, first_stream=1 << 20, device=device))
     pal = mapper(get_z_latents("0-4", w_dim).float())
     lat = audio.gaussian_filter(latent.sequence_weighted(latent.spline_loops(pal[:2], n, 2), latent.spline_loops(pal[2:4], n, 2), env), 2)
     rng = torch.Generator().manual_seed(1)

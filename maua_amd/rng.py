@@ -26,6 +26,15 @@ def philox_normal(shape, seed, stream, offset=0, mean=0.0, std=1.0, device=None)
     return out
 
 
+def clip_audio(n_samples, sr, seed=1234, device=None):
+    """SURVEY 8(d)'s synthetic clip (tone + 2 Hz clicks + noise floor) drawn on the device: float32 [n_samples]."""
+    L.require_device()
+    out = torch.empty((int(n_samples),), dtype=torch.float32, device="cuda" if device is None else device)
+    L.check(L.lib().maua_philox_clip_audio(L.ctx(out.device), C.c_ulonglong(int(seed)), C.c_long(int(n_samples)), C.c_double(float(sr)),
+                                           L.ptr(out)))
+    return out
+
+
 class PhiloxStreams:
     """A callable for ``init_synthesis_params(generator=...)`` / the noise modules: the k-th tensor it is asked for is stream
     ``first_stream + k`` of ``seed`` (so a tensor's numbers depend on its position in the construction order only)."""

@@ -469,8 +469,9 @@ class MappingNetwork(torch.nn.Module):
         self._params = {}
         for i in range(num_layers):
             self._params[f"fcs.{i}.weight"] = _randn([feats[i + 1], feats[i]], generator) / lr_multiplier
-            self._params[f"fcs.{i}.bias"] = torch.zeros([feats[i + 1]])
-        self._params["w_avg"] = torch.zeros([w_dim])
+            # (a device generator - rng.PhiloxStreams - leaves the whole parameter set on its device: nothing is uploaded at forward time)
+            self._params[f"fcs.{i}.bias"] = torch.zeros([feats[i + 1]], device=self._params[f"fcs.{i}.weight"].device)
+        self._params["w_avg"] = torch.zeros([w_dim], device=self._params["fcs.0.weight"].device)
 
     def state_dict(self, *a, **k):
         return dict(self._params)

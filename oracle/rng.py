@@ -50,3 +50,15 @@ def normal(seed, stream, n, offset=0, mean=0.0, std=1.0):
     z = np.stack([r * np.cos(th), r * np.sin(th)], -1).astype(np.float32)     # [counters, 2 pairs, 2]
     z = z.reshape(-1)[skip:skip + n]
     return (z * np.float32(std) + np.float32(mean)).astype(np.float32)
+
+
+def clip_audio(seed, n, sr):
+    """maua_philox_clip_audio: 0.3 sin(2 pi 220 t) + 0.2 (u - 0.5) [(2t mod 1) < 0.05] + 0.01 n with u = stream 0's words, n = stream
+    1's normals (SURVEY 8(d)'s synthetic clip); float64 phase, float32 sum in the kernel's order."""
+    t = np.arange(n, dtype=np.float64) / float(sr)
+    ph = 2.0 * t
+    click = (ph - np.floor(ph)) < 0.05
+    tone = (0.3 * np.sin(6.283185307179586 * 220.0 * t)).astype(np.float32)
+    u = ((u32(seed, 0, n) >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    amp = np.where(click, np.float32(0.2) * (u - np.float32(0.5)), np.float32(0.0)).astype(np.float32)
+    return ((tone + amp) + np.float32(0.01) * normal(seed, 1, n)).astype(np.float32)

@@ -244,3 +244,43 @@ def test_device_counter_rng_matches_its_oracle_twin_and_seeds_the_synthetic_netw
     net_dev(ws, rgb8_out=a)
     net_host(ws, rgb8_out=b)
     assert torch.equal(a, b)
+
+
+def test_device_drawn_clip_waveform_and_latent_schedule_match_their_host_twins():
+    """The benchmark clip's waveform drawn on the device (maua_philox_clip_audio: SURVEY 8(d)'s tone + 2 Hz clicks + noise floor from
+    the counter RNG) equals oracle/rng.py clip_audio to float32 rounding, has the signal model's structure (clicks only in the first 5 %
+    of every half second), and the latent schedule bench.py builds from it with a device-initialised mapper
+    (pipeline.synthetic_clip_latents(device_rng=True)) equals the ORACLE's composition - onset envelope, mapping network, spline loops,
+    blend, gaussian - of the same waveform and mapper weights."""
+    import numpy as np
+    from maua_amd import pipeline
+    from maua_amd.rng import clip_audio
+    from maua_amd.stylegan2 import get_z_latents
+    from oracle import audio as OA, latent as OL, rng as OR, stylegan2 as OSG
+    sr = 30720
+    for n, seed in ((1, 3), (4 * 15360 + 3, 1234), (100001, 7)):
+        got = clip_audio(n, sr, seed=seed).cpu().numpy()
+        assert float(np.abs(got - OR.clip_audio(seed, n, sr)).max()) <= 2e-6, (n, seed)
+    y = clip_audio(4 * 15360, sr, seed=1234).cpu()
+    tone = 0.3 * torch.sin(2 * torch.pi * 220 * torch.arange(4 * 15360, dtype=torch.float64) / sr).float()
+    resid = (y - tone).reshape(4, 15360)                       # clicks + noise floor per half second
+    assert float(resid[:, 768:].abs().max()) < 0.06 and float(resid[:, :768].abs().max()) > 0.08      # |0.01 n| stays small; clicks reach 0.1
+    assert abs(float(resid[:, 768:].std()) - 0.01) < 1e-3
+    T, fps, num_ws, w_dim = 600, 30, 18, 512
+    keep = {}
+    lat, info = pipeline.synthetic_clip_latents(T, fps, num_ws, w_dim, device_rng=True, keep=keep)
+    assert info["audio_and_mapper"] == "device counter RNG" and keep["wav"].is_cuda and tuple(lat.shape) == (T, num_ws, w_dim)
+    wav = keep["wav"].cpu()
+    assert float((wav - torch.from_numpy(OR.clip_audio(1234, T * 1024, 1024 * fps))).abs().max()) <= 2e-6
+    mp = {k: v.cpu() for k, v in keep["mapper"].state_dict().items()}
+    twin = torch.from_numpy(OR.normal(0, (1 << 20) + 3, 512 * 512)).reshape(512, 512) / 0.01            # the 4th matrix = stream 2^20 + 3
+    assert float((mp["fcs.3.weight"] - twin).abs().max()) <= 1e-3                                     # (values ~ 100: 4e-6 relative)
+    env = OA.onsets(wav, 1024 * fps).squeeze(-1)
+    pal = OSG.mapping_network(mp, get_z_latents("0-60", w_dim).float(), num_ws_=num_ws)
+    half = pal.shape[0] // 2
+    sub = (slice(None), slice(0, num_ws, 6), slice(0, w_dim, 64))
+    low, high = OL.spline_loops(pal[:half][sub], T, 4), OL.spline_loops(pal[half:2 * half][sub], T, 4)
+    want = OA.gaussian_filter(low * (1 - env[:, None, None]) + high * env[:, None, None], 2)
+    got = lat.cpu()[sub]
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    assert err <= 3e-4, err
