@@ -350,7 +350,12 @@ def extra_diffusion(batch=16, steps=100, size=256):
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
         return best, bool(torch.isfinite(out).all()), model.guided_graph_active()
-    best, finite, graphed = guided_leg(secondary)     # the default: the secondary model in exact f32, like the reference keeps it
+    # the default (create_models): the secondary model in float32 like the reference keeps it, its products as bf16 split products
+    best, finite, graphed = guided_leg(secondary)
+    sec32 = SecondaryDiffusionImageNet2(dtype=torch.float32, exact=True)   # every product on the exact-f32 matrix path
+    sec32.load_state_dict(secondary.state_dict())
+    best32, finite32, graphed32 = guided_leg(sec32)
+    del sec32
     sec16 = SecondaryDiffusionImageNet2(dtype=torch.bfloat16)
     sec16.load_state_dict(secondary.state_dict())
     best16, finite16, graphed16 = guided_leg(sec16)
@@ -381,7 +386,12 @@ def extra_diffusion(batch=16, steps=100, size=256):
             "unit": "samples/s", "guided": True,
             "guidance": "speed 'fast' (reference default): secondary model forward + VJP every step, image-MSE grad module, one target "
                         "per frame switched at the clip's onset peaks; text prompts (CLIP) unpinnable here - DESIGN section 2",
-            "secondary_dtype": "f32 (the reference keeps the secondary model in fp32; exact-f32 MFMA mode)",
+            "secondary_dtype": "f32 tensors (the reference keeps the secondary model in fp32), products as three bf16 split products on "
+                               "the bf16 matrix cores (MAUA_F32_SPLIT, ~2^-17 per product; guidance gradient within 1e-3 of the reference's "
+                               "float32 autograd, tests/test_gpu_diffusion.py)",
+            "guided_exact_f32_secondary": {"value": batch / best32, "unit": "samples/s", "seconds_per_batch": best32, "hipgraph": graphed32,
+                                           "finite": finite32, "note": "every product of the secondary model on the exact-f32 matrix path "
+                                                                       "(v_mfma_f32_32x32x2_f32): rounds 4-5's default"},
             "prompt_switches_in_timed_frames": int((idx[1:n_frames] != idx[:n_frames - 1]).sum()),
             "batch": batch, "steps": steps, "seconds_per_batch": best, "ms_per_step": best / steps * 1e3, "dtype": "bf16",
             "data": "synthetic (random-init UNet of the reference's configuration, 552.8 M parameters; random-init secondary model, 13.9 M)",
@@ -389,11 +399,11 @@ def extra_diffusion(batch=16, steps=100, size=256):
             "guided_bf16_secondary": {"value": batch / best16, "unit": "samples/s", "seconds_per_batch": best16, "hipgraph": graphed16,
                                       "finite": finite16, "note": "opt-in: secondary model in bf16 (guidance gradient 3.5 % off the reference's in L2 norm)"},
             "guided_regular": regular,
-            "unguided": unguided, "guided_over_unguided": best_u / best, "guided_bf16_secondary_over_unguided": best_u / best16,
+            "unguided": unguided, "guided_over_unguided": best_u / best, "guided_exact_f32_secondary_over_unguided": best_u / best32, "guided_bf16_secondary_over_unguided": best_u / best16,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
                          "gflop_per_forward_per_sample": gf, "gflop_secondary_forward_and_vjp_per_sample": gf_sec,
-                         "note": "both networks' algorithmic FLOPs over the guided loop's time against the bf16 peak; the f32 secondary "
-                                 "model's share runs on the f32 MFMA path (1/16 of that rate)",
+                         "note": "both networks' algorithmic FLOPs over the guided loop's time against the bf16 peak (the secondary model's "
+                                 "share executes 3 bf16 products per algorithmic product)",
                          "traffic": tr,
                          "traffic_note": tr_note + " - UNet forward only, collected at batch 8, this leg runs batch %d (weights, 1.1 GB per forward, do not scale)" % batch}}
 

@@ -31,7 +31,11 @@ extern "C" {
 #define MAUA_OK 0
 #define MAUA_ERR (-1)
 
-enum maua_dtype { MAUA_F32 = 0, MAUA_BF16 = 1, MAUA_F16 = 2 };
+enum maua_dtype { MAUA_F32 = 0, MAUA_BF16 = 1, MAUA_F16 = 2,
+                  /* float32 tensors whose products run on the bf16 matrix cores as three split products (x = hi + lo, both bf16:
+                   * hi_w hi_x + lo_w hi_x + hi_w lo_x, f32 accumulate; ~2^-17 per product - between TF32's 2^-11, the CUDA default for
+                   * the reference's fp32 convolutions, and exact f32).  Accepted by maua_secondary_create only. */
+                  MAUA_F32_SPLIT = 3 };
 /* activation ids: reference ops.py:9-19 / :44-62 */
 enum maua_act {
   MAUA_ACT_LINEAR = 0, MAUA_ACT_RELU = 1, MAUA_ACT_LRELU = 2, MAUA_ACT_TANH = 3, MAUA_ACT_SIGMOID = 4,

@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("MAUA_HIP_LIB", _HERE / "csrc" / "libmaua_hip.so"
 HEADER = _HERE.parent / "include" / "maua_hip.h"
 
 F32, BF16, F16 = 0, 1, 2
+F32_SPLIT = 3   # float32 tensors, products as bf16 split products (maua_secondary_create only)
 ACTS = {"linear": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "elu": 5, "selu": 6, "softplus": 7, "swish": 8}
 PAD_MODES = {"circular": 0, "reflect": 1, "replicate": 2, "constant": 3}
 

@@ -65,6 +65,13 @@ template <> struct Elem<float> {
   __device__ static __forceinline__ float load(const float* p) { return *p; }
   __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
 };
+// float32 storage whose PRODUCTS run on the bf16 matrix cores as three split products (MAUA_F32_SPLIT): same bytes as float
+struct f32s_t { float v; };
+template <> struct Elem<f32s_t> {
+  static constexpr int kDtype = MAUA_F32_SPLIT;
+  __device__ static __forceinline__ float load(const f32s_t* p) { return p->v; }
+  __device__ static __forceinline__ void store(f32s_t* p, float v) { p->v = v; }
+};
 template <> struct Elem<bf16_t> {
   static constexpr int kDtype = MAUA_BF16;
   __device__ static __forceinline__ float load(const bf16_t* p) { return bf2f(*p); }

@@ -138,6 +138,8 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
                         int up, int flip, int Cop, int Cip);
+// MAUA_F32_SPLIT: a float32 weight buffer prepared by launch_prep_weights(MAUA_F32, ...) -> [hi x 4 | lo x 4] bf16 per 4 floats, in place
+int launch_f32_split_inplace(hipStream_t stream, void* w, long n_floats);
 
 // modconv_tconv.hip: up-layer as the minimal stride-2 transposed convolution; writes the raw tensor
 // t [B][2H+1][2W+1][Co] (uses x, x_bstride, w (from launch_prep_tconv_weights), s, y, B, H, W, Ci, Co of ConvArgs)

@@ -29,8 +29,14 @@ namespace maua {
 
 // KCB = bytes of K (input channels) per LDS row chunk (template parameter: 64 or 128); the LDS row stride is KCB + 16
 
+// An operand fragment is prepared once (Mma<T>::prep_w for the weight side, prep_x for the pixel side) and used in WM x WN steps:
+// the identity for every type but the split-f32 one.
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
+  using FW = u32x4;
+  using FX = u32x4;
+  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return v; }
+  __device__ static __forceinline__ FX prep_x(const u32x4& v) { return v; }
   __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
                                                   0, 0);
@@ -45,6 +51,10 @@ template <> struct Mma<bf16_t> {
   }
 };
 template <> struct Mma<f16_t> {
+  using FW = u32x4;
+  using FX = u32x4;
+  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return v; }
+  __device__ static __forceinline__ FX prep_x(const u32x4& v) { return v; }
   __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
   }
@@ -57,6 +67,10 @@ template <> struct Mma<f16_t> {
   }
 };
 template <> struct Mma<float> {
+  using FW = u32x4;
+  using FX = u32x4;
+  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return v; }
+  __device__ static __forceinline__ FX prep_x(const u32x4& v) { return v; }
   // lane half h holds k = 8j+4h+e (e = 0..3): MFMA e consumes element e of both operands, so A and B see the
   // same K permutation and the sum is over the same set of products.
   __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
@@ -70,6 +84,37 @@ template <> struct Mma<float> {
     f32x4 f = __builtin_bit_cast(f32x4, v);
     f[0] *= sv[0]; f[1] *= sv[1]; f[2] *= sv[2]; f[3] *= sv[3];
     return __builtin_bit_cast(u32x4, f);
+  }
+};
+
+// MAUA_F32_SPLIT: float32 tensors, products on the bf16 matrix cores.  Every aligned group of 4 floats (the 16 bytes a lane holds of
+// an operand: k = 8j + 4h + e, like the exact path) is kept in LDS - and, for the weights, in HBM: launch_f32_split_inplace after
+// launch_prep_weights - as [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] bf16: x = hi + lo, hi = bf16(x) (round to nearest even),
+// lo = bf16(x - hi) (x - hi is exact in f32).  The pixel side is split ONCE per element when the halo tile is staged (scale());
+// the 8 bf16 slots of a v_mfma_f32_32x32x16_bf16 operand then carry two of the three products at once:
+//     MFMA 1:  w [hi | hi]  x  x [hi | lo]   = sum w_hi x_hi + w_hi x_lo
+//     MFMA 2:  w [lo |  0]  x  x [hi | lo]   = sum w_lo x_hi
+// (w_lo x_lo, <= 2^-16 of the product, is dropped).  64 matrix-core cycles where the exact path's four v_mfma_f32_32x32x2_f32 take
+// 256, and four register moves per weight fragment instead of arithmetic.
+__device__ __forceinline__ u32x4 f32_split4(const f32x4& f) {
+  const uint32_t h0 = pack2bf(f[0], f[1]), h1 = pack2bf(f[2], f[3]);
+  return u32x4{h0, h1, pack2bf(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u)),
+               pack2bf(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u))};
+}
+template <> struct Mma<f32s_t> {
+  struct FW { u32x4 hh, l0; };
+  using FX = u32x4;
+  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return FW{u32x4{v[0], v[1], v[0], v[1]}, u32x4{v[2], v[3], 0u, 0u}}; }
+  __device__ static __forceinline__ FX prep_x(const u32x4& v) { return v; }
+  __device__ static __forceinline__ void step(f32x16& acc, const FW& w, const FX& x) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.hh), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.l0), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  }
+  // the halo tile's 4 floats x 4 styles -> split form
+  __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
+    f32x4 f = __builtin_bit_cast(f32x4, v);
+    f[0] *= sv[0]; f[1] *= sv[1]; f[2] *= sv[2]; f[3] *= sv[3];
+    return f32_split4(f);
   }
 };
 
@@ -257,13 +302,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
         const int tapoff = (dy * g.hw2 + dx) * RS;
 #pragma unroll
         for (int ks = 0; ks < KCB / 32; ks++) {
-          u32x4 af[WM], bf[WN];
+          typename Mma<T>::FX af[WM];
+          typename Mma<T>::FW bf[WN];
 #pragma unroll
-          for (int i = 0; i < WM; i++) af[i] = *reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + ks * 32);
+          for (int i = 0; i < WM; i++) af[i] = Mma<T>::prep_x(*reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + ks * 32));
 #pragma unroll
           for (int j = 0; j < WN; j++)
-            bf[j] = DMAW ? *reinterpret_cast<const u32x4*>(wtb + t * BN * KCB + offb[j] + (((h + 2 * ks) ^ swz) << 4))
-                         : *reinterpret_cast<const u32x4*>(wtb + t * BN * RS + offb[j] + ks * 32);
+            bf[j] = Mma<T>::prep_w(DMAW ? *reinterpret_cast<const u32x4*>(wtb + t * BN * KCB + offb[j] + (((h + 2 * ks) ^ swz) << 4))
+                                        : *reinterpret_cast<const u32x4*>(wtb + t * BN * RS + offb[j] + ks * 32));
 #pragma unroll
           for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -578,7 +624,23 @@ int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {
   if (dtype == MAUA_BF16) return launch_modconv_t<bf16_t>(stream, a);
   if (dtype == MAUA_F16) return launch_modconv_t<f16_t>(stream, a);
   if (dtype == MAUA_F32) return launch_modconv_t<float>(stream, a);
+  if (dtype == MAUA_F32_SPLIT) return launch_modconv_t<f32s_t>(stream, a);
   return fail("modconv3x3: unsupported dtype");
+}
+
+// a prepared float32 weight buffer (launch_prep_weights, MAUA_F32) -> the split form above, in place: n floats, n % 4 == 0
+__global__ __launch_bounds__(256) void f32_split_inplace_kernel(float* __restrict__ w, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 f = *reinterpret_cast<const f32x4*>(w + 4 * i);
+  *reinterpret_cast<u32x4*>(w + 4 * i) = f32_split4(f);
+}
+int launch_f32_split_inplace(hipStream_t stream, void* w, long n) {
+  MAUA_REQUIRE(w && n >= 0 && n % 4 == 0, "f32_split_inplace: bad argument");
+  if (n == 0) return MAUA_OK;
+  hipLaunchKernelGGL(f32_split_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (float*)w, n / 4);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ weight prep

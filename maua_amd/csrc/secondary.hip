@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void sec_grad_out_kernel(const T* __restrict__
 struct maua_secondary {
   maua_ctx* ctx;
   int dtype;
+  int conv_dtype;
   size_t esize;
   SConv conv[NCONV];
   float* wemb = nullptr;   // [8] FourierFeatures weight
@@ -354,7 +355,7 @@ int run_conv(maua_secondary* n, const SConv& c, bool transposed, const void* x, 
   a.noise = nullptr; a.bias = transposed ? c.zero_bias : c.bias; a.y = y; a.y_pstride = yps; a.y_coff = ycoff; a.y_bstride = (long)h * w * yps;
   a.B = B; a.H = h; a.W = w; a.Ci = Ci; a.Co = Co; a.up = 1;
   a.act = relu ? MAUA_ACT_LRELU : MAUA_ACT_LINEAR; a.alpha = relu ? 0.f : 1.f; a.gain = 1.f; a.clamp = -1.f;
-  return launch_modconv3x3(n->ctx->stream, n->dtype, a);
+  return launch_modconv3x3(n->ctx->stream, n->conv_dtype, a);
 }
 
 #define SEC_LAUNCH(KERNEL, TOTAL, ...)                                                                         \
@@ -495,9 +496,11 @@ extern "C" {
 
 int maua_secondary_create(maua_ctx* ctx, int dtype, maua_secondary** out) {
   MAUA_REQUIRE(ctx && out, "maua_secondary_create: NULL argument");
-  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16, "maua_secondary_create: dtype must be MAUA_F32 or MAUA_BF16");
+  MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16 || dtype == MAUA_F32_SPLIT,
+               "maua_secondary_create: dtype must be MAUA_F32, MAUA_F32_SPLIT or MAUA_BF16");
   maua_secondary* n = new maua_secondary();
-  n->ctx = ctx; n->dtype = dtype; n->esize = dtype == MAUA_BF16 ? 2 : 4;
+  // MAUA_F32_SPLIT: float32 tensors everywhere (dtype below), only the convolutions' products differ (conv_dtype)
+  n->ctx = ctx; n->conv_dtype = dtype; n->dtype = dtype == MAUA_F32_SPLIT ? MAUA_F32 : dtype; n->esize = n->dtype == MAUA_BF16 ? 2 : 4;
   int ci[NCONV], co[NCONV];
   conv_plan(ci, co);
   for (int i = 0; i < NCONV; i++) {
@@ -581,6 +584,10 @@ int maua_secondary_load(maua_secondary* n, int index, int what, const float* hos
     MAUA_HIP_CHECK(hipMemcpy(tmp, wt.data(), count * 4, hipMemcpyHostToDevice));
     MAUA_HIP_CHECK(hipMemsetAsync(c.wt_t, 0, we, st));
     rc = launch_prep_weights(st, n->dtype, tmp, c.wt_t, nullptr, c.Ci, c.Co, 3, 1, 0, c.Cip, c.Cop);
+    if (!rc && n->conv_dtype == MAUA_F32_SPLIT) {   // both copies in the split form the matrix cores read
+      rc = launch_f32_split_inplace(st, c.wt, (long)9 * c.Cop * c.Cip);
+      if (!rc) rc = launch_f32_split_inplace(st, c.wt_t, (long)9 * c.Cop * c.Cip);
+    }
     hipStreamSynchronize(st);
   }
   hipFree(tmp);

@@ -582,7 +582,8 @@ CHECKPOINTS = {"uncondImageNet512": ("modelzoo/512x512_diffusion_uncond_finetune
 
 
 def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diffusion_steps=1000, use_secondary=False,
-                  allow_random_init=False, dtype=torch.bfloat16, generator=None, secondary_dtype=torch.float32, **overrides):
+                  allow_random_init=False, dtype=torch.bfloat16, generator=None, secondary_dtype=torch.float32, secondary_exact=False,
+                  **overrides):
     """guided.py:164-209.  The checkpoint file is loaded when it exists (upstream state-dict keys); there is no network
     access to download it: without the file this raises unless ``allow_random_init`` (seeded random weights of the same
     architecture - what the bench and the tests run).  ``overrides``: model_config entries (tests build small networks)."""
@@ -603,9 +604,11 @@ def create_models(checkpoint="uncondImageNet512", timestep_respacing="100", diff
     secondary = None
     if use_secondary:   # guided.py:198-205
         spath = "modelzoo/secondary_model_imagenet_2.pth"
-        # (the reference keeps this 13.9 M-parameter model in fp32, guided.py:198-205, whatever the UNet runs in: exact-f32 MFMA mode by
-        #  default - the guidance gradient lands within 4e-4 of the reference's; bf16 is an opt-in, 3.5 % off in L2 norm)
-        secondary = SecondaryDiffusionImageNet2(dtype=secondary_dtype, generator=generator)
+        # (the reference keeps this 13.9 M-parameter model in fp32, guided.py:198-205, whatever the UNet runs in: float32 tensors here
+        #  too; by default its products run as bf16 split products, ~2^-17 each - the guidance gradient stays within 1e-3 of the
+        #  reference's float32 autograd at a quarter of the matrix-core cycles; secondary_exact=True: the exact-f32 matrix path;
+        #  secondary_dtype=torch.bfloat16 is an opt-in, 3.5 % off in L2 norm)
+        secondary = SecondaryDiffusionImageNet2(dtype=secondary_dtype, generator=generator, exact=secondary_exact)
         if os.path.exists(spath):
             secondary.load_state_dict(torch.load(spath, map_location="cpu"))
         elif not allow_random_init:
@@ -640,11 +643,15 @@ class SecondaryDiffusionImageNet2(torch.nn.Module):
     """guided.py:68-143 on the device: ``forward(input, t) -> DiffusionOutput(v, pred, eps)`` and - what the "fast" conditioning
     needs instead of autograd - ``vjp(g_v) -> (d v / d input)^T g_v`` for the input of the LAST forward.  State-dict keys are the
     reference's (``timestep_embed.weight``, ``net.<...>.weight / .bias``), so its checkpoint loads unchanged.  ``dtype``:
-    torch.bfloat16 (default) or torch.float32 (exact-f32 MFMA mode; the reference keeps this model in fp32)."""
+    torch.bfloat16 (default) or torch.float32 (the reference keeps this model in fp32).  ``exact`` (float32 only): True = every
+    product on the exact-f32 matrix path (v_mfma_f32_32x32x2_f32); False = MAUA_F32_SPLIT: float32 tensors, each product as three
+    bf16 split products on the bf16 matrix cores (x = hi + lo; ~2^-17 per product, f32 accumulate - finer than the TF32 (2^-11) a CUDA
+    device gives the reference's fp32 convolutions by default), 4 x fewer matrix-core cycles."""
 
-    def __init__(self, dtype=torch.bfloat16, generator=None):
+    def __init__(self, dtype=torch.bfloat16, generator=None, exact=True):
         super().__init__()
         self.dtype = dtype
+        self.exact = bool(exact) or dtype != torch.float32
         self._keys = secondary_conv_keys()
         g = generator if generator is not None else torch.Generator().manual_seed(0)
         ci, co = C.c_int(), C.c_int()
@@ -697,7 +704,7 @@ class SecondaryDiffusionImageNet2(torch.nn.Module):
     def _handle(self):
         if self._net is None:
             net = C.c_void_p()
-            L.check(L.lib().maua_secondary_create(L.ctx("cuda"), L.dtype_id(self.dtype), C.byref(net)))
+            L.check(L.lib().maua_secondary_create(L.ctx("cuda"), L.dtype_id(self.dtype) if self.exact else L.F32_SPLIT, C.byref(net)))
             lib = L.lib()
 
             def up(i, what, t):
@@ -905,7 +912,7 @@ class GuidedDiffusion(torch.nn.Module):
 
     def __init__(self, grad_modules, sampler="ddim", timesteps=100, model_checkpoint="uncondImageNet512", device="cuda",
                  ddim_eta=0, plms_order=2, speed="fast", model=None, diffusion=None, secondary_model=None, allow_random_init=False,
-                 dtype=torch.bfloat16, secondary_dtype=torch.float32):
+                 dtype=torch.bfloat16, secondary_dtype=torch.float32, secondary_exact=False):
         super().__init__()
         if sampler not in ("ddim", "p", "plms"):
             raise NotImplementedError()
@@ -913,9 +920,10 @@ class GuidedDiffusion(torch.nn.Module):
         if model is None:
             model, diffusion, secondary_model = create_models(            # (:292: "ddimN" spacing only for DDIM)
                 checkpoint=model_checkpoint, timestep_respacing=f"ddim{timesteps}" if sampler == "ddim" else str(timesteps),
-                use_secondary=speed == "fast", allow_random_init=allow_random_init, dtype=dtype, secondary_dtype=secondary_dtype)
+                use_secondary=speed == "fast", allow_random_init=allow_random_init, dtype=dtype, secondary_dtype=secondary_dtype,
+                secondary_exact=secondary_exact)
         elif speed == "fast" and secondary_model is None and mods:
-            secondary_model = SecondaryDiffusionImageNet2(dtype=secondary_dtype) if allow_random_init else None
+            secondary_model = SecondaryDiffusionImageNet2(dtype=secondary_dtype, exact=secondary_exact) if allow_random_init else None
             if secondary_model is None:
                 raise ValueError('speed="fast" with ready objects needs secondary_model= (or allow_random_init=True)')
         self.model, self.diffusion, self.ddim_eta = model, diffusion, ddim_eta
