@@ -757,6 +757,11 @@ struct maua_unet {
   size_t gd_tab_cap = 0;
   int* gd_flag = nullptr;            // [gd_flags] one NaN flag per step, zeroed before every loop (outside the graph)
   int gd_flags = 0;
+  // the guidance branch of a step (secondary forward, grad module, secondary VJP) depends on x only: it runs BESIDE the UNet forward
+  // on a side stream (a parallel branch of the captured graph) and joins at the DDIM update; option "guided_fork" = 0: one stream
+  int gd_fork = 1;
+  hipStream_t side_stream = nullptr, cap_side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // input gradient (maua_unet_forward_keep + maua_unet_vjp; option "vjp" = 1 before the weights are loaded)
   int vjp = 0;
   float* zero_bias = nullptr;        // [max padded channels] zeros: the gradient convolutions have no bias
@@ -1426,6 +1431,10 @@ void maua_unet_destroy(maua_unet* n) {
   if (n->graph_exec) hipGraphExecDestroy(n->graph_exec);
   if (n->gd_exec) hipGraphExecDestroy(n->gd_exec);
   if (n->cap_stream) hipStreamDestroy(n->cap_stream);
+  if (n->side_stream) hipStreamDestroy(n->side_stream);
+  if (n->cap_side) hipStreamDestroy(n->cap_side);
+  if (n->ev_fork) hipEventDestroy(n->ev_fork);
+  if (n->ev_join) hipEventDestroy(n->ev_join);
   for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
     if (p) hipFree(p);
   for (void* p : n->owned) hipFree(p);
@@ -1448,6 +1457,11 @@ int maua_unet_set_option(maua_unet* n, const char* key, int value) {
   }
   if (!strcmp(key, "route")) {
     n->route = value;
+    drop_sampler_graphs(n);
+    return MAUA_OK;
+  }
+  if (!strcmp(key, "guided_fork")) {   // 1 (default): the guidance branch of maua_ddim_guided_loop beside the UNet forward; 0: behind it
+    n->gd_fork = value ? 1 : 0;
     drop_sampler_graphs(n);
     return MAUA_OK;
   }
@@ -1976,18 +1990,45 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   MAUA_HIP_CHECK(hipMemcpyAsync(bx, x, tb * 4, hipMemcpyDeviceToDevice, st));
   MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
   const long tstride = target_bstride ? chw : 0;
-  auto body = [&](int s) -> int {
+  if (n->gd_fork && !n->ev_fork) {
+    MAUA_HIP_CHECK(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+    MAUA_HIP_CHECK(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    MAUA_HIP_CHECK(hipStreamCreateWithFlags(&n->side_stream, hipStreamNonBlocking));
+    MAUA_HIP_CHECK(hipStreamCreateWithFlags(&n->cap_side, hipStreamNonBlocking));
+  }
+  // one step on (main, side): the UNet forward on main; the guidance branch - it reads x and nothing the forward writes - on side
+  // (main itself when the fork is off); the DDIM update on main behind both.  Every launcher reads the context's stream.
+  auto step_on = [&](int s, hipStream_t main, hipStream_t side) -> int {
+    const bool fork = side != main;
+    if (fork) {
+      MAUA_HIP_CHECK(hipEventRecord(n->ev_fork, main));
+      MAUA_HIP_CHECK(hipStreamWaitEvent(side, n->ev_fork, 0));
+    }
+    n->ctx->stream = main;
     n->emb_row = n->emb_table + (size_t)s * n->emb_total;
     int rc = maua_unet_forward(n, bx, n->g_t + (size_t)s * B, B, H, W, n->g_out);
     n->emb_row = nullptr;
+    if (!rc) {
+      n->ctx->stream = side;
+      rc = maua_secondary_forward(sec, bx, t_ct + (size_t)s * B, B, H, W, bv, bp, be);
+      if (!rc) rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg);
+      if (!rc) rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false);
+      if (!rc) rc = maua_secondary_vjp(sec, bg, B, H, W, bjv);
+      if (!rc) rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad);
+    }
+    n->ctx->stream = main;
+    if (fork) {   // (joined whatever happened: a capture must not end with an unjoined stream)
+      hipError_t e1 = hipEventRecord(n->ev_join, side), e2 = hipStreamWaitEvent(main, n->ev_join, 0);
+      if (!rc && (e1 != hipSuccess || e2 != hipSuccess)) rc = fail("maua_ddim_guided_loop: joining the guidance branch failed");
+    }
     if (rc) return rc;
-    if ((rc = maua_secondary_forward(sec, bx, t_ct + (size_t)s * B, B, H, W, bv, bp, be))) return rc;
-    if ((rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg))) return rc;
-    if ((rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false))) return rc;
-    if ((rc = maua_secondary_vjp(sec, bg, B, H, W, bjv))) return rc;
-    if ((rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad))) return rc;
     return maua_ddim_step(n->ctx, bx, n->g_out, bgrad, nullptr, n->g_cf + (size_t)s * B * 8, B, n->in_ch, n->out_ch, (long)H * W, bx,
                           n->g_pred);
+  };
+  auto body = [&](int s) -> int {   // eager: on the caller's stream (+ the side stream)
+    int rc = step_on(s, st, n->gd_fork ? n->side_stream : st);
+    n->ctx->stream = st;
+    return rc;
   };
   if (use_graph && !n->gd_failed) {
     if (!n->gd_exec || n->gd_key != key) {
@@ -2006,8 +2047,7 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
       hipError_t e = hipStreamBeginCapture(n->cap_stream, hipStreamCaptureModeThreadLocal);
       int rc = MAUA_OK;
       if (e == hipSuccess) {
-        n->ctx->stream = n->cap_stream;   // the launchers of both networks read the context's stream
-        for (int s = 0; s < n_steps && !rc; s++) rc = body(s);
+        for (int s = 0; s < n_steps && !rc; s++) rc = step_on(s, n->cap_stream, n->gd_fork ? n->cap_side : n->cap_stream);
         n->ctx->stream = st;
         e = hipStreamEndCapture(n->cap_stream, &graph);
       }
