@@ -193,6 +193,16 @@ def build_inputs(device, rank, world, seed=0, host_rng=False):
             box["noise"] = [Loop(rng, T_FRAMES, (s, s), n_loops=4, sigma=5) for s in NOISE_SIZES]
         else:   # module j's planes = Philox stream j of seed 42 + seed (streams 0 .. 16; the network's tensors use their own seed)
             from maua_amd.rng import philox_normal
+            if os.environ.get("MAUA_BENCH_SETUP_TRACE"):
+                box["noise"] = []
+                for j, s in enumerate(NOISE_SIZES):
+                    ta = time.perf_counter()
+                    pl = philox_normal((3, s, s), 42 + seed, j, device=device)
+                    tb = time.perf_counter()
+                    box["noise"].append(Loop(None, T_FRAMES, (s, s), n_loops=4, sigma=5, noise=pl))
+                    print("[bench set-up]   plane %d (%d^2): draw %.2f ms, module %.2f ms" % (j, s, (tb - ta) * 1e3, (time.perf_counter() - tb) * 1e3),
+                          file=sys.stderr)
+                return
             box["noise"] = [Loop(None, T_FRAMES, (s, s), n_loops=4, sigma=5, noise=philox_normal((3, s, s), 42 + seed, j, device=device))
                             for j, s in enumerate(NOISE_SIZES)]
     if host_rng:
@@ -203,9 +213,19 @@ def build_inputs(device, rank, world, seed=0, host_rng=False):
         for th in ths:
             th.join()
     else:   # everything is device work behind a few milliseconds of host calls: one thread, one stream
+        trace = os.environ.get("MAUA_BENCH_SETUP_TRACE")
+        t0 = time.perf_counter()
         make_net()
+        if trace:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
         make_noise()
+        if trace:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
         latents, info = pipeline.synthetic_clip_latents(T_FRAMES, FPS, 18, W_DIM, device_rng=True)
+        if trace:
+            torch.cuda.synchronize()
+            print("[bench set-up] network %.1f ms, noise planes %.1f ms, clip chain %.1f ms" %
+                  ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3), file=sys.stderr)
     net, noise = box["net"], box["noise"]
     info = dict(info, weights_and_noise_planes="torch host generators" if host_rng else
                 "device counter RNG (Philox4x32-10, maua_philox_normal): network = streams of seed %d, noise planes = streams of seed %d" % (seed, 42 + seed))
@@ -488,6 +508,12 @@ def main():
     t_w = time.perf_counter()
     pipeline.warm_up(device)
     torch.cuda.synchronize()
+    # (part of the once-per-process work: a full collection now, and the interpreter's long-lived objects - torch's import alone leaves
+    #  over a million - out of the collector's way: a generation-2 pass over them, 35 ms, otherwise lands wherever the allocation
+    #  counters trip, e.g. in the middle of a clip's 15 ms set-up)
+    import gc
+    gc.collect()
+    gc.freeze()
     warmup_s = time.perf_counter() - t_w
     t_ctx = time.perf_counter()  # HIP context up and warm; everything after this is the clip's own set-up
     net, latents, noise, info = build_inputs(device, rank, world)

@@ -548,6 +548,16 @@ def test_guided_loop_as_one_graph_equals_the_step_by_step_loop(sec_dt, sec_exact
     assert torch.equal(nan_g, gd.forward(img, [ImageTarget(bad)], 0.3, t_end=0.8, noise=nz))
     # (a zero gradient still takes condition_score's eps -> pred round trip: equal to the unguided loop up to that rounding)
     assert bool(torch.isfinite(nan_g).all()) and rel(nan_g, plain) <= 1e-5 and rel(res["a"], plain) > 100 * rel(nan_g, plain)
+    # the guidance branch runs BESIDE the UNet forward (a parallel branch of the graph / a side stream); behind it (option
+    # "guided_fork" = 0: one stream, a new capture) the loop gives the same bits, as a graph and launch by launch
+    guide.target = t1.cuda()
+    net.set_option("guided_fork", 0)
+    for use_graph in (True, False):
+        gd.use_graph = use_graph
+        assert torch.equal(res["a"], gd.forward(img, [ImageTarget(t1)], 0.3, t_end=0.8, noise=nz)), use_graph
+    net.set_option("guided_fork", 1)
+    gd.use_graph = True
+    assert torch.equal(res["a"], gd.forward(img, [ImageTarget(t1)], 0.3, t_end=0.8, noise=nz)) and net.guided_graph_active()
     # before any forward the secondary model has nothing to differentiate
     with pytest.raises(RuntimeError):
         SecondaryDiffusionImageNet2(dtype=torch.float32).vjp(torch.zeros(1, 3, 64, 64))
