@@ -172,11 +172,26 @@ def test_full_size_unet_matches_oracle():
     net = build(torch.float32)
     got = net(x, t)
     assert rel(got, want) <= 2e-4, rel(got, want)
+    # ... and its input gradient (speed "regular", guided.py:250-272: eps = the first three output channels) against torch.autograd
+    # through the oracle's full-size network: there and back through ~330 layers each way
+    g_out = torch.zeros(1, 6, 256, 256)
+    g_out[:, :3] = torch.randn(1, 3, 256, 256, generator=g)
+    want_vjp = OD.unet_input_vjp(p, cfg, x, t, g_out)
+    net.forward_keep(x, t)
+    got_vjp = net.vjp(g_out).cpu()
+    l2 = float((got_vjp - want_vjp).norm() / want_vjp.norm())
+    print("full-size UNet input gradient, f32: l2", l2, "max", rel(got_vjp, want_vjp))
+    assert l2 <= 2e-4 and rel(got_vjp, want_vjp) <= 1e-3, (l2, rel(got_vjp, want_vjp))
     del net
     torch.cuda.empty_cache()
     net16 = build(torch.bfloat16)
     got16 = net16(x, t)
     assert psnr(got16, want) >= 40.0, psnr(got16, want)
+    net16.forward_keep(x, t)
+    v16 = net16.vjp(g_out).cpu()
+    cos16 = float((v16 * want_vjp).sum() / (v16.norm() * want_vjp.norm()))
+    print("full-size UNet input gradient, bf16: cosine", cos16, "l2", float((v16 - want_vjp).norm() / want_vjp.norm()))
+    assert cos16 >= 0.98, cos16
     # two sampler steps inside the library (hipGraph) == the same two steps issued one by one
     sd = SpacedDiffusion(space_timesteps(1000, "ddim100"), OD.linear_betas(1000), rescale_timesteps=True)
     xa, xb = x.cuda().clone(), x.cuda().clone()
