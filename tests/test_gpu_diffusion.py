@@ -780,3 +780,13 @@ def test_regular_speed_conditioning_matches_the_oracle_and_guides_the_sampler():
     twice = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
     del sd._model_output
     assert torch.equal(twice, guided)
+    # the other two samplers of guided.py:302-311 take the same conditioning (plms evaluates the model - and cond_fn - twice in its first step)
+    for sampler in ("plms", "p"):
+        sdk = SpacedDiffusion(space_timesteps(1000, "20"), OD.linear_betas(1000), rescale_timesteps=True)
+        gk = GuidedDiffusion([MSEGuide(scale=2000.0)], sampler=sampler, timesteps=20, model=net, diffusion=sdk, speed="regular")
+        torch.manual_seed(3)
+        a = gk.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+        sdk._model_output = lambda model, x, mt, cond_fn: model(x, mt)
+        torch.manual_seed(3)
+        b = gk.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+        assert torch.isfinite(a).all() and torch.equal(a, b), sampler
