@@ -55,7 +55,7 @@ def test_attention_matches_legacy_qkv_attention(dt, B, T, heads, ch):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(70, 96, 64), (1024, 256, 512), (5, 32, 32), (300, 1536, 512), (65600, 256, 128), (66000, 512, 64)])
+@pytest.mark.parametrize("M,N,K", [(70, 96, 64), (1024, 256, 512), (5, 32, 32), (300, 1536, 512), (65600, 256, 128), (66000, 512, 64), (65537, 256, 192), (70000, 128, 64), (40000, 384, 512)])
 def test_linear_nt_matches_torch(dt, M, N, K):
     from maua_amd import _lib as L
     g = torch.Generator().manual_seed(M + N)
