@@ -21,14 +21,16 @@ OUT = os.path.join(ROOT, "gpurun_out", "traffic")
 BATCH = int(os.environ.get("BATCH", "128"))  # frames per step (bench.py default)
 
 
-def run(counter):
-    os.makedirs(OUT, exist_ok=True)
-    env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", OUT, "-o", counter, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
-           "--batch", str(BATCH)]
-    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT)
-    f = glob.glob(os.path.join(OUT, f"{counter}_counter_collection.csv"))[0]
+def run(counter, batch=None, steps=4, timeout=None, out=None):
+    out = out or OUT
+    os.makedirs(out, exist_ok=True)
+    # (the child must not start its own counter passes: bench.py runs these two by itself at the end of a default run)
+    env = dict(os.environ, TMPDIR="/tmp", MAUA_BENCH_NO_LIVE_TRAFFIC="1")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", counter, "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+           "--batch", str(batch or BATCH)]
+    subprocess.run(cmd, check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=ROOT, timeout=timeout)
+    f = glob.glob(os.path.join(out, "**", f"{counter}_counter_collection.csv"), recursive=True)[0]
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
