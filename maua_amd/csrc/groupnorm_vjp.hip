@@ -210,14 +210,15 @@ __global__ __launch_bounds__(256) void gn_vjp_finalize_kernel(const double* __re
 // its input row with it (the per-piece constants are 100+ bytes of loads: amortised like the forward's gn_apply_group_kernel)
 constexpr int VJP_PX = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void gn_vjp_apply_kernel(GnVjpArgs a, const float* __restrict__ m) {
+__global__ __launch_bounds__(256) void gn_vjp_apply_kernel(GnVjpArgs a, const float* __restrict__ m, int b0) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const unsigned C = a.C0 + a.C1, PPP = C / EPC, cpg = C / 32;
   const unsigned li = blockIdx.x * 256u + threadIdx.x;
   const unsigned nxg = ((unsigned)a.W + VJP_PX - 1) / VJP_PX;
   if (li >= nxg * PPP) return;
   const unsigned xg = li / PPP, pc = li - xg * PPP;
-  const unsigned b = blockIdx.y / (unsigned)a.H, iy = blockIdx.y - b * (unsigned)a.H;
+  const unsigned bl = blockIdx.y / (unsigned)a.H, iy = blockIdx.y - bl * (unsigned)a.H;
+  const unsigned b = (unsigned)b0 + bl;   // (the grid's y extent holds at most 65535 rows: large batches come in sample ranges)
   const unsigned c = pc * EPC;
   const long HW = (long)a.H * a.W;
   const bool first = c < (unsigned)a.C0;
@@ -300,7 +301,10 @@ int run(hipStream_t st, const GnVjpArgs& a, void* ws) {
   hipLaunchKernelGGL(gn_vjp_partial_kernel<T>, dim3((unsigned)p.nchunk, a.B), dim3(nt), (size_t)nt * EPC * 8, st, a, p.ppc, part);
   hipLaunchKernelGGL(gn_vjp_finalize_kernel, dim3(32, a.B), dim3(256), 0, st, part, (int)p.nchunk, C, HW, m);
   const unsigned nxg = (unsigned)((a.W + VJP_PX - 1) / VJP_PX);
-  hipLaunchKernelGGL(gn_vjp_apply_kernel<T>, dim3((nxg * (unsigned)PPP + 255) / 256, (unsigned)(a.B * a.H)), dim3(256), 0, st, a, m);
+  const int bmax = std::max(1, 65535 / a.H);
+  for (int b0 = 0; b0 < a.B; b0 += bmax)
+    hipLaunchKernelGGL(gn_vjp_apply_kernel<T>, dim3((nxg * (unsigned)PPP + 255) / 256, (unsigned)(std::min(bmax, a.B - b0) * a.H)), dim3(256), 0,
+                       st, a, m, b0);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
@@ -319,7 +323,7 @@ int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, voi
   MAUA_REQUIRE(C % 32 == 0 && C / EPC <= 1024 && a.C0 % EPC == 0 && a.C1 % EPC == 0 && (a.C1 == 0 || (a.x1 && a.dx1)),
                "group_norm_vjp: C % 32 == 0, at most 1024 16-byte pieces per pixel");
   MAUA_REQUIRE(a.mode >= 0 && a.mode <= 2 && (a.mode != 1 || (a.H % 2 == 0 && a.W % 2 == 0)), "group_norm_vjp: bad resample mode");
-  MAUA_REQUIRE((long)a.B * a.H <= 65535, "group_norm_vjp: B * H must fit one grid dimension");
+  MAUA_REQUIRE(a.H <= 65535 && a.B <= 65535, "group_norm_vjp: grid too large");
   if (a.B == 0) return MAUA_OK;
   return dtype == MAUA_BF16 ? run<bf16_t>(stream, a, workspace) : run<float>(stream, a, workspace);
 }
