@@ -914,6 +914,51 @@ def golden_secondary():
     print("  strict load:", missing)
 
 
+def golden_regular():
+    """g32: guidance speed "regular" (guided.py:214-218, 236-272) - the gradient the REFERENCE's own GradientGuidedConditioning.forward
+    returns when it differentiates through `diffusion.p_mean_variance(model=...)["pred_xstart"]`.  The guided_diffusion submodule is
+    empty in the reference checkout, so the diffusion object handed to the reference's class is a stand-in whose p_mean_variance is the
+    published arithmetic on the oracle's restated network (respaced index -> model timestep, eps = the first half of the learn_sigma
+    output, pred_xstart = sqrt_recip_alphas_cumprod x - sqrt_recipm1_alphas_cumprod eps); everything around it - the timestep
+    mapping `timestep_map.index`, img = out * sigma + x * (1 - sigma), the grad modules' sum, the sign, torch.autograd.grad - is the
+    reference's code.  Small network (oracle.diffusion.unet_config of the tests' SMALL shape, seed 0: rebuilt from the seed)."""
+    from types import SimpleNamespace
+    import maua.diffusion.processors.guided as RG
+    from oracle import diffusion as OD
+    cfg = OD.unet_config(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions=(16, 8), channel_mult=(1, 2, 2),
+                         num_head_channels=32)
+    params = OD.init_unet_params(cfg, torch.Generator().manual_seed(0))
+    sch = OD.Schedule(1000, "ddim20")
+
+    def p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=None):
+        assert not clip_denoised
+        out = OD._unet_forward(params, cfg, x, sch.model_timesteps(t.cpu()))
+        return {"pred_xstart": OD._ex(sch.sqrt_recip_alphas_cumprod, t, x.shape) * x
+                               - OD._ex(sch.sqrt_recipm1_alphas_cumprod, t, x.shape) * out[:, :x.shape[1]]}
+    diffusion = SimpleNamespace(timestep_map=list(sch.timestep_map), sqrt_alphas_cumprod=sch.sqrt_alphas_cumprod,
+                                sqrt_one_minus_alphas_cumprod=sch.sqrt_one_minus_alphas_cumprod, p_mean_variance=p_mean_variance)
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 2, 64, 64
+    target = torch.randn(3, H, W, generator=g) * 0.5
+
+    class MSE(torch.nn.Module):
+        scale = 500.0
+
+        def set_targets(self, prompts):
+            pass
+
+        def forward(self, img, t):
+            return (2.0 * self.scale / img[0].numel()) * (img - target)
+    cond = RG.GradientGuidedConditioning(diffusion, None, [MSE()], speed="regular")
+    steps = torch.tensor([12, 5])
+    t_model = torch.tensor([float(sch.timestep_map[int(i)]) for i in steps])
+    xt = torch.randn(B, 3, H, W, generator=g)
+    cond.set_targets([], torch.zeros_like(xt))
+    grad = cond(xt, t_model)
+    save("g32_regular_conditioning", steps=steps, t_model=t_model, xt=xt, target=target, cond_grad=grad, mse_scale=np.float32(500.0),
+         unet_seed=np.int64(0))
+
+
 def golden_architectures():
     """g29: the "orig" / "resnet" block architectures (inference/stylegan2.py:275-382).  The reference's constructors run, its
     up = 2 forwards do not, so this pins: (i) the constructors' key set, shapes, draw order and num_ws; (ii) the

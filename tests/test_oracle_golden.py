@@ -680,3 +680,18 @@ def test_orig_and_resnet_architectures_match_the_reference_pieces(golden):
     x1 = S.synthesis_layer(p, "bs.1.conv1", x0, ws[:, 1], up=1, gain=sqrt(0.5))
     assert torch.allclose(x1, g["blk__conv1"], rtol=1e-4, atol=1e-5)
     assert torch.allclose(y + x1, g["blk__out"], rtol=1e-4, atol=1e-5)
+
+def test_regular_speed_conditioning_matches_the_reference_class(golden):
+    """g32: what the REFERENCE's GradientGuidedConditioning.forward returns for speed "regular" (guided.py:214-218, 236-272: timestep
+    mapping, img = pred_xstart * sigma + x * (1 - sigma), summed grad modules, -autograd.grad) around the restated network - the
+    oracle's regular_conditioning must reproduce it (this pins the conditioning's arithmetic; the UNet itself is the published
+    algorithm restated, the submodule being empty in the reference checkout)."""
+    from oracle import diffusion as OD
+    g = golden("g32_regular_conditioning")
+    cfg = OD.unet_config(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions=(16, 8), channel_mult=(1, 2, 2),
+                         num_head_channels=32)
+    p = OD.init_unet_params(cfg, torch.Generator().manual_seed(int(g["unet_seed"])))
+    sch = OD.Schedule(1000, "ddim20")
+    k = 2.0 * float(g["mse_scale"]) / g["target"].numel()
+    got = OD.regular_conditioning(p, cfg, sch, lambda im, _t: k * (im - g["target"]), g["xt"], g["t_model"])
+    close(got, g["cond_grad"], 1e-5)
