@@ -415,20 +415,21 @@ def extra_diffusion(batch=32, steps=100, size=256):
     sec16.load_state_dict(secondary.state_dict())
     best16, finite16, graphed16 = guided_leg(sec16)
     # ---- speed "regular" (guided.py:250-252): the loss gradient through the diffusion UNet itself - a kept forward + the network
-    # walked backwards every step (maua_unet_forward_keep / maua_unet_vjp); a Python loop of library calls, timed on a 10-step run
+    # walked backwards every step (maua_unet_forward_keep / maua_unet_vjp), the loop one hipGraph like the "fast" one
+    # (maua_ddim_guided_loop without a secondary model); timed on a 10-step run
     def regular_leg(n_timed=10):
         gd = GuidedDiffusion([MSEGuide(1000.0)], timesteps=steps, model=model, diffusion=diffusion, speed="regular")
         gr = torch.Generator().manual_seed(5)
         x0, nz = (torch.randn(batch, 3, size, size, generator=gr).cuda() for _ in range(2))
         pr = [prompts[int(idx[j])] for j in range(batch)]
-        gd.run(x0, pr, n - 1, 2, noise=nz, per_sample=True)       # weights' transposed copies + arena (untimed)
+        gd.run(x0, pr, n - 1, n_timed, noise=nz, per_sample=True)   # weights' transposed copies, arena, capture + first replay (untimed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = gd.run(x0, pr, n - 1, n_timed, noise=nz, per_sample=True)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_timed
         return {"value": batch / (dt * steps), "unit": "samples/s", "ms_per_step": dt * 1e3, "steps_timed": n_timed,
-                "finite": bool(torch.isfinite(out).all()), "hipgraph": False,
+                "finite": bool(torch.isfinite(out).all()), "hipgraph": model.guided_graph_active(),
                 "note": "speed 'regular': UNet forward (kept) + input gradient through the UNet + DDIM update per step; value = the "
                         "%d-step rate extrapolated from %d timed steps of the same loop" % (steps, n_timed)}
     try:

@@ -518,7 +518,11 @@ int maua_ddim_sample_loop(maua_unet* net, float* x, int B, int H, int W, const f
  * out = unet(x, t); pred = secondary(x, cos_t).pred; img; g; grad = c0 g + c1 (dv/dx)^T g; x, pred_xstart = ddim_step(x, out, grad).
  * model_t / coef as maua_ddim_sample_loop; guide: host f32 [n_steps][5] = {cos_t, sigma, 1 - sigma, -(sigma a_c + 1 - sigma),
  * sigma s_c} (the host evaluates them like :249-252, :266-268 do); target: device f32 [B][3][H][W] (target_bstride = 3 H W) or one
- * image for every sample (target_bstride = 0).  Both networks must have been created on the same context. */
+ * image for every sample (target_bstride = 0).  Both networks must have been created on the same context.
+ * sec == NULL: speed "regular" (guided.py:214-218, 250-252) - img is built from THIS network's pred_xstart and the gradient goes back
+ * through it: per step out = forward_keep(x, t); pred = ra x - rm eps (eps = the first in_channels of out); img; g; grad = c0 g +
+ * c1 (d eps / d x)^T g (maua_unet_vjp); DDIM update.  guide[s] = {-, sigma, 1 - sigma, -(sigma ra + 1 - sigma), sigma rm}; option
+ * "vjp" = 1 before the weights are loaded.  One hipGraph as well. */
 int maua_ddim_guided_loop(maua_unet* net, maua_secondary* sec, float* x, int B, int H, int W, const float* model_t, const float* coef,
                           const float* guide, int n_steps, const float* target, long target_bstride, float mse_k, int use_graph,
                           float* pred_xstart);

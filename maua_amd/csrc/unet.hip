@@ -661,6 +661,16 @@ __global__ __launch_bounds__(256) void mse_guide_grad_kernel(const float* __rest
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 // GradientGuidedConditioning.forward (guided.py:262-265): a grad module whose output holds a NaN contributes zeros
+// eps = the first C channels of a model output [B][Cm][HW], made contiguous (speed "regular": pred_xstart is built from it with
+// axpby_rows_kernel, exactly as the step-by-step path does - same kernel, same bits)
+__global__ __launch_bounds__(256) void eps_rows_kernel(const float* __restrict__ model_out, long chw, long cmhw, long total,
+                                                       float* __restrict__ eps) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / chw;
+  eps[i] = model_out[b * cmhw + (i - b * chw)];
+}
+
 __global__ __launch_bounds__(256) void zero_if_flag_kernel(float* __restrict__ g, long total, const int* __restrict__ flag) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   // (an agent-scope load: served by L2, where the previous launch's atomicOr landed - not by the scalar / vector L1)
@@ -952,6 +962,7 @@ struct Runner {
   float* gather_ws = nullptr;
   size_t gather_ws_bytes = 0;
   bool keep = false;         // record the tape and keep what the input gradient needs out of the per-layer scratch
+  int g_channels = 0;        // backward: channels of the output gradient handed in (0: all of them)
   std::vector<TapeOp>* tape = nullptr;
   // gradients known so far, by forward tensor (backward pass)
   std::unordered_map<const void*, T*> grads;
@@ -1307,7 +1318,7 @@ struct Runner {
     int rc;
     const long px = (long)B * H * W;
     T* dy = alloc(px, n->conv_out.Cop);
-    if (!plan && (rc = launch_nchw_to_nhwc<float, T>(st, g_out, dy, B, n->out_ch, H * W, n->conv_out.Cop))) return rc;
+    if (!plan && (rc = launch_nchw_to_nhwc<float, T>(st, g_out, dy, B, g_channels ? g_channels : n->out_ch, H * W, n->conv_out.Cop))) return rc;
     T* d_a = alloc(px, n->tape_cf);
     if ((rc = conv_t(n->conv_out, dy, d_a, H, W, nullptr))) return rc;
     bool had = false;
@@ -1382,13 +1393,15 @@ int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int 
 }
 
 // the gradient's walk continues on the arena where the kept forward stopped (its tensors stay where they are)
+// g_channels: channels of g_out actually handed in ([B][g_channels][H][W]; the remaining output channels' gradient is zero)
 template <typename T>
-int run_vjp(maua_unet* n, const float* g_out, float* g_x) {
+int run_vjp(maua_unet* n, const float* g_out, float* g_x, int g_channels = 0) {
   hipStream_t st = n->ctx->stream;
   n->arena.plan = false; n->arena.top = n->tape_top;
   Runner<T> r(n, st, n->tape_B, false, true);
   r.n_gather_bytes = n->gather_bytes;
   r.gather_ws = n->tape_gather_ws;
+  r.g_channels = g_channels ? g_channels : n->out_ch;
   return r.backward(n->tape, g_out, n->tape_H, n->tape_W, g_x);
 }
 
@@ -1943,19 +1956,29 @@ int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, lo
 //   grad = c0_s g + c1_s (dv/dx)^T g                         x, pred_xstart = ddim_step(x, out, grad)   (:266-268, ddim_sample)
 // guide: host f32 [n_steps][5] = {cos_t, sigma, 1 - sigma, -(sigma a_c + 1 - sigma), sigma s_c} as GradientGuidedConditioning.forward
 // evaluates them.  target: device [B][C][H][W] (target_bstride = C H W) or one image for all samples (0).  x is updated in place.
+// sec == NULL: speed "regular" - out = forward_keep(x, t_s); eps = out[:, :C]; pred = ra x - rm eps; img, g as above;
+// grad = c0_s g + c1_s (d eps / d x)^T g from maua_unet_vjp's walk; guide[s] = {-, sigma, 1 - sigma, -(sigma ra + 1 - sigma), sigma rm}.
 int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, int H, int W, const float* model_t, const float* coef,
                           const float* guide, int n_steps, const float* target, long target_bstride, float mse_k, int use_graph,
                           float* pred_xstart) {
-  MAUA_REQUIRE(n && sec && x && model_t && coef && guide && target && n_steps > 0, "maua_ddim_guided_loop: NULL argument");
-  MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: the secondary model guides 3-channel images");
-  MAUA_REQUIRE(secondary_ctx(sec) == n->ctx, "maua_ddim_guided_loop: both networks must live on one context (one stream)");
+  MAUA_REQUIRE(n && x && model_t && coef && guide && target && n_steps > 0, "maua_ddim_guided_loop: NULL argument");
+  // sec == NULL: speed "regular" (guided.py:214-218, 250-252) - the gradient goes through THIS network: a kept forward + its input
+  // gradient per step, no secondary model
+  const bool regular = sec == nullptr;
+  if (regular) {
+    MAUA_REQUIRE(n->vjp && n->conv_in.wt_t && n->conv_out.wt_t, "maua_ddim_guided_loop: speed \"regular\" needs option \"vjp\" = 1 before the weights are loaded");
+    MAUA_REQUIRE(n->out_ch >= n->in_ch, "maua_ddim_guided_loop: the model output must hold an epsilon per image channel");
+  } else {
+    MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: the secondary model guides 3-channel images");
+    MAUA_REQUIRE(secondary_ctx(sec) == n->ctx, "maua_ddim_guided_loop: both networks must live on one context (one stream)");
+  }
   const long chw = (long)n->in_ch * H * W;
   MAUA_REQUIRE(target_bstride == 0 || target_bstride == chw, "maua_ddim_guided_loop: target_bstride is 0 or C * H * W");
   if (B == 0) return MAUA_OK;
   hipStream_t st = n->ctx->stream;
-  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52) ^ ((size_t)(uintptr_t)sec << 1) ^ (target_bstride ? 1u : 0u);
+  const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52) ^ ((size_t)(uintptr_t)sec << 1) ^ (target_bstride ? 1u : 0u) ^ (regular ? 2u : 0u);
   if (int rc = prepare_sampler(n, B, H, W, model_t, coef, n_steps)) return rc;
-  const size_t tb = (size_t)B * chw, tab = (size_t)n_steps * B * 5 + B;
+  const size_t tb = (size_t)B * chw, tab = (size_t)n_steps * B * 7 + B;
   if (n->gd_cap < 9 * tb || n->gd_tab_cap < tab || !n->gd_flag || n->gd_flags < n_steps) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
@@ -1970,7 +1993,7 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   float *bx = n->gd_buf, *bv = bx + tb, *bp = bv + tb, *be = bp + tb, *bimg = be + tb, *bg = bimg + tb, *bjv = bg + tb,
         *bgrad = bjv + tb, *btgt = bgrad + tb;
   float *t_ct = n->gd_tab, *t_img = t_ct + (size_t)n_steps * B, *t_grad = t_img + (size_t)n_steps * B * 2,
-        *t_k = t_grad + (size_t)n_steps * B * 2;
+        *t_pred = t_grad + (size_t)n_steps * B * 2, *t_k = t_pred + (size_t)n_steps * B * 2;
   {
     std::vector<float> h(tab);
     for (int s = 0; s < n_steps; s++)
@@ -1981,8 +2004,10 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
         h[(size_t)n_steps * B + ((size_t)s * B + b) * 2 + 1] = gs[2];
         h[(size_t)n_steps * B * 3 + ((size_t)s * B + b) * 2] = gs[3];
         h[(size_t)n_steps * B * 3 + ((size_t)s * B + b) * 2 + 1] = gs[4];
+        h[(size_t)n_steps * B * 5 + ((size_t)s * B + b) * 2] = coef[(size_t)s * 8];        // (ra, -rm): pred_xstart from eps (regular)
+        h[(size_t)n_steps * B * 5 + ((size_t)s * B + b) * 2 + 1] = -coef[(size_t)s * 8 + 1];
       }
-    for (int b = 0; b < B; b++) h[(size_t)n_steps * B * 5 + b] = mse_k;
+    for (int b = 0; b < B; b++) h[(size_t)n_steps * B * 7 + b] = mse_k;
     MAUA_HIP_CHECK(hipMemcpyAsync(n->gd_tab, h.data(), tab * 4, hipMemcpyHostToDevice, st));
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
   }
@@ -1998,7 +2023,31 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   }
   // one step on (main, side): the UNet forward on main; the guidance branch - it reads x and nothing the forward writes - on side
   // (main itself when the fork is off); the DDIM update on main behind both.  Every launcher reads the context's stream.
+  // speed "regular": no parallel branch (the gradient needs the forward it differentiates); everything on `main`
+  auto step_regular = [&](int s, hipStream_t main) -> int {
+    n->ctx->stream = main;
+    n->emb_row = n->emb_table + (size_t)s * n->emb_total;
+    int rc = n->dtype == MAUA_BF16 ? run_forward<bf16_t>(n, bx, n->g_t + (size_t)s * B, B, H, W, n->g_out, true)
+                                   : run_forward<float>(n, bx, n->g_t + (size_t)s * B, B, H, W, n->g_out, true);
+    if (!rc) {
+      // pred_xstart = ra x - rm eps (gaussian_diffusion.py _predict_xstart_from_eps), img = sigma pred + (1 - sigma) x (:252)
+      const long total = (long)B * chw;
+      hipLaunchKernelGGL(eps_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, main, n->g_out, chw, (long)n->out_ch * H * W,
+                         total, be);
+      if (hipGetLastError() != hipSuccess) rc = fail("maua_ddim_guided_loop: launch failed");
+      if (!rc) rc = maua_axpby_rows(n->ctx, bx, be, t_pred + (size_t)s * B * 2, B, chw, bp);
+      if (!rc) rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg);
+    }
+    if (!rc) rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false);
+    if (!rc) rc = n->dtype == MAUA_BF16 ? run_vjp<bf16_t>(n, bg, bjv, n->in_ch) : run_vjp<float>(n, bg, bjv, n->in_ch);
+    n->emb_row = nullptr;
+    if (!rc) rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad);
+    if (rc) return rc;
+    return maua_ddim_step(n->ctx, bx, n->g_out, bgrad, nullptr, n->g_cf + (size_t)s * B * 8, B, n->in_ch, n->out_ch, (long)H * W, bx,
+                          n->g_pred);
+  };
   auto step_on = [&](int s, hipStream_t main, hipStream_t side) -> int {
+    if (regular) return step_regular(s, main);
     const bool fork = side != main;
     if (fork) {
       MAUA_HIP_CHECK(hipEventRecord(n->ev_fork, main));

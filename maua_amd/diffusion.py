@@ -538,7 +538,14 @@ class SpacedDiffusion:
         else:
             raise ValueError(f"ddim_guided_loop: target shape {tuple(tgt.shape)} fits neither {tuple(x.shape[1:])} nor {tuple(x.shape)}")
         pred = torch.empty_like(x)
-        L.check(L.lib().maua_ddim_guided_loop(model._handle(), conditioning.model._handle(), L.ptr(x), B, H, W,
+        if conditioning.speed == "fast":
+            second = conditioning.model._handle()
+        else:   # "regular": the gradient goes through the UNet itself (maua_ddim_guided_loop without a secondary model)
+            if conditioning.model is not model:
+                raise ValueError('speed="regular" differentiates through the network that is being sampled')
+            model.enable_vjp()
+            second = None
+        L.check(L.lib().maua_ddim_guided_loop(model._handle(), second, L.ptr(x), B, H, W,
                                               mt.ctypes.data_as(C.c_void_p), cf.ctypes.data_as(C.c_void_p),
                                               gc.ctypes.data_as(C.c_void_p), n_steps, L.ptr(tgt), C.c_long(tstride),
                                               C.c_float(gm.factor(x[0].numel())), int(bool(use_graph)), L.ptr(pred)))
@@ -798,14 +805,18 @@ class GradientGuidedConditioning(torch.nn.Module):
         what maua_ddim_guided_loop takes per step."""
         idx = torch.tensor([self.timestep_map.index(int(v)) for v in torch.as_tensor(t).long().cpu().reshape(-1)])
         alpha, sigma = self.sqrt_alphas_cumprod[idx], self.sqrt_one_minus_alphas_cumprod[idx]
+        if self.speed not in ("hyper", "fast"):   # "regular": {-, sigma, 1 - sigma, -(sigma ra + 1 - sigma), sigma rm} (forward's own expressions)
+            ra = self.diffusion._f32(self.diffusion.sqrt_recip_alphas_cumprod, idx)
+            rm = self.diffusion._f32(self.diffusion.sqrt_recipm1_alphas_cumprod, idx)
+            return torch.stack([torch.zeros_like(sigma), sigma, 1 - sigma, -(sigma * ra + 1 - sigma), sigma * rm], 1).float().contiguous()
         cosine_t = torch.atan2(sigma, alpha) * 2 / math.pi
         a_c, s_c = torch.cos(cosine_t * math.pi / 2), torch.sin(cosine_t * math.pi / 2)
         return torch.stack([cosine_t, sigma, 1 - sigma, -(sigma * a_c + 1 - sigma), sigma * s_c], 1).float().contiguous()
 
     def graphable(self):
-        """True when the whole guided step is library work (speed "fast", exactly one image-MSE grad module with a target): the
-        sampler loop then runs as one hipGraph (SpacedDiffusion.ddim_guided_loop)."""
-        return (self.speed == "fast" and len(self.grad_modules) == 1 and isinstance(self.grad_modules[0], MSEGuide)
+        """True when the whole guided step is library work (speed "fast" or "regular", exactly one image-MSE grad module with a
+        target): the sampler loop then runs as one hipGraph (SpacedDiffusion.ddim_guided_loop)."""
+        return (self.speed != "hyper" and len(self.grad_modules) == 1 and isinstance(self.grad_modules[0], MSEGuide)
                 and self.grad_modules[0].target is not None)
 
     def forward(self, x, t, kw={}):

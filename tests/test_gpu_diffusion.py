@@ -797,13 +797,20 @@ def test_regular_speed_conditioning_matches_the_oracle_and_guides_the_sampler():
     gd = GuidedDiffusion([MSEGuide(scale=2000.0)], timesteps=20, model=net, diffusion=sd, speed="regular")
     assert gd.conditioning.speed == "regular"
     guided = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+    # that ran inside the library as ONE hipGraph (maua_ddim_guided_loop without a secondary model: kept forward, img, grad module,
+    # input gradient, DDIM update per step) ...
+    assert gd.conditioning.graphable() and net.guided_graph_active()
     plain = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd).forward(img, [], 0.3, t_end=0.6, noise=nz).cpu()
     assert torch.isfinite(guided).all()
     assert float((guided - target).norm()) < float((plain - target).norm())
+    # ... launch by launch from Python (ddim_sample + the conditioning) it gives the same bits
+    gd.use_graph = False
+    stepwise = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+    assert torch.equal(stepwise, guided)
     # the sampler hands its own (kept) evaluation of the network to the conditioning; the reference evaluates it twice per step
     # (guided.py:251 inside cond_fn): the same bits either way
     sd._model_output = lambda model, x, mt, cond_fn: model(x, mt)
-    twice = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()
+    twice = gd.forward(img, [ImageTarget(target)], 0.3, t_end=0.6, noise=nz).cpu()      # (use_graph is still False: the Python loop)
     del sd._model_output
     assert torch.equal(twice, guided)
     # the other two samplers of guided.py:302-311 take the same conditioning (plms evaluates the model - and cond_fn - twice in its first step)
