@@ -87,36 +87,43 @@ template <> struct Mma<float> {
   }
 };
 
-// MAUA_F32_SPLIT: float32 tensors, products on the bf16 matrix cores.  Every aligned group of 4 floats (the 16 bytes a lane holds of
-// an operand: k = 8j + 4h + e, like the exact path) is kept in LDS - and, for the weights, in HBM: launch_f32_split_inplace after
-// launch_prep_weights - as [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3] bf16: x = hi + lo, hi = bf16(x) (round to nearest even),
-// lo = bf16(x - hi) (x - hi is exact in f32).  The pixel side is split ONCE per element when the halo tile is staged (scale());
-// the 8 bf16 slots of a v_mfma_f32_32x32x16_bf16 operand then carry two of the three products at once:
-//     MFMA 1:  w [hi | hi]  x  x [hi | lo]   = sum w_hi x_hi + w_hi x_lo
-//     MFMA 2:  w [lo |  0]  x  x [hi | lo]   = sum w_lo x_hi
-// (w_lo x_lo, <= 2^-16 of the product, is dropped).  64 matrix-core cycles where the exact path's four v_mfma_f32_32x32x2_f32 take
-// 256, and four register moves per weight fragment instead of arithmetic.
+// MAUA_F32_SPLIT: float32 tensors, products on the bf16 matrix cores.  x = hi + lo, hi = bf16(x) (round to nearest even),
+// lo = bf16(x - hi) (x - hi is exact in f32).  Every aligned group of 8 floats (two 16-byte pieces: what the two lane halves of one
+// k-step hold) is kept in LDS - and, for the weights, in HBM: launch_f32_split_inplace after launch_prep_weights - as
+// [hi0 .. hi7 | lo0 .. lo7] bf16: piece 2 j = the eight hi parts, piece 2 j + 1 = the eight lo parts.  The pixel side is split ONCE
+// per element when the halo tile is staged (scale() + one exchange between the two lanes that hold a group); a k-step of the
+// convolution is then three full v_mfma_f32_32x32x16_bf16 over 16 real k:
+//     w_hi x_hi  +  w_hi x_lo  +  w_lo x_hi          (w_lo x_lo, <= 2^-16 of the product, is dropped)
+// 96 matrix-core cycles per 16 k where the exact path's eight v_mfma_f32_32x32x2_f32 take 512 (a first form with [hi x 4 | lo x 4] per
+// piece spent one of four operand slots on zeros: 128 cycles).
 __device__ __forceinline__ u32x4 f32_split4(const f32x4& f) {
   const uint32_t h0 = pack2bf(f[0], f[1]), h1 = pack2bf(f[2], f[3]);
   return u32x4{h0, h1, pack2bf(f[0] - __uint_as_float(h0 << 16), f[1] - __uint_as_float(h0 & 0xffff0000u)),
                pack2bf(f[2] - __uint_as_float(h1 << 16), f[3] - __uint_as_float(h1 & 0xffff0000u))};
 }
+// {hi x 4 | lo x 4} of this lane's piece q and of lane ^ 1's piece q ^ 1 -> this lane's piece of the group format above
+__device__ __forceinline__ u32x4 f32_split_pair(const u32x4& v, int q) {
+  const bool odd = q & 1;
+  const uint32_t r0 = __shfl_xor(odd ? v[0] : v[2], 1), r1 = __shfl_xor(odd ? v[1] : v[3], 1);   // even lanes receive hi, odd lanes lo
+  return odd ? u32x4{r0, r1, v[2], v[3]} : u32x4{v[0], v[1], r0, r1};
+}
 template <> struct Mma<f32s_t> {
-  struct FW { u32x4 hh, l0; };
+  using FW = u32x4;
   using FX = u32x4;
-  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return FW{u32x4{v[0], v[1], v[0], v[1]}, u32x4{v[2], v[3], 0u, 0u}}; }
+  __device__ static __forceinline__ FW prep_w(const u32x4& v) { return v; }
   __device__ static __forceinline__ FX prep_x(const u32x4& v) { return v; }
-  __device__ static __forceinline__ void step(f32x16& acc, const FW& w, const FX& x) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.hh), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.l0), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  __device__ static __forceinline__ void step(f32x16& acc, const FW& w, const FX& x) {   // (one of the three products of a k-step)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
   }
-  // the halo tile's 4 floats x 4 styles -> split form
+  // the halo tile's 4 floats x 4 styles -> {hi x 4 | lo x 4} (the staging code then exchanges halves with the neighbouring lane)
   __device__ static __forceinline__ u32x4 scale(const u32x4& v, const float* sv) {
     f32x4 f = __builtin_bit_cast(f32x4, v);
     f[0] *= sv[0]; f[1] *= sv[1]; f[2] *= sv[2]; f[3] *= sv[3];
     return f32_split4(f);
   }
 };
+template <typename T> struct IsSplit { static constexpr bool value = false; };
+template <> struct IsSplit<f32s_t> { static constexpr bool value = true; };
 
 struct ConvGeom {
   int tw_log2, th;      // tile = th x (1 << tw_log2) pixels
@@ -177,10 +184,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
   for (int i = 0; i < WM; i++) {
     int m = (wm * WM + i) * 32 + r;
     int ty = m >> g.tw_log2, tx = m & (tw - 1);
-    offa[i] = ((ty + 1) * g.hw2 + (tx + 1)) * RS + h * 16;
+    offa[i] = ((ty + 1) * g.hw2 + (tx + 1)) * RS + h * (IsSplit<T>::value ? 32 : 16);   // (split f32: a half owns a 32-byte group)
   }
 #pragma unroll
-  for (int j = 0; j < WN; j++) offb[j] = DMAW ? ((wn * WN + j) * 32 + r) * KCB : ((wn * WN + j) * 32 + r) * RS + h * 16;
+  for (int j = 0; j < WN; j++)
+    offb[j] = DMAW ? ((wn * WN + j) * 32 + r) * KCB : ((wn * WN + j) * 32 + r) * RS + h * (IsSplit<T>::value ? 32 : 16);
   const int swz = (r >> 1) & 7;  // DMAW: piece p of weight row n sits at piece p ^ ((n >> 1) & 7) (conflict-free b128 reads)
 
   f32x16 acc[WM][WN];
@@ -262,7 +270,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
 #define MAUA_STORE_H()                                                                                    \
   _Pragma("unroll") for (int i = 0; i < HREGS; i++) {                                                    \
     int p = rq + i * (NT / PR);                                                                            \
-    if (p < g.halo_px) *reinterpret_cast<u32x4*>(halo + p * RS + q * 16) = Mma<T>::scale(hreg[i], sv);    \
+    if (p < g.halo_px) {                                                                                   \
+      u32x4 sv_ = Mma<T>::scale(hreg[i], sv);                                                              \
+      if constexpr (IsSplit<T>::value) sv_ = f32_split_pair(sv_, q);                                       \
+      *reinterpret_cast<u32x4*>(halo + p * RS + q * 16) = sv_;                                             \
+    }                                                                                                      \
   }
 
   constexpr int NG = 9 / TG;
@@ -300,6 +312,36 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void modconv3x3_kernel(ConvA
         const int tap = gi * TG + t;                       // compile-time after unrolling
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         const int tapoff = (dy * g.hw2 + dx) * RS;
+        if constexpr (IsSplit<T>::value) {
+          // split f32: a k-step covers 16 floats = two 32-byte groups (one per lane half), each as a hi piece and a lo piece
+#pragma unroll
+          for (int s2 = 0; s2 < KCB / 64; s2++) {
+            u32x4 xh[WM], xl[WM], wh[WN], wl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; i++) {
+              xh[i] = *reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + s2 * 64);
+              xl[i] = *reinterpret_cast<const u32x4*>(halo + offa[i] + tapoff + s2 * 64 + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+              if constexpr (DMAW) {
+                wh[j] = *reinterpret_cast<const u32x4*>(wtb + t * BN * KCB + offb[j] + (((2 * (2 * s2 + h)) ^ swz) << 4));
+                wl[j] = *reinterpret_cast<const u32x4*>(wtb + t * BN * KCB + offb[j] + (((2 * (2 * s2 + h) + 1) ^ swz) << 4));
+              } else {
+                wh[j] = *reinterpret_cast<const u32x4*>(wtb + t * BN * RS + offb[j] + s2 * 64);
+                wl[j] = *reinterpret_cast<const u32x4*>(wtb + t * BN * RS + offb[j] + s2 * 64 + 16);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+              for (int j = 0; j < WN; j++) {
+                Mma<T>::step(acc[i][j], wh[j], xh[i]);
+                Mma<T>::step(acc[i][j], wh[j], xl[i]);
+                Mma<T>::step(acc[i][j], wl[j], xh[i]);
+              }
+          }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KCB / 32; ks++) {
           typename Mma<T>::FX af[WM];
@@ -628,17 +670,19 @@ int launch_modconv3x3(hipStream_t stream, int dtype, const ConvArgs& a) {
   return fail("modconv3x3: unsupported dtype");
 }
 
-// a prepared float32 weight buffer (launch_prep_weights, MAUA_F32) -> the split form above, in place: n floats, n % 4 == 0
-__global__ __launch_bounds__(256) void f32_split_inplace_kernel(float* __restrict__ w, long n4) {
+// a prepared float32 weight buffer (launch_prep_weights, MAUA_F32) -> the split form above, in place: n floats, n % 8 == 0 (K, the
+// innermost dimension, is a multiple of 32 channels)
+__global__ __launch_bounds__(256) void f32_split_inplace_kernel(float* __restrict__ w, long n8) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const f32x4 f = *reinterpret_cast<const f32x4*>(w + 4 * i);
-  *reinterpret_cast<u32x4*>(w + 4 * i) = f32_split4(f);
+  if (i >= n8) return;
+  const u32x4 a = f32_split4(*reinterpret_cast<const f32x4*>(w + 8 * i)), b = f32_split4(*reinterpret_cast<const f32x4*>(w + 8 * i + 4));
+  *reinterpret_cast<u32x4*>(w + 8 * i) = u32x4{a[0], a[1], b[0], b[1]};        // hi of floats 0 .. 7
+  *reinterpret_cast<u32x4*>(w + 8 * i + 4) = u32x4{a[2], a[3], b[2], b[3]};    // lo of floats 0 .. 7
 }
 int launch_f32_split_inplace(hipStream_t stream, void* w, long n) {
-  MAUA_REQUIRE(w && n >= 0 && n % 4 == 0, "f32_split_inplace: bad argument");
+  MAUA_REQUIRE(w && n >= 0 && n % 8 == 0, "f32_split_inplace: bad argument");
   if (n == 0) return MAUA_OK;
-  hipLaunchKernelGGL(f32_split_inplace_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, (float*)w, n / 4);
+  hipLaunchKernelGGL(f32_split_inplace_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, (float*)w, n / 8);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
