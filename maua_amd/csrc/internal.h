@@ -138,7 +138,8 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
                         int up, int flip, int Cop, int Cip);
-// MAUA_F32_SPLIT: a float32 weight buffer prepared by launch_prep_weights(MAUA_F32, ...) -> [hi x 4 | lo x 4] bf16 per 4 floats, in place
+// MAUA_F32_SPLIT: a float32 weight buffer prepared by launch_prep_weights(MAUA_F32, ...) -> [hi x 8 | lo x 8] bf16 per 8 floats (one 32-byte
+// group per lane half of modconv.hip's k-step), in place; n_floats % 8 == 0
 int launch_f32_split_inplace(hipStream_t stream, void* w, long n_floats);
 
 // modconv_tconv.hip: up-layer as the minimal stride-2 transposed convolution; writes the raw tensor
@@ -300,5 +301,7 @@ int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, voi
 
 // secondary.hip: the context a secondary diffusion model was created on
 maua_ctx* secondary_ctx(maua_secondary* n);
+// (uid, epoch) of a secondary model's device buffers: whoever caches pointers into them (a captured graph) compares both before reuse
+void secondary_stamp(maua_secondary* n, unsigned long long* uid, unsigned long long* epoch);
 
 }  // namespace maua

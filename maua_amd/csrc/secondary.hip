@@ -19,6 +19,7 @@
 // convolution = unit styles, no demodulation; ReLU = leaky ReLU with slope 0 on its fast epilogue), the element-wise steps are
 // 16-byte streaming kernels with the mask / add / pool-gradient fused.  Forward keeps every activation (13.9 M parameters, about 1 GB
 // of activations per 16 samples at 256^2 in bf16); vjp() consumes the state of the LAST forward of the same shape.
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -254,6 +255,10 @@ __global__ __launch_bounds__(256) void sec_grad_out_kernel(const T* __restrict__
 
 struct maua_secondary {
   maua_ctx* ctx;
+  // identity of this model and of its device buffers: a captured graph that holds pointers into them (unet.hip's guided loop) is valid
+  // for one (uid, epoch) only.  uid is never reused (an allocator may hand a later model the freed one's address); epoch moves whenever
+  // a workspace or table is freed or reallocated.
+  unsigned long long uid = 0, epoch = 0;
   int dtype;
   int conv_dtype;
   size_t esize;
@@ -290,6 +295,7 @@ void free_ws(maua_secondary* n) {
   for (auto& p : n->dec) f(p);
   n->cap_px = 0;
   n->B = n->H = n->W = 0;
+  n->epoch++;
 }
 
 // the 24 convolutions in execution order: channels in / out (guided.py:77-134)
@@ -337,6 +343,7 @@ int ensure_ws(maua_secondary* n, int B, int H, int W) {
   if (B > n->ones_b) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     if (n->ones) hipFree(n->ones);
+    n->epoch++;
     std::vector<float> h((size_t)B * 512, 1.f);
     MAUA_HIP_CHECK(hipMalloc((void**)&n->ones, h.size() * 4));
     MAUA_HIP_CHECK(hipMemcpy(n->ones, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -490,6 +497,10 @@ int vjp_t(maua_secondary* n, const float* g_v, float* g_x) {
 
 namespace maua {
 maua_ctx* secondary_ctx(maua_secondary* n) { return n ? n->ctx : nullptr; }
+void secondary_stamp(maua_secondary* n, unsigned long long* uid, unsigned long long* epoch) {
+  *uid = n ? n->uid : 0;
+  *epoch = n ? n->epoch : 0;
+}
 }
 
 extern "C" {
@@ -499,6 +510,8 @@ int maua_secondary_create(maua_ctx* ctx, int dtype, maua_secondary** out) {
   MAUA_REQUIRE(dtype == MAUA_F32 || dtype == MAUA_BF16 || dtype == MAUA_F32_SPLIT,
                "maua_secondary_create: dtype must be MAUA_F32, MAUA_F32_SPLIT or MAUA_BF16");
   maua_secondary* n = new maua_secondary();
+  static std::atomic<unsigned long long> next_uid{1};
+  n->uid = next_uid.fetch_add(1);
   // MAUA_F32_SPLIT: float32 tensors everywhere (dtype below), only the convolutions' products differ (conv_dtype)
   n->ctx = ctx; n->conv_dtype = dtype; n->dtype = dtype == MAUA_F32_SPLIT ? MAUA_F32 : dtype; n->esize = n->dtype == MAUA_BF16 ? 2 : 4;
   int ci[NCONV], co[NCONV];

@@ -760,6 +760,7 @@ struct maua_unet {
   // library buffers, so one capture serves every call of a shape
   hipGraphExec_t gd_exec = nullptr;
   size_t gd_key = 0;
+  unsigned long long gd_sec_uid = 0, gd_sec_epoch = 0;   // the secondary model (and its buffers' generation) gd_exec points into
   int gd_failed = 0;
   float* gd_buf = nullptr;           // x | v | pred | eps | img | g | jv | grad | target, B * C * H * W floats each
   size_t gd_cap = 0;
@@ -1368,10 +1369,13 @@ int run_forward(maua_unet* n, const float* x, const float* t, int B, int H, int 
       n->arena.base = nullptr; n->arena.cap = 0;
       MAUA_HIP_CHECK(hipMalloc((void**)&n->arena.base, need));
       n->arena.cap = need;
+      drop_sampler_graphs(n);   // (their pointers were into the old arena)
     }
+    // a replan inside the same arena keeps the captured loops: each was captured under its own mode's plan (the graphs' keys hold
+    // shape and mode), its offsets are baked in and stay inside [base, base + cap) - alternating an ordinary and a kept forward at
+    // one shape no longer destroys and recaptures both
     n->gather_bytes = pr.gather_ws_bytes;
     n->planned_key = key;
-    drop_sampler_graphs(n);
   }
   if (B > n->ones_b) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
@@ -2079,8 +2083,15 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
     n->ctx->stream = st;
     return rc;
   };
+  // the captured graph holds raw pointers into the secondary model's weights and workspaces: it is this model's, at this generation
+  // of its buffers, or it is recaptured (the address alone does not identify a model: a freed one's can be handed out again)
+  unsigned long long sec_uid = 0, sec_epoch = 0;
+  auto sec_matches = [&]() {
+    secondary_stamp(sec, &sec_uid, &sec_epoch);
+    return sec_uid == n->gd_sec_uid && sec_epoch == n->gd_sec_epoch;
+  };
   if (use_graph && !n->gd_failed) {
-    if (!n->gd_exec || n->gd_key != key) {
+    if (!n->gd_exec || n->gd_key != key || !sec_matches()) {
       // one eager step on scratch copies first: it plans both networks' workspaces and sets the kernels' attributes (none of that
       // can be captured); bx is restored afterwards
       {
@@ -2111,6 +2122,7 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
                   rc ? maua_last_error() : hipGetErrorString(e));
       } else {
         n->gd_key = key;
+        secondary_stamp(sec, &n->gd_sec_uid, &n->gd_sec_epoch);   // (after the eager step: that is what sized the workspaces)
       }
     }
   }

@@ -1037,8 +1037,12 @@ def sample(prompts: List, audio=None, sr=None, fps=30, n_frames=None, size=(256,
         e = f + 1
         while e < n_frames and e - f < batch and (per_sample or idx[e] == idx[f]):
             e += 1
-        x0 = torch.randn((e - f, 3, H, W), generator=g) if init is None else torch.as_tensor(init).expand(e - f, 3, H, W)
-        nz = torch.randn((e - f, 3, H, W), generator=g)
+        # drawn frame by frame (x0 then the q_sample noise, in frame order): a frame's draws do not depend on how the frames around it
+        # were grouped into batches, so `batch` and the per-sample / per-prompt grouping leave the result for a seed unchanged
+        draws = [(torch.randn((3, H, W), generator=g) if init is None else None, torch.randn((3, H, W), generator=g))
+                 for _ in range(f, e)]
+        x0 = torch.stack([d[0] for d in draws]) if init is None else torch.as_tensor(init).expand(e - f, 3, H, W)
+        nz = torch.stack([d[1] for d in draws])
         if per_sample:
             frames[f:e] = gd.run(x0, [prompts[int(idx[j])] for j in range(f, e)], n - 1, n, noise=nz, per_sample=True)
             f = e

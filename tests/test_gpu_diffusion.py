@@ -371,6 +371,11 @@ def test_onset_prompt_schedule_and_sample():
     b, _ = sample(prompts, wav, 1024 * fps, fps, n_frames=6, size=(64, 64), timesteps=5, model=net, diffusion=sd,
                   grad_modules=[MSEGuide(100.0)], seed=4)
     assert tuple(a.shape) == (6, 3, 64, 64) and torch.equal(ia, idx[:6]) and torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # a frame's x0 / noise draws do not depend on how the frames were batched: another batch size gives the same frames up
+    # to the kernels' batch-dependent summation order
+    c, _ = sample(prompts, wav, 1024 * fps, fps, n_frames=6, size=(64, 64), timesteps=5, model=net, diffusion=sd,
+                  grad_modules=[MSEGuide(100.0)], seed=4, batch=2)
+    assert float((a - c).abs().max()) <= 0.05 * float(a.abs().max())
 
 
 # ------------------------------------------------------------------------------------------------ secondary model / "fast" guidance
