@@ -533,6 +533,57 @@ int maua_unet_guided_graph_active(maua_unet* net, int* active);
 int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, long target_bstride, float k, int B, long row,
                         float* out);
 
+/* ---- text-prompt guidance: CLIPGrads (configs[3]: "audio-onset-switched text prompts") ------------------------------------
+ * Replaces maua/grad.py:96-165: per sampler step, `cutout_batches` x { MauaCutouts of the image estimate (maua/ops/cutouts.py:8-50),
+ * Normalize, clip_model.encode_image (OpenAI CLIP VisionTransformer: un-vendored pip dependency, published architecture restated,
+ * parity unpinned), spherical_dist_loss to the target embeddings (maua/loss.py:22-25), weights, mean over cutouts,
+ * torch.autograd.grad(loss.sum() * scale, img) / cutout_batches }, clamp_gradient.  The gradient is evaluated on the transposed
+ * network inside the library (csrc/clip.hip, cutouts.hip, gemm_dma.hip).  The text tower is NOT here: target embeddings are handed
+ * in (TextPrompt embeddings computed once, off the loop - set_targets :117-143); image (style) targets can be embedded with
+ * maua_clip_encode_image.  dtype: MAUA_BF16 (the reference runs the perceptor in fp16) or MAUA_F32 (exact products, parity mode).
+ * Parameter names: CLIP's state-dict keys below "visual." (conv1.weight, class_embedding, positional_embedding, ln_pre.*,
+ * transformer.resblocks.<i>.{attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.*, ln_1.*, mlp.c_fc.*, mlp.c_proj.*, ln_2.*},
+ * ln_post.*, proj), host float32 in the checkpoint's layout. */
+typedef struct maua_clip maua_clip;
+int maua_clip_create(maua_ctx* ctx, int input_resolution, int patch_size, int width, int layers, int heads, int output_dim, int dtype,
+                     maua_clip** out);
+void maua_clip_destroy(maua_clip* net);
+int maua_clip_load(maua_clip* net, const char* name, const float* host_data, size_t count);
+/* VisionTransformer.forward (clip/model.py): images device f32 [N][3][R][R], already normalised -> embeds device f32 [N][E];
+ * keep != 0 keeps the activations for maua_clip_encode_image_vjp: d_embeds [N][E] -> d_images [N][3][R][R] */
+int maua_clip_encode_image(maua_clip* net, const float* images, int N, int keep, float* embeds);
+int maua_clip_encode_image_vjp(maua_clip* net, const float* d_embeds, int N, float* d_images);
+/* the buffers CLIPGrads.set_targets registers (:134-143): S sets of P target embeddings [S][P][E] (host or device; normalised here
+ * as spherical_dist_loss does) with prompt weights [S][P] (already divided by |sum|, :139-143); sel: host [B] - the set each sample
+ * of a batch is guided towards (prompts switched per frame by the clip's onsets) - or NULL: set 0 for every sample */
+int maua_clip_set_targets(maua_clip* net, const float* targets, const float* weights, int S, int P, const int* sel, int B);
+/* CLIPGrads.forward (:145-159): img device f32 [B][3][H][W] in [-1, 1]; rects HOST int [batches][cutn][3] = (size, top, left) of
+ * every cutout of every cutout batch (the host draws them like MauaCutouts.forward does); grad device f32 [B][3][H][W];
+ * clamp_gradient <= 0: none; a result holding a NaN is returned as zeros (guided.py:262-265) */
+int maua_clip_guide_grad(maua_clip* net, const float* img, int B, int H, int W, const int* rects, int cutn, int batches, float scale,
+                         float clamp_gradient, float* grad);
+/* sum_p w_p dist_p of the first `count` cutout images of the last pass through the tower (cutout-major; device f32 [count]) */
+int maua_clip_last_image_losses(maua_clip* net, int count, float* out);
+/* the guided loop with THIS grad module: the following maua_ddim_guided_loop calls on `net` (speed "fast": a secondary model, or
+ * "regular") evaluate CLIPGrads on the image estimate instead of the image-MSE module (their target / mse_k arguments are ignored);
+ * rects: HOST int [n_steps][batches][cutn][3], one draw per step and cutout batch, read at every call of the loop.  clip == NULL:
+ * back to the image-MSE module.  The whole step - UNet, secondary model, cutouts, image tower forward and backward, DDIM update -
+ * stays one hipGraph. */
+int maua_unet_set_clip_guide(maua_unet* net, maua_clip* clip, const int* rects, int n_steps, int cutn, int batches, float scale,
+                             float clamp_gradient);
+/* operator-level pieces.  maua_cutouts: random_cutouts (cutouts.py:8-38) on HOST rectangles [n_cut][3] applied to img * mul + add,
+ * resized to cut_size^2 by the `resize_right` algorithm (cubic, antialiased, zero padding), Normalize(mean3, std3) -> out device f32
+ * [n_cut * B][3][cut_size][cut_size] (cutout-major, like torch.cat); maua_cutouts_vjp: d_out -> d_img [B][3][H][W] */
+int maua_cutouts(maua_ctx* ctx, const float* img, int B, int H, int W, const int* rects, int n_cut, int cut_size, float mul, float add,
+                 const float* mean3, const float* std3, float* out);
+int maua_cutouts_vjp(maua_ctx* ctx, const float* d_out, int B, int H, int W, const int* rects, int n_cut, int cut_size, float mul,
+                     const float* std3, float* d_img);
+/* nn.LayerNorm over the last dimension of x [rows][C] in dtype (float32 statistics, eps 1e-5; clip/model.py LayerNorm); stats:
+ * optional device f32 [rows][2] = (mean, rstd), what maua_layer_norm_vjp needs: dx = d LayerNorm / d x applied to dy (+ add) */
+int maua_layer_norm(maua_ctx* ctx, const void* x, const float* gamma, const float* beta, long rows, int C, int dtype, void* y, float* stats);
+int maua_layer_norm_vjp(maua_ctx* ctx, const void* x, const float* stats, const float* gamma, const void* dy, const void* add, long rows,
+                        int C, int dtype, void* dx);
+
 /* ---- build-owned counter RNG: Philox4x32-10, identical on every device / rank and in the oracle twin (oracle/rng.py,
  * pinned to the published known-answer vectors).  No reference counterpart: the reference's random-init generator and noise planes
  * come from torch's host generator (inference/stylegan2.py:216-227, selfsupervised/noise.py:42-53); the benchmark's synthetic

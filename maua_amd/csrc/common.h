@@ -149,6 +149,8 @@ struct maua_ctx {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   int dma_conv = 1;  // operator-level modconv: eligible shapes run the LDS-direct-load kernel (maua_ctx_set_option)
+  int gemm_dma = 1;  // clip.hip: large plain GEMMs on gemm_dma.hip (option "gemm_dma")
+  int linear_dma = 0;  // maua_linear_nt: the same routing for operator-level callers (option "linear_dma")
 };
 
 namespace maua {

@@ -60,6 +60,14 @@ int maua_ctx_set_option(maua_ctx* ctx, const char* key, int value) {
     ctx->dma_conv = value;
     return MAUA_OK;
   }
+  if (std::string(key) == "linear_dma") {
+    ctx->linear_dma = value;
+    return MAUA_OK;
+  }
+  if (std::string(key) == "gemm_dma") {   // the CLIP tower's large GEMMs on the LDS-direct kernel (0: gemm.hip's register-staged kernels)
+    ctx->gemm_dma = value;
+    return MAUA_OK;
+  }
   return maua::fail(std::string("maua_ctx_set_option: unknown option ") + key);
 }
 

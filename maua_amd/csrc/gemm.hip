@@ -282,6 +282,8 @@ int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
                "gemm_nt: K parts must be multiples of 64 bytes");
   MAUA_REQUIRE(g.N % 32 == 0 && g.N > 0 && g.lda0 % 4 == 0 && g.ldc % 4 == 0, "gemm_nt: N must be a multiple of 32");
   if (g.M == 0) return MAUA_OK;
+  if (g.prefer_dma && gemm_dma_supported(dtype, g)) return launch_gemm_dma(stream, g);
+  MAUA_REQUIRE(g.epi == 0, "gemm_nt: the QuickGELU epilogue forms exist on the LDS-direct kernel only (callers check gemm_dma_supported)");
   const int kcw = dtype == MAUA_BF16 ? 64 : 32;   // channels per 128-byte chunk
   const int epc = dtype == MAUA_BF16 ? 8 : 4;
   if (!g.c_f32 && g.K0 % kcw == 0 && g.K1 % kcw == 0 && g.M >= 128 && g.ldc % epc == 0 && (!g.res || g.ldr % epc == 0) &&

@@ -244,8 +244,16 @@ struct GemmArgs {
   long M;
   int N;
   int c_f32;
+  // gemm_dma.hip only (prefer_dma: large plain GEMMs of the CLIP image tower, clip.hip; bf16, N % 128 == 0, K % 64 == 0):
+  int prefer_dma;       // route to the LDS-direct kernel when the shape allows it
+  int epi;              // 0; 1: c2 <- QuickGELU(c) as well; 2: c <- c * QuickGELU'(aux)
+  void* c2; long ldc2;
+  const void* aux; long ldaux;
 };
 int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g);
+// gemm_dma.hip: 256 x 128 tiles on LDS-direct loads (see there); launch_gemm_nt routes when g.prefer_dma
+bool gemm_dma_supported(int dtype, const GemmArgs& g);
+int launch_gemm_dma(hipStream_t stream, const GemmArgs& g);
 
 // ---- attention.hip: softmax(Q K^T / sqrt(D)) V per (sample, head); qkv [B][T][ld_qkv] with head-major [q | k | v] channel
 // layout (guided-diffusion's QKVAttentionLegacy), out [B][T][ld_out] with channel = head * D + d
@@ -299,9 +307,37 @@ struct GnVjpArgs {
 size_t group_norm_vjp_workspace(int B, int C, long HW, int esize);
 int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, void* workspace);
 
+// cutouts.hip: random cutouts resized to the perceptor's input (maua/ops/cutouts.py:8-50 as CLIPGrads calls it) and their gradient.
+// rects: DEVICE [n_cut][3] (size, top, left); tables: cutouts_table_bytes() of device scratch filled by launch_cutout_tables;
+// out / d_out: planar f32 [n_cut * B][3][cs][cs] (patch == 0) or patch rows in dtype [n_cut * B * (cs / patch)^2][3 * patch^2];
+// th: cutouts_th_bytes() of scratch; grad: [B][3][H][W] f32
+struct CutoutPlan {
+  const float* img;
+  const int* rects;
+  int B, H, W, n_cut, cs;
+  float mul, add;          // affine applied to the image first ((img + 1) / 2: 0.5, 0.5)
+  float mean[3], std[3];   // Normalize applied to the cutouts
+  int patch;
+};
+size_t cutouts_table_bytes(int n_cut, int cs);
+size_t cutouts_th_bytes(int n_cut, int B, int cs, int smax);
+int launch_cutout_tables(hipStream_t stream, const CutoutPlan& p, void* tables);
+int launch_cutouts_forward(hipStream_t stream, int dtype, const CutoutPlan& p, void* tables, void* out);
+int launch_cutouts_vjp(hipStream_t stream, int dtype, const CutoutPlan& p, void* tables, const void* d_out, float* th, float* grad,
+                       int accumulate);
+
 // secondary.hip: the context a secondary diffusion model was created on
 maua_ctx* secondary_ctx(maua_secondary* n);
 // (uid, epoch) of a secondary model's device buffers: whoever caches pointers into them (a captured graph) compares both before reuse
 void secondary_stamp(maua_secondary* n, unsigned long long* uid, unsigned long long* epoch);
+
+// clip.hip: pieces the captured guided loop (unet.hip) drives.  clip_prepare_guide allocates (never inside a capture);
+// clip_guide_grad = CLIPGrads.forward on DEVICE rectangles [batches][cutn][3]
+maua_ctx* clip_ctx(maua_clip* n);
+void clip_stamp(maua_clip* n, unsigned long long* uid, unsigned long long* epoch);
+int clip_group_size(maua_clip* n, int B, int cutn);
+int clip_prepare_guide(maua_clip* n, int B, int H, int W, int n_cut_group);
+int clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, int cutn, int batches, float scale,
+                    float clamp_gradient, float* grad);
 
 }  // namespace maua

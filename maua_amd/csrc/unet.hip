@@ -761,6 +761,14 @@ struct maua_unet {
   hipGraphExec_t gd_exec = nullptr;
   size_t gd_key = 0;
   unsigned long long gd_sec_uid = 0, gd_sec_epoch = 0;   // the secondary model (and its buffers' generation) gd_exec points into
+  // text-prompt guidance (maua_unet_set_clip_guide): CLIPGrads instead of the image-MSE module in the guided loop
+  maua_clip* gd_clip = nullptr;
+  int* gd_rects = nullptr;           // device [n_steps][batches][cutn][3]
+  size_t gd_rects_cap = 0;
+  std::vector<int> gd_rects_host;
+  int gd_rect_steps = 0, gd_cutn = 0, gd_batches = 0;
+  float gd_clip_scale = 1.f, gd_clip_clamp = 0.f;
+  unsigned long long gd_clip_uid = 0, gd_clip_epoch = 0, gd_guide_gen = 0, gd_guide_gen_seen = 0;
   int gd_failed = 0;
   float* gd_buf = nullptr;           // x | v | pred | eps | img | g | jv | grad | target, B * C * H * W floats each
   size_t gd_cap = 0;
@@ -1452,7 +1460,7 @@ void maua_unet_destroy(maua_unet* n) {
   if (n->cap_side) hipStreamDestroy(n->cap_side);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_join) hipEventDestroy(n->ev_join);
-  for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
+  for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag, (void*)n->gd_rects})
     if (p) hipFree(p);
   for (void* p : n->owned) hipFree(p);
   if (n->arena.base) hipFree(n->arena.base);
@@ -1723,6 +1731,7 @@ int maua_linear_nt(maua_ctx* ctx, const void* a, const void* w, const float* bia
   MAUA_REQUIRE(ctx, "maua_linear_nt: ctx is NULL");
   GemmArgs g{};
   g.a0 = a; g.lda0 = K; g.K0 = K; g.w = w; g.bias = bias; g.res = res; g.ldr = N; g.c = c; g.ldc = N; g.M = M; g.N = N;
+  g.prefer_dma = ctx->linear_dma;   // (option "linear_dma": large shapes on gemm_dma.hip - what the CLIP tower's projections run on)
   return launch_gemm_nt(ctx->stream, dtype, g);
 }
 
@@ -1965,7 +1974,7 @@ int maua_mse_guide_grad(maua_ctx* ctx, const float* img, const float* target, lo
 int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, int H, int W, const float* model_t, const float* coef,
                           const float* guide, int n_steps, const float* target, long target_bstride, float mse_k, int use_graph,
                           float* pred_xstart) {
-  MAUA_REQUIRE(n && x && model_t && coef && guide && target && n_steps > 0, "maua_ddim_guided_loop: NULL argument");
+  MAUA_REQUIRE(n && x && model_t && coef && guide && n_steps > 0, "maua_ddim_guided_loop: NULL argument");
   // sec == NULL: speed "regular" (guided.py:214-218, 250-252) - the gradient goes through THIS network: a kept forward + its input
   // gradient per step, no secondary model
   const bool regular = sec == nullptr;
@@ -1981,6 +1990,19 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   if (B == 0) return MAUA_OK;
   hipStream_t st = n->ctx->stream;
   const size_t key = shape_key(B, H, W) ^ ((size_t)n_steps << 52) ^ ((size_t)(uintptr_t)sec << 1) ^ (target_bstride ? 1u : 0u) ^ (regular ? 2u : 0u);
+  maua_clip* const clip = n->gd_clip;
+  if (clip) {
+    MAUA_REQUIRE(clip_ctx(clip) == n->ctx, "maua_ddim_guided_loop: the image tower must live on the networks' context");
+    MAUA_REQUIRE(n->gd_rect_steps == n_steps, "maua_ddim_guided_loop: maua_unet_set_clip_guide was given another number of steps");
+    MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: CLIP guides 3-channel images");
+    for (size_t i = 0; i < n->gd_rects_host.size(); i += 3)
+      MAUA_REQUIRE(n->gd_rects_host[i] > 0 && n->gd_rects_host[i + 1] >= 0 && n->gd_rects_host[i + 2] >= 0 &&
+                       n->gd_rects_host[i + 1] + n->gd_rects_host[i] <= H && n->gd_rects_host[i + 2] + n->gd_rects_host[i] <= W,
+                   "maua_ddim_guided_loop: a cutout leaves the image");
+    if (int rc = clip_prepare_guide(clip, B, H, W, clip_group_size(clip, B, n->gd_cutn))) return rc;
+  } else {
+    MAUA_REQUIRE(target, "maua_ddim_guided_loop: target is NULL");
+  }
   if (int rc = prepare_sampler(n, B, H, W, model_t, coef, n_steps)) return rc;
   const size_t tb = (size_t)B * chw, tab = (size_t)n_steps * B * 7 + B;
   if (n->gd_cap < 9 * tb || n->gd_tab_cap < tab || !n->gd_flag || n->gd_flags < n_steps) {
@@ -2017,7 +2039,14 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   }
   MAUA_HIP_CHECK(hipMemsetAsync(n->gd_flag, 0, (size_t)n_steps * 4, st));
   MAUA_HIP_CHECK(hipMemcpyAsync(bx, x, tb * 4, hipMemcpyDeviceToDevice, st));
-  MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
+  if (!clip) MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
+  // the grad module of step s on the context's current stream: bimg -> bg
+  auto guide_grad = [&](int s) -> int {
+    if (clip)
+      return clip_guide_grad(clip, bimg, B, H, W, n->gd_rects + (size_t)s * n->gd_batches * n->gd_cutn * 3, n->gd_cutn, n->gd_batches,
+                             n->gd_clip_scale, n->gd_clip_clamp, bg);
+    return mse_guide_grad(n->ctx, bimg, btgt, target_bstride ? chw : 0, t_k, B, chw, bg, n->gd_flag + s, false);
+  };
   const long tstride = target_bstride ? chw : 0;
   if (n->gd_fork && !n->ev_fork) {
     MAUA_HIP_CHECK(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
@@ -2042,7 +2071,7 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
       if (!rc) rc = maua_axpby_rows(n->ctx, bx, be, t_pred + (size_t)s * B * 2, B, chw, bp);
       if (!rc) rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg);
     }
-    if (!rc) rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false);
+    if (!rc) rc = guide_grad(s);
     if (!rc) rc = n->dtype == MAUA_BF16 ? run_vjp<bf16_t>(n, bg, bjv, n->in_ch) : run_vjp<float>(n, bg, bjv, n->in_ch);
     n->emb_row = nullptr;
     if (!rc) rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad);
@@ -2065,7 +2094,7 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
       n->ctx->stream = side;
       rc = maua_secondary_forward(sec, bx, t_ct + (size_t)s * B, B, H, W, bv, bp, be);
       if (!rc) rc = maua_axpby_rows(n->ctx, bp, bx, t_img + (size_t)s * B * 2, B, chw, bimg);
-      if (!rc) rc = mse_guide_grad(n->ctx, bimg, btgt, tstride, t_k, B, chw, bg, n->gd_flag + s, false);
+      if (!rc) rc = guide_grad(s);
       if (!rc) rc = maua_secondary_vjp(sec, bg, B, H, W, bjv);
       if (!rc) rc = maua_axpby_rows(n->ctx, bg, bjv, t_grad + (size_t)s * B * 2, B, chw, bgrad);
     }
@@ -2086,9 +2115,12 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   // the captured graph holds raw pointers into the secondary model's weights and workspaces: it is this model's, at this generation
   // of its buffers, or it is recaptured (the address alone does not identify a model: a freed one's can be handed out again)
   unsigned long long sec_uid = 0, sec_epoch = 0;
+  unsigned long long clip_uid = 0, clip_ep = 0;
   auto sec_matches = [&]() {
     secondary_stamp(sec, &sec_uid, &sec_epoch);
-    return sec_uid == n->gd_sec_uid && sec_epoch == n->gd_sec_epoch;
+    clip_stamp(clip, &clip_uid, &clip_ep);
+    return sec_uid == n->gd_sec_uid && sec_epoch == n->gd_sec_epoch && clip_uid == n->gd_clip_uid && clip_ep == n->gd_clip_epoch &&
+           n->gd_guide_gen == n->gd_guide_gen_seen;
   };
   if (use_graph && !n->gd_failed) {
     if (!n->gd_exec || n->gd_key != key || !sec_matches()) {
@@ -2123,6 +2155,8 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
       } else {
         n->gd_key = key;
         secondary_stamp(sec, &n->gd_sec_uid, &n->gd_sec_epoch);   // (after the eager step: that is what sized the workspaces)
+        clip_stamp(clip, &n->gd_clip_uid, &n->gd_clip_epoch);
+        n->gd_guide_gen_seen = n->gd_guide_gen;
       }
     }
   }
@@ -2137,6 +2171,38 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   }
   MAUA_HIP_CHECK(hipMemcpyAsync(x, bx, tb * 4, hipMemcpyDeviceToDevice, st));
   if (pred_xstart) MAUA_HIP_CHECK(hipMemcpyAsync(pred_xstart, n->g_pred, tb * 4, hipMemcpyDeviceToDevice, st));
+  return MAUA_OK;
+}
+
+// CLIPGrads as the guided loop's grad module (maua/grad.py:96-165 in place of the image-MSE module); rects: host [n_steps][batches][cutn][3]
+int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, int n_steps, int cutn, int batches, float scale,
+                             float clamp_gradient) {
+  MAUA_REQUIRE(n, "maua_unet_set_clip_guide: net is NULL");
+  if (!clip) {
+    if (n->gd_clip) n->gd_guide_gen++;
+    n->gd_clip = nullptr;
+    return MAUA_OK;
+  }
+  MAUA_REQUIRE(rects && n_steps > 0 && cutn > 0 && batches > 0, "maua_unet_set_clip_guide: bad arguments");
+  hipStream_t st = n->ctx->stream;
+  const size_t cnt = (size_t)n_steps * batches * cutn * 3;
+  if (cnt > n->gd_rects_cap) {
+    MAUA_HIP_CHECK(hipStreamSynchronize(st));
+    if (n->gd_rects) hipFree(n->gd_rects);
+    n->gd_rects = nullptr; n->gd_rects_cap = 0;
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_rects, cnt * 4));
+    n->gd_rects_cap = cnt;
+    n->gd_guide_gen++;
+  }
+  // (everything a captured loop bakes into its launches moves the generation; the rectangles themselves are data it reads)
+  if (n->gd_clip != clip || n->gd_rect_steps != n_steps || n->gd_cutn != cutn || n->gd_batches != batches || n->gd_clip_scale != scale ||
+      n->gd_clip_clamp != clamp_gradient)
+    n->gd_guide_gen++;
+  n->gd_rects_host.assign(rects, rects + cnt);
+  MAUA_HIP_CHECK(hipMemcpyAsync(n->gd_rects, n->gd_rects_host.data(), cnt * 4, hipMemcpyHostToDevice, st));
+  MAUA_HIP_CHECK(hipStreamSynchronize(st));
+  n->gd_clip = clip; n->gd_rect_steps = n_steps; n->gd_cutn = cutn; n->gd_batches = batches; n->gd_clip_scale = scale;
+  n->gd_clip_clamp = clamp_gradient;
   return MAUA_OK;
 }
 

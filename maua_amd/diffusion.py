@@ -19,10 +19,13 @@ maua_unet_vjp - the network walked backwards in the library: every convolution's
 transposed kernel, GroupNorm / SiLU / resampling and attention have hand-written input-gradient kernels).  All three samplers of guided.py:302-311 exist ("ddim":
 configs[3]; "p"; "plms": the fork's sampler restated from its published algorithm).
 
-What is NOT here, and why: the reference's text prompts go through CLIP / LPIPS perceptors (maua/grad.py:48-199: un-vendored
-models, no network for weights) - **parity of text-prompt guidance is unpinnable here**.  ``grad_modules`` are caller-supplied
-objects with the contract of maua/grad.py:15-25 (``scale``, ``set_targets(prompts)``, ``__call__(img, t) -> d loss / d img`` on the
-device); ``MSEGuide`` (image targets) is the one shipped, and BASELINE configs[3] is measured with it.
+Grad modules: ``maua_amd.grad.CLIPGrads`` (round 6: maua/grad.py:96-165 - MauaCutouts, the CLIP image tower forward AND its input
+gradient, spherical distance to the target embeddings - inside the library, also inside the captured guided loop) is what
+configs[3]'s "text prompts" go through; the perceptor itself is an un-vendored pip dependency (published architecture restated,
+**parity unpinned**; no weights in the image: benchmarks run it random-init like the UNet) and the text tower stays outside (target
+embeddings are handed in).  ``MSEGuide`` (image targets) is the module that needs no perceptor.  Any other caller-supplied object with
+the contract of maua/grad.py:15-25 (``scale``, ``set_targets(prompts)``, ``__call__(img, t) -> d loss / d img`` on the device) works
+step by step; ColorMatch / VGG / LPIPS grads (:48-93, :167-199) are not built.
 """
 import ctypes as C
 import math
@@ -529,14 +532,26 @@ class SpacedDiffusion:
         gc = np.ascontiguousarray(conditioning.guide_coefficients(mtt).numpy(), dtype=np.float32)
         gm = conditioning.grad_modules[0]
         x = L.dev_tensor(x, torch.float32)
-        tgt = L.dev_tensor(gm.target, torch.float32)
         B, _, H, W = x.shape
-        if tuple(tgt.shape) == tuple(x.shape[1:]):
-            tstride = 0
-        elif tuple(tgt.shape) == tuple(x.shape):
-            tstride = x[0].numel()
+        spec = gm.graph_spec() if hasattr(gm, "graph_spec") else None
+        if spec is not None:
+            # text-prompt guidance (CLIPGrads, maua/grad.py:96-165): the cutout rectangles of every step and cutout batch are drawn
+            # here, in the order the step-by-step path draws them (per step: grad.py:149's t[[0]] = that step's model timestep)
+            gm.install_targets(0, B)
+            rects = np.ascontiguousarray(np.stack([gm.draw_rects(0, H, W, mtt[s:s + 1]) for s in range(n_steps)]), dtype=np.int32)
+            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), spec["clip"]._handle(), rects.ctypes.data_as(C.c_void_p), n_steps,
+                                                     spec["cutn"], spec["batches"], C.c_float(spec["scale"]), C.c_float(spec["clamp"])))
+            tgt, tstride, mse_k = None, 0, 0.0
         else:
-            raise ValueError(f"ddim_guided_loop: target shape {tuple(tgt.shape)} fits neither {tuple(x.shape[1:])} nor {tuple(x.shape)}")
+            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), None, None, 0, 0, 0, C.c_float(0.0), C.c_float(0.0)))
+            tgt = L.dev_tensor(gm.target, torch.float32)
+            mse_k = gm.factor(x[0].numel())
+            if tuple(tgt.shape) == tuple(x.shape[1:]):
+                tstride = 0
+            elif tuple(tgt.shape) == tuple(x.shape):
+                tstride = x[0].numel()
+            else:
+                raise ValueError(f"ddim_guided_loop: target shape {tuple(tgt.shape)} fits neither {tuple(x.shape[1:])} nor {tuple(x.shape)}")
         pred = torch.empty_like(x)
         if conditioning.speed == "fast":
             second = conditioning.model._handle()
@@ -548,7 +563,7 @@ class SpacedDiffusion:
         L.check(L.lib().maua_ddim_guided_loop(model._handle(), second, L.ptr(x), B, H, W,
                                               mt.ctypes.data_as(C.c_void_p), cf.ctypes.data_as(C.c_void_p),
                                               gc.ctypes.data_as(C.c_void_p), n_steps, L.ptr(tgt), C.c_long(tstride),
-                                              C.c_float(gm.factor(x[0].numel())), int(bool(use_graph)), L.ptr(pred)))
+                                              C.c_float(mse_k), int(bool(use_graph)), L.ptr(pred)))
         return x, pred
 
 
@@ -814,10 +829,15 @@ class GradientGuidedConditioning(torch.nn.Module):
         return torch.stack([cosine_t, sigma, 1 - sigma, -(sigma * a_c + 1 - sigma), sigma * s_c], 1).float().contiguous()
 
     def graphable(self):
-        """True when the whole guided step is library work (speed "fast" or "regular", exactly one image-MSE grad module with a
-        target): the sampler loop then runs as one hipGraph (SpacedDiffusion.ddim_guided_loop)."""
-        return (self.speed != "hyper" and len(self.grad_modules) == 1 and isinstance(self.grad_modules[0], MSEGuide)
-                and self.grad_modules[0].target is not None)
+        """True when the whole guided step is library work (speed "fast" or "regular", exactly one grad module the library has: the
+        image-MSE module with a target, or CLIPGrads with one perceptor): the sampler loop then runs as one hipGraph
+        (SpacedDiffusion.ddim_guided_loop)."""
+        if self.speed == "hyper" or len(self.grad_modules) != 1:
+            return False
+        gm = self.grad_modules[0]
+        if hasattr(gm, "graph_spec"):      # CLIPGrads (maua_amd/grad.py): one perceptor, targets set
+            return gm.graph_spec() is not None
+        return isinstance(gm, MSEGuide) and gm.target is not None
 
     def forward(self, x, t, kw={}):
         ot = t.clone()

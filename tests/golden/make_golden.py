@@ -1073,6 +1073,45 @@ def golden_offpath():
     save("g31_offpath_ops", **out)
 
 
+def golden_cutouts():
+    """g33: the text-prompt guidance path's two in-tree pieces, computed by the reference's own functions.
+    (a) maua/loss.py:22-25 spherical_dist_loss on random embeddings (incl. the broadcast shape CLIPGrads uses).
+    (b) maua/ops/cutouts.py:8-50 random_cutouts / MauaCutouts on seeded inputs: the ``resize_right`` package is absent from the image,
+        so the reference's function runs with oracle.clip.resize (the published algorithm restated) standing in for it - what this
+        pins is everything AROUND the resize: the rectangle arithmetic, the draws from torch's global generator and their order, the
+        pow schedule over t, the concatenation order.  The rectangles are recovered from the views the reference hands to ``resize``."""
+    import maua.loss as RL
+    import maua.ops.cutouts as RC
+    from oracle import clip as OC
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(64, 1, 24, generator=g)
+    y = torch.randn(1, 5, 24, generator=g)
+    out = {"sd_x": x, "sd_y": y, "sd_out": RL.spherical_dist_loss(x, y)}
+    seen = []
+
+    def spy_resize(cutout, out_shape):
+        base = cutout._base if cutout._base is not None else cutout
+        W = base.shape[-1]
+        off = cutout.storage_offset() - base.storage_offset()
+        seen.append((cutout.shape[-1], (off // W) % base.shape[-2], off % W))
+        return OC.resize(cutout, out_shape)
+    RC.resize = spy_resize
+    for k, (H, W, cs, cutn, t, seed) in enumerate(((40, 40, 32, 8, 900, 1), (48, 36, 32, 8, 100, 2), (30, 44, 32, 12, 500, 3),
+                                                   (256, 256, 224, 32, 981, 4), (24, 24, 32, 8, 300, 5))):
+        img = torch.rand(2, 3, H, W, generator=g)
+        seen.clear()
+        torch.manual_seed(seed)
+        cuts = RC.MauaCutouts(cs, cutn)(img, torch.tensor([float(t), 3.0])[[0]].long())   # (grad.py:149: t[[0]].long())
+        out[f"cut{k}_cfg"] = np.array([H, W, cs, cutn, t, seed], dtype=np.int64)
+        out[f"cut{k}_rects"] = np.array(seen, dtype=np.int64)
+        if H <= 64:
+            out[f"cut{k}_img"] = img
+            out[f"cut{k}_out"] = cuts
+        else:   # (the full-size case: rectangles only - what the sampler draws per step at 256^2 / 224)
+            out[f"cut{k}_sum"] = cuts.double().sum((1, 2, 3)).float()
+    save("g33_cutouts", **out)
+
+
 if __name__ == "__main__":
     import_reference()
     which = sys.argv[1:] or ["ops", "modules", "audio", "latents", "noise", "io"]
