@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--strict", action="store_true",
                     help="exit with status 3 (after printing the headline line) when the clip leg's exchange fails or hangs at N > 1; "
                          "by default the status stays 0 and the line carries \"ok\": false")
+    ap.add_argument("--diffusion-arms", action="store_true",
+                    help="configs[3] leg: also time the secondary model's other arithmetic modes (exact f32, bf16): four more 100-step loops")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the configs[3] (guided-diffusion DDIM) and configs[4] (render -> RealESRGAN x4) legs (extra keys)")
     return ap.parse_args()
@@ -289,6 +291,58 @@ def leg_traffic(leg):
         return None, f"unmeasured ({type(e).__name__}: no PMC file for this leg)"
 
 
+def live_leg_traffic(leg, batch, timeout_s=150):
+    """HBM bytes per unit of an extra leg measured NOW, at the leg's own batch: two counter passes (rocprofv3
+    --kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE; separate child runs, the guide's unit and gfx950 corrections) over
+    scripts/leg_probe.py - a few launch-by-launch steps of the leg - summed over EVERY kernel between the last two marker launches
+    (diffusion: one ddim_step_kernel per guided step; upscale: one fused last-block walk per synthesis call).  (None, why) when the
+    profiler is unavailable - the caller then replays the newest profiles/ file and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("MAUA_BENCH_NO_LIVE_TRAFFIC"):
+        return None, "live counter passes disabled (MAUA_BENCH_NO_LIVE_TRAFFIC)"
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself under rocprofv3"
+    root = os.path.dirname(os.path.abspath(__file__))
+    if leg == "diffusion":
+        cmd = [sys.executable, os.path.join(root, "scripts", "leg_probe.py"), "diffusion", "--batch", str(batch), "--steps", "3"]
+        marker, per, unit = "ddim_step_kernel", 1, f"one guided step (UNet forward + secondary forward / VJP + update) at batch {batch}"
+    else:
+        cmd = [sys.executable, os.path.join(root, "scripts", "leg_probe.py"), "upscale", "--frames", str(batch), "--steps", "2"]
+        marker, per, unit = "upwalk_fused_kernel", batch, "one 1024^2 frame rendered and up-scaled x4 to 4096^2 u8"
+    t0 = time.perf_counter()
+    try:
+        tot = {}
+        with tempfile.TemporaryDirectory(prefix="maua_legtraffic_") as tmp:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                env = dict(os.environ, TMPDIR="/tmp", MAUA_BENCH_NO_LIVE_TRAFFIC="1")
+                subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", counter, "--", *cmd],
+                               check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root, timeout=timeout_s)
+                f = glob.glob(os.path.join(tmp, "**", f"{counter}_counter_collection.csv"), recursive=True)[0]
+                per_disp, names = {}, {}
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter:
+                        d = int(r["Dispatch_Id"])
+                        per_disp[d] = per_disp.get(d, 0.0) + float(r["Counter_Value"])
+                        names[d] = r["Kernel_Name"]
+                marks = sorted(d for d, nm in names.items() if marker in nm)
+                if len(marks) < 2:
+                    return None, f"the counter pass saw {len(marks)} launches of {marker}"
+                lo, hi = marks[-2], marks[-1]
+                tot[counter] = sum(v for d, v in per_disp.items() if lo < d <= hi)
+        by = (2.0 * 1024 * tot["FETCH_SIZE"] + 1024 * tot["WRITE_SIZE"]) / per
+        return by, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two separate child passes of "
+                    "scripts/leg_probe.py at this leg's batch, every kernel between the last two %s launches summed; per %s "
+                    "(FETCH_SIZE x 2 and KiB -> B per the guide's gfx950 corrections; %.0f s)" % (marker, unit, time.perf_counter() - t0))
+    except Exception as e:   # noqa: BLE001
+        return None, "live counter passes failed: " + repr(e)[:200]
+
+
 def measured_traffic(kernel_name, batch=None):
     """HBM bytes per launch measured with rocprofv3 --pmc in an EARLIER run of this same command: profiles/traffic.json,
     written by scripts/collect_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes with the corrections of
@@ -346,7 +400,7 @@ def live_traffic(kernel_name, batch, timeout_s=90):
         return None, "live counter passes failed: " + repr(e)[:200]
 
 
-def extra_diffusion(batch=32, steps=100, size=256):
+def extra_diffusion(batch=32, steps=100, size=256, clip_batch=8, full_arms=False, traffic=True):
     """configs[3] as BASELINE states it: guided-diffusion UNet (guided.py:171-190's architecture, random init), `steps`-step DDIM at
     `size`^2 with the reference's DEFAULT guidance (speed "fast": secondary-model forward + the gradient back through it every step,
     guided.py:236-272) towards image targets that switch with the clip's onset peaks (onset_prompt_schedule; text prompts need CLIP
@@ -407,64 +461,150 @@ def extra_diffusion(batch=32, steps=100, size=256):
         return best, bool(torch.isfinite(out).all()), model.guided_graph_active()
     # the default (create_models): the secondary model in float32 like the reference keeps it, its products as bf16 split products
     best, finite, graphed = guided_leg(secondary)
-    sec32 = SecondaryDiffusionImageNet2(dtype=torch.float32, exact=True)   # every product on the exact-f32 matrix path
-    sec32.load_state_dict(secondary.state_dict())
-    best32, finite32, graphed32 = guided_leg(sec32)
-    del sec32
-    sec16 = SecondaryDiffusionImageNet2(dtype=torch.bfloat16)
-    sec16.load_state_dict(secondary.state_dict())
-    best16, finite16, graphed16 = guided_leg(sec16)
+    arms = {}
+    if full_arms:   # (--diffusion-arms: the secondary model's other arithmetic modes, rounds 4-5's sub-keys; 2 more 100-step loops each)
+        sec32 = SecondaryDiffusionImageNet2(dtype=torch.float32, exact=True)   # every product on the exact-f32 matrix path
+        sec32.load_state_dict(secondary.state_dict())
+        best32, finite32, graphed32 = guided_leg(sec32)
+        del sec32
+        sec16 = SecondaryDiffusionImageNet2(dtype=torch.bfloat16)
+        sec16.load_state_dict(secondary.state_dict())
+        best16, finite16, graphed16 = guided_leg(sec16)
+        del sec16
+        arms = {"guided_exact_f32_secondary": {"value": batch / best32, "unit": "samples/s", "seconds_per_batch": best32, "hipgraph": graphed32,
+                                               "finite": finite32, "over_unguided": best_u / best32,
+                                               "note": "every product of the secondary model on the exact-f32 matrix path (v_mfma_f32_32x32x2_f32)"},
+                "guided_bf16_secondary": {"value": batch / best16, "unit": "samples/s", "seconds_per_batch": best16, "hipgraph": graphed16,
+                                          "finite": finite16, "over_unguided": best_u / best16,
+                                          "note": "opt-in: secondary model in bf16 (guidance gradient 3.5 % off the reference's in L2 norm)"}}
     # ---- speed "regular" (guided.py:250-252): the loss gradient through the diffusion UNet itself - a kept forward + the network
     # walked backwards every step (maua_unet_forward_keep / maua_unet_vjp), the loop one hipGraph like the "fast" one
-    # (maua_ddim_guided_loop without a secondary model); timed on a 10-step run
-    def regular_leg(n_timed=10):
+    # (maua_ddim_guided_loop without a secondary model); the whole 100-step loop is timed (round 6; round 5 extrapolated from 10 steps)
+    def regular_leg():
         gd = GuidedDiffusion([MSEGuide(1000.0)], timesteps=steps, model=model, diffusion=diffusion, speed="regular")
         gr = torch.Generator().manual_seed(5)
         x0, nz = (torch.randn(batch, 3, size, size, generator=gr).cuda() for _ in range(2))
         pr = [prompts[int(idx[j])] for j in range(batch)]
-        gd.run(x0, pr, n - 1, n_timed, noise=nz, per_sample=True)   # weights' transposed copies, arena, capture + first replay (untimed)
+        gd.run(x0, pr, n - 1, 2, noise=nz, per_sample=True)    # weights' transposed copies, arena (untimed, 2 steps)
+        gd.run(x0, pr, n - 1, n, noise=nz, per_sample=True)    # capture + first replay of the 100-step loop (untimed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = gd.run(x0, pr, n - 1, n_timed, noise=nz, per_sample=True)
+        out = gd.run(x0, pr, n - 1, n, noise=nz, per_sample=True)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n_timed
-        return {"value": batch / (dt * steps), "unit": "samples/s", "ms_per_step": dt * 1e3, "steps_timed": n_timed,
+        dt = time.perf_counter() - t0
+        return {"value": batch / dt, "unit": "samples/s", "seconds_per_batch": dt, "ms_per_step": dt / steps * 1e3, "steps_timed": steps,
                 "finite": bool(torch.isfinite(out).all()), "hipgraph": model.guided_graph_active(),
-                "note": "speed 'regular': UNet forward (kept) + input gradient through the UNet + DDIM update per step; value = the "
-                        "%d-step rate extrapolated from %d timed steps of the same loop" % (steps, n_timed)}
+                "note": "speed 'regular': UNet forward (kept) + input gradient through the UNet + DDIM update per step, all %d steps timed" % steps}
     try:
         regular = regular_leg()
     except Exception as e:   # (an extra of an extra: never takes the leg down)
         regular = {"error": repr(e)[:300]}
+    # ---- text-prompt guidance, configs[3] as BASELINE words it: CLIPGrads (maua/grad.py:96-165, the reference's defaults: ViT-B/16,
+    # MauaCutouts cutn = 32, 8 cutout batches per step) as the grad module of the default "fast" conditioning - per step 8 x 32 cutouts
+    # of the image estimate through the CLIP image tower forward AND backward (random init like the UNet: no weights in the image),
+    # spherical distance to the prompts' embeddings (two prompts switched by the clip's onsets, handed in as embeddings: the text tower
+    # runs once, off the loop), one hipGraph for the whole 100-step loop.  Smaller batch than the other arms: a step is ~9 x the UNet's FLOPs
+    def clip_leg(cb):
+        from bench_clip import vit_gflop
+        from maua_amd.clip import load as clip_load
+        from maua_amd.grad import CLIPGrads, EmbeddingPrompt
+        cm, _ = clip_load("ViT-B/16", allow_random_init=True, generator=torch.Generator().manual_seed(6))
+        gm = CLIPGrads(scale=1000.0, clip_models=[cm], clamp_gradient=0.05)
+        gd = GuidedDiffusion([gm], timesteps=steps, model=model, diffusion=diffusion, secondary_model=secondary)
+        gr = torch.Generator().manual_seed(7)
+        tp = [EmbeddingPrompt(torch.randn(512, generator=gr)) for _ in range(2)]
+        x0, nz = (torch.randn(cb, 3, size, size, generator=gr).cuda() for _ in range(2))
+        pr = [tp[int(idx[batch - cb // 2 + j])] for j in range(cb)]   # (frames either side of the clip's prompt switch)
+        torch.manual_seed(8)
+        gd.run(x0, pr, n - 1, n, noise=nz, per_sample=True)      # eager step + capture + first replay (untimed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = gd.run(x0, pr, n - 1, n, noise=nz, per_sample=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r, m = gm.merge_identical(gm.draw_rects(0, size, size, torch.tensor([500.0])))
+        imgs = r.shape[0] * r.shape[1]                           # images through the tower per sample and step
+        gf_clip = vit_gflop() * imgs
+        tfc = (gf + gf_sec + gf_clip) * cb * steps / dt / 1e3
+        del gd, gm, cm
+        return {"value": cb / dt, "unit": "samples/s", "guidance": "clip", "batch": cb, "seconds_per_batch": dt, "ms_per_step": dt / steps * 1e3,
+                "steps_timed": steps, "hipgraph": model.guided_graph_active(), "finite": bool(torch.isfinite(out).all()),
+                "perceptor": "ViT-B/16 image tower, random init, bf16; cutn 32 x 8 cutout batches per step (the reference's defaults); the %d "
+                             "identical whole-image cutouts of a cutout batch pass once with their joint weight: %d tower images per sample "
+                             "and step instead of 256, same gradient (tests/test_gpu_clip.py)" % (32 // 4, imgs),
+                "gflop_per_sample_step": {"unet_forward": gf, "secondary_forward_and_vjp": gf_sec, "clip_forward_and_input_gradient": gf_clip},
+                "roofline": {"bound": "mfma", "achieved": tfc, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tfc / MFMA_BF16_PEAK_TF,
+                             "note": "algorithmic FLOPs of the EXECUTED work (merged cutouts) of all three networks over the loop's time"},
+                "over_unguided_rate": (cb / dt) / (batch / best_u)}
+    try:
+        clip_arm = clip_leg(clip_batch)
+    except Exception as e:
+        clip_arm = {"error": repr(e)[:300]}
     tf = (gf + gf_sec) * batch * steps / best / 1e3
-    tr, tr_note = leg_traffic("diffusion")
-    return {"metric": "samples/sec, guided-diffusion 256x256, 100-step DDIM, onset-switched prompts (configs[3])", "value": batch / best,
-            "unit": "samples/s", "guided": True,
-            "guidance": "speed 'fast' (reference default): secondary model forward + VJP every step, image-MSE grad module, one target "
-                        "per frame switched at the clip's onset peaks; text prompts (CLIP) unpinnable here - DESIGN section 2",
-            "secondary_dtype": "f32 tensors (the reference keeps the secondary model in fp32), products as three bf16 split products on "
-                               "the bf16 matrix cores (MAUA_F32_SPLIT, ~2^-17 per product; guidance gradient within 1e-3 of the reference's "
-                               "float32 autograd, tests/test_gpu_diffusion.py)",
-            "guided_exact_f32_secondary": {"value": batch / best32, "unit": "samples/s", "seconds_per_batch": best32, "hipgraph": graphed32,
-                                           "finite": finite32, "note": "every product of the secondary model on the exact-f32 matrix path "
-                                                                       "(v_mfma_f32_32x32x2_f32): rounds 4-5's default"},
-            "prompt_switches_in_timed_frames": int((idx[batch + 1:n_frames] != idx[batch:n_frames - 1]).sum()),
-            "batch": batch, "steps": steps, "seconds_per_batch": best, "ms_per_step": best / steps * 1e3, "dtype": "bf16",
-            "data": "synthetic (random-init UNet of the reference's configuration, 552.8 M parameters; random-init secondary model, 13.9 M)",
-            "hipgraph": graphed, "finite": finite,
-            "guided_bf16_secondary": {"value": batch / best16, "unit": "samples/s", "seconds_per_batch": best16, "hipgraph": graphed16,
-                                      "finite": finite16, "note": "opt-in: secondary model in bf16 (guidance gradient 3.5 % off the reference's in L2 norm)"},
-            "guided_regular": regular,
-            "unguided": unguided, "guided_over_unguided": best_u / best, "guided_exact_f32_secondary_over_unguided": best_u / best32, "guided_bf16_secondary_over_unguided": best_u / best16,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
-                         "gflop_per_forward_per_sample": gf, "gflop_secondary_forward_and_vjp_per_sample": gf_sec,
-                         "note": "both networks' algorithmic FLOPs over the guided loop's time against the bf16 peak (the secondary model's "
-                                 "share executes 3 bf16 products per algorithmic product)",
-                         "traffic": tr,
-                         "traffic_note": tr_note + " - UNet forward only, collected at batch 8, this leg runs batch %d (weights, 1.1 GB per forward, do not scale)" % batch}}
+    del model, secondary
+    torch.cuda.empty_cache()
+    tr, tr_note = live_leg_traffic("diffusion", batch) if traffic else (None, "not collected (traffic=False)")
+    if tr is None and traffic:
+        why = tr_note
+        tr, tr_note = leg_traffic("diffusion")
+        tr_note += " - fallback (" + why + "); that file: UNet forward only at batch 8"
+    res = {"metric": "samples/sec, guided-diffusion 256x256, 100-step DDIM, onset-switched prompts (configs[3])", "value": batch / best,
+           "unit": "samples/s", "guided": True,
+           "headline_arm": "guided_mse: image-MSE targets (speed 'fast'); the TEXT-PROMPT arm - configs[3] as BASELINE words it, CLIPGrads "
+                           "through a ViT-B/16 image tower - is `guided_clip` below with its own FLOP count and roofline",
+           "guidance": "speed 'fast' (reference default): secondary model forward + VJP every step, image-MSE grad module, one target "
+                       "per frame switched at the clip's onset peaks",
+           "secondary_dtype": "f32 tensors (the reference keeps the secondary model in fp32), products as three bf16 split products on "
+                              "the bf16 matrix cores (MAUA_F32_SPLIT, ~2^-17 per product; guidance gradient within 1e-3 of the reference's "
+                              "float32 autograd, tests/test_gpu_diffusion.py)",
+           "prompt_switches_in_timed_frames": int((idx[batch + 1:n_frames] != idx[batch:n_frames - 1]).sum()),
+           "batch": batch, "steps": steps, "seconds_per_batch": best, "ms_per_step": best / steps * 1e3, "dtype": "bf16",
+           "data": "synthetic (random-init UNet of the reference's configuration, 552.8 M parameters; random-init secondary model, 13.9 M; "
+                   "random-init CLIP ViT-B/16 image tower, 86 M)",
+           "hipgraph": graphed, "finite": finite,
+           "guided_clip": clip_arm,
+           "guided_regular": regular,
+           "unguided": unguided, "guided_over_unguided": best_u / best,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TF,
+                        "gflop_per_forward_per_sample": gf, "gflop_secondary_forward_and_vjp_per_sample": gf_sec,
+                        "note": "both networks' algorithmic FLOPs over the guided loop's time against the bf16 peak (the secondary model's "
+                                "share executes 3 bf16 products per algorithmic product)",
+                        "traffic": tr, "traffic_note": tr_note}}
+    res.update(arms)
+    return res
 
 
-def extra_upscale(steps=3, frames=8, upscale_batch=4):
+def extra_f16(batch, steps=10):
+    """The reference's own render dtype (render/ffmpeg.py:45, wrappers/__init__.py fp16=True) on the headline's kernels (round 6: the
+    LDS-direct, transposed-conv + FIR, register-stationary and fused-walk kernels have float16 forms): `steps` synthesis calls of
+    `batch` 1024^2 frames -> u8, float16 network, timed beside the SAME loop on the bf16 network (same parameters, same noise
+    tensors; the noise-map kernels of the headline step are not part of either)."""
+    from maua_amd.stylegan2 import SynthesisNetwork, init_synthesis_params_device
+    p = init_synthesis_params_device(RES, W_DIM, seed=0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ws = torch.randn(batch, 18, W_DIM, generator=g, device="cuda")
+    noise = [torch.randn(batch, 1, s_, s_, generator=g, device="cuda") for s_ in NOISE_SIZES]
+    u8 = torch.empty((batch, RES, RES, 3), dtype=torch.uint8, device="cuda")
+    out = {}
+    for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        net = SynthesisNetwork(W_DIM, RES, 3, dtype=dt, _params=p)
+        for _ in range(2):
+            net(ws, noise=noise, rgb8_out=u8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(ws, noise=noise, rgb8_out=u8)
+        torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / steps
+        net._destroy()
+    return {"metric": "frames/sec, 1024^2 StyleGAN2 synthesis -> u8, float16 network (the reference's render dtype)", "value": batch / out["f16"],
+            "unit": "frames/s", "dtype": "f16", "batch": batch, "steps": steps, "ms_per_step": out["f16"] * 1e3,
+            "bf16_same_loop_ms_per_step": out["bf16"] * 1e3, "f16_over_bf16_rate": out["bf16"] / out["f16"],
+            "note": "synthesis calls only (caller-supplied noise tensors); parity: tests/test_gpu_synth.py "
+                    "test_synth_fp16_full_size_runs_the_fast_kernels (>= 65 dB against the fp32 oracle)"}
+
+
+def extra_upscale(steps=3, frames=8, upscale_batch=4, traffic=True):
     """configs[4], one GPU's slice, through the product path (audiovisual/sample.py generate(upscale=...) runs exactly this per
     batch): `frames` 1024^2 StyleGAN2 frames rendered in one call -> RealESRGANer.enhance_frames (x4plus: 23 RRDB blocks, random
     init; the reference's enhance arithmetic per frame: / 255, reflect pre_pad 10 -> 1034^2, network, crop, clamp, round),
@@ -493,7 +633,11 @@ def extra_upscale(steps=3, frames=8, upscale_batch=4):
     rdb = 9 * sum((f + k * g) * (f if k == 4 else g) for k in range(5))
     macs_px = 23 * 3 * rdb + 9 * (3 * f + f * f) + 9 * f * f * 4 + 9 * f * f * 16 + 9 * f * f * 16 + 9 * f * 3 * 16
     tf = 2 * macs_px * RES * RES / 1e12 / dt     # algorithmic: the 1024^2 frame (the pre_pad border's 2 % extra pixels are not counted)
-    tr, tr_note = leg_traffic("upscale")
+    tr, tr_note = live_leg_traffic("upscale", 4) if traffic else (None, "not collected (traffic=False)")
+    if tr is None and traffic:
+        why = tr_note
+        tr, tr_note = leg_traffic("upscale")
+        tr_note += " - fallback (" + why + ")"
     return {"metric": "frames/sec per GPU, 1024^2 StyleGAN2 render -> RealESRGAN x4 -> 4096^2 u8 (configs[4], one GPU's slice)",
             "value": 1.0 / dt, "unit": "frames/s", "ms_per_frame": dt * 1e3, "dtype": "bf16", "data": "synthetic",
             "frames_per_render_call": frames, "frames_per_upscaler_call": upscale_batch,
@@ -761,7 +905,8 @@ def main():
             del latents, noise
             net._destroy()
             torch.cuda.empty_cache()
-            for key, fn in (("diffusion", extra_diffusion), ("upscale", extra_upscale)):
+            for key, fn in (("f16", lambda: extra_f16(B)), ("diffusion", lambda: extra_diffusion(full_arms=a.diffusion_arms)),
+                            ("upscale", extra_upscale)):
                 try:
                     res[key] = fn()
                 except Exception as e:   # an extra leg must not take the headline line down with it

@@ -559,18 +559,22 @@ int maua_clip_encode_image_vjp(maua_clip* net, const float* d_embeds, int N, flo
 int maua_clip_set_targets(maua_clip* net, const float* targets, const float* weights, int S, int P, const int* sel, int B);
 /* CLIPGrads.forward (:145-159): img device f32 [B][3][H][W] in [-1, 1]; rects HOST int [batches][cutn][3] = (size, top, left) of
  * every cutout of every cutout batch (the host draws them like MauaCutouts.forward does); grad device f32 [B][3][H][W];
- * clamp_gradient <= 0: none; a result holding a NaN is returned as zeros (guided.py:262-265) */
-int maua_clip_guide_grad(maua_clip* net, const float* img, int B, int H, int W, const int* rects, int cutn, int batches, float scale,
-                         float clamp_gradient, float* grad);
+ * clamp_gradient <= 0: none; a result holding a NaN is returned as zeros (guided.py:262-265).
+ * mult: NULL, or HOST float [batches][cutn] - cutout i stands for mult[i] IDENTICAL cutouts of the reference's list (its first
+ * cutn // 4 cutouts of a square image are the same rectangle, cutouts.py:16-27): one pass through the tower carries their weight; the
+ * mean over cutouts then divides by the sum of a batch's multiplicities.  Same gradient, fewer images. */
+int maua_clip_guide_grad(maua_clip* net, const float* img, int B, int H, int W, const int* rects, const float* mult, int cutn, int batches,
+                         float scale, float clamp_gradient, float* grad);
 /* sum_p w_p dist_p of the first `count` cutout images of the last pass through the tower (cutout-major; device f32 [count]) */
 int maua_clip_last_image_losses(maua_clip* net, int count, float* out);
 /* the guided loop with THIS grad module: the following maua_ddim_guided_loop calls on `net` (speed "fast": a secondary model, or
  * "regular") evaluate CLIPGrads on the image estimate instead of the image-MSE module (their target / mse_k arguments are ignored);
- * rects: HOST int [n_steps][batches][cutn][3], one draw per step and cutout batch, read at every call of the loop.  clip == NULL:
+ * rects: HOST int [n_steps][batches][cutn][3], one draw per step and cutout batch (mult: NULL or [n_steps][batches][cutn], as above),
+ * read at every call of the loop.  clip == NULL:
  * back to the image-MSE module.  The whole step - UNet, secondary model, cutouts, image tower forward and backward, DDIM update -
  * stays one hipGraph. */
-int maua_unet_set_clip_guide(maua_unet* net, maua_clip* clip, const int* rects, int n_steps, int cutn, int batches, float scale,
-                             float clamp_gradient);
+int maua_unet_set_clip_guide(maua_unet* net, maua_clip* clip, const int* rects, const float* mult, int n_steps, int cutn, int batches,
+                             float scale, float clamp_gradient);
 /* operator-level pieces.  maua_cutouts: random_cutouts (cutouts.py:8-38) on HOST rectangles [n_cut][3] applied to img * mul + add,
  * resized to cut_size^2 by the `resize_right` algorithm (cubic, antialiased, zero padding), Normalize(mean3, std3) -> out device f32
  * [n_cut * B][3][cut_size][cut_size] (cutout-major, like torch.cat); maua_cutouts_vjp: d_out -> d_img [B][3][H][W] */

@@ -259,6 +259,7 @@ struct HeadArgs {
   void* dx;                 // [N][Tk][w] (T) or NULL: row 0 of each image receives the gradient (the other rows are the caller's to zero)
   int Tk, w, E, P, B;
   float coef;               // d total / d (sum_p w_p dist_p) of one image: scale / cutn / cutout_batches
+  const float* mult;        // [n_cut] or NULL: how many identical cutouts each image of cutout n stands for (coef is multiplied by it)
 };
 
 __device__ __forceinline__ float block_sum(float v, float* red) {   // 256 threads; red: 4 floats of LDS
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void clip_head_kernel(HeadArgs a) {
     for (int j = tid; j < a.E; j += 256) {
       float acc = 0.f;
       for (int p = 0; p < a.P; p++) acc = fmaf(gp[p], tg[(long)p * a.E + j], acc);
-      const float dj = a.coef * (e[j] * gsum - acc);   // d / d ehat
+      const float dj = a.coef * (a.mult ? a.mult[n / a.B] : 1.f) * (e[j] * gsum - acc);   // d / d ehat
       de[j] = dj;
       dot = fmaf(dj, e[j], dot);
     }
@@ -426,7 +427,7 @@ struct maua_clip {
   // cutout scratch
   void* cut_tables = nullptr; size_t cut_tables_bytes = 0;
   float* cut_th = nullptr; size_t cut_th_bytes = 0;
-  int* rects_dev = nullptr; size_t rects_cap = 0;
+  int* rects_dev = nullptr; size_t rects_cap = 0;   // + the multiplicities behind the rectangles (floats)
   double* parts = nullptr;
   unsigned long long uid = 0, epoch = 0;   // identity of this tower / generation of its buffers (a captured graph holds pointers into
 };                                          // them: unet.hip compares both before a replay)
@@ -563,12 +564,12 @@ int run_forward(maua_clip* n, long N, bool keep) {
   return MAUA_OK;
 }
 
-int run_head(maua_clip* n, long N, bool with_grad, const float* d_embed, int B, float coef, bool write_loss) {
+int run_head(maua_clip* n, long N, bool with_grad, const float* d_embed, int B, float coef, bool write_loss, const float* mult = nullptr) {
   HeadArgs h{};
   h.x = n->x_last; h.g = n->lnpost_g; h.b = n->lnpost_b; h.proj = n->proj; h.tgt = n->tgt; h.twt = n->twt;
   h.sel = n->sel_B > 0 ? n->sel : nullptr;
   h.embed = n->embed; h.loss = write_loss ? n->loss : nullptr; h.d_embed = d_embed; h.dx = with_grad ? n->dxa : nullptr;
-  h.Tk = n->Tk; h.w = n->width; h.E = n->E; h.P = n->P; h.B = B > 0 ? B : 1; h.coef = coef;
+  h.Tk = n->Tk; h.w = n->width; h.E = n->E; h.P = n->P; h.B = B > 0 ? B : 1; h.coef = coef; h.mult = mult;
   const size_t smem = ((size_t)2 * n->width + 2 * n->E + std::max(n->P, 1) + 8) * 4;
   MAUA_REQUIRE(smem <= 64 * 1024, "maua_clip: too many targets / too wide a tower for the head kernel's LDS");
   if (n->dtype == MAUA_BF16) hipLaunchKernelGGL(clip_head_kernel<bf16_t>, dim3((unsigned)N), dim3(256), smem, n->ctx->stream, h);
@@ -682,8 +683,8 @@ maua_ctx* clip_ctx(maua_clip* n) { return n ? n->ctx : nullptr; }
 
 // One cutout batch group of CLIPGrads.forward on device rectangles: cutouts of img -> tower -> loss head -> back to d img, added into
 // (or written to) grad.  rects_dev: [n_cut][3].  coef: the head's factor (scale excluded: applied at the end with the clamp).
-int clip_grad_group(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, int n_cut, float coef, float* grad,
-                    int accumulate) {
+int clip_grad_group(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, const float* mult_dev, int n_cut, float coef,
+                    float* grad, int accumulate) {
   hipStream_t st = n->ctx->stream;
   const long N = (long)n_cut * B;
   CutoutPlan p{};
@@ -695,7 +696,7 @@ int clip_grad_group(maua_clip* n, const float* img, int B, int H, int W, const i
   if (int rc = launch_cutouts_forward(st, n->dtype, p, n->cut_tables, n->patches)) return rc;
   if (int rc = forward_any(n, N, true)) return rc;
   if (int rc = zero_dx(n, N)) return rc;
-  if (int rc = run_head(n, N, true, nullptr, B, coef, true)) return rc;
+  if (int rc = run_head(n, N, true, nullptr, B, coef, true, mult_dev)) return rc;
   if (int rc = backward_any(n, N)) return rc;
   return launch_cutouts_vjp(st, n->dtype, p, n->cut_tables, n->dwide, n->cut_th, grad, accumulate);
 }
@@ -725,16 +726,20 @@ int clip_group_size(maua_clip* n, int B, int cutn) {
   return (int)std::max<long>(1, std::min<long>(cutn, max_images / std::max(B, 1)));
 }
 
-// the whole of CLIPGrads.forward (:145-159) on device rectangles [batches][cutn][3]
-int clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, int cutn, int batches, float scale,
-                    float clamp_gradient, float* grad) {
+// the whole of CLIPGrads.forward (:145-159) on device rectangles [batches][cutn][3].  mult_dev: NULL, or [batches][cutn] multiplicities -
+// cutout n stands for mult identical cutouts of the reference's list (on a square image its first cutn // 4 cutouts are the same
+// rectangle, cutouts.py:16-27: one pass through the tower carries their weight) and cutn_total = what the multiplicities of a batch sum to
+int clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, const float* mult_dev, int cutn, int cutn_total,
+                    int batches, float scale, float clamp_gradient, float* grad) {
   const int grp = clip_group_size(n, B, cutn);
-  const float coef = 1.f / ((float)cutn * (float)batches);
+  const float coef = 1.f / ((float)cutn_total * (float)batches);
   bool first = true;
   for (int k = 0; k < batches; k++)
     for (int c0 = 0; c0 < cutn; c0 += grp) {
       const int nc = std::min(grp, cutn - c0);
-      if (int rc = clip_grad_group(n, img, B, H, W, rects_dev + ((long)k * cutn + c0) * 3, nc, coef, grad, first ? 0 : 1)) return rc;
+      if (int rc = clip_grad_group(n, img, B, H, W, rects_dev + ((long)k * cutn + c0) * 3, mult_dev ? mult_dev + (long)k * cutn + c0 : nullptr, nc,
+                                   coef, grad, first ? 0 : 1))
+        return rc;
       first = false;
     }
   const long cnt = (long)B * 3 * H * W;
@@ -926,8 +931,8 @@ int maua_clip_set_targets(maua_clip* n, const float* targets, const float* weigh
 // CLIPGrads.forward (:145-159): img [B][3][H][W] f32 in [-1, 1] (device), rects: HOST ints [batches][cutn][3] = (size, top, left) of
 // every cutout of every cutout batch (what MauaCutouts draws), -> grad [B][3][H][W] f32 = d (scale * sum_b loss_b) / d img, averaged
 // over the cutout batches, with clamp_gradient (<= 0: none) applied
-int maua_clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects, int cutn, int batches, float scale,
-                         float clamp_gradient, float* grad) {
+int maua_clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects, const float* mult, int cutn, int batches,
+                         float scale, float clamp_gradient, float* grad) {
   MAUA_REQUIRE(n && img && rects && grad, "maua_clip_guide_grad: NULL argument");
   MAUA_REQUIRE(B >= 0 && cutn > 0 && batches > 0, "maua_clip_guide_grad: bad sizes");
   if (int rc = clip_loaded(n)) return rc;
@@ -937,7 +942,19 @@ int maua_clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, co
     const int s = rects[3 * i], oy = rects[3 * i + 1], ox = rects[3 * i + 2];
     MAUA_REQUIRE(s > 0 && oy >= 0 && ox >= 0 && oy + s <= H && ox + s <= W, "maua_clip_guide_grad: a cutout leaves the image");
   }
-  const size_t cnt = (size_t)batches * cutn * 3;
+  int cutn_total = cutn;
+  if (mult) {
+    double tot = 0;
+    for (int i = 0; i < cutn; i++) tot += mult[i];
+    cutn_total = (int)(tot + 0.5);
+    for (int k = 1; k < batches; k++) {
+      double t = 0;
+      for (int i = 0; i < cutn; i++) t += mult[(long)k * cutn + i];
+      MAUA_REQUIRE((int)(t + 0.5) == cutn_total, "maua_clip_guide_grad: every cutout batch must stand for the same number of cutouts");
+    }
+    MAUA_REQUIRE(cutn_total >= cutn, "maua_clip_guide_grad: multiplicities are >= 1");
+  }
+  const size_t cnt = (size_t)batches * cutn * 4;   // 3 ints + 1 float per cutout
   if (cnt > n->rects_cap) {
     MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));
     dfree(n->rects_dev);
@@ -945,10 +962,12 @@ int maua_clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, co
     if (int rc = dalloc((void**)&n->rects_dev, cnt * 4)) return rc;
     n->rects_cap = cnt;
   }
-  MAUA_HIP_CHECK(hipMemcpyAsync(n->rects_dev, rects, cnt * 4, hipMemcpyHostToDevice, n->ctx->stream));
-  MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));   // (the caller's array may be a temporary)
+  float* mult_dev = mult ? (float*)(n->rects_dev + (size_t)batches * cutn * 3) : nullptr;
+  MAUA_HIP_CHECK(hipMemcpyAsync(n->rects_dev, rects, (size_t)batches * cutn * 12, hipMemcpyHostToDevice, n->ctx->stream));
+  if (mult) MAUA_HIP_CHECK(hipMemcpyAsync(mult_dev, mult, (size_t)batches * cutn * 4, hipMemcpyHostToDevice, n->ctx->stream));
+  MAUA_HIP_CHECK(hipStreamSynchronize(n->ctx->stream));   // (the caller's arrays may be temporaries)
   if (int rc = clip_prepare_guide(n, B, H, W, clip_group_size(n, B, cutn))) return rc;
-  return clip_guide_grad(n, img, B, H, W, n->rects_dev, cutn, batches, scale, clamp_gradient, grad);
+  return clip_guide_grad(n, img, B, H, W, n->rects_dev, mult_dev, cutn, cutn_total, batches, scale, clamp_gradient, grad);
 }
 
 // sum_p w_p dist_p of each cutout image of the LAST pass through the tower ([n] floats, device; n <= cutn * B: cutout-major, what

@@ -59,6 +59,19 @@ template <> struct Fmt16<f16_t> {
   __device__ static __forceinline__ float round(float f) { return h2f((uint16_t)(pack2h(f, 0.f) & 0xffffu)); }
 };
 
+// the 32x32x16 matrix instruction of a 16-bit storage format (operands as raw 16-byte register quads)
+template <typename F> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma16<f16_t> {
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int kDtype = MAUA_F32;

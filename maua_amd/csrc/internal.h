@@ -78,9 +78,10 @@ bool modconv_rgb_fusable(int dtype, int Ci, int Co, int up, int H, int W);
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W);
 bool dma_rgb_fusable(int Co);
 bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W);  // 32 / 64 output channels (plain convs: x_pstride / y_pstride / y_coff / res honoured)
-int launch_modconv_dma(hipStream_t stream, const ConvArgs& a);
+int launch_modconv_dma(hipStream_t stream, const ConvArgs& a, int dtype = MAUA_BF16);
 int dma_psum_rows(const ConvArgs& a);   // rows per sample of ConvArgs.psum for such a launch
-int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci);
+int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci,
+                       int dtype = MAUA_BF16);
 
 // lowest-resolution layers (modconv_lowres.hip, <= 8x8 input pixels per sample): the GEMM over all samples at once,
 // split-K + deterministic reduce/epilogue.  xm / ws: workspaces of at least lowres_workspace() bytes.
@@ -120,20 +121,21 @@ struct HiresArgs {
   int rgb_skip_f32;       // with rgb8_out: do not store the f32 image (nobody reads it)
 };
 bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W);
-int launch_modconv_hires(hipStream_t stream, const HiresArgs& a);
+int launch_modconv_hires(hipStream_t stream, const HiresArgs& a, int dtype = MAUA_BF16);
 // modconv_upwalk.hip: the 64 -> 32 channel up-layer in half-folded form (horizontal FIR in the weights, vertical FIR on
 // the accumulators of a row walk); a.w = weights from launch_prep_upwalk_weights ([3][2][3][Co][Ci] bf16)
 bool upwalk_supported(int dtype, int Ci, int Co, int up, int H, int W);
 size_t upwalk_weight_elems(int Co, int Ci);
-int launch_upwalk(hipStream_t stream, const HiresArgs& a);
-int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int Co, int Ci, int flip);
+int launch_upwalk(hipStream_t stream, const HiresArgs& a, int dtype = MAUA_BF16);
+int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int Co, int Ci, int flip, int dtype = MAUA_BF16);
 // ... and the whole block (that up-layer, the 3x3 conv1 behind it, toRGB + skip, optional u8 pack) in one walk: the
 // block's features never reach HBM.  up = conv0's arguments (w from launch_prep_upwalk_weights, y unused), c1 = conv1's
 // (w from launch_prep_weights, rgb_* set, y unused)
 bool upwalk_fused_supported(int dtype, int Ci, int Cm, int H, int W);
 // force_segs > 0: that many row segments instead of the cost model's choice; narrow_ok: walk a last strip of <= 32 columns as two
 // half-height sub-items (both: results are identical by construction, tests compare them)
-int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs = 0, int narrow_ok = 1);
+int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs = 0, int narrow_ok = 1,
+                        int dtype = MAUA_BF16);
 
 // weight preparation: f32 [Co][Ci][k][k] -> T [phases][k*k][Cop][Cip] (+ Wsq f32 [Co][Ci] = sum_k W^2)
 int launch_prep_weights(hipStream_t stream, int dtype, const float* w, void* wt, float* wsq, int Co, int Ci, int k,
@@ -148,8 +150,8 @@ int launch_tconv2(hipStream_t stream, int dtype, const ConvArgs& a);
 constexpr int TCONV_EDGES_ONLY = 100;  // ConvArgs.variant: launch_tconv2 covers only the last row / column of positions
 // modconv_tconv_dma.hip: the main H x W block on LDS-direct loads; x already multiplied by the styles (bf16)
 bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W);
-int launch_tconv_dma(hipStream_t stream, const ConvArgs& a);
-int launch_tconv_edges(hipStream_t stream, const ConvArgs& a);   // the thin last row / column of positions (bf16, pre-modulated x)
+int launch_tconv_dma(hipStream_t stream, const ConvArgs& a, int dtype = MAUA_BF16);
+int launch_tconv_edges(hipStream_t stream, const ConvArgs& a, int dtype = MAUA_BF16);   // the thin last row / column of positions (bf16, pre-modulated x)
 int launch_prep_tconv_weights(hipStream_t stream, int dtype, const float* w, void* wt, int Co, int Ci, int flip);
 
 // second half of the minimal up-layer: out = act(d * FIR4x4(t) + noise + bias) (ops.py:225 upfirdn2d pad 1 gain 4,
@@ -172,7 +174,7 @@ int launch_upfir_epilogue(hipStream_t stream, int dtype, const UpfirArgs& a);
 // modconv_tconv_fir.hip: both halves in one kernel, t stays in LDS (bf16; x already multiplied by the styles); the output is
 // bit-identical to launch_tconv_dma (+ edges) followed by launch_upfir_epilogue
 bool tconv_fir_supported(int dtype, int Ci, int Co, int H, int W);
-int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u);
+int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u, int dtype = MAUA_BF16);
 size_t prepped_weight_elems(int k, int up, int Cop, int Cip);
 
 // resize.hip: bicubic / pad / crop of NHWC features (network dtype) or planar images; optional per-channel noise
@@ -337,7 +339,7 @@ maua_ctx* clip_ctx(maua_clip* n);
 void clip_stamp(maua_clip* n, unsigned long long* uid, unsigned long long* epoch);
 int clip_group_size(maua_clip* n, int B, int cutn);
 int clip_prepare_guide(maua_clip* n, int B, int H, int W, int n_cut_group);
-int clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, int cutn, int batches, float scale,
-                    float clamp_gradient, float* grad);
+int clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, const int* rects_dev, const float* mult_dev, int cutn, int cutn_total,
+                    int batches, float scale, float clamp_gradient, float* grad);
 
 }  // namespace maua

@@ -52,15 +52,17 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
                : "memory");
 }
 
+template <typename F>
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  Mma16<F>::step(acc, a, b);
 }
 
 }  // namespace
 
 // x' = bf16(x * s): only for callers whose producer could not apply the styles (operator-level entry point, hooks)
-__global__ __launch_bounds__(256) void premod_nhwc_kernel(const bf16_t* __restrict__ x, long x_bstride,
-                                                          const float* __restrict__ s, bf16_t* __restrict__ y, int B,
+template <typename F>
+__global__ __launch_bounds__(256) void premod_nhwc_kernel(const uint16_t* __restrict__ x, long x_bstride,
+                                                          const float* __restrict__ s, uint16_t* __restrict__ y, int B,
                                                           long HW, int Ci) {
   const int ppp = Ci / 8;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,26 +75,30 @@ __global__ __launch_bounds__(256) void premod_nhwc_kernel(const bf16_t* __restri
   const float4 s1 = *reinterpret_cast<const float4*>(s + (long)b * Ci + pc * 8 + 4);
   const u32x4 v = *reinterpret_cast<const u32x4*>(x + (long)b * x_bstride + p * Ci + pc * 8);
   u32x4 o;
-  o[0] = pack2bf(bf2f((bf16_t)(v[0] & 0xffff)) * s0.x, bf2f((bf16_t)(v[0] >> 16)) * s0.y);
-  o[1] = pack2bf(bf2f((bf16_t)(v[1] & 0xffff)) * s0.z, bf2f((bf16_t)(v[1] >> 16)) * s0.w);
-  o[2] = pack2bf(bf2f((bf16_t)(v[2] & 0xffff)) * s1.x, bf2f((bf16_t)(v[2] >> 16)) * s1.y);
-  o[3] = pack2bf(bf2f((bf16_t)(v[3] & 0xffff)) * s1.z, bf2f((bf16_t)(v[3] >> 16)) * s1.w);
+  o[0] = Fmt16<F>::pack2(Fmt16<F>::lo(v[0]) * s0.x, Fmt16<F>::hi(v[0]) * s0.y);
+  o[1] = Fmt16<F>::pack2(Fmt16<F>::lo(v[1]) * s0.z, Fmt16<F>::hi(v[1]) * s0.w);
+  o[2] = Fmt16<F>::pack2(Fmt16<F>::lo(v[2]) * s1.x, Fmt16<F>::hi(v[2]) * s1.y);
+  o[3] = Fmt16<F>::pack2(Fmt16<F>::lo(v[3]) * s1.z, Fmt16<F>::hi(v[3]) * s1.w);
   *reinterpret_cast<u32x4*>(y + bp * Ci + pc * 8) = o;
 }
 
-int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci) {
+int launch_premod_nhwc(hipStream_t stream, const void* x, long x_bstride, const float* s, void* y, int B, long HW, int Ci, int dtype) {
   MAUA_REQUIRE(Ci % 8 == 0, "premod: Ci must be a multiple of 8");
   if (B == 0) return MAUA_OK;
   const long n = (long)B * HW * (Ci / 8);
-  hipLaunchKernelGGL(premod_nhwc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)x,
-                     x_bstride, s, (bf16_t*)y, B, HW, Ci);
+  if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(premod_nhwc_kernel<f16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)x, x_bstride, s,
+                       (uint16_t*)y, B, HW, Ci);
+  else
+    hipLaunchKernelGGL(premod_nhwc_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const uint16_t*)x, x_bstride, s,
+                       (uint16_t*)y, B, HW, Ci);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 
 // PSUM: also emit ConvArgs.psum (its own instantiation: the 16 accumulators of the copy-out loop cost the 128-register
 // variants a few spilled registers, which the StyleGAN2 path's launches do not pay)
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false, typename F = bf16_t>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modconv_dma_kernel(ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;
   static_assert(WAVES_M * WM == TH, "the M tile is 8 image rows of 32 pixels");
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
   }
 #define MAUA_MMA(AF_, BF_)                                                                               \
   _Pragma("unroll") for (int i = 0; i < WM; i++) _Pragma("unroll") for (int j = 0; j < WN; j++)         \
-      mma(acc[i][j], BF_[j], AF_[i]);  /* rows = channels, columns = pixels */
+      mma<F>(acc[i][j], BF_[j], AF_[i]);  /* rows = channels, columns = pixels */
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
               v[k] = t;
             }
           }
-          *reinterpret_cast<uint2*>(epi + m * ES + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          *reinterpret_cast<uint2*>(epi + m * ES + nl * 2) = make_uint2(Fmt16<F>::pack2(v[0], v[1]), Fmt16<F>::pack2(v[2], v[3]));
         }
       }
     }
@@ -442,12 +448,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
       u32x4 wf;
 #pragma unroll
-      for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * bf2f(f2bf(wv[k]))) * row_mask;  // hi rows: w, lo rows: w - bf16(w)
+      for (int k = 0; k < 8; k++) wv[k] = (wv[k] - lo_mask * Fmt16<F>::round(wv[k])) * row_mask;  // hi rows: w, lo rows: w - bf16(w)
 #pragma unroll
-      for (int k = 0; k < 4; k++) wf[k] = pack2bf(wv[2 * k], wv[2 * k + 1]);
+      for (int k = 0; k < 4; k++) wf[k] = Fmt16<F>::pack2(wv[2 * k], wv[2 * k + 1]);
       const u32x4 av = *reinterpret_cast<const u32x4*>(epi + mrow * ES + (ks * 16 + 8 * h) * 2);
-      racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, av), racc, 0,
-                                                     0, 0);
+      Mma16<F>::step(racc, wf, av);
     }
     if (px_ok) {
       float o3[3] = {racc[0] + racc[4] + rb0, racc[1] + racc[5] + rb1, racc[2] + racc[6] + rb2};
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
     if (yy < a.H && xx < a.W) {
       const long HWl = (long)a.H * a.W, pix = (long)yy * a.W + xx;
       const uint2 t2 = *reinterpret_cast<const uint2*>(epi + m * ES);
-      const float v3[3] = {bf2f((bf16_t)(t2.x & 0xffff)), bf2f((bf16_t)(t2.x >> 16)), bf2f((bf16_t)(t2.y & 0xffff))};
+      const float v3[3] = {Fmt16<F>::lo(t2.x), Fmt16<F>::hi(t2.x), Fmt16<F>::lo(t2.y)};
 #pragma unroll
       for (int cch = 0; cch < 3; cch++) {
         const float cv = fminf(fmaxf(v3[cch], 0.f), 1.f);
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       u32x4 vs;
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        vs[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * osc[2 * k], bf2f((bf16_t)(v[k] >> 16)) * osc[2 * k + 1]);
+        vs[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) * osc[2 * k], Fmt16<F>::hi(v[k]) * osc[2 * k + 1]);
       if (a.y_scaled) {   // both forms leave: the plain features to y (below), the scaled ones here (what premod_nhwc_kernel would write)
         if (ty0 + (m >> 5) < a.H && tx0 + (m & 31) < a.W)
           *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.y_scaled) + (((long)b * a.H * a.W + pix) * a.Co + n0 + pc * 8) * 2) = vs;
@@ -539,20 +544,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       const u32x4 rv = rvs[it];
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        v[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(rv[k] & 0xffff)), bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(rv[k] >> 16)));
+        v[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) + Fmt16<F>::lo(rv[k]), Fmt16<F>::hi(v[k]) + Fmt16<F>::hi(rv[k]));
       if (rb2) {   // second residual on the rounded sum (RRDB: (conv5 * 0.2 + x) * 0.2 + block input): what a separate pass would compute
         const u32x4 r2 = rvs2[it];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          v[k] = pack2bf(a.res_gain * bf2f((bf16_t)(v[k] & 0xffff)) + bf2f((bf16_t)(r2[k] & 0xffff)),
-                         a.res_gain * bf2f((bf16_t)(v[k] >> 16)) + bf2f((bf16_t)(r2[k] >> 16)));
+          v[k] = Fmt16<F>::pack2(a.res_gain * Fmt16<F>::lo(v[k]) + Fmt16<F>::lo(r2[k]),
+                         a.res_gain * Fmt16<F>::hi(v[k]) + Fmt16<F>::hi(r2[k]));
       }
     }
     if (ty0 + (m >> 5) < a.H && tx0 + (m & 31) < a.W) *reinterpret_cast<u32x4*>(yb + (pix * yps + n0 + pc * 8) * 2) = v;
     if constexpr (PSUM) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float f0 = bf2f((bf16_t)(v[k] & 0xffff)), f1 = bf2f((bf16_t)(v[k] >> 16));
+        const float f0 = Fmt16<F>::lo(v[k]), f1 = Fmt16<F>::hi(v[k]);
         ps_s[2 * k] += f0; ps_s[2 * k + 1] += f1;
         ps_q[2 * k] = fmaf(f0, f0, ps_q[2 * k]); ps_q[2 * k + 1] = fmaf(f1, f1, ps_q[2 * k + 1]);
       }
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
 int dma_psum_rows(const ConvArgs& a) { return (a.H / TH) * (a.W / TW); }   // one row per 8 x 32-pixel tile
 
 bool dma_conv_supported(int dtype, int Ci, int Co, int up, int H, int W) {
-  return dtype == MAUA_BF16 && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && up == 1 && Ci % 64 == 0 && Co % 128 == 0 && H % TH == 0 && W % TW == 0;
 }
 // ... and the narrow plain convolutions of the RRDB up-scaler (super.hip): 32 or 64 output channels, K a multiple of 64
 // (any H, W >= one tile: tiles that overhang the image read zeros - the convolution's own padding - and mask their stores;
@@ -602,14 +607,14 @@ bool dma_conv_narrow_supported(int dtype, int Ci, int Co, int H, int W) {
          W >= TW;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int TPS, int KB, bool PSUM = false, bool ODDK = false, typename F = bf16_t>
 static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   constexpr int BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
   const size_t smem = std::max<size_t>((size_t)2 * TPS * BN * KB + 2 * HALO_PX * KB, (size_t)TH * TW * (BN * 2 + 16));
   MAUA_REQUIRE(smem <= 160 * 1024, "modconv_dma: LDS budget exceeded");
   MAUA_REQUIRE(((a.Ci / (KB / 2)) % TPS == 0) != ODDK, "modconv_dma: chunk count must be a multiple of the taps per stage");
   MAUA_REQUIRE(!a.rgb_out || (a.Co == BN && a.rgb_wmod && a.rgb_bias), "modconv_dma: fused toRGB needs all channels in one N tile");
-  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM, ODDK>;
+  auto kern = modconv_dma_kernel<WAVES_M, WAVES_N, WM, WN, TPS, KB, PSUM, ODDK, F>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid(((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW), a.B, a.Co / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, a);
@@ -617,8 +622,17 @@ static int launch_dma_variant(hipStream_t stream, const ConvArgs& a) {
   return MAUA_OK;
 }
 
-// a.x must already carry the styles (x * s[b, ci]); a.s is not read
-int launch_modconv_dma(hipStream_t stream, const ConvArgs& a) {
+// a.x must already carry the styles (x * s[b, ci]); a.s is not read.  dtype: MAUA_BF16, or MAUA_F16 on the two wide tiles (round 6: the
+// reference's own render dtype, render/ffmpeg.py:45 - same kernel, v_mfma_f32_32x32x16_f16, half conversions)
+int launch_modconv_dma(hipStream_t stream, const ConvArgs& a, int dtype) {
+  if (dtype == MAUA_F16) {
+    MAUA_REQUIRE(dma_conv_supported(MAUA_F16, a.Ci, a.Co, a.up, a.H, a.W) && !a.psum && !a.x_up2 && a.B <= 65535 &&
+                     (long)a.H * a.W * (a.x_pstride ? a.x_pstride : a.Ci) * 2 < (1L << 32) && (!a.y_scaled || (a.out_scale && !a.res)),
+                 "modconv_dma (f16): unsupported shape / arguments");
+    if (a.B == 0) return MAUA_OK;
+    if (a.Co % 256 == 0 && a.variant != 128) return launch_dma_variant<2, 4, 4, 2, 1, 128, false, false, f16_t>(stream, a);
+    return launch_dma_variant<4, 2, 2, 2, 2, 64, false, false, f16_t>(stream, a);
+  }
   const bool narrow = dma_conv_narrow_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W) && a.up == 1;
   MAUA_REQUIRE(narrow || dma_conv_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_dma: unsupported shape");
   MAUA_REQUIRE(a.B <= 65535, "modconv_dma: grid too large");

@@ -17,7 +17,7 @@
 
 namespace maua {
 
-template <int CI, int CO, int UP>
+template <int CI, int CO, int UP, typename F>
 __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(HiresArgs a) {
   constexpr int P = UP * UP;                      // output parities
   constexpr int NV = CO * P;                      // virtual output channels
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * a.H * a.W * CI;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(a.x) + (long)b * a.H * a.W * CI;
   const float* sb = a.s + (long)b * CI;
 
   // ---- role of this wave
@@ -68,17 +68,17 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
     for (int cs = 0; cs < KS; cs++)
 #pragma unroll
       for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e] * dco;
-    const bf16_t* wbase = reinterpret_cast<const bf16_t*>(a.w);
+    const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.w);
 #pragma unroll
     for (int tap = 0; tap < 9; tap++)
 #pragma unroll
       for (int cs = 0; cs < KS; cs++) {
-        const bf16_t* src = wbase + (((long)tap * P + phase) * CO + nsub * 32 + r) * CI + cs * 16 + 8 * h;
+        const uint16_t* src = wbase + (((long)tap * P + phase) * CO + nsub * 32 + r) * CI + cs * 16 + 8 * h;
         u32x4 v = *reinterpret_cast<const u32x4*>(src);
         u32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[cs][2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[cs][2 * k + 1]);
+          o[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) * sv[cs][2 * k], Fmt16<F>::hi(v[k]) * sv[cs][2 * k + 1]);
         wf[tap * KS + cs] = o;
       }
   }
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           float w0 = src[2 * k], w1 = src[2 * k + 1];
-          const float h0 = bf2f(f2bf(w0)), h1 = bf2f(f2bf(w1));
+          const float h0 = Fmt16<F>::round(w0), h1 = Fmt16<F>::round(w1);
           if (r >= 8) { w0 -= h0; w1 -= h1; }
-          o[k] = pack2bf(w0, w1);
+          o[k] = Fmt16<F>::pack2(w0, w1);
         }
       }
       if constexpr (LEAN) { if (wave == 0) rf_s[ks * 64 + lane] = o; }
@@ -221,11 +221,11 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
 #pragma unroll
         for (int cs = 0; cs < KS; cs++) {
           const char* ap = abase + (dy * HW2 + dx) * RSH + cs * 32;
-          const bf16x8 wv = __builtin_bit_cast(bf16x8, wf[tap * KS + cs]);
+          const u32x4 wv = wf[tap * KS + cs];
 #pragma unroll
           for (int i = 0; i < PAIR; i++) {
             const u32x4 av = *reinterpret_cast<const u32x4*>(ap + i * HW2 * RSH);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, av), acc[i], 0, 0, 0);
+            Mma16<F>::step(acc[i], wv, av);
           }
         }
       }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
             v[k] = __builtin_amdgcn_fmed3f(t, -cl, cl);  // clamp
           }
           const int nv = phase * CO + nsub * 32 + 8 * qd + 4 * h;
-          *reinterpret_cast<uint2*>(epi + m * ES + nv * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+          *reinterpret_cast<uint2*>(epi + m * ES + nv * 2) = make_uint2(Fmt16<F>::pack2(v[0], v[1]), Fmt16<F>::pack2(v[2], v[3]));
         }
       }
     }
@@ -289,8 +289,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
 #pragma unroll
           for (int ks = 0; ks < CO / 16; ks++) {
             const u32x4 av = *reinterpret_cast<const u32x4*>(epi + (row_m * 32 + r) * ES + (ks * 16 + 8 * h) * 2);
-            racc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf_s[ks * 64 + lane]),
-                                                           __builtin_bit_cast(bf16x8, av), racc, 0, 0, 0);
+            Mma16<F>::step(racc, rf_s[ks * 64 + lane], av);
           }
           if (rw == 0 || h == rw) { o3[0] = racc[0] + racc[4]; o3[1] = racc[1] + racc[5]; o3[2] = racc[2] + racc[6]; }
         }
@@ -346,13 +345,13 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 3) void modconv_hires_kernel(Hi
 #undef MAUA_HIRES_LOAD_HALO
 }
 
-template <int CI, int CO, int UP>
+template <int CI, int CO, int UP, typename F>
 static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
   constexpr int TH = CI == 32 ? 8 : 4, TW = 32, BM = TH * TW, NV = CO * UP * UP;
   constexpr int HALO_PX = (TH + 2) * (TW + 2);
   size_t smem = (size_t)HALO_PX * (CI * 2 + 16) + (size_t)BM * (NV * 2 + 16) + CO * 4 + (CO / 16) * 64 * 16 +
                 ((3 * (TH / 2 + 2) * (TW / 2 + 2) + 255) / 256 + UP) * 1024;  // + previous-image window + noise
-  auto kern = modconv_hires_kernel<CI, CO, UP>;
+  auto kern = modconv_hires_kernel<CI, CO, UP, F>;
   if (smem > 64 * 1024)
     MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const int n_tiles = (a.W / TW) * (a.H / TH);
@@ -368,7 +367,7 @@ static int launch_hires_variant(hipStream_t stream, const HiresArgs& a) {
 }
 
 bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W) {
-  if (dtype != MAUA_BF16) return false;
+  if (dtype != MAUA_BF16 && dtype != MAUA_F16) return false;
   const bool shape = (Ci == 32 && Co == 32 && up == 1) || (Ci == 64 && Co == 64 && up == 1) ||
                      (Ci == 64 && Co == 32 && up == 2);
   if (!shape) return false;
@@ -376,9 +375,9 @@ bool hires_supported(int dtype, int Ci, int Co, int up, int H, int W) {
   return W % 32 == 0 && H % th == 0;
 }
 
-int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
+int launch_modconv_hires(hipStream_t stream, const HiresArgs& a, int dtype) {
   if (a.B == 0) return MAUA_OK;
-  MAUA_REQUIRE(hires_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "modconv_hires: unsupported shape");
+  MAUA_REQUIRE(hires_supported(dtype, a.Ci, a.Co, a.up, a.H, a.W), "modconv_hires: unsupported shape");
   MAUA_REQUIRE((long)a.H * a.up * a.W * a.up * std::max(a.Ci, a.Co) * 2 < (1L << 31),
                "modconv_hires: a sample must stay below 2 GiB (32-bit in-sample offsets)");
   MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "modconv_hires: lrelu / linear only");
@@ -386,10 +385,16 @@ int launch_modconv_hires(hipStream_t stream, const HiresArgs& a) {
   HiresArgs b = a;
   if (a.act == MAUA_ACT_LINEAR) b.alpha = 1.f;
   MAUA_REQUIRE(b.alpha >= 0.f && b.alpha <= 1.f && b.gain > 0.f, "modconv_hires: needs 0 <= alpha <= 1 and gain > 0");
-  if (a.Ci == 32) return launch_hires_variant<32, 32, 1>(stream, b);
-  if (a.up == 1) return launch_hires_variant<64, 64, 1>(stream, b);
+  if (dtype == MAUA_F16) {   // (round 6: the reference's own render dtype on the same kernels - v_mfma_f32_32x32x16_f16, half conversions)
+    if (a.Ci == 32) return launch_hires_variant<32, 32, 1, f16_t>(stream, b);
+    if (a.up == 1) return launch_hires_variant<64, 64, 1, f16_t>(stream, b);
+    MAUA_REQUIRE(!a.rgb_out, "modconv_hires: toRGB fusion is for conv1 layers");
+    return launch_hires_variant<64, 32, 2, f16_t>(stream, b);
+  }
+  if (a.Ci == 32) return launch_hires_variant<32, 32, 1, bf16_t>(stream, b);
+  if (a.up == 1) return launch_hires_variant<64, 64, 1, bf16_t>(stream, b);
   MAUA_REQUIRE(!a.rgb_out, "modconv_hires: toRGB fusion is for conv1 layers");
-  return launch_hires_variant<64, 32, 2>(stream, b);
+  return launch_hires_variant<64, 32, 2, bf16_t>(stream, b);
 }
 
 }  // namespace maua

@@ -42,13 +42,15 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
                : "memory");
 }
+template <typename F>
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  Mma16<F>::step(acc, w, x);
 }
 __device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
 
 }  // namespace
 
+template <typename F>
 __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
   constexpr int ES = 128 * 2 + 16, PPP = 16;  // epilogue tile row stride, 16-byte pieces per position (128 virtual ch)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -144,21 +146,21 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
     u32x4 A20 = TD_A(2, 0, KS_, BUF_), A21 = TD_A(2, 1, KS_, BUF_);   /* halo row 2w+2 */                 \
     {                                                                                                    \
       const u32x4 B0 = TD_B(0, KS_, BUF_), B1 = TD_B(1, KS_, BUF_), B2 = TD_B(2, KS_, BUF_);              \
-      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);            /* shift (1,1) */                     \
-      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);            /* shift (1,0), class 1 */            \
-      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);            /* shift (1,0), class 0 */            \
+      mma<F>(acc[0][0], B0, A00); mma<F>(acc[1][0], B0, A10);            /* shift (1,1) */                     \
+      mma<F>(acc[0][1], B2, A01); mma<F>(acc[1][1], B2, A11);            /* shift (1,0), class 1 */            \
+      mma<F>(acc[0][0], B1, A01); mma<F>(acc[1][0], B1, A11);            /* shift (1,0), class 0 */            \
     }                                                                                                    \
     {                                                                                                    \
       const u32x4 B3 = TD_B(3, KS_, BUF_), B4 = TD_B(4, KS_, BUF_);                                       \
-      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);            /* shift (0,1), class 2 */            \
-      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);            /* shift (0,1), class 0 */            \
+      mma<F>(acc[0][2], B4, A10); mma<F>(acc[1][2], B4, A20);            /* shift (0,1), class 2 */            \
+      mma<F>(acc[0][0], B3, A10); mma<F>(acc[1][0], B3, A20);            /* shift (0,1), class 0 */            \
     }                                                                                                    \
     {                                                                                                    \
       const u32x4 B5 = TD_B(5, KS_, BUF_), B6 = TD_B(6, KS_, BUF_), B7 = TD_B(7, KS_, BUF_), B8 = TD_B(8, KS_, BUF_); \
-      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);            /* shift (0,0) */                     \
-      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);                                                  \
-      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);                                                  \
-      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);                                                  \
+      mma<F>(acc[0][3], B8, A11); mma<F>(acc[1][3], B8, A21);            /* shift (0,0) */                     \
+      mma<F>(acc[0][1], B6, A11); mma<F>(acc[1][1], B6, A21);                                                  \
+      mma<F>(acc[0][2], B7, A11); mma<F>(acc[1][2], B7, A21);                                                  \
+      mma<F>(acc[0][0], B5, A11); mma<F>(acc[1][0], B5, A21);                                                  \
     }                                                                                                    \
   }
   for (int c = 0; c < n_chunks; c++) {
@@ -175,15 +177,15 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
       __syncthreads();                                  // ... for everybody; chunk c's buffers are free
       if (c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
-      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);
-      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);
-      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);
-      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);
-      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);
-      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);
-      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);
-      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);
-      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);
+      mma<F>(acc[0][0], B0, A00); mma<F>(acc[1][0], B0, A10);
+      mma<F>(acc[0][1], B2, A01); mma<F>(acc[1][1], B2, A11);
+      mma<F>(acc[0][0], B1, A01); mma<F>(acc[1][0], B1, A11);
+      mma<F>(acc[0][2], B4, A10); mma<F>(acc[1][2], B4, A20);
+      mma<F>(acc[0][0], B3, A10); mma<F>(acc[1][0], B3, A20);
+      mma<F>(acc[0][3], B8, A11); mma<F>(acc[1][3], B8, A21);
+      mma<F>(acc[0][1], B6, A11); mma<F>(acc[1][1], B6, A21);
+      mma<F>(acc[0][2], B7, A11); mma<F>(acc[1][2], B7, A21);
+      mma<F>(acc[0][0], B5, A11); mma<F>(acc[1][0], B5, A21);
     }
   }
 #undef TD_ISSUE
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
 #pragma unroll
       for (int qd = 0; qd < 4; qd++)
         *reinterpret_cast<uint2*>(epi + m * ES + (c * 32 + 8 * qd + 4 * h) * 2) =
-            make_uint2(pack2bf(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), pack2bf(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
+            make_uint2(Fmt16<F>::pack2(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), Fmt16<F>::pack2(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
   }
   __syncthreads();
   char* yb = reinterpret_cast<char*>(a.y) + (long)b * Ht * Wt * a.Co * 2;
@@ -225,13 +227,14 @@ __global__ __launch_bounds__(NT, 2) void tconv_dma_kernel(ConvArgs a) {
 // from global memory (L2) as MFMA fragments.  One wave per (32 positions, 32 channels, sample); K runs over all input
 // channels in 16-channel steps.  (tconv2_kernel's thin regions did this work in 8 x 32 / 64 x 4 tiles at 12 - 25 % use
 // with all nine blocks: 0.06 ms per layer at B = 32 for 0.4 % of the layer's MACs.)
+template <typename F>
 __global__ __launch_bounds__(64) void tconv_edges_kernel(ConvArgs a, int row_tiles) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y, cb = blockIdx.z, CB = a.Co >> 5;
   const bool row_edge = (int)blockIdx.x < row_tiles;
   const int e0 = (row_edge ? (int)blockIdx.x : (int)blockIdx.x - row_tiles) * 32 + r;   // j (row edge) or i (column edge)
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * a.x_bstride;
-  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w);
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(a.x) + (long)b * a.x_bstride;
+  const uint16_t* wp = reinterpret_cast<const uint16_t*>(a.w);
   // input fragments: X0 = shift (1,1), X1 = shift (1,0) [row edge] or (0,1) [column edge]
   long x0 = -1, x1 = -1;
   if (row_edge) {
@@ -243,9 +246,9 @@ __global__ __launch_bounds__(64) void tconv_edges_kernel(ConvArgs a, int row_til
   }
   // weight blocks [slot][CB][class][32][Ci]: W0 = (slot 0, class 0); row edge: W1 = (1, 0), W2 = (1, 1); column: (2, 0), (2, 2)
   const int s1 = row_edge ? 1 : 2, c2 = row_edge ? 1 : 2;
-  const bf16_t* w0 = wp + ((((long)0 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
-  const bf16_t* w1 = wp + ((((long)s1 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
-  const bf16_t* w2 = wp + ((((long)s1 * CB + cb) * 4 + c2) * 32 + r) * a.Ci + 8 * h;
+  const uint16_t* w0 = wp + ((((long)0 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
+  const uint16_t* w1 = wp + ((((long)s1 * CB + cb) * 4 + 0) * 32 + r) * a.Ci + 8 * h;
+  const uint16_t* w2 = wp + ((((long)s1 * CB + cb) * 4 + c2) * 32 + r) * a.Ci + 8 * h;
   f32x16 acc0, acc1;
 #pragma unroll
   for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -256,12 +259,12 @@ __global__ __launch_bounds__(64) void tconv_edges_kernel(ConvArgs a, int row_til
                 A2 = *reinterpret_cast<const u32x4*>(w2 + k);
     const u32x4 X0 = x0 >= 0 ? *reinterpret_cast<const u32x4*>(xb + x0 + k + 8 * h) : zero;
     const u32x4 X1 = x1 >= 0 ? *reinterpret_cast<const u32x4*>(xb + x1 + k + 8 * h) : zero;
-    mma(acc0, A0, X0);
-    mma(acc1, A2, X1);
-    mma(acc0, A1, X1);
+    mma<F>(acc0, A0, X0);
+    mma<F>(acc1, A2, X1);
+    mma<F>(acc0, A1, X1);
   }
   const int Wt = 2 * a.W + 1, Ht = 2 * a.H + 1;
-  bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long)b * Ht * Wt * a.Co + cb * 32 + 4 * h;
+  uint16_t* yb = reinterpret_cast<uint16_t*>(a.y) + (long)b * Ht * Wt * a.Co + cb * 32 + 4 * h;
   long o0 = -1, o1 = -1;   // class (0,0) and the edge's second class
   if (row_edge) {
     if (e0 <= a.W) o0 = ((long)(2 * a.H) * Wt + 2 * e0) * a.Co;
@@ -273,40 +276,48 @@ __global__ __launch_bounds__(64) void tconv_edges_kernel(ConvArgs a, int row_til
 #pragma unroll
   for (int qd = 0; qd < 4; qd++) {
     if (o0 >= 0)
-      *reinterpret_cast<uint2*>(yb + o0 + 8 * qd) = make_uint2(pack2bf(acc0[qd * 4], acc0[qd * 4 + 1]), pack2bf(acc0[qd * 4 + 2], acc0[qd * 4 + 3]));
+      *reinterpret_cast<uint2*>(yb + o0 + 8 * qd) = make_uint2(Fmt16<F>::pack2(acc0[qd * 4], acc0[qd * 4 + 1]), Fmt16<F>::pack2(acc0[qd * 4 + 2], acc0[qd * 4 + 3]));
     if (o1 >= 0)
-      *reinterpret_cast<uint2*>(yb + o1 + 8 * qd) = make_uint2(pack2bf(acc1[qd * 4], acc1[qd * 4 + 1]), pack2bf(acc1[qd * 4 + 2], acc1[qd * 4 + 3]));
+      *reinterpret_cast<uint2*>(yb + o1 + 8 * qd) = make_uint2(Fmt16<F>::pack2(acc1[qd * 4], acc1[qd * 4 + 1]), Fmt16<F>::pack2(acc1[qd * 4 + 2], acc1[qd * 4 + 3]));
   }
 }
 
 // last row / column of positions; a.x must already carry the styles (as for launch_tconv_dma)
-int launch_tconv_edges(hipStream_t stream, const ConvArgs& a) {
+int launch_tconv_edges(hipStream_t stream, const ConvArgs& a, int dtype) {
   MAUA_REQUIRE(a.Ci % 16 == 0 && a.Co % 32 == 0, "tconv_edges: Ci % 16, Co % 32");
   if (a.B == 0) return MAUA_OK;
   const int row_tiles = (a.W + 1 + 31) / 32, col_tiles = (a.H + 31) / 32;
   MAUA_REQUIRE(a.B <= 65535 && a.Co / 32 <= 65535, "tconv_edges: grid too large");
-  hipLaunchKernelGGL(tconv_edges_kernel, dim3(row_tiles + col_tiles, a.B, a.Co / 32), dim3(64), 0, stream, a, row_tiles);
+  if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(tconv_edges_kernel<f16_t>, dim3(row_tiles + col_tiles, a.B, a.Co / 32), dim3(64), 0, stream, a, row_tiles);
+  else
+    hipLaunchKernelGGL(tconv_edges_kernel<bf16_t>, dim3(row_tiles + col_tiles, a.B, a.Co / 32), dim3(64), 0, stream, a, row_tiles);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 
 bool tconv_dma_supported(int dtype, int Ci, int Co, int H, int W) {
-  return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H % PTH == 0 && W % PTW == 0 &&
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && Ci % 32 == 0 && Co % 32 == 0 && H % PTH == 0 && W % PTW == 0 &&
          (long)H * W * Ci * 2 < (1L << 32) && 16L * Co * Ci * 2 < (1L << 32);
 }
 
 // main H x W block of the position grid; a.x must already carry the styles.  The caller adds the last row / column with
 // launch_tconv2 (variant = TCONV_EDGES_ONLY, unit styles).
-int launch_tconv_dma(hipStream_t stream, const ConvArgs& a) {
-  MAUA_REQUIRE(tconv_dma_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W), "tconv_dma: unsupported shape");
+int launch_tconv_dma(hipStream_t stream, const ConvArgs& a, int dtype) {
+  MAUA_REQUIRE(tconv_dma_supported(dtype, a.Ci, a.Co, a.H, a.W), "tconv_dma: unsupported shape");
   if (a.B == 0) return MAUA_OK;
   const int tiles = (a.H / PTH) * (a.W / PTW), CB = a.Co / 32, cbg = CB < 8 ? CB : 8;
   MAUA_REQUIRE(CB % cbg == 0, "tconv_dma: channel blocks must split into groups of 8");
   const long n_ts = (long)tiles * a.B, grid = ((n_ts + 7) / 8) * 8 * cbg * (CB / cbg);
   MAUA_REQUIRE(grid < (1L << 31), "tconv_dma: grid too large");
   const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * HBUF, (size_t)PTH * PTW * (128 * 2 + 16));
-  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(tconv_dma_kernel, dim3((unsigned)grid), dim3(NT), smem, stream, a);
+  if (dtype == MAUA_F16) {
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(tconv_dma_kernel<f16_t>, dim3((unsigned)grid), dim3(NT), smem, stream, a);
+  } else {
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_dma_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(tconv_dma_kernel<bf16_t>, dim3((unsigned)grid), dim3(NT), smem, stream, a);
+  }
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

@@ -42,8 +42,9 @@ __device__ __forceinline__ void dma16_s(const void* sbase, unsigned voff, unsign
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst)
                : "memory");
 }
+template <typename F>
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& w, const u32x4& x) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  Mma16<F>::step(acc, w, x);
 }
 __device__ __forceinline__ int swz(int n) { return (n >> 2) & 3; }
 
@@ -60,6 +61,7 @@ __device__ __forceinline__ int t_col(int tc, int pc) {
 
 // the two horizontal [1,3,3,1] sums of one t row for the output columns xl, xl + 1 (upfir_hrow's arithmetic); tcol[rx] =
 // t_col(xl - 1 + rx, pc)
+template <typename F>
 __device__ __forceinline__ void fir_hrow(const char* tile, int tr, const int (&tcol)[5], f32x2_t (&h)[2][4]) {
   f32x2_t c[5][4];
   const int rowb = (tr >> 1) * (PTW * ES), rsw = (tr & 1) << 7;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void fir_hrow(const char* tile, int tr, const int (&t
   for (int rx = 0; rx < 5; rx++) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(tile + rowb + (tcol[rx] ^ rsw));
 #pragma unroll
-    for (int k = 0; k < 4; k++) c[rx][k] = f32x2_t{__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+    for (int k = 0; k < 4; k++) c[rx][k] = f32x2_t{Fmt16<F>::lo(v[k]), Fmt16<F>::hi(v[k])};
   }
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -81,7 +83,7 @@ __device__ __forceinline__ void fir_hrow(const char* tile, int tr, const int (&t
 // PTH_ = 8: 4 waves, 75 KB of LDS, two workgroups per CU, 6 x 30 useful positions of 8 x 32 (1.42x MACs).  The kernel is
 // written for any even PTH_; PTH_ = 16 (8 waves, 136 KB, ONE workgroup per CU, 14 x 30 of 16 x 32 = 1.22x MACs) measured
 // 3.78 vs 3.50 ms on the 256^2 -> 512^2 layer at B = 128 - two workgroups out of phase are worth more than the saved rows.
-template <int PTH_>
+template <int PTH_, typename F>
 __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel(ConvArgs a, UpfirArgs u) {
   constexpr int PTH = PTH_, UPR = PTH - 2;           // position rows computed / useful
   constexpr int HPX = (PTH + 1) * HW1, HBUF = HPX * KB;
@@ -182,21 +184,21 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
     u32x4 A20 = TD_A(2, 0, KS_, BUF_), A21 = TD_A(2, 1, KS_, BUF_);   /* halo row 2w+2 */                 \
     {                                                                                                    \
       const u32x4 B0 = TD_B(0, KS_, BUF_), B1 = TD_B(1, KS_, BUF_), B2 = TD_B(2, KS_, BUF_);              \
-      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);            /* shift (1,1) */                     \
-      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);            /* shift (1,0), class 1 */            \
-      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);            /* shift (1,0), class 0 */            \
+      mma<F>(acc[0][0], B0, A00); mma<F>(acc[1][0], B0, A10);            /* shift (1,1) */                     \
+      mma<F>(acc[0][1], B2, A01); mma<F>(acc[1][1], B2, A11);            /* shift (1,0), class 1 */            \
+      mma<F>(acc[0][0], B1, A01); mma<F>(acc[1][0], B1, A11);            /* shift (1,0), class 0 */            \
     }                                                                                                    \
     {                                                                                                    \
       const u32x4 B3 = TD_B(3, KS_, BUF_), B4 = TD_B(4, KS_, BUF_);                                       \
-      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);            /* shift (0,1), class 2 */            \
-      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);            /* shift (0,1), class 0 */            \
+      mma<F>(acc[0][2], B4, A10); mma<F>(acc[1][2], B4, A20);            /* shift (0,1), class 2 */            \
+      mma<F>(acc[0][0], B3, A10); mma<F>(acc[1][0], B3, A20);            /* shift (0,1), class 0 */            \
     }                                                                                                    \
     {                                                                                                    \
       const u32x4 B5 = TD_B(5, KS_, BUF_), B6 = TD_B(6, KS_, BUF_), B7 = TD_B(7, KS_, BUF_), B8 = TD_B(8, KS_, BUF_); \
-      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);            /* shift (0,0) */                     \
-      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);                                                  \
-      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);                                                  \
-      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);                                                  \
+      mma<F>(acc[0][3], B8, A11); mma<F>(acc[1][3], B8, A21);            /* shift (0,0) */                     \
+      mma<F>(acc[0][1], B6, A11); mma<F>(acc[1][1], B6, A21);                                                  \
+      mma<F>(acc[0][2], B7, A11); mma<F>(acc[1][2], B7, A21);                                                  \
+      mma<F>(acc[0][0], B5, A11); mma<F>(acc[1][0], B5, A21);                                                  \
     }                                                                                                    \
   }
   for (int c = 0; c < n_chunks; c++) {
@@ -213,15 +215,15 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk c+1 (issued one chunk ago) has landed
       __syncthreads();                                  // ... for everybody; chunk c's buffers are free
       if (c + 2 < n_chunks) TD_ISSUE(c + 2, buf)
-      mma(acc[0][0], B0, A00); mma(acc[1][0], B0, A10);
-      mma(acc[0][1], B2, A01); mma(acc[1][1], B2, A11);
-      mma(acc[0][0], B1, A01); mma(acc[1][0], B1, A11);
-      mma(acc[0][2], B4, A10); mma(acc[1][2], B4, A20);
-      mma(acc[0][0], B3, A10); mma(acc[1][0], B3, A20);
-      mma(acc[0][3], B8, A11); mma(acc[1][3], B8, A21);
-      mma(acc[0][1], B6, A11); mma(acc[1][1], B6, A21);
-      mma(acc[0][2], B7, A11); mma(acc[1][2], B7, A21);
-      mma(acc[0][0], B5, A11); mma(acc[1][0], B5, A21);
+      mma<F>(acc[0][0], B0, A00); mma<F>(acc[1][0], B0, A10);
+      mma<F>(acc[0][1], B2, A01); mma<F>(acc[1][1], B2, A11);
+      mma<F>(acc[0][0], B1, A01); mma<F>(acc[1][0], B1, A11);
+      mma<F>(acc[0][2], B4, A10); mma<F>(acc[1][2], B4, A20);
+      mma<F>(acc[0][0], B3, A10); mma<F>(acc[1][0], B3, A20);
+      mma<F>(acc[0][3], B8, A11); mma<F>(acc[1][3], B8, A21);
+      mma<F>(acc[0][1], B6, A11); mma<F>(acc[1][1], B6, A21);
+      mma<F>(acc[0][2], B7, A11); mma<F>(acc[1][2], B7, A21);
+      mma<F>(acc[0][0], B5, A11); mma<F>(acc[1][0], B5, A21);
     }
   }
 #undef TD_ISSUE
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
 #pragma unroll
       for (int qd = 0; qd < 4; qd++)
         *reinterpret_cast<uint2*>(tt + m * ES + (((c ^ (r & 3)) << 6) | ((qd ^ ((r >> 2) & 3)) << 4) | (h << 3))) =
-            make_uint2(pack2bf(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), pack2bf(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
+            make_uint2(Fmt16<F>::pack2(acc[R][c][qd * 4 + 0], acc[R][c][qd * 4 + 1]), Fmt16<F>::pack2(acc[R][c][qd * 4 + 2], acc[R][c][qd * 4 + 3]));
   }
   __syncthreads();
   // ---- FIR + epilogue (upfir_epilogue_kernel's arithmetic)
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
 #pragma unroll
       for (int rx = 0; rx < 5; rx++) tcol[rx] = t_col(xl - 1 + rx, pc);
       f32x2_t hr[4][2][4];
-      fir_hrow(tt, yl0 - 1, tcol, hr[0]);
-      fir_hrow(tt, yl0, tcol, hr[1]);
-      fir_hrow(tt, yl0 + 1, tcol, hr[2]);
+      fir_hrow<F>(tt, yl0 - 1, tcol, hr[0]);
+      fir_hrow<F>(tt, yl0, tcol, hr[1]);
+      fir_hrow<F>(tt, yl0 + 1, tcol, hr[2]);
 #pragma unroll
       for (int k = 0; k < FROWS; k++) {
-        fir_hrow(tt, yl0 + k + 2, tcol, hr[(k + 3) & 3]);
+        fir_hrow<F>(tt, yl0 + k + 2, tcol, hr[(k + 3) & 3]);
         const int Y = 2 * ty0 + yl0 + k;
         if (Y < Ho) {
           const float nz[2] = {nzv[k].x * nzs, nzv[k].y * nzs};
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
               o[e] = f32x2_t{__builtin_amdgcn_fmed3f(t[0], -cl, cl), __builtin_amdgcn_fmed3f(t[1], -cl, cl)} * sv[e];
             }
             *reinterpret_cast<u32x4*>(yb + (((long)Y * Wo + X + j) * a.Co + cho) * 2) =
-                u32x4{pack2bf(o[0][0], o[0][1]), pack2bf(o[1][0], o[1][1]), pack2bf(o[2][0], o[2][1]), pack2bf(o[3][0], o[3][1])};
+                u32x4{Fmt16<F>::pack2(o[0][0], o[0][1]), Fmt16<F>::pack2(o[1][0], o[1][1]), Fmt16<F>::pack2(o[2][0], o[2][1]), Fmt16<F>::pack2(o[3][0], o[3][1])};
           }
         }
       }
@@ -321,14 +323,14 @@ __global__ __launch_bounds__(PTH_ * 32, PTH_ == 8 ? 2 : 1) void tconv_fir_kernel
 }
 
 bool tconv_fir_supported(int dtype, int Ci, int Co, int H, int W) {
-  return dtype == MAUA_BF16 && Ci % 32 == 0 && Co % 32 == 0 && H >= 16 && W >= 32 && (long)H * W * Ci * 2 < (1L << 32) &&
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && Ci % 32 == 0 && Co % 32 == 0 && H >= 16 && W >= 32 && (long)H * W * Ci * 2 < (1L << 32) &&
          16L * Co * Ci * 2 < (1L << 32);
 }
 
 // the whole up-layer: a = the transposed convolution's arguments (x already multiplied by the styles, w from
 // launch_prep_tconv_weights; y unused), u = the FIR / epilogue arguments (t unused; lrelu with 0 <= alpha <= 1, gain > 0)
-int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u) {
-  MAUA_REQUIRE(tconv_fir_supported(MAUA_BF16, a.Ci, a.Co, a.H, a.W), "tconv_fir: unsupported shape");
+int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u, int dtype) {
+  MAUA_REQUIRE(tconv_fir_supported(dtype, a.Ci, a.Co, a.H, a.W), "tconv_fir: unsupported shape");
   MAUA_REQUIRE(u.act == MAUA_ACT_LRELU && u.alpha >= 0.f && u.alpha <= 1.f && u.gain > 0.f, "tconv_fir: lrelu epilogue only");
   MAUA_REQUIRE(!u.noise || (((uintptr_t)u.noise % 8) == 0 && u.noise_bstride % 2 == 0), "tconv_fir: noise must be 8-byte aligned");
   if (a.B == 0) return MAUA_OK;
@@ -338,8 +340,13 @@ int launch_tconv_fir(hipStream_t stream, const ConvArgs& a, const UpfirArgs& u) 
   const long n_ts = (long)tiles * a.B, grid = ((n_ts + 7) / 8) * 8 * cbg * (CB / cbg);
   MAUA_REQUIRE(grid < (1L << 31), "tconv_fir: grid too large");
   const size_t smem = std::max<size_t>((size_t)2 * WBUF + 2 * (pth + 1) * HW1 * KB, (size_t)pth * PTW * ES);
-  MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_fir_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(tconv_fir_kernel<8>, dim3((unsigned)grid), dim3(256), smem, stream, a, u);
+  if (dtype == MAUA_F16) {
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_fir_kernel<8, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((tconv_fir_kernel<8, f16_t>), dim3((unsigned)grid), dim3(256), smem, stream, a, u);
+  } else {
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)tconv_fir_kernel<8, bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((tconv_fir_kernel<8, bf16_t>), dim3((unsigned)grid), dim3(256), smem, stream, a, u);
+  }
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

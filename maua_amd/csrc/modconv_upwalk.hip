@@ -31,7 +31,15 @@ namespace {
 constexpr int UW_TW = 64;  // positions per strip
 }
 
-template <int CI, int CO>
+// the 32x32x16 matrix instruction of the kernel's 16-bit format on operands held as any 16-byte register type
+template <typename F, typename A, typename B>
+__device__ __forceinline__ f32x16 mfma16(const A& a, const B& b, const f32x16& c) {
+  f32x16 r = c;
+  Mma16<F>::step(r, __builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, b));
+  return r;
+}
+
+template <int CI, int CO, typename F>
 __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_rows) {
   constexpr int KS = CI / 16;
   constexpr int PIECES = CI * 2 / 16;
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_row
   const int j0 = blockIdx.x * TW;
   const int r0 = blockIdx.y * seg_rows, r1 = min(r0 + seg_rows, a.H);
   const int nsteps = r1 - r0 + 2;
-  const bf16_t* xb = reinterpret_cast<const bf16_t*>(a.x) + (long)b * a.H * a.W * CI;
+  const uint16_t* xb = reinterpret_cast<const uint16_t*>(a.x) + (long)b * a.H * a.W * CI;
   const int Wo = a.W * 2;
   char* yb = reinterpret_cast<char*>(a.y) + (long)b * (a.H * 2) * Wo * CO * 2;
   const float* nb = a.noise ? a.noise + (long)b * a.noise_bstride : nullptr;
@@ -70,19 +78,19 @@ __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_row
     for (int cs = 0; cs < KS; cs++)
 #pragma unroll
       for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e] * dco;
-    const bf16_t* wbase = reinterpret_cast<const bf16_t*>(a.w);
+    const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.w);
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
       for (int kx = 0; kx < 3; kx++)
 #pragma unroll
         for (int cs = 0; cs < KS; cs++) {
-          const bf16_t* src = wbase + ((((long)i * 2 + pb) * 3 + kx) * CO + r) * CI + cs * 16 + 8 * h;
+          const uint16_t* src = wbase + ((((long)i * 2 + pb) * 3 + kx) * CO + r) * CI + cs * 16 + 8 * h;
           const u32x4 v = *reinterpret_cast<const u32x4*>(src);
           u32x4 o;
 #pragma unroll
           for (int k = 0; k < 4; k++)
-            o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[cs][2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[cs][2 * k + 1]);
+            o[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) * sv[cs][2 * k], Fmt16<F>::hi(v[k]) * sv[cs][2 * k + 1]);
           if (i == 1) { if (wave < 2) wl[((pb * 3 + kx) * KS + cs) * 64 + lane] = o; }
           else wf[((i >> 1) * 3 + kx) * KS + cs] = o;
         }
@@ -159,9 +167,9 @@ __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_row
       for (int cs = 0; cs < KS; cs++) {
         const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(abase + kx * RSH + cs * 32));
         const bf16x8 wo = __builtin_bit_cast(bf16x8, wl[((pb * 3 + kx) * KS + cs) * 64 + lane]);
-        ecur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[(1 * 3 + kx) * KS + cs]), av, ecur, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wo, av, o, 0, 0, 0);
-        enext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[(0 * 3 + kx) * KS + cs]), av, enext, 0, 0, 0);
+        ecur = mfma16<F>(__builtin_bit_cast(bf16x8, wf[(1 * 3 + kx) * KS + cs]), av, ecur);
+        o = mfma16<F>(wo, av, o);
+        enext = mfma16<F>(__builtin_bit_cast(bf16x8, wf[(0 * 3 + kx) * KS + cs]), av, enext);
       }
     // ---- vertical FIR on the accumulators + epilogue: lane = position jbase + r, 16 channels in 4 quads
     // (each lane finishes both rows of its pixel: the other row's noise sits in the lane 32 away)
@@ -191,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void upwalk_kernel(HiresArgs a, int seg_row
         v0[kk] = __builtin_amdgcn_fmed3f(y0, -cl, cl);
         v1[kk] = __builtin_amdgcn_fmed3f(y1, -cl, cl);
       }
-      *reinterpret_cast<uint2*>(et + ((qd ^ esw) * 16)) = make_uint2(pack2bf(v0[0], v0[1]), pack2bf(v0[2], v0[3]));
-      *reinterpret_cast<uint2*>(et + OPX * ES + ((qd ^ esw) * 16)) = make_uint2(pack2bf(v1[0], v1[1]), pack2bf(v1[2], v1[3]));
+      *reinterpret_cast<uint2*>(et + ((qd ^ esw) * 16)) = make_uint2(Fmt16<F>::pack2(v0[0], v0[1]), Fmt16<F>::pack2(v0[2], v0[3]));
+      *reinterpret_cast<uint2*>(et + OPX * ES + ((qd ^ esw) * 16)) = make_uint2(Fmt16<F>::pack2(v1[0], v1[1]), Fmt16<F>::pack2(v1[2], v1[3]));
     }
     ecur = enext;
   }
@@ -245,7 +253,7 @@ __device__ __forceinline__ void lds_dma_b32(const void* sbase, unsigned voff_byt
                : "memory");
 }
 
-template <int CI, int CM, bool DBG>
+template <int CI, int CM, bool DBG, typename F>
 __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, int seg_rows, int nseg, int strips,
                                                              int n_items, int items_per_wg, int narrow_last, long long* dbg) {
   constexpr int KS = CI / 16, KS1 = CM / 16;
@@ -317,19 +325,19 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         for (int cs = 0; cs < KS; cs++)
 #pragma unroll
           for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e] * dco;
-        const bf16_t* wbase = reinterpret_cast<const bf16_t*>(a.w);
+        const uint16_t* wbase = reinterpret_cast<const uint16_t*>(a.w);
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
           for (int kx = 0; kx < 3; kx++)
 #pragma unroll
             for (int cs = 0; cs < KS; cs++) {
-              const bf16_t* src = wbase + ((((long)i * 2 + pb) * 3 + kx) * CM + r) * CI + cs * 16 + 8 * h;
+              const uint16_t* src = wbase + ((((long)i * 2 + pb) * 3 + kx) * CM + r) * CI + cs * 16 + 8 * h;
               const u32x4 v = *reinterpret_cast<const u32x4*>(src);
               u32x4 o;
 #pragma unroll
               for (int k = 0; k < 4; k++)
-                o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[cs][2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[cs][2 * k + 1]);
+                o[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) * sv[cs][2 * k], Fmt16<F>::hi(v[k]) * sv[cs][2 * k + 1]);
               if (widx < 2) wl[(((pb * 3 + i) * 3 + kx) * KS + cs) * 64 + lane] = o;
             }
       }
@@ -445,9 +453,9 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
           if (it + PD - 1 < 3 * KS) MAUA_UWF_PLOAD(it + PD - 1)
           __builtin_amdgcn_sched_barrier(0);
           const bf16x8 av = __builtin_bit_cast(bf16x8, pa[it % PD]);
-          ecur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pw2[it % PD]), av, ecur, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pw1[it % PD]), av, o, 0, 0, 0);
-          enext = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pw0[it % PD]), av, enext, 0, 0, 0);
+          ecur = mfma16<F>(__builtin_bit_cast(bf16x8, pw2[it % PD]), av, ecur);
+          o = mfma16<F>(__builtin_bit_cast(bf16x8, pw1[it % PD]), av, o);
+          enext = mfma16<F>(__builtin_bit_cast(bf16x8, pw0[it % PD]), av, enext);
           __builtin_amdgcn_sched_barrier(0);
         }
 #undef MAUA_UWF_PLOAD
@@ -479,8 +487,8 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
             y0 += nz0;
             y1 += nz1;
             const f32x2_t s0 = y0 * al, s1 = y1 * al;
-            w0[kk >> 1] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(y0[0], s0[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(y0[1], s0[1]), -cl, cl));
-            w1[kk >> 1] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(y1[0], s1[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(y1[1], s1[1]), -cl, cl));
+            w0[kk >> 1] = Fmt16<F>::pack2(__builtin_amdgcn_fmed3f(fmaxf(y0[0], s0[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(y0[1], s0[1]), -cl, cl));
+            w1[kk >> 1] = Fmt16<F>::pack2(__builtin_amdgcn_fmed3f(fmaxf(y1[0], s1[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(y1[1], s1[1]), -cl, cl));
           }
           *reinterpret_cast<uint2*>(et + ((qd ^ esw) * 16)) = make_uint2(w0[0], w0[1]);
           *reinterpret_cast<uint2*>(et + RROW + ((qd ^ esw) * 16)) = make_uint2(w1[0], w1[1]);
@@ -531,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         for (int cs = 0; cs < KS1; cs++)
 #pragma unroll
           for (int e = 0; e < 8; e++) sv[cs][e] = sb[cs * 16 + 8 * h + e] * dco;
-        const bf16_t* wbase = reinterpret_cast<const bf16_t*>(c.w);
+        const uint16_t* wbase = reinterpret_cast<const uint16_t*>(c.w);
 #pragma unroll
         for (int tap = 0; tap < 9; tap++)
 #pragma unroll
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
             u32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; k++)
-              o[k] = pack2bf(bf2f((bf16_t)(v[k] & 0xffff)) * sv[cs][2 * k], bf2f((bf16_t)(v[k] >> 16)) * sv[cs][2 * k + 1]);
+              o[k] = Fmt16<F>::pack2(Fmt16<F>::lo(v[k]) * sv[cs][2 * k], Fmt16<F>::hi(v[k]) * sv[cs][2 * k + 1]);
             w1[tap * KS1 + cs] = o;
           }
         // toRGB A fragments: rows 0..2 = bf16(hi) of the pre-modulated RGB weights, rows 8..10 the bf16 remainder, rows
@@ -556,9 +564,9 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               float w0 = src[8 * (k >> 1) + 2 * (k & 1)], w1v = src[8 * (k >> 1) + 2 * (k & 1) + 1];
-              const float h0 = bf2f(f2bf(w0)), h1 = bf2f(f2bf(w1v));
+              const float h0 = Fmt16<F>::round(w0), h1 = Fmt16<F>::round(w1v);
               if (r >= 8) { w0 -= h0; w1v -= h1; }
-              o[k] = pack2bf(w0, w1v);
+              o[k] = Fmt16<F>::pack2(w0, w1v);
             }
           }
           rf[ks] = o;
@@ -646,22 +654,22 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 3 * KS1; i++) {   // taps dy = -1 of accA / dy = +1 of accB
-          accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, f0[i]), accA, 0, 0, 0);
-          accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[2 * 3 * KS1 + i]), __builtin_bit_cast(bf16x8, f3[i]), accB, 0, 0, 0);
+          accA = mfma16<F>(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, f0[i]), accA);
+          accB = mfma16<F>(__builtin_bit_cast(bf16x8, w1[2 * 3 * KS1 + i]), __builtin_bit_cast(bf16x8, f3[i]), accB);
         }
         __builtin_amdgcn_sched_barrier(0);
         MAUA_UWF_CLOAD(f0, s1)               // ring row arow
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 3 * KS1; i++) {   // ring row arow - 1: dy = 0 of accA, dy = -1 of accB
-          accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[3 * KS1 + i]), __builtin_bit_cast(bf16x8, f1[i]), accA, 0, 0, 0);
-          accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, f1[i]), accB, 0, 0, 0);
+          accA = mfma16<F>(__builtin_bit_cast(bf16x8, w1[3 * KS1 + i]), __builtin_bit_cast(bf16x8, f1[i]), accA);
+          accB = mfma16<F>(__builtin_bit_cast(bf16x8, w1[i]), __builtin_bit_cast(bf16x8, f1[i]), accB);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 3 * KS1; i++) {   // ring row arow: dy = +1 of accA, dy = 0 of accB
-          accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[2 * 3 * KS1 + i]), __builtin_bit_cast(bf16x8, f0[i]), accA, 0, 0, 0);
-          accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1[3 * KS1 + i]), __builtin_bit_cast(bf16x8, f0[i]), accB, 0, 0, 0);
+          accA = mfma16<F>(__builtin_bit_cast(bf16x8, w1[2 * 3 * KS1 + i]), __builtin_bit_cast(bf16x8, f0[i]), accA);
+          accB = mfma16<F>(__builtin_bit_cast(bf16x8, w1[3 * KS1 + i]), __builtin_bit_cast(bf16x8, f0[i]), accB);
         }
 #undef MAUA_UWF_CLOAD
         const long long tc = MAUA_NOW();
@@ -674,8 +682,8 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
           for (int e = 0; e < 16; e += 2) {
             const f32x2_t ya = f32x2_t{accA[e], accA[e + 1]} + nA, yb = f32x2_t{accB[e], accB[e + 1]} + nB;
             const f32x2_t sa = ya * al, sb = yb * al;
-            fa[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(ya[0], sa[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(ya[1], sa[1]), -cl, cl));
-            fb[e >> 3][(e >> 1) & 3] = pack2bf(__builtin_amdgcn_fmed3f(fmaxf(yb[0], sb[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(yb[1], sb[1]), -cl, cl));
+            fa[e >> 3][(e >> 1) & 3] = Fmt16<F>::pack2(__builtin_amdgcn_fmed3f(fmaxf(ya[0], sa[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(ya[1], sa[1]), -cl, cl));
+            fb[e >> 3][(e >> 1) & 3] = Fmt16<F>::pack2(__builtin_amdgcn_fmed3f(fmaxf(yb[0], sb[0]), -cl, cl), __builtin_amdgcn_fmed3f(fmaxf(yb[1], sb[1]), -cl, cl));
           }
         }
         f32x16 ra, rb;
@@ -683,8 +691,8 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
         for (int e = 0; e < 16; e++) { ra[e] = 0.f; rb[e] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS1; ks++) {
-          ra = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fa[ks]), ra, 0, 0, 0);
-          rb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fb[ks]), rb, 0, 0, 0);
+          ra = mfma16<F>(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fa[ks]), ra);
+          rb = mfma16<F>(__builtin_bit_cast(bf16x8, rf[ks]), __builtin_bit_cast(bf16x8, fb[ks]), rb);
         }
         // ---- B: skip = rows m - 1 (staged at step k - 2) and m (step k - 1) of the previous image, m = rho - 2
         const int oy = arow - 1 + h;
@@ -733,12 +741,12 @@ __global__ __launch_bounds__(512, 1) void upwalk_fused_kernel(WalkFusedArgs A, i
 }
 
 bool upwalk_fused_supported(int dtype, int Ci, int Cm, int H, int W) {
-  return dtype == MAUA_BF16 && Ci == 64 && Cm == 32 && H >= 2 && W >= 2 && (long)H * W * 4 * 3 < (1L << 31);
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && Ci == 64 && Cm == 32 && H >= 2 && W >= 2 && (long)H * W * 4 * 3 < (1L << 31);
 }
 
-int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs, int narrow_ok) {
+int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs& c1, int force_segs, int narrow_ok, int dtype) {
   if (up.B == 0) return MAUA_OK;
-  MAUA_REQUIRE(upwalk_fused_supported(MAUA_BF16, up.Ci, up.Co, up.H, up.W) && c1.Ci == up.Co && c1.Co == up.Co &&
+  MAUA_REQUIRE(upwalk_fused_supported(dtype, up.Ci, up.Co, up.H, up.W) && c1.Ci == up.Co && c1.Co == up.Co &&
                    c1.H == 2 * up.H && c1.W == 2 * up.W && up.up == 2 && c1.up == 1,
                "upwalk_fused: unsupported shapes");
   MAUA_REQUIRE((long)up.H * up.W * up.Ci * 2 < (1L << 31), "upwalk_fused: a sample must stay below 2 GiB");
@@ -755,7 +763,8 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
   constexpr int CI = 64, CM = 32;
   const size_t smem = 2 * 9 * 1024 + 6 * 132 * (CM * 2) + 2 * 3 * 3 * (CI / 16) * 64 * 16 + 3 * 256 * 4 + 2 * CM * 4;
   static const bool want_dbg = getenv("MAUA_UW_DBG") != nullptr;
-  auto kern = want_dbg ? upwalk_fused_kernel<CI, CM, true> : upwalk_fused_kernel<CI, CM, false>;
+  auto kern = dtype == MAUA_F16 ? upwalk_fused_kernel<CI, CM, false, f16_t>
+                                : want_dbg ? upwalk_fused_kernel<CI, CM, true, bf16_t> : upwalk_fused_kernel<CI, CM, false, bf16_t>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   int dev = 0, cus = 256;
   MAUA_HIP_CHECK(hipGetDevice(&dev));
@@ -806,14 +815,14 @@ int launch_upwalk_fused(hipStream_t stream, const HiresArgs& up, const HiresArgs
 }
 
 bool upwalk_supported(int dtype, int Ci, int Co, int up, int H, int W) {
-  return dtype == MAUA_BF16 && Ci == 64 && Co == 32 && up == 2 && W % UW_TW == 0 && H >= 2;
+  return (dtype == MAUA_BF16 || dtype == MAUA_F16) && Ci == 64 && Co == 32 && up == 2 && W % UW_TW == 0 && H >= 2;
 }
 
 size_t upwalk_weight_elems(int Co, int Ci) { return (size_t)18 * Co * Ci; }
 
-int launch_upwalk(hipStream_t stream, const HiresArgs& a) {
+int launch_upwalk(hipStream_t stream, const HiresArgs& a, int dtype) {
   if (a.B == 0) return MAUA_OK;
-  MAUA_REQUIRE(upwalk_supported(MAUA_BF16, a.Ci, a.Co, a.up, a.H, a.W), "upwalk: unsupported shape");
+  MAUA_REQUIRE(upwalk_supported(dtype, a.Ci, a.Co, a.up, a.H, a.W), "upwalk: unsupported shape");
   MAUA_REQUIRE((long)a.H * 2 * a.W * 2 * std::max(a.Ci, a.Co) * 2 < (1L << 31),
                "upwalk: a sample must stay below 2 GiB (32-bit in-sample offsets)");
   MAUA_REQUIRE(a.act == MAUA_ACT_LRELU || a.act == MAUA_ACT_LINEAR, "upwalk: lrelu / linear only");
@@ -823,7 +832,7 @@ int launch_upwalk(hipStream_t stream, const HiresArgs& a) {
   MAUA_REQUIRE(b.alpha >= 0.f && b.alpha <= 1.f && b.gain > 0.f, "upwalk: needs 0 <= alpha <= 1 and gain > 0");
   constexpr int CI = 64, CO = 32;
   const size_t smem = 2 * (UW_TW + 2) * (CI * 2 + 16) + 4 * (2 * UW_TW) * (CO * 2) + 2 * 3 * (CI / 16) * 64 * 16 + CO * 4;
-  auto kern = upwalk_kernel<CI, CO>;
+  auto kern = dtype == MAUA_F16 ? upwalk_kernel<CI, CO, f16_t> : upwalk_kernel<CI, CO, bf16_t>;
   MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   // two workgroups per CU over the whole batch: split every 64-position strip into row segments (each segment pays two
   // extra steps for the rows above / below it)
@@ -839,7 +848,8 @@ int launch_upwalk(hipStream_t stream, const HiresArgs& a) {
 }
 
 // ---- weights: f32 [Co][Ci][3][3] -> bf16 [i 3][pb 2][kx 3][Co][Ci] = Kh[i][2 kx + 1 - pb]
-__global__ __launch_bounds__(256) void prep_upwalk_weights_kernel(const float* __restrict__ w, bf16_t* __restrict__ wt,
+template <typename F>
+__global__ __launch_bounds__(256) void prep_upwalk_weights_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt,
                                                                   int Co, int Ci, int flip) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)Co * Ci) return;
@@ -861,14 +871,16 @@ __global__ __launch_bounds__(256) void prep_upwalk_weights_kernel(const float* _
       kh[v] = s;
     }
     for (int pb = 0; pb < 2; pb++)
-      for (int kx = 0; kx < 3; kx++) wt[(((long)i * 2 + pb) * 3 + kx) * plane + idx] = f2bf(kh[2 * kx + 1 - pb]);
+      for (int kx = 0; kx < 3; kx++) wt[(((long)i * 2 + pb) * 3 + kx) * plane + idx] = (uint16_t)(Fmt16<F>::pack2(kh[2 * kx + 1 - pb], 0.f) & 0xffffu);
   }
 }
 
-int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int Co, int Ci, int flip) {
+int launch_prep_upwalk_weights(hipStream_t stream, const float* w, void* wt, int Co, int Ci, int flip, int dtype) {
   const long n = (long)Co * Ci;
-  hipLaunchKernelGGL(prep_upwalk_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w,
-                     (bf16_t*)wt, Co, Ci, flip);
+  if (dtype == MAUA_F16)
+    hipLaunchKernelGGL(prep_upwalk_weights_kernel<f16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, (uint16_t*)wt, Co, Ci, flip);
+  else
+    hipLaunchKernelGGL(prep_upwalk_weights_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, (uint16_t*)wt, Co, Ci, flip);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

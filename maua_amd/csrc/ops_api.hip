@@ -110,9 +110,9 @@ extern "C" int maua_modconv2d(maua_ctx* ctx, const void* x, const float* weight,
   a.bias = bp; a.y = yn; a.B = N; a.H = H; a.W = W; a.Ci = Cip; a.Co = Cop; a.up = up;
   a.act = act; a.alpha = alpha; a.gain = gain; a.clamp = clamp;
   if (dma) {  // the hot path's kernel for this shape: styles applied to the input first (there the producer does it)
-    if ((rc = launch_premod_nhwc(st, xn, a.x_bstride, sp, base + o_xm, N, (long)H * W, Cip))) return rc;
+    if ((rc = launch_premod_nhwc(st, xn, a.x_bstride, sp, base + o_xm, N, (long)H * W, Cip, dtype))) return rc;
     a.x = base + o_xm;
-    if ((rc = launch_modconv_dma(st, a))) return rc;
+    if ((rc = launch_modconv_dma(st, a, dtype))) return rc;
   } else if ((rc = launch_modconv3x3(st, dtype, a))) {
     return rc;
   }

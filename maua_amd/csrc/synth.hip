@@ -64,7 +64,7 @@ struct maua_synth {
   void* const_x = nullptr;  // NHWC [4][4][C0]
   int keep_features = 0;
   int lowres = 1;      // <= 8x8 layers as one batch-wide split-K GEMM (option "lowres")
-  int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16)
+  int use_hires = 1;   // weights-in-registers kernels for the 512^2 / 1024^2 layers (bf16 / f16)
   int upwalk = 2;      // ... and their 64 -> 32 channel up-layer on the half-folded row walk (modconv_upwalk.hip);
                        // 2: the last block as one fused walk when nothing else reads its features
   int walk_segs = 0;   // fused walk: force this many row segments (0: cost model); walk_narrow: a <= 32-column last strip as two
@@ -77,7 +77,7 @@ struct maua_synth {
   const float* nz_scales = nullptr;   // [num_layers][nz_scale_stride] per-sample noise factors (maua_synth_set_noise_scale) or NULL
   long nz_scale_stride = 0;
   int tconv_min = 32;  // ... from this input size up (below: the phase kernels / the batch-wide low-resolution GEMM)
-  int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16)
+  int dma_conv = 1;    // conv1 layers behind such an up-layer: LDS-direct-load kernel on pre-modulated input (bf16 / f16)
   int dual_store = 1;  // ... whose toRGB is a separate pass (512 channels): plain + style-scaled output in one epilogue (no premod pass)
   int tconv_dma = 2;   // the up-layers' transposed conv on LDS-direct loads (main block; pre-modulated input)
   float* ones = nullptr;   // [Bcap][max channels] unit styles (kernels that take already-modulated input)
@@ -575,7 +575,7 @@ int maua_synth_load(maua_synth* n, const char* name, const float* host, size_t c
                                  (c->up == 2) ? (n->nv_compat & 1) : 0, c->Co, c->Ci);
     if (!rc && c->up == 2)
       rc = launch_prep_tconv_weights(st, n->dtype, tmp, c->wt_t, c->Co, c->Ci, n->nv_compat & 1);
-    if (!rc && c->wt_h) rc = launch_prep_upwalk_weights(st, tmp, c->wt_h, c->Co, c->Ci, n->nv_compat & 1);
+    if (!rc && c->wt_h) rc = launch_prep_upwalk_weights(st, tmp, c->wt_h, c->Co, c->Ci, n->nv_compat & 1, n->dtype);
     hipStreamSynchronize(st);
     hipFree(tmp);
     return rc;
@@ -726,7 +726,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             premod_in_xm = true;
           }
         }
-        if (int rc = launch_modconv_dma(st, a)) return rc;
+        if (int rc = launch_modconv_dma(st, a, n->dtype)) return rc;
       } else if (!via_tconv && n->use_hires && hires_supported(n->dtype, c.Ci, c.Co, c.up, c.ih, c.iw)) {
         HiresArgs a{};
         a.x = x; a.w = c.wt; a.s = c.s; a.d = c.d; a.noise = nz; a.noise_bstride = nz_stride;
@@ -779,14 +779,14 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
                 f.rgb_skip_f32 = img_out == nullptr;
               }
               a.y = nullptr;
-              if (int rc = launch_upwalk_fused(st, a, f, n->walk_segs, n->walk_narrow)) return rc;
+              if (int rc = launch_upwalk_fused(st, a, f, n->walk_segs, n->walk_narrow, n->dtype)) return rc;
               fused_walk = true;
               walk_skip = true;
             }
           }
           if (!fused_walk)
-            if (int rc = launch_upwalk(st, a)) return rc;
-        } else if (int rc = launch_modconv_hires(st, a)) {
+            if (int rc = launch_upwalk(st, a, n->dtype)) return rc;
+        } else if (int rc = launch_modconv_hires(st, a, n->dtype)) {
           return rc;
         }
       } else if (via_tconv) {
@@ -804,7 +804,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
             a.x = n->xm;
             a.x_bstride = (long)c.ih * c.iw * c.Ci;
           } else if (!premod_up_in) {
-            if (int rc = launch_premod_nhwc(st, x, x_bstride, c.s, n->xm, B, (long)c.ih * c.iw, c.Ci)) return rc;
+            if (int rc = launch_premod_nhwc(st, x, x_bstride, c.s, n->xm, B, (long)c.ih * c.iw, c.Ci, n->dtype)) return rc;
             a.x = n->xm;
             a.x_bstride = (long)c.ih * c.iw * c.Ci;
           }
@@ -819,7 +819,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
               x_premod = true;
             }
             u.act = MAUA_ACT_LRELU; u.alpha = 0.2f; u.gain = std::sqrt(2.0f); u.clamp = 256.f;
-            if (int rc = launch_tconv_fir(st, a, u)) return rc;
+            if (int rc = launch_tconv_fir(st, a, u, n->dtype)) return rc;
             prof_mark(n, "conv0_tconv");   // (two profile slots like the two-launch path: the second measures ~0)
             up_fused = true;
           }
@@ -827,7 +827,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           //  measured no different: 8.06 vs 8.08 ms per forward)
           if (up_fused) {
           } else if (n->tconv_dma >= 2) {          // dedicated edge kernel (3 of 9 weight blocks, no tile waste)
-            if (int rc = launch_tconv_edges(st, a)) return rc;
+            if (int rc = launch_tconv_edges(st, a, n->dtype)) return rc;
           } else {
             ConvArgs e = a;
             e.variant = TCONV_EDGES_ONLY;
@@ -835,7 +835,7 @@ int maua_synth_render_rgb8(maua_synth* n, const float* ws, const float* const* n
           }
           a.variant = 0;
           if (!up_fused)
-            if (int rc = launch_tconv_dma(st, a)) return rc;
+            if (int rc = launch_tconv_dma(st, a, n->dtype)) return rc;
         } else if (int rc = launch_tconv2(st, n->dtype, a)) {
           return rc;
         }

@@ -763,7 +763,10 @@ struct maua_unet {
   unsigned long long gd_sec_uid = 0, gd_sec_epoch = 0;   // the secondary model (and its buffers' generation) gd_exec points into
   // text-prompt guidance (maua_unet_set_clip_guide): CLIPGrads instead of the image-MSE module in the guided loop
   maua_clip* gd_clip = nullptr;
-  int* gd_rects = nullptr;           // device [n_steps][batches][cutn][3]
+  int* gd_rects = nullptr;           // device [n_steps][batches][cutn][3] (+ [n_steps][batches][cutn] float multiplicities behind them)
+  float* gd_mult = nullptr;          // NULL: every cutout counts once
+  int gd_last_graph = 0;             // the LAST guided loop replayed a captured graph (maua_unet_guided_graph_active)
+  int gd_cutn_total = 0;
   size_t gd_rects_cap = 0;
   std::vector<int> gd_rects_host;
   int gd_rect_steps = 0, gd_cutn = 0, gd_batches = 0;
@@ -2043,8 +2046,9 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   // the grad module of step s on the context's current stream: bimg -> bg
   auto guide_grad = [&](int s) -> int {
     if (clip)
-      return clip_guide_grad(clip, bimg, B, H, W, n->gd_rects + (size_t)s * n->gd_batches * n->gd_cutn * 3, n->gd_cutn, n->gd_batches,
-                             n->gd_clip_scale, n->gd_clip_clamp, bg);
+      return clip_guide_grad(clip, bimg, B, H, W, n->gd_rects + (size_t)s * n->gd_batches * n->gd_cutn * 3,
+                             n->gd_mult ? n->gd_mult + (size_t)s * n->gd_batches * n->gd_cutn : nullptr, n->gd_cutn, n->gd_cutn_total,
+                             n->gd_batches, n->gd_clip_scale, n->gd_clip_clamp, bg);
     return mse_guide_grad(n->ctx, bimg, btgt, target_bstride ? chw : 0, t_k, B, chw, bg, n->gd_flag + s, false);
   };
   const long tstride = target_bstride ? chw : 0;
@@ -2165,7 +2169,9 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
     //  the replay independent of how the runtime orders copy engines against graph launches)
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     MAUA_HIP_CHECK(hipGraphLaunch(n->gd_exec, st));
+    n->gd_last_graph = 1;
   } else {
+    n->gd_last_graph = 0;
     for (int s = 0; s < n_steps; s++)
       if (int rc = body(s)) return rc;
   }
@@ -2175,8 +2181,8 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
 }
 
 // CLIPGrads as the guided loop's grad module (maua/grad.py:96-165 in place of the image-MSE module); rects: host [n_steps][batches][cutn][3]
-int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, int n_steps, int cutn, int batches, float scale,
-                             float clamp_gradient) {
+int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, const float* mult, int n_steps, int cutn, int batches,
+                             float scale, float clamp_gradient) {
   MAUA_REQUIRE(n, "maua_unet_set_clip_guide: net is NULL");
   if (!clip) {
     if (n->gd_clip) n->gd_guide_gen++;
@@ -2185,7 +2191,17 @@ int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, in
   }
   MAUA_REQUIRE(rects && n_steps > 0 && cutn > 0 && batches > 0, "maua_unet_set_clip_guide: bad arguments");
   hipStream_t st = n->ctx->stream;
-  const size_t cnt = (size_t)n_steps * batches * cutn * 3;
+  const size_t per = (size_t)n_steps * batches * cutn, cnt = per * 4;   // 3 ints + 1 float per cutout
+  int cutn_total = cutn;
+  if (mult) {
+    for (size_t b = 0; b < (size_t)n_steps * batches; b++) {
+      double t = 0;
+      for (int i = 0; i < cutn; i++) t += mult[b * cutn + i];
+      if (b == 0) cutn_total = (int)(t + 0.5);
+      MAUA_REQUIRE((int)(t + 0.5) == cutn_total && cutn_total >= cutn,
+                   "maua_unet_set_clip_guide: every cutout batch must stand for the same number (>= cutn) of cutouts");
+    }
+  }
   if (cnt > n->gd_rects_cap) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     if (n->gd_rects) hipFree(n->gd_rects);
@@ -2194,22 +2210,24 @@ int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, in
     n->gd_rects_cap = cnt;
     n->gd_guide_gen++;
   }
+  float* mult_dev = mult ? (float*)(n->gd_rects + per * 3) : nullptr;
   // (everything a captured loop bakes into its launches moves the generation; the rectangles themselves are data it reads)
   if (n->gd_clip != clip || n->gd_rect_steps != n_steps || n->gd_cutn != cutn || n->gd_batches != batches || n->gd_clip_scale != scale ||
-      n->gd_clip_clamp != clamp_gradient)
+      n->gd_clip_clamp != clamp_gradient || n->gd_mult != mult_dev || n->gd_cutn_total != cutn_total)
     n->gd_guide_gen++;
-  n->gd_rects_host.assign(rects, rects + cnt);
-  MAUA_HIP_CHECK(hipMemcpyAsync(n->gd_rects, n->gd_rects_host.data(), cnt * 4, hipMemcpyHostToDevice, st));
+  n->gd_rects_host.assign(rects, rects + per * 3);
+  MAUA_HIP_CHECK(hipMemcpyAsync(n->gd_rects, n->gd_rects_host.data(), per * 12, hipMemcpyHostToDevice, st));
+  if (mult) MAUA_HIP_CHECK(hipMemcpyAsync(mult_dev, mult, per * 4, hipMemcpyHostToDevice, st));
   MAUA_HIP_CHECK(hipStreamSynchronize(st));
   n->gd_clip = clip; n->gd_rect_steps = n_steps; n->gd_cutn = cutn; n->gd_batches = batches; n->gd_clip_scale = scale;
-  n->gd_clip_clamp = clamp_gradient;
+  n->gd_clip_clamp = clamp_gradient; n->gd_mult = mult_dev; n->gd_cutn_total = cutn_total;
   return MAUA_OK;
 }
 
 // 1 when the last maua_ddim_guided_loop(use_graph = 1) replayed a captured hipGraph
 int maua_unet_guided_graph_active(maua_unet* n, int* active) {
   MAUA_REQUIRE(n && active, "maua_unet_guided_graph_active: NULL argument");
-  *active = n->gd_exec && !n->gd_failed ? 1 : 0;
+  *active = n->gd_exec && !n->gd_failed && n->gd_last_graph ? 1 : 0;
   return MAUA_OK;
 }
 

@@ -538,12 +538,22 @@ class SpacedDiffusion:
             # text-prompt guidance (CLIPGrads, maua/grad.py:96-165): the cutout rectangles of every step and cutout batch are drawn
             # here, in the order the step-by-step path draws them (per step: grad.py:149's t[[0]] = that step's model timestep)
             gm.install_targets(0, B)
-            rects = np.ascontiguousarray(np.stack([gm.draw_rects(0, H, W, mtt[s:s + 1]) for s in range(n_steps)]), dtype=np.int32)
-            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), spec["clip"]._handle(), rects.ctypes.data_as(C.c_void_p), n_steps,
-                                                     spec["cutn"], spec["batches"], C.c_float(spec["scale"]), C.c_float(spec["clamp"])))
+            rects, mult = np.stack([gm.draw_rects(0, H, W, mtt[s:s + 1]) for s in range(n_steps)]), None
+            if gm.merge_cutouts:   # (identical rectangles of a cutout batch - the whole-image cutouts of a square image - pass once)
+                rects, mult = gm.merge_identical(rects)
+            rects = np.ascontiguousarray(rects, dtype=np.int32)
+            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), spec["clip"]._handle(), rects.ctypes.data_as(C.c_void_p),
+                                                     None if mult is None else mult.ctypes.data_as(C.c_void_p), n_steps,
+                                                     rects.shape[2], spec["batches"], C.c_float(spec["scale"]), C.c_float(spec["clamp"])))
             tgt, tstride, mse_k = None, 0, 0.0
+            # a text-guided step is ~2 500 launches (8 cutout batches x ~200 for the tower's forward + backward): 250 000 for a
+            # 100-step loop.  The loop still runs inside the library in one call, but launch by launch - the launches' host cost
+            # (~12 ms) is 4 % of such a step, and capturing a graph of that size faulted inside the HIP runtime (ROCm 7.0.2); short
+            # loops (tests, previews) are captured
+            if n_steps * spec["batches"] > 64:
+                use_graph = False
         else:
-            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), None, None, 0, 0, 0, C.c_float(0.0), C.c_float(0.0)))
+            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), None, None, None, 0, 0, 0, C.c_float(0.0), C.c_float(0.0)))
             tgt = L.dev_tensor(gm.target, torch.float32)
             mse_k = gm.factor(x[0].numel())
             if tuple(tgt.shape) == tuple(x.shape[1:]):

@@ -127,12 +127,14 @@ def test_vision_transformer_forward_and_input_gradient_match_the_oracle(dt):
     assert torch.equal(vt(x), out)          # (without kept activations the layers share one set of buffers: same result)
 
 
-def test_tower_on_the_lds_direct_gemm_matches_the_register_staged_one():
-    """A tower whose GEMMs are big enough for gemm_dma.hip (66 560 token rows, 128-column tiles): embeddings and input gradients
+@pytest.mark.parametrize("width", [128, 256], ids=["256x128-tiles", "256x256-tiles"])
+def test_tower_on_the_lds_direct_gemm_matches_the_register_staged_one(width):
+    """A tower whose GEMMs are big enough for gemm_dma.hip (66 560 token rows; width 128: its 256 x 128 tile, width 256: the 256 x 256
+    tile the ViT-B towers run on): embeddings and input gradients
     with the LDS-direct kernel (QuickGELU and its derivative riding on the epilogues) against the same tower on gemm.hip's kernels +
     the separate element-wise passes (ctx option "gemm_dma" = 0), and against the float32 oracle on a subset."""
     from maua_amd import _lib as L
-    cfg = dict(input_resolution=64, patch_size=8, width=128, layers=2, heads=2, output_dim=64)
+    cfg = dict(input_resolution=64, patch_size=8, width=width, layers=2, heads=width // 64, output_dim=64)
     vt, p = _tower(cfg, torch.bfloat16, seed=3)
     g = torch.Generator().manual_seed(9)
     N = 1024
@@ -184,7 +186,7 @@ def test_clip_guide_grad_matches_autograd_on_the_oracle(dt):
     r = np.ascontiguousarray(np.asarray(rects, dtype=np.int32))
     imgd = img.cuda()
     out = torch.empty_like(imgd)
-    L.check(lib.maua_clip_guide_grad(vt._handle(), L.ptr(imgd), B, H, W, r.ctypes.data_as(C.c_void_p), cutn, batches, C.c_float(scale),
+    L.check(lib.maua_clip_guide_grad(vt._handle(), L.ptr(imgd), B, H, W, r.ctypes.data_as(C.c_void_p), None, cutn, batches, C.c_float(scale),
                                      C.c_float(0.0), L.ptr(out)))
     if dt == torch.float32:
         assert rel(out, want) <= 3e-4
@@ -197,7 +199,7 @@ def test_clip_guide_grad_matches_autograd_on_the_oracle(dt):
         # clamp_gradient
         mag = float(want.square().mean().sqrt())
         clamped = OC.clip_grads(p, SMALL, img, rects, tgt, w, scale=scale, clamp_gradient=0.5 * mag)
-        L.check(lib.maua_clip_guide_grad(vt._handle(), L.ptr(imgd), B, H, W, r.ctypes.data_as(C.c_void_p), cutn, batches, C.c_float(scale),
+        L.check(lib.maua_clip_guide_grad(vt._handle(), L.ptr(imgd), B, H, W, r.ctypes.data_as(C.c_void_p), None, cutn, batches, C.c_float(scale),
                                          C.c_float(0.5 * mag), L.ptr(out)))
         assert rel(out, clamped) <= 3e-4
     else:
@@ -225,6 +227,14 @@ def test_clipgrads_module_prompts_per_sample_targets_and_seeded_cutouts():
     rects = [OC.cutout_rects(H, W, 32, 8, OC.maua_cutouts_pow(t[[0]].long())) for _ in range(2)]
     want = OC.clip_grads(p, SMALL, img, rects, torch.stack([e0, e1]), OC.normalise_weights([1.0, 3.0]), scale=80.0)
     assert rel(got, want) <= 3e-4
+    # the square image's identical whole-image cutouts went through the tower once (merge_identical): the same gradient as the
+    # reference's full list (that is what `want` was computed from), and as the unmerged run
+    r0, m0 = CLIPGrads.merge_identical(np.asarray(rects, dtype=np.int32))
+    assert m0 is not None and r0.shape == (2, 7, 3) and m0.tolist() == [[2.0] + [1.0] * 6] * 2
+    gm.merge_cutouts = False
+    torch.manual_seed(77)
+    assert rel(gm(img, t), got) <= 1e-5
+    gm.merge_cutouts = True
     # per-sample prompts: sample 0 -> e0, sample 1 -> e1
     p0, p1 = EmbeddingPrompt(e0), EmbeddingPrompt(e1)
     gm.set_targets_per_sample([p0, p1])
