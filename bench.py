@@ -858,9 +858,17 @@ def main():
     if world > 1:
         watchdog.start()
     clip_s = gather_ms = full = sg = None
-    try:
+    from maua_amd.distributed import clip_batch
+    # frames per call of the clip leg: a batch that divides the longest shard (3600 / N frames: 150 at N = 1, 2, 4, 8) - no ragged
+    # last call - measured against the timed steps' batch B, the faster one is the leg's; every rank takes the
+    # same one (the streamed gather's rounds are chunks of equal size)
+    cb_div = clip_batch(pipeline.frame_range(T_FRAMES, 0, world)[1] - pipeline.frame_range(T_FRAMES, 0, world)[0], B)
+    clip_runs = {}
+
+    def clip_once(cb):
+        nonlocal sg
         fence()
-        sg = StreamingGather(T_FRAMES, (RES, RES, 3), B, dtype=torch.uint8, device=device, rank=rank, world=world)
+        sg = StreamingGather(T_FRAMES, (RES, RES, 3), cb, dtype=torch.uint8, device=device, rank=rank, world=world)
         fence()
         tc = time.perf_counter()
         for off, b in sg.chunks():
@@ -870,16 +878,27 @@ def main():
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(device))
         done.synchronize()                      # the render stream only: the side stream may still be sending
-        clip_s = time.perf_counter() - tc
-        full = sg.finish()
+        c_s = time.perf_counter() - tc
+        out = sg.finish()
         fence()
-        total_s = time.perf_counter() - tc
-        gather_ms = None
+        t_s = time.perf_counter() - tc
         if dist is not None:
-            t = torch.tensor([clip_s, total_s], device=device, dtype=torch.float64)
+            t = torch.tensor([c_s, t_s], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            clip_s, total_s = float(t[0].item()), float(t[1].item())
-            gather_ms = max(0.0, total_s - clip_s) * 1e3
+            c_s, t_s = float(t[0].item()), float(t[1].item())
+        return c_s, t_s, out
+    try:
+        if cb_div != B:   # the alternative first (untimed warm-up of its workspace size included in its own first calls)
+            c_s, t_s, full = clip_once(B)
+            clip_runs[B] = {"render_s": c_s, "total_s": t_s}
+            del full, sg
+            full = sg = None
+        clip_s, total_s, full = clip_once(cb_div)
+        clip_runs[cb_div] = {"render_s": clip_s, "total_s": total_s}
+        clip_b = cb_div
+        if cb_div != B and clip_runs[B]["total_s"] < total_s:   # the divisor batch lost: quote the timed steps' batch
+            clip_s, total_s, clip_b = clip_runs[B]["render_s"], clip_runs[B]["total_s"], B
+        gather_ms = max(0.0, total_s - clip_s) * 1e3 if dist is not None else None
     except Exception as e:   # N > 1 only: a failing exchange must not take the measured headline with it
         if world == 1:
             raise
@@ -894,12 +913,22 @@ def main():
     watchdog.cancel()
     if rank == 0:
         assert tuple(full.shape) == (T_FRAMES, RES, RES, 3)
-    gather_transport = sg.transport
+    gather_transport, gather_nranks = sg.transport, sg.nranks
     del full, sg
 
     if rank == 0:
         res = build_result(clip_s, gather_ms)
         res["config"]["gather"] += f"; transport: {gather_transport}"
+        # the metric BASELINE states - the 3600-frame clip, sharded across the node's GPUs, WITH its gather - as a first-class key
+        # beside `value` (which stays the K-step rate the driver's consistency check reads; at N > 1 that one is weak-scaling by
+        # construction).  rccl_nranks is read back from the communicator that moved the frames, not echoed from the launcher.
+        res["strong"] = {"metric": "frames/sec (whole node), the 3600-frame clip rendered and gathered once", "clip_frames": T_FRAMES,
+                         "seconds": total_s, "fps": T_FRAMES / total_s, "render_s": clip_s, "gather_s_not_overlapped": max(0.0, total_s - clip_s),
+                         "n_gpus": world, "rccl_nranks": gather_nranks, "transport": gather_transport, "scaling": "strong",
+                         "frames_per_call": clip_b,
+                         "frames_per_call_measured": {str(k): v for k, v in clip_runs.items()},
+                         "frames_per_call_rule": "a batch that divides the shard (distributed.clip_batch), kept when it is not slower than the "
+                                                 "timed steps' batch on this run"}
         if world == 1 and not a.no_extras:
             # the other single-GPU BASELINE configs, as extra keys (each with its own metric / roofline; never part of `value`)
             del latents, noise

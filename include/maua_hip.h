@@ -391,6 +391,10 @@ int maua_rrdb_load(maua_rrdbnet* net, const char* name, const float* host_data, 
 int maua_rrdb_forward(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, float* out_nchw, uint8_t* out_rgb8);
 /* the RRDB forward without the [0,1] clamp on out_nchw (RealESRGANer clamps AFTER its tile stitching / pre-pad crop; the
  * u8 output is always clamped).  clamp01 = 1 is maua_rrdb_forward. */
+/* RealESRGANer.enhance (realesrgan utils; as super/video/frame_by_frame.py:22-33 applies it per frame) for a batch of device-resident
+ * u8 frames [B][h][w][3] in one call: x / 255, reflect pre_pad on the right / bottom, the network, clamp, round(255 y), crop ->
+ * out_rgb8 [B][4h][4w][3].  No separate convert / pad / crop passes (round 6). */
+int maua_rrdb_enhance_u8(maua_rrdbnet* net, const uint8_t* frames, int B, int h, int w, int pre_pad, uint8_t* out_rgb8);
 int maua_rrdb_forward_ex(maua_rrdbnet* net, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
                          uint8_t* out_rgb8);
 
@@ -623,6 +627,8 @@ int maua_gather_frames_at(maua_comm* comm, const uint8_t* send, const long* byte
  * side stream that waits on an event of the render stream, so that a round travels while the next chunk renders
  * (use_ctx_stream != 0: back to the context's stream). */
 int maua_comm_set_stream(maua_comm* comm, void* stream, int use_ctx_stream);
+/* the communicator's own rank count / rank (ncclCommCount, ncclCommUserRank): what a result line quotes as its RCCL world */
+int maua_comm_count(maua_comm* comm, int* nranks, int* rank);
 int maua_comm_destroy(maua_comm* comm);
 
 #ifdef __cplusplus

@@ -21,6 +21,7 @@ typedef int (*fn_send)(const void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_recv)(void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char* (*fn_err)(int);
+typedef int (*fn_count)(void*, int*);
 
 struct Rccl {
   void* lib = nullptr;
@@ -31,6 +32,7 @@ struct Rccl {
   fn_recv recv = nullptr;
   fn_group group_start = nullptr, group_end = nullptr;
   fn_err error_string = nullptr;
+  fn_count comm_count = nullptr, comm_user_rank = nullptr;   // optional (ncclCommCount / ncclCommUserRank)
 };
 
 Rccl g_rccl;
@@ -55,6 +57,8 @@ int bind_rccl() {
   r.group_start = (fn_group)dlsym(lib, "ncclGroupStart");
   r.group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
   r.error_string = (fn_err)dlsym(lib, "ncclGetErrorString");
+  r.comm_count = (fn_count)dlsym(lib, "ncclCommCount");
+  r.comm_user_rank = (fn_count)dlsym(lib, "ncclCommUserRank");
   if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.send || !r.recv || !r.group_start || !r.group_end)
     return maua::fail("maua_comm: librccl lacks the point-to-point API");
   g_rccl = r;
@@ -104,6 +108,20 @@ int maua_comm_set_stream(maua_comm* comm, void* stream, int use_ctx_stream) {
   MAUA_REQUIRE(comm, "maua_comm_set_stream: comm is NULL");
   comm->own_stream = !use_ctx_stream;
   comm->stream = (hipStream_t)stream;
+  return MAUA_OK;
+}
+
+// what the COMMUNICATOR says about itself (ncclCommCount / ncclCommUserRank), not what the caller passed to maua_comm_init: a
+// benchmark line that names its rank count reads it back from RCCL
+int maua_comm_count(maua_comm* comm, int* nranks, int* rank) {
+  MAUA_REQUIRE(comm && comm->comm && nranks, "maua_comm_count: NULL argument");
+  MAUA_REQUIRE(g_rccl.comm_count, "maua_comm_count: this librccl has no ncclCommCount");
+  if (int rc = g_rccl.comm_count(comm->comm, nranks)) return rccl_fail("ncclCommCount", rc);
+  if (rank) {
+    *rank = -1;
+    if (g_rccl.comm_user_rank)
+      if (int rc = g_rccl.comm_user_rank(comm->comm, rank)) return rccl_fail("ncclCommUserRank", rc);
+  }
   return MAUA_OK;
 }
 

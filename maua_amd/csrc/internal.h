@@ -65,6 +65,8 @@ struct ConvArgs {
   float* img_f32;
   uint8_t* img_u8;
   int img_clamp;
+  int img_h, img_w;       // the u8 frame's own size (0 = H x W): only the top-left img_h x img_w window is written, densely - an up-scaler
+                          // whose input was reflect-padded (RealESRGANer.pre_pad) crops its output in the store instead of in a copy
   const float* prelu;     // optional per-channel negative slopes [Co] (PReLU: replaces act / alpha; SRVGGNetCompact, super.hip)
   // modconv_dma (wide tiles) only: optional side output for a GroupNorm that follows (unet.hip) - per (sample, 8 x 32-pixel tile)
   // row and 8-channel piece the sum and the sum of squares of the STORED values: psum[b][tile][Co / 8][16] floats

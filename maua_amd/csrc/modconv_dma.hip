@@ -487,7 +487,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, KB == 64 ? 4 : 2) void modco
       for (int cch = 0; cch < 3; cch++) {
         const float cv = fminf(fmaxf(v3[cch], 0.f), 1.f);
         if (a.img_f32) a.img_f32[((long)b * 3 + cch) * HWl + pix] = a.img_clamp ? cv : v3[cch];
-        if (a.img_u8) a.img_u8[((long)b * HWl + pix) * 3 + cch] = (uint8_t)__float2int_rn(cv * 255.0f);
+        if (a.img_u8) {
+          const int oh = a.img_h ? a.img_h : a.H, ow = a.img_w ? a.img_w : a.W;
+          if (yy < oh && xx < ow) a.img_u8[(((long)b * oh + yy) * ow + xx) * 3 + cch] = (uint8_t)__float2int_rn(cv * 255.0f);
+        }
       }
     }
     return;

@@ -82,16 +82,36 @@ __global__ __launch_bounds__(256) void upsample2_nearest_nhwc_kernel(const T* __
 // (RealESRGANer.enhance: output.clamp_(0, 1), then (x * 255).round() for 8-bit images)
 template <typename T>
 __global__ __launch_bounds__(256) void rrdb_output_kernel(const T* __restrict__ x, int Cp, long HW, int B, int do_clamp,
-                                                          float* __restrict__ out_f32, uint8_t* __restrict__ out_u8) {
+                                                          float* __restrict__ out_f32, uint8_t* __restrict__ out_u8, int W, int oh,
+                                                          int ow) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * HW) return;
   const long b = idx / HW, p = idx - b * HW;
+  const int yy = (int)(p / W), xx = (int)(p - (long)yy * W);
 #pragma unroll
   for (int c = 0; c < 3; c++) {
     float v = Elem<T>::load(x + idx * Cp + c);
     if (out_f32) out_f32[(b * 3 + c) * HW + p] = do_clamp ? fminf(fmaxf(v, 0.f), 1.f) : v;
-    if (out_u8) out_u8[idx * 3 + c] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
+    if (out_u8 && yy < oh && xx < ow)   // (the u8 frame may be a cropped window: oh x ow, dense)
+      out_u8[((b * oh + yy) * ow + xx) * 3 + c] = (uint8_t)__float2int_rn(fminf(fmaxf(v, 0.f), 1.f) * 255.0f);
   }
+}
+
+// u8 HWC frames [B][h][w][3] -> the first convolution's input: NHWC [B][H][W][32] in the network dtype (3 real channels), value / 255,
+// REFLECT-padded on the right / bottom to H x W (RealESRGANer.enhance: img / 255, F.pad(.., (0, pre_pad, 0, pre_pad), "reflect")) -
+// what enhance_frames used to build with three torch passes (convert, pad, layout)
+template <typename T>
+__global__ __launch_bounds__(256) void frames_u8_to_nhwc32_kernel(const uint8_t* __restrict__ f, T* __restrict__ y, int B, int h, int w,
+                                                                  int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * H * W) return;
+  const int xx = (int)(idx % W), yy = (int)((idx / W) % H);
+  const long b = idx / ((long)W * H);
+  const int sy = yy < h ? yy : 2 * (h - 1) - yy, sx = xx < w ? xx : 2 * (w - 1) - xx;
+  const uint8_t* src = f + ((b * h + sy) * w + sx) * 3;
+  T* dst = y + idx * 32;
+#pragma unroll
+  for (int c = 0; c < 32; c++) Elem<T>::store(dst + c, c < 3 ? (float)src[c] / 255.0f : 0.f);
 }
 
 }  // namespace
@@ -225,7 +245,8 @@ int maua_rrdb_load(maua_rrdbnet* n, const char* name, const float* host, size_t 
 namespace {
 
 template <typename T>
-int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_clamp, float* out_f32, uint8_t* out_u8) {
+int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_clamp, float* out_f32, uint8_t* out_u8,
+              const uint8_t* frames = nullptr, int fh = 0, int fw = 0) {
   hipStream_t st = n->ctx->stream;
   const int F = n->num_feat, G = n->grow, D = F + 4 * G;
   const size_t es = n->esize;
@@ -285,7 +306,16 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
     return MAUA_OK;
   };
 
-  int rc = launch_nchw_to_nhwc<float, T>(st, img, n->in32, B, 3, H * W, 32);
+  int rc = MAUA_OK;
+  const int oh = frames ? 4 * fh : 4 * H, ow = frames ? 4 * fw : 4 * W;   // the u8 frame's size (frames: the un-padded input's x4)
+  if (frames) {
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(frames_u8_to_nhwc32_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, (T*)n->in32, B, fh, fw,
+                       H, W);
+    MAUA_HIP_CHECK(hipGetLastError());
+  } else {
+    rc = launch_nchw_to_nhwc<float, T>(st, img, n->in32, B, 3, H * W, 32);
+  }
   if (rc) return rc;
   if ((rc = conv(n->conv_first, n->in32, 32, n->feat0, F, 0, H, W, false, 1.f, nullptr, 0))) return rc;
   // the trunk: block input in channels [0, F) of dense[ia].  Three dense-block buffers rotate: a block's input stays untouched in
@@ -338,19 +368,31 @@ int forward_t(maua_rrdbnet* n, const float* img, int B, int H, int W, int do_cla
     a.x = n->f4; a.x_bstride = (long)16 * H * W * F; a.x_pstride = F; a.w = c.wt; a.s = n->ones; a.bias = c.bias;
     a.B = B; a.H = 4 * H; a.W = 4 * W; a.Ci = c.Cip; a.Co = 32; a.up = 1;
     a.act = MAUA_ACT_LINEAR; a.alpha = 0.2f; a.gain = 1.f; a.clamp = -1.f;
-    a.img_f32 = out_f32; a.img_u8 = out_u8; a.img_clamp = do_clamp;
+    a.img_f32 = out_f32; a.img_u8 = out_u8; a.img_clamp = do_clamp; a.img_h = oh; a.img_w = ow;
     return launch_modconv_dma(st, a);
   }
   if (!n->f5) MAUA_HIP_CHECK(hipMalloc(&n->f5, n->cap_px * 16 * 32 * es));
   if ((rc = conv(n->conv_last, n->f4, F, n->f5, 32, 0, 4 * H, 4 * W, false, 1.f, nullptr, 0))) return rc;
   const long opx = (long)B * 16 * H * W;
   hipLaunchKernelGGL(rrdb_output_kernel<T>, dim3((unsigned)((opx + 255) / 256)), dim3(256), 0, st, (const T*)n->f5, 32,
-                     (long)16 * H * W, B, do_clamp, out_f32, out_u8);
+                     (long)16 * H * W, B, do_clamp, out_f32, out_u8, 4 * W, oh, ow);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 
 }  // namespace
+
+// RealESRGANer.enhance for a batch of device-resident u8 frames in ONE call (BASELINE configs[4]: render -> x4 per frame): frames
+// [B][h][w][3] u8 -> out [B][4h][4w][3] u8 = round(255 clamp(net(reflect_pad(frames / 255, pre_pad)), 0, 1)) cropped to 4h x 4w - the
+// conversion and the padding ride on the first convolution's input staging, the clamp / round / crop on the last one's store
+extern "C" int maua_rrdb_enhance_u8(maua_rrdbnet* n, const uint8_t* frames, int B, int h, int w, int pre_pad, uint8_t* out_rgb8) {
+  MAUA_REQUIRE(n && frames && out_rgb8, "maua_rrdb_enhance_u8: NULL argument");
+  MAUA_REQUIRE(B >= 0 && h > 0 && w > 0 && pre_pad >= 0 && pre_pad < h && pre_pad < w, "maua_rrdb_enhance_u8: bad shape (reflect padding needs pre_pad < h, w)");
+  if (B == 0) return MAUA_OK;
+  const int H = h + pre_pad, W = w + pre_pad;
+  return n->dtype == MAUA_BF16 ? forward_t<bf16_t>(n, nullptr, B, H, W, 1, nullptr, out_rgb8, frames, h, w)
+                               : forward_t<float>(n, nullptr, B, H, W, 1, nullptr, out_rgb8, frames, h, w);
+}
 
 extern "C" int maua_rrdb_forward_ex(maua_rrdbnet* n, const float* img_nchw, int B, int H, int W, int clamp01, float* out_nchw,
                                     uint8_t* out_rgb8) {

@@ -189,6 +189,20 @@ def gather_frames(local, n_frames, rank=None, world=None, dst=0, transport=None)
     return _gather_p2p(local, n_frames, rank, world, dst)
 
 
+def clip_batch(n_local, preferred):
+    """Frames per synthesis call for a rank that renders ``n_local`` frames of a clip: a batch that DIVIDES the shard (no ragged
+    last call - at 8 GPUs a 450-frame shard in batches of 128 ends in a 66-frame call that costs most of a full one), as close to
+    ``preferred`` as the divisors allow: the largest divisor in [preferred / 2, 1.25 * preferred], else ``preferred`` itself (the
+    tail then stays).  3600 -> 150 (24 calls), 1800 -> 150, 900 -> 150, 450 -> 150 (3 calls) for preferred = 128."""
+    n_local, preferred = int(n_local), int(preferred)
+    if n_local <= 0 or preferred <= 0:
+        return max(1, preferred)
+    if n_local <= preferred * 5 // 4:
+        return n_local
+    cands = [d for d in range(max(1, preferred // 2), preferred * 5 // 4 + 1) if n_local % d == 0]
+    return max(cands) if cands else preferred
+
+
 class StreamingGather:
     """The gather of a frame-sharded render, STREAMED: every rank renders its contiguous frame range in chunks; as soon as
     a chunk is finished it travels to the root (side stream, RCCL point-to-point over xGMI) while the next chunk renders,
@@ -246,6 +260,17 @@ class StreamingGather:
             if self._comm is not None:
                 # this communicator's transfers run on the side stream from here on (finish() hands it back)
                 L.check(L.lib().maua_comm_set_stream(self._comm, C.c_void_p(self._side.cuda_stream), 0))
+        # the exchange's rank count as the TRANSPORT reports it (read back, not echoed): RCCL's ncclCommCount for the library's
+        # communicator, torch.distributed's group size otherwise
+        self.nranks = 1
+        if world > 1:
+            self.nranks = dist.get_world_size()
+            if getattr(self, "_comm", None) is not None:
+                import ctypes as C
+                from . import _lib as L
+                nr = C.c_int(0)
+                L.check(L.lib().maua_comm_count(self._comm, C.byref(nr), None))
+                self.nranks = int(nr.value)
         self.transport = ("none (one rank)" if world == 1 else "torch.distributed isend / irecv" if self._side is None or
                           getattr(self, "_comm", None) is None else "maua_gather_frames_at (RCCL point-to-point, C ABI)")
 

@@ -113,6 +113,17 @@ class RRDBNet(torch.nn.Module):
         L.check(L.lib().maua_rrdb_forward_ex(self._handle(), L.ptr(x), b, h, w, int(bool(clamp)), L.ptr(out), L.ptr(rgb8_out)))
         return out if out is not None else rgb8_out
 
+    def enhance_u8(self, frames_u8, pre_pad=0, out=None):
+        """RealESRGANer.enhance's arithmetic for device-resident uint8 frames [B, h, w, 3] in one library call (maua_rrdb_enhance_u8:
+        x / 255 and the reflect pre_pad in the first convolution's input staging, clamp / round(255 y) / crop in the last one's
+        store) -> uint8 [B, 4h, 4w, 3]."""
+        f = frames_u8.cuda().contiguous()
+        b, h, w, _ = f.shape
+        if out is None:
+            out = torch.empty((b, 4 * h, 4 * w, 3), dtype=torch.uint8, device=f.device)
+        L.check(L.lib().maua_rrdb_enhance_u8(self._handle(), L.ptr(f), b, h, w, int(pre_pad), L.ptr(out)))
+        return out
+
 
 def _flipped(params, first, last, flip):
     """The parameter dict with the colour channels of the first convolution's input and the last convolution's output
@@ -273,6 +284,9 @@ class RealESRGANer:
             raise ValueError("enhance_frames expects uint8 [B, H, W, 3] frames")
         f = f.cuda()
         b, h, w, _ = f.shape
+        if self.tile_size <= 0 and hasattr(self.model, "enhance_u8"):
+            # (round 6) the whole of enhance() inside the library: no torch convert / pad / crop passes around the network
+            return self.model.enhance_u8(f, self.pre_pad)
         x = f.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
         if self.pre_pad:
             x = ops.pad2d(x, (0, self.pre_pad, 0, self.pre_pad), "reflect")

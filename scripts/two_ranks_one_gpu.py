@@ -72,7 +72,8 @@ def main():
         if js:
             import json
             d = json.loads(js[-1])
-            print("JSON line:", {k: d.get(k) for k in ("value", "n_gpus", "steps", "ms_per_step", "sustained", "gather_ms", "clip_leg")})
+            print("JSON line:", {k: d.get(k) for k in ("value", "scaling", "n_gpus", "steps", "ms_per_step", "sustained", "gather_ms", "clip_leg")})
+            print("  weak (the K timed steps, `value`):", d.get("value"), " strong (the clip rendered + gathered once):", d.get("strong"))
         else:
             print("\n".join(lines[-12:]))
 

@@ -258,3 +258,22 @@ def test_upscaled_render_part_files_are_joined_in_rank_order(tmp_path, world, T,
     (cmd,) = res[0][5]
     assert cmd[:3] == ["ffmpeg", "-y", "-loglevel"] and cmd[cmd.index("-f") + 1] == "concat" and cmd[-3:-1] == ["-c:v", "copy"]
     assert cmd[cmd.index("-ss") + 1] == "1.5" and cmd[cmd.index("-t") + 1] == "4" and "clip.mp3" in cmd and "-shortest" in cmd
+
+
+def test_clip_leg_batch_divides_the_shard():
+    """bench.py's clip leg (VERDICT r5 item 7): frames per synthesis call = distributed.clip_batch(longest shard, the timed steps'
+    batch) - a divisor of the shard near the preferred batch, so that no rank ends its range with a ragged call (450 frames at 8
+    GPUs: 3 x 150 instead of 128 + 128 + 128 + 66); shards without such a divisor keep the preferred batch."""
+    from maua_amd.distributed import clip_batch
+    from maua_amd.pipeline import frame_range
+    for world in (1, 2, 4, 8):
+        lo, hi = frame_range(3600, 0, world)
+        cb = clip_batch(hi - lo, 128)
+        assert cb == 150 and (hi - lo) % cb == 0, (world, cb)
+    assert clip_batch(451, 128) == 128 and clip_batch(449, 128) == 128      # (primes / near-primes: no divisor in [64, 160])
+    assert clip_batch(100, 128) == 100 and clip_batch(160, 128) == 160 and clip_batch(161, 128) == 128
+    assert clip_batch(3600, 32) == 40 and clip_batch(0, 128) == 128 and clip_batch(7, 128) == 7
+    # every rank of a world takes the SAME batch (the streamed gather's rounds are equal chunks): it comes from rank 0's range, the longest
+    for world in (3, 7):
+        longest = max(frame_range(3600, r, world)[1] - frame_range(3600, r, world)[0] for r in range(world))
+        assert longest == frame_range(3600, 0, world)[1] - frame_range(3600, 0, world)[0]
