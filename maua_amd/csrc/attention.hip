@@ -75,16 +75,30 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     for (int e = 0; e < 16; e++) o[i][e] = 0.f;
   float m_i = -1.0e30f, l_i = 0.f;
 
+  // K / V rows travel HBM -> registers one key block AHEAD of their use (round 6; see attention_vjp.hip), registers -> LDS between the
+  // loop's barriers
+  constexpr int NP = (32 * PPR + 255) / 256;
+  u32x4 nk[NP], nv[NP];
+#define MAUA_AT_LOAD(KB_)                                                       \
+  _Pragma("unroll") for (int it = 0; it < NP; it++) {                          \
+    const int p = tid + it * 256;                                               \
+    const int kk = p / PPR, pc = p - kk * PPR;                                  \
+    nk[it] = nv[it] = u32x4{0u, 0u, 0u, 0u};                                    \
+    if (p < 32 * PPR && (KB_) + kk < T_) {                                      \
+      const T* row = base + (long)((KB_) + kk) * a.ld_qkv + pc * EPC;           \
+      nk[it] = *reinterpret_cast<const u32x4*>(row + D);                        \
+      nv[it] = *reinterpret_cast<const u32x4*>(row + 2 * D);                    \
+    }                                                                           \
+  }
+  MAUA_AT_LOAD(0)
   for (int kb = 0; kb < T_; kb += 32) {
     __syncthreads();  // the previous block's fragment reads are done
-    for (int p = tid; p < 32 * PPR; p += 256) {
+#pragma unroll
+    for (int it = 0; it < NP; it++) {
+      const int p = tid + it * 256;
+      if (p >= 32 * PPR) break;
       const int kk = p / PPR, pc = p - kk * PPR;
-      u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-      if (kb + kk < T_) {
-        const T* row = base + (long)(kb + kk) * a.ld_qkv + pc * EPC;
-        kv = *reinterpret_cast<const u32x4*>(row + D);
-        vv = *reinterpret_cast<const u32x4*>(row + 2 * D);
-      }
+      const u32x4 kv = nk[it], vv = nv[it];
       *reinterpret_cast<u32x4*>(k_s + kk * KRS + pc * 16) = kv;
       // V^T[d][key]
       if constexpr (SZ == 2) {
@@ -99,6 +113,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       }
     }
     __syncthreads();
+    if (kb + 32 < T_) MAUA_AT_LOAD(kb + 32)   // (flies during this block's products)
 
     // S^T block: rows = keys, columns = queries
     f32x16 s;
@@ -180,6 +195,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         *reinterpret_cast<float4*>(orow + d) = make_float4(v0, v1, v2, v3);
     }
 }
+
+#undef MAUA_AT_LOAD
 
 }  // namespace
 

@@ -125,21 +125,44 @@ __global__ __launch_bounds__(256) void attention_vjp_kernel(AttnVjpArgs a) {
       for (int e = 0; e < 16; e++) g2[i][e] = 0.f;
   }
 
+  // the walked block's rows travel HBM -> registers one block AHEAD of their use (round 6: a block's loads used to be issued between
+  // the loop's two barriers and waited for there - 7 exposed round trips per 197-token head - now they fly under the previous block's
+  // products), registers -> LDS (rows and transposes) between the barriers; same values, same order
+  constexpr int NP = (32 * PPR + 255) / 256;   // pieces per thread and block (1 or 2)
+  u32x4 n1[NP], n2[NP];
+  float nl = 1.0e30f, nd = 0.f;
+#define MAUA_AV_LOAD(YB_)                                                                            \
+  {                                                                                                  \
+    _Pragma("unroll") for (int it = 0; it < NP; it++) {                                             \
+      const int p = tid + it * 256;                                                                  \
+      const int kk = p / PPR, pc = p - kk * PPR;                                                     \
+      n1[it] = n2[it] = u32x4{0u, 0u, 0u, 0u};                                                       \
+      if (p < 32 * PPR && (YB_) + kk < T_) {                                                         \
+        if (MODE == 0) {                                                                             \
+          const T* row = qbase + (long)((YB_) + kk) * a.ld_qkv + pc * EPC;                           \
+          n1[it] = *reinterpret_cast<const u32x4*>(row + D);                                         \
+          n2[it] = *reinterpret_cast<const u32x4*>(row + 2 * D);                                     \
+        } else {                                                                                     \
+          n1[it] = *reinterpret_cast<const u32x4*>(qbase + (long)((YB_) + kk) * a.ld_qkv + pc * EPC); \
+          n2[it] = *reinterpret_cast<const u32x4*>(gbase + (long)((YB_) + kk) * a.ld_out + pc * EPC); \
+        }                                                                                            \
+      }                                                                                              \
+    }                                                                                                \
+    if (MODE == 1 && tid < 32) {                                                                     \
+      const bool in = (YB_) + tid < T_;                                                              \
+      nl = in ? lse[(YB_) + tid] : 1.0e30f; /* exp(s - 1e30) = 0: rows past the end weigh nothing */ \
+      nd = in ? delta[(YB_) + tid] : 0.f;                                                            \
+    }                                                                                                \
+  }
+  MAUA_AV_LOAD(0)
   for (int yb = 0; yb < T_; yb += 32) {
     __syncthreads();  // the previous block's fragment reads are done
-    for (int p = tid; p < 32 * PPR; p += 256) {
+#pragma unroll
+    for (int it = 0; it < NP; it++) {
+      const int p = tid + it * 256;
+      if (p >= 32 * PPR) break;
       const int kk = p / PPR, pc = p - kk * PPR;
-      u32x4 v1 = u32x4{0u, 0u, 0u, 0u}, v2 = u32x4{0u, 0u, 0u, 0u};
-      if (yb + kk < T_) {
-        if (MODE == 0) {
-          const T* row = qbase + (long)(yb + kk) * a.ld_qkv + pc * EPC;
-          v1 = *reinterpret_cast<const u32x4*>(row + D);
-          v2 = *reinterpret_cast<const u32x4*>(row + 2 * D);
-        } else {
-          v1 = *reinterpret_cast<const u32x4*>(qbase + (long)(yb + kk) * a.ld_qkv + pc * EPC);
-          v2 = *reinterpret_cast<const u32x4*>(gbase + (long)(yb + kk) * a.ld_out + pc * EPC);
-        }
-      }
+      const u32x4 v1 = n1[it], v2 = n2[it];
       *reinterpret_cast<u32x4*>(y1_s + kk * RS + pc * 16) = v1;
       *reinterpret_cast<u32x4*>(y2_s + kk * RS + pc * 16) = v2;
       if constexpr (SZ == 2) {
@@ -161,11 +184,11 @@ __global__ __launch_bounds__(256) void attention_vjp_kernel(AttnVjpArgs a) {
       }
     }
     if (MODE == 1 && tid < 32) {
-      const bool in = yb + tid < T_;
-      lse_s[tid] = in ? lse[yb + tid] : 1.0e30f;   // exp(s - 1e30) = 0: rows past the end weigh nothing
-      delta_s[tid] = in ? delta[yb + tid] : 0.f;
+      lse_s[tid] = nl;
+      delta_s[tid] = nd;
     }
     __syncthreads();
+    if (yb + 32 < T_) MAUA_AV_LOAD(yb + 32)   // (flies during this block's products)
 
     // s, dp: rows = the walked block, columns = own rows
     f32x16 s, dp;
@@ -249,6 +272,8 @@ __global__ __launch_bounds__(256) void attention_vjp_kernel(AttnVjpArgs a) {
       }
     }
 }
+
+#undef MAUA_AV_LOAD
 
 }  // namespace
 

@@ -381,8 +381,17 @@ __global__ __launch_bounds__(256) void sq_partial_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void clamp_scale_kernel(float* __restrict__ g, long n, const double* __restrict__ part, int nparts, float clamp,
                                                           float scale) {
-  double s = 0.0;
-  for (int i = 0; i < nparts; i++) s += part[i];
+  // the partial sums once per workgroup, in a fixed order (every thread used to walk all 1024 of them: 0.86 ms for a 6 M-value gradient)
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double s = red[0];
   float f = scale;
   if (clamp > 0.f) {
     const float mag = sqrtf((float)(s / (double)n)) * fabsf(scale);
