@@ -108,11 +108,11 @@ th.start()
 p.wait()
 stop.set()
 th.join()
-good = [s for s in samples if s > 600]
+good = [s for s in samples if s >= 0.9 * max(samples)] if samples else []   # (the loop's own samples: not its start / end)
 P_STEP = sum(good) / len(good) if good else 1290.0
 
 lines = [f"# per-kernel energy account of one 1024^2 synthesis forward at B = {B} (scripts/energy_by_kernel.py; prices: profiles/r05_energy_prices.txt)",
-         f"# socket power over an un-profiled loop of the forward: {P_STEP:.0f} W (mean of {len(good)} rocm-smi samples >= 600 W: {[round(s) for s in good]})",
+         f"# socket power over an un-profiled loop of the forward: {P_STEP:.0f} W (mean of the {len(good)} rocm-smi samples within 10 % of the largest: {[round(s) for s in good]})",
          f"# model: E = 11.47 n_mfma + 4.10 n_lds + 1.1 (n_valu - n_mfma) + 0.3 n_salu + 20.39 (n_vmem_rd + n_vmem_wr) nJ + 0.11 nJ/B x HBM bytes + (270 + 380 x mfma_busy) W x t",
          "# columns: ms per launch | launches in the averaged half | mfma_busy | J: mfma / lds / valu / salu / vmem / hbm / idle / busy-share | model J | P_step x t J | residual"]
 tot_m = tot_t = tot_ms = 0.0

@@ -34,3 +34,5 @@ avg = [sum(ms[f * per + j] for f in range(reps)) / reps for j in range(per)]
 names = {9: "up16", 12: "up32", 13: "fir32", 14: "c1_64", 16: "up64", 17: "fir64", 18: "c1_128", 20: "up128", 21: "fir128", 22: "c1_256", 24: "up256", 25: "fir256", 26: "c1_512", 28: "walk"}
 tag = os.path.basename(os.environ.get("MAUA_HIP_LIB", "tree"))
 print(f"{tag:28s} " + " ".join(f"{names[j]}={avg[j]:.3f}" for j in sorted(names)) + f" | sum {sum(avg):.3f}")
+if os.environ.get("MAUA_SLOTS_ALL"):   # every profile slot of the forward, in launch order
+    print("  all slots (ms): " + " ".join(f"{j}:{avg[j]:.3f}" for j in range(per)))
