@@ -587,6 +587,19 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "piptrack", "maua_amd.cqt", "piptrack"),
     ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "estimate_tuning", "maua_amd.cqt", "estimate_tuning"),
     ("audiovisual/audioreactive/selfsupervised/features/rosa/pitch.py", "pitch_tuning", "maua_amd.cqt", "pitch_tuning"),
+    # round 6: the text-prompt guidance surface (maua/grad.py, ops/cutouts.py, loss.py, prompt.py)
+    ("grad.py", "GradModule.__init__", "maua_amd.grad", "GradModule.__init__"),
+    ("grad.py", "GradModule.forward", "maua_amd.grad", "GradModule.forward"),
+    ("grad.py", "CLIPGrads.__init__", "maua_amd.grad", "CLIPGrads.__init__"),
+    ("grad.py", "CLIPGrads.set_targets", "maua_amd.grad", "CLIPGrads.set_targets"),
+    ("grad.py", "CLIPGrads.forward", "maua_amd.grad", "CLIPGrads.forward"),
+    ("ops/cutouts.py", "random_cutouts", "maua_amd.grad", "random_cutouts"),
+    ("ops/cutouts.py", "MauaCutouts.__init__", "maua_amd.grad", "MauaCutouts.__init__"),
+    ("ops/cutouts.py", "MauaCutouts.forward", "maua_amd.grad", "MauaCutouts.forward"),
+    ("ops/cutouts.py", "make_cutouts", "maua_amd.grad", "make_cutouts"),
+    ("loss.py", "spherical_dist_loss", "maua_amd.grad", "spherical_dist_loss"),
+    ("prompt.py", "TextPrompt.__init__", "maua_amd.grad", "TextPrompt.__init__"),
+    ("prompt.py", "ImagePrompt.__init__", "maua_amd.grad", "ImagePrompt.__init__"),
 ]
 
 

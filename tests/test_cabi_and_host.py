@@ -255,6 +255,15 @@ def test_maua_namespace_resolves_to_the_native_package():
     from maua.super.image.models.realesrgan import SRVGGNetCompact, load_model
     assert GuidedDiffusion is native_df.GuidedDiffusion and create_models is native_df.create_models and callable(sample)
     assert callable(load_model) and SRVGGNetCompact.__module__ == "maua_amd.super"
+    # round 6: the text-prompt guidance modules under the reference's paths
+    import maua_amd.grad as native_gr
+    from maua.grad import CLIPGrads, GradModule
+    from maua.loss import spherical_dist_loss
+    from maua.ops.cutouts import MauaCutouts, make_cutouts, random_cutouts
+    from maua.prompt import ContentPrompt, StylePrompt, TextPrompt
+    assert CLIPGrads is native_gr.CLIPGrads and GradModule is native_gr.GradModule and MauaCutouts is native_gr.MauaCutouts
+    assert callable(spherical_dist_loss) and callable(make_cutouts) and callable(random_cutouts)
+    assert issubclass(StylePrompt, native_gr.ImagePrompt) and issubclass(ContentPrompt, native_gr.ImagePrompt) and TextPrompt("x", 2.0)()[1] == 2.0
     # the reference's default patch file resolves through the namespace to a class defined in that module
     cls = get_patch_from_file("maua/audiovisual/patches/examples/stylegan2.py")
     assert issubclass(cls, StyleGAN2Patch) and issubclass(cls, MauaPatch)
@@ -365,7 +374,10 @@ def test_host_layer_signatures_match_the_reference():
                     (e["name"], e["reference"], n, d, got)
                 continue
             if isinstance(want, (list, tuple)) or (torch.is_tensor(want) and want.dim() > 0):
-                want, got = [float(v) for v in want], [float(v) for v in got]
+                try:
+                    want, got = [float(v) for v in want], [float(v) for v in got]
+                except (TypeError, ValueError):     # (lists of names: perceptors=["ViT-B/16"])
+                    want, got = list(want), list(got)
             elif torch.is_tensor(want):
                 want, got = float(want), float(got)
             assert got == want, (e["name"], e["reference"], n, d, p.default)
