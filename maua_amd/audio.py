@@ -559,16 +559,17 @@ def _pow2(n):
 
 
 def stft_general(y, n_fft, hop_length, window=None):
-    """rosa/spectral.py:10-21 for any power-of-two n_fft <= 2048 and any hop (centre / reflect) -> complex64
+    """rosa/spectral.py:10-21 for any n_fft <= 8192 and any hop (centre / reflect; powers of two on the LDS FFT - round 6: above 2048
+    too -, other lengths as an exact-f32 DFT GEMM) -> complex64
     [n_fft // 2 + 1, 1 + len(y) // hop] as a transposed view of the frame-major buffer."""
     y = _f32(y).reshape(-1)
     win = _f32(torch.hann_window(n_fft) if window is None else window).to(y.device)
     if not _pow2(n_fft):
-        if n_fft > 2048:
-            raise NotImplementedError("stft: lengths up to 2048")
+        if n_fft > 8192:
+            raise NotImplementedError("stft: lengths up to 8192")
         return _stft_dft(y, n_fft, hop_length, win)
-    if n_fft > 2048:
-        raise NotImplementedError("the HIP FFT handles power-of-two lengths up to 2048")
+    if n_fft > 8192:
+        raise NotImplementedError("the HIP FFT handles power-of-two lengths up to 8192 (two buffers of n_fft complex values in LDS)")
     frames = 1 + y.numel() // hop_length
     out = torch.empty((frames, n_fft // 2 + 1, 2), dtype=torch.float32, device=y.device)
     L.check(L.lib().maua_stft_general(L.ctx(y.device), L.ptr(y), y.numel(), n_fft, hop_length, L.ptr(win), L.ptr(out)))

@@ -213,8 +213,8 @@ def vqt(y, sr, hop_length=1024, fmin=None, n_bins=84, gamma=None, bins_per_octav
         if key not in _BASIS_CACHE:
             with L.host_threads(1):   # dozens of tiny host tensors (0.29 s -> 0.04 s for the seven octaves of one CQT)
                 basis, n_fft, _ = cqt_filter_fft(my_sr, fmin_t * 2.0 ** -i, n_filters, bins_per_octave, filter_scale, sparsity, gamma)
-                if n_fft > 2048:
-                    raise NotImplementedError(f"cqt: the filters need a {n_fft}-point FFT at sr={sr}; the HIP FFT stops at 2048")
+                if n_fft > 8192:
+                    raise NotImplementedError(f"cqt: the filters need a {n_fft}-point FFT at sr={sr}; the HIP FFT stops at 8192")
                 basis = basis[n_filters - (hi - lo):] * (np.sqrt(2 ** i) / torch.sqrt(lengths_full[lo:hi])[:, None])
                 # interleaved real matrix: row 2n = (re, -im) -> Re(resp_n), row 2n+1 = (im, re) -> Im(resp_n)
                 re, im = basis.real, basis.imag

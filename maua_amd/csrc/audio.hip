@@ -18,6 +18,7 @@
 namespace maua {
 
 constexpr int NFFT = 2048, HOPL = 1024, NBIN = NFFT / 2 + 1;
+constexpr int GFFT = 8192;   // the general-framing entry points (any power-of-two n_fft, caller's window) go up to this length: 2 x 64 KB of LDS
 
 __device__ __forceinline__ int reflect_index(int i, int n) {
   // torch 'reflect' padding (no edge repeat); valid for pad < n
@@ -34,10 +35,11 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 // (conjugated twiddles, no 1/N scaling).  Returns the buffer holding the result.
 // The same network runs any power-of-two length N <= 2048 (the tempogram of beat.py:33-39 uses 1024): the twiddle
 // table is read with stride 2048 / N.
-__device__ float2* fft_pow2(float2* a, float2* b, const float2* __restrict__ tw, int dir, int N, int logN) {
+// twn: the length the twiddle table was built for (tw[k] = exp(-2 pi i k / twn), k < twn / 2)
+__device__ float2* fft_pow2(float2* a, float2* b, const float2* __restrict__ tw, int dir, int N, int logN, int twn = NFFT) {
   float2* src = a;
   float2* dst = b;
-  const int tws = NFFT / N;
+  const int tws = twn / N;
   for (int t = 0; t < logN; t++) {
     const int s = 1 << t;
     for (int i = threadIdx.x; i < N / 2; i += blockDim.x) {
@@ -116,16 +118,19 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   y[i] = (f1 < n_frames || (f0 >= 0 && f0 < n_frames)) ? acc / env : 0.f;
 }
 
-// ---- general framing (n_fft a power of two <= 2048, any hop, caller's window): beat.py:33-39 fourier_tempogram ----
+// ---- general framing (n_fft a power of two <= 8192, any hop, caller's window): beat.py:33-39 fourier_tempogram, rosa/spectral.py:10-21
+// stft at any n_fft (round 6: lengths above 2048 - dynamic LDS, 2 x n_fft complex values, and the twiddle table of that length) ----
 __global__ __launch_bounds__(256) void stft_general_kernel(const float* __restrict__ y, int n, const float* __restrict__ win,
                                                            const float2* __restrict__ tw, float2* __restrict__ out,
-                                                           int n_fft, int logn, int hop) {
-  __shared__ float2 A[NFFT], B[NFFT];
+                                                           int n_fft, int logn, int hop, int twn) {
+  extern __shared__ float2 fft_sm[];
+  float2* A = fft_sm;
+  float2* B = fft_sm + n_fft;
   const int f = blockIdx.x;
   for (int i = threadIdx.x; i < n_fft; i += blockDim.x)
     A[i] = make_float2(y[reflect_index(f * hop - n_fft / 2 + i, n)] * win[i], 0.f);
   __syncthreads();
-  float2* r = fft_pow2(A, B, tw, +1, n_fft, logn);
+  float2* r = fft_pow2(A, B, tw, +1, n_fft, logn, twn);
   const int nb = n_fft / 2 + 1;
   for (int k = threadIdx.x; k < nb; k += blockDim.x) out[(long)f * nb + k] = r[k];
 }
@@ -133,8 +138,10 @@ __global__ __launch_bounds__(256) void stft_general_kernel(const float* __restri
 __global__ __launch_bounds__(256) void istft_general_frames_kernel(const float2* __restrict__ spec,
                                                                    const float* __restrict__ win,
                                                                    const float2* __restrict__ tw, float* __restrict__ frames,
-                                                                   int n_fft, int logn) {
-  __shared__ float2 A[NFFT], B[NFFT];
+                                                                   int n_fft, int logn, int twn) {
+  extern __shared__ float2 fft_sm[];
+  float2* A = fft_sm;
+  float2* B = fft_sm + n_fft;
   const int f = blockIdx.x, nb = n_fft / 2 + 1;
   for (int k = threadIdx.x; k < n_fft; k += blockDim.x) {
     float2 v;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void istft_general_frames_kernel(const float2*
     A[k] = v;
   }
   __syncthreads();
-  float2* r = fft_pow2(A, B, tw, -1, n_fft, logn);
+  float2* r = fft_pow2(A, B, tw, -1, n_fft, logn, twn);
   for (int i = threadIdx.x; i < n_fft; i += blockDim.x) frames[(long)f * n_fft + i] = (r[i].x * (1.0f / n_fft)) * win[i];
 }
 
@@ -634,6 +641,7 @@ namespace {
 struct AudioTables {
   float2* tw = nullptr;
   float* win = nullptr;
+  float2* tw_big = nullptr;   // exp(-2 pi i k / GFFT), k < GFFT / 2: the general entry points above 2048 points
 };
 static thread_local std::vector<std::pair<maua_ctx*, AudioTables>> g_tables;
 
@@ -654,6 +662,13 @@ int get_tables(maua_ctx* ctx, AudioTables& t) {
   MAUA_HIP_CHECK(hipMalloc((void**)&t.win, sizeof(float) * win.size()));
   MAUA_HIP_CHECK(hipMemcpy(t.tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
   MAUA_HIP_CHECK(hipMemcpy(t.win, win.data(), sizeof(float) * win.size(), hipMemcpyHostToDevice));
+  std::vector<float2> twb(GFFT / 2);
+  for (int k = 0; k < GFFT / 2; k++) {
+    double a = -2.0 * M_PI * k / GFFT;
+    twb[k] = make_float2((float)cos(a), (float)sin(a));
+  }
+  MAUA_HIP_CHECK(hipMalloc((void**)&t.tw_big, sizeof(float2) * twb.size()));
+  MAUA_HIP_CHECK(hipMemcpy(t.tw_big, twb.data(), sizeof(float2) * twb.size(), hipMemcpyHostToDevice));
   g_tables.push_back({ctx, t});
   return MAUA_OK;
 }
@@ -685,14 +700,19 @@ int maua_stft_general(maua_ctx* ctx, const float* y, int n_samples, int n_fft, i
                       float* out_frames_bins_complex) {
   MAUA_REQUIRE(ctx && y && window_dev && out_frames_bins_complex, "maua_stft_general: NULL argument");
   const int logn = log2_exact(n_fft);
-  MAUA_REQUIRE(logn >= 1 && n_fft <= NFFT, "maua_stft_general: n_fft must be a power of two in [2, 2048]");
+  MAUA_REQUIRE(logn >= 1 && n_fft <= GFFT, "maua_stft_general: n_fft must be a power of two in [2, 8192]");
   MAUA_REQUIRE(hop >= 1, "maua_stft_general: hop must be positive");
   MAUA_REQUIRE(n_samples > n_fft / 2, "maua_stft_general: signal shorter than the reflect padding (n_fft/2)");
   AudioTables t;
   if (int rc = get_tables(ctx, t)) return rc;
   const int frames = 1 + n_samples / hop;
-  hipLaunchKernelGGL(stft_general_kernel, dim3(frames), dim3(256), 0, ctx->stream, y, n_samples, window_dev, t.tw,
-                     (float2*)out_frames_bins_complex, n_fft, logn, hop);
+  // (lengths up to 2048 keep the 2048-point table: the same twiddles, bit for bit, as before round 6)
+  const bool big = n_fft > NFFT;
+  const size_t smem = (size_t)2 * n_fft * sizeof(float2);
+  if (smem > 64 * 1024)
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)stft_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(stft_general_kernel, dim3(frames), dim3(256), smem, ctx->stream, y, n_samples, window_dev, big ? t.tw_big : t.tw,
+                     (float2*)out_frames_bins_complex, n_fft, logn, hop, big ? GFFT : NFFT);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
@@ -701,14 +721,18 @@ int maua_istft_general(maua_ctx* ctx, const float* spec_frames_bins_complex, int
                        const float* window_dev, int length, float* y) {
   MAUA_REQUIRE(ctx && spec_frames_bins_complex && window_dev && y, "maua_istft_general: NULL argument");
   const int logn = log2_exact(n_fft);
-  MAUA_REQUIRE(logn >= 1 && n_fft <= NFFT, "maua_istft_general: n_fft must be a power of two in [2, 2048]");
+  MAUA_REQUIRE(logn >= 1 && n_fft <= GFFT, "maua_istft_general: n_fft must be a power of two in [2, 8192]");
   MAUA_REQUIRE(hop >= 1 && n_frames > 0 && length > 0, "maua_istft_general: empty input");
   AudioTables t;
   if (int rc = get_tables(ctx, t)) return rc;
   if (int rc = scratch_reserve(ctx, (size_t)n_frames * n_fft * sizeof(float))) return rc;
   float* frames = (float*)ctx->scratch;
-  hipLaunchKernelGGL(istft_general_frames_kernel, dim3(n_frames), dim3(256), 0, ctx->stream,
-                     (const float2*)spec_frames_bins_complex, window_dev, t.tw, frames, n_fft, logn);
+  const bool big = n_fft > NFFT;
+  const size_t smem = (size_t)2 * n_fft * sizeof(float2);
+  if (smem > 64 * 1024)
+    MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)istft_general_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(istft_general_frames_kernel, dim3(n_frames), dim3(256), smem, ctx->stream,
+                     (const float2*)spec_frames_bins_complex, window_dev, big ? t.tw_big : t.tw, frames, n_fft, logn, big ? GFFT : NFFT);
   hipLaunchKernelGGL(istft_general_ola_kernel, dim3(cdiv(length, 256)), dim3(256), 0, ctx->stream, frames, window_dev,
                      n_frames, n_fft, hop, length, y);
   MAUA_HIP_CHECK(hipGetLastError());
