@@ -592,6 +592,49 @@ int maua_layer_norm(maua_ctx* ctx, const void* x, const float* gamma, const floa
 int maua_layer_norm_vjp(maua_ctx* ctx, const void* x, const float* stats, const float* gamma, const void* dy, const void* add, long rows,
                         int C, int dtype, void* dx);
 
+/* ---- image-prompt grad modules: ColorMatchGrads, VGGGrads, LPIPSGrads (the other members of get_diffusion_model's list,
+ * maua/diffusion/image.py:92-97) ------------------------------------------------------------------------------------------
+ * ColorMatchGrads (maua/grad.py:27-70): hue histogram of clamp((img + 1) / 2) under kornia's rgb_to_hsv (restated; radians clamped
+ * to [0, 1] as the reference does), weighted by sqrt(sat * val), normalised to sum 1 - differentiable_histogram's 255 masked passes
+ * as one pass with 64-bit fixed-point sums (bit-identical from run to run).  img device f32 [B][3][H][W] in [-1, 1].
+ *   maua_colormatch_hist : hist device f32 [B][nbins]                                   (histogram(), set_targets :65-69)
+ *   maua_colormatch_grad : grad = d (scale * mse_loss(hist, target)) / d img in closed form (forward :67-70); target device f32
+ *                          [nbins] (target_per_sample == 0) or [B][nbins]; loss: optional device f32 [B], the samples' shares of the
+ *                          loss (their sum is the reference's scalar) */
+int maua_colormatch_hist(maua_ctx* ctx, const float* img, int B, int H, int W, int nbins, int sat_weighting, float* hist);
+int maua_colormatch_grad(maua_ctx* ctx, const float* img, int B, int H, int W, int nbins, int sat_weighting, const float* target,
+                         int target_per_sample, float scale, float* grad, float* loss);
+/* VGG perceptors (csrc/perceptor.hip).  plan: n_ops entries, > 0 = Conv2d(3x3, pad 1) to that many channels (multiples of 64) + ReLU,
+ * 0 = MaxPool2d(2) - torchvision's vgg19 / vgg16 `features` cut after the last tap; replicate_first: the first convolution pads by
+ * replication (vgg_kbc.py:40); the network sees ((img * in_mul + in_add) - mean) / std (VGGGrads: img.add(1).div(2) + ImageNet
+ * Normalize, vgg_kbc.py:33; LPIPS: its ScalingLayer).  dtype MAUA_F32 (exact products, parity mode) or MAUA_BF16.  Weights: torch
+ * layout [Co][Ci][3][3] / [Co] per convolution, in plan order (torchvision keys "<features index>.weight / .bias"); the published
+ * networks are un-vendored (torchvision, lpips: parity unpinned), random-init in tests and bench. */
+typedef struct maua_vgg maua_vgg;
+int maua_vgg_create(maua_ctx* ctx, int dtype, const int* plan, int n_ops, int replicate_first, float in_mul, float in_add,
+                    const float* mean3, const float* std3, maua_vgg** out);
+void maua_vgg_destroy(maua_vgg* net);
+int maua_vgg_conv_count(maua_vgg* net);
+int maua_vgg_conv_shape(maua_vgg* net, int index, int* ci, int* co);
+int maua_vgg_load(maua_vgg* net, int conv_index, int what /* 0 weight, 1 bias */, const float* host_data, size_t count);
+/* forward of img device f32 [B][3][H][W]; every activation is kept for the calls below (plan entry index `op`):
+ * maua_vgg_features -> planar f32 [B][C][h][w]; maua_vgg_gram -> Gram matrices [B][C][C] (loss.py:57-80 gram_matrix per image:
+ * Perceptor.get_target_embeddings, perceptors/__init__.py:44-76); maua_vgg_lpips_features -> unit-normalised features [B][h w][C] */
+int maua_vgg_forward(maua_vgg* net, const float* img, int B, int H, int W);
+int maua_vgg_features(maua_vgg* net, int op, float* out);
+int maua_vgg_gram(maua_vgg* net, int op, float* out);
+int maua_vgg_lpips_features(maua_vgg* net, int op, float* out);
+/* VGGGrads.forward (maua/grad.py:90-93): grad = d sum_taps strength * feature_loss(gram(tap), target) / d img, per image
+ * (feature_loss = scaled_mse_loss / numel, loss.py:33-54); taps HOST int [n_taps] (plan entries), targets HOST array of n_taps DEVICE
+ * pointers to f32 [C][C] (target_bstride NULL / 0) or [B][C][C] (target_bstride[k] = C * C); loss optional device f32 [B] */
+int maua_vgg_style_grad(maua_vgg* net, const float* img, int B, int H, int W, const int* taps, int n_taps, const float* const* targets,
+                        const long* target_bstride, float strength, float* grad, float* loss);
+/* LPIPSGrads.forward (maua/grad.py:189-193) at the network's own size: grad = d (scale * sum_b lpips(img_b, target)) / d img;
+ * targets: HOST array of DEVICE pointers to the target's unit-normalised tap features (maua_vgg_lpips_features: [hw][C], shared, or
+ * [B][hw][C] with target_bstride[k] = hw * C), lins: DEVICE pointers to the lin layers' weights [C]; dist optional device f32 [B] */
+int maua_vgg_lpips_grad(maua_vgg* net, const float* img, int B, int H, int W, const int* taps, int n_taps, const float* const* targets,
+                        const long* target_bstride, const float* const* lins, float scale, float* grad, float* dist);
+
 /* ---- build-owned counter RNG: Philox4x32-10, identical on every device / rank and in the oracle twin (oracle/rng.py,
  * pinned to the published known-answer vectors).  No reference counterpart: the reference's random-init generator and noise planes
  * come from torch's host generator (inference/stylegan2.py:216-227, selfsupervised/noise.py:42-53); the benchmark's synthetic

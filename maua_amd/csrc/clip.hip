@@ -948,7 +948,7 @@ int maua_clip_guide_grad(maua_clip* n, const float* img, int B, int H, int W, co
   if (B == 0) return MAUA_OK;
   MAUA_REQUIRE(n->sel_B == 0 || n->sel_B == B, "maua_clip_guide_grad: the per-sample target selection was set for another batch size");
   for (long i = 0; i < (long)batches * cutn; i++) {
-    const int s = rects[3 * i], oy = rects[3 * i + 1], ox = rects[3 * i + 2];
+    const int s = rects[3 * i] & CUT_SIZE_MASK, oy = rects[3 * i + 1], ox = rects[3 * i + 2];
     MAUA_REQUIRE(s > 0 && oy >= 0 && ox >= 0 && oy + s <= H && ox + s <= W, "maua_clip_guide_grad: a cutout leaves the image");
   }
   int cutn_total = cutn;

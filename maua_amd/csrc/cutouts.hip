@@ -6,6 +6,10 @@
 // the reference tree and the image (parity unpinned; the published algorithm: 1-D passes, cubic kernel a = -0.5, kernel stretched by
 // 1 / scale when shrinking, weights normalised per output sample, zero padding around the CUTOUT).
 //
+// DangoCutouts (cutouts.py:101-206, skip_augs): the same kernels; a rectangle's size entry carries a grey and a mirror flag
+// (internal.h CUT_GREY / CUT_FLIP): luma of the three planes in the vertical pass, mirrored store; the adjoints mirror the load and
+// spread the three planes' sum over the luma coefficients.
+//
 // Who draws the rectangles: the host (maua_amd/grad.py restates the reference's draws from torch's generator, pinned by
 // tests/golden/g33_cutouts.npz); this file takes (size, top, left) per cutout in device memory, so a captured sampler loop reads
 // its step's rectangles from a table uploaded before the loop.
@@ -45,7 +49,7 @@ __global__ void cutout_tables_kernel(const int* __restrict__ rects, int n_cut, i
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_cut * cs) return;
   const int n = idx / cs, o = idx - n * cs;
-  const int size = rects[3 * n];
+  const int size = rects[3 * n] & CUT_SIZE_MASK;
   const double scale_d = (double)cs / (double)size;
   const float scale = (float)scale_d;
   float pf = (float)o / scale;
@@ -108,20 +112,28 @@ __global__ __launch_bounds__(256) void cutouts_fwd_kernel(CutArgs a) {
   extern __shared__ float band[];
   const int image = blockIdx.z, c = blockIdx.y, y0 = blockIdx.x * CT_BAND;
   const int n = image / a.B, b = image - n * a.B;
-  const int size = a.rects[3 * n], oy = a.rects[3 * n + 1], ox = a.rects[3 * n + 2];
+  const int rs = a.rects[3 * n], size = rs & CUT_SIZE_MASK, oy = a.rects[3 * n + 1], ox = a.rects[3 * n + 2];
+  const bool grey = (rs & CUT_GREY) != 0, flip = (rs & CUT_FLIP) != 0;
   const int taps = a.taps[n];
   const int rows = min(CT_BAND, a.cs - y0);
   const int* lt = a.left + (long)n * a.cs;
   const float* wt = a.wts + (long)n * a.cs * CT_MAXT;
-  const float* src = a.img + ((long)b * 3 + c) * a.H * a.W + (long)oy * a.W + ox;
-  // vertical pass (the reference resizes rows first): band[yl][X] = sum_i w[y][i] * I[left(y) + i][X]
+  const long plane = (long)a.H * a.W;
+  const float* src = a.img + ((long)b * 3 + (grey ? 0 : c)) * plane + (long)oy * a.W + ox;
+  // vertical pass (the reference resizes rows first): band[yl][X] = sum_i w[y][i] * I[left(y) + i][X]; a grey cutout reads the luma
+  // of the three planes instead of its own (resize and the luma are both linear: grey before or after the resize is the same image)
   for (int e = threadIdx.x; e < rows * size; e += 256) {
     const int yl = e / size, X = e - yl * size;
     const int y = y0 + yl, l = lt[y];
     float acc = 0.f;
     for (int i = 0; i < taps; i++) {
       const int Y = l + i;
-      if (Y >= 0 && Y < size) acc = fmaf(wt[(long)y * CT_MAXT + i], fmaf(src[(long)Y * a.W + X], a.mul, a.add), acc);
+      if (Y >= 0 && Y < size) {
+        const float* sp = src + (long)Y * a.W + X;
+        float v = fmaf(sp[0], a.mul, a.add);
+        if (grey) v = 0.2989f * v + 0.587f * fmaf(sp[plane], a.mul, a.add) + 0.114f * fmaf(sp[2 * plane], a.mul, a.add);
+        acc = fmaf(wt[(long)y * CT_MAXT + i], v, acc);
+      }
     }
     band[yl * size + X] = acc;
   }
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256) void cutouts_fwd_kernel(CutArgs a) {
       const int X = l + j;
       if (X >= 0 && X < size) acc = fmaf(wt[(long)x * CT_MAXT + j], band[yl * size + X], acc);
     }
-    store_px<T>(a, image, c, y0 + yl, x, (acc - mean) * inv_std);
+    store_px<T>(a, image, c, y0 + yl, flip ? a.cs - 1 - x : x, (acc - mean) * inv_std);
   }
 }
 
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(256) void cutouts_bwd_h_kernel(CutArgs a, const voi
   int* left_s = reinterpret_cast<int*>(sm + CT_BAND * a.cs);  // [cs]
   const int image = blockIdx.z, c = blockIdx.y, y0 = blockIdx.x * CT_BAND;
   const int n = image / a.B;
-  const int size = a.rects[3 * n];
+  const int size = a.rects[3 * n] & CUT_SIZE_MASK;
+  const bool flip = (a.rects[3 * n] & CUT_FLIP) != 0;
   const int taps = a.taps[n];
   const int rows = min(CT_BAND, a.cs - y0);
   const float* wt = a.wts + (long)n * a.cs * CT_MAXT;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256) void cutouts_bwd_h_kernel(CutArgs a, const voi
   for (int e = threadIdx.x; e < a.cs; e += 256) left_s[e] = a.left[(long)n * a.cs + e];
   for (int e = threadIdx.x; e < rows * a.cs; e += 256) {
     const int yl = e / a.cs, x = e - yl * a.cs;
-    rows_s[e] = load_px<T>(a, d, image, c, y0 + yl, x) * inv_std;
+    rows_s[e] = load_px<T>(a, d, image, c, y0 + yl, flip ? a.cs - 1 - x : x) * inv_std;
   }
   __syncthreads();
   // left() is non-decreasing in x with slope 1 / scale: the candidates of X start near (X - taps - left(0)) * cs / size
@@ -183,7 +196,8 @@ __global__ __launch_bounds__(256) void cutouts_bwd_v_kernel(CutArgs a, const flo
   const int bc = blockIdx.z, b = bc / 3, c = bc - b * 3;
   float acc = 0.f;
   for (int n = 0; n < a.n_cut; n++) {
-    const int size = a.rects[3 * n], oy = a.rects[3 * n + 1], ox = a.rects[3 * n + 2];
+    const int rs = a.rects[3 * n], size = rs & CUT_SIZE_MASK, oy = a.rects[3 * n + 1], ox = a.rects[3 * n + 2];
+    const bool grey = (rs & CUT_GREY) != 0;
     const int Y = Yg - oy;
     if (Y < 0 || Y >= size) continue;     // (block-uniform)
     const int taps = a.taps[n];
@@ -195,10 +209,17 @@ __global__ __launch_bounds__(256) void cutouts_bwd_v_kernel(CutArgs a, const flo
     while (y > 0 && lt[y] + taps > Y) y--;
     const int Xc = X - ox;
     const bool in = X < a.W && Xc >= 0 && Xc < size;
-    const float* tp = th + (((long)(n * a.B + b) * 3 + c) * a.cs) * a.smax + Xc;
+    // a grey cutout's three output planes all came from the luma: plane c receives its luma coefficient x the sum of their adjoints
+    const long tplane = (long)a.cs * a.smax;
+    const float* tp = th + (((long)(n * a.B + b) * 3 + (grey ? 0 : c)) * a.cs) * a.smax + Xc;
+    const float lum = c == 0 ? 0.2989f : c == 1 ? 0.587f : 0.114f;
     for (; y < a.cs && lt[y] <= Y; y++) {
       const int i = Y - lt[y];
-      if (i < taps && in) acc = fmaf(wt[(long)y * CT_MAXT + i], tp[(long)y * a.smax], acc);
+      if (i < taps && in) {
+        const float* q = tp + (long)y * a.smax;
+        const float tv = grey ? lum * (q[0] + q[tplane] + q[2 * tplane]) : q[0];
+        acc = fmaf(wt[(long)y * CT_MAXT + i], tv, acc);
+      }
     }
   }
   if (X >= a.W) return;

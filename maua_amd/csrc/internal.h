@@ -315,9 +315,12 @@ int launch_group_norm_vjp(hipStream_t stream, int dtype, const GnVjpArgs& a, voi
 // rects: DEVICE [n_cut][3] (size, top, left); tables: cutouts_table_bytes() of device scratch filled by launch_cutout_tables;
 // out / d_out: planar f32 [n_cut * B][3][cs][cs] (patch == 0) or patch rows in dtype [n_cut * B * (cs / patch)^2][3 * patch^2];
 // th: cutouts_th_bytes() of scratch; grad: [B][3][H][W] f32
+// a rectangle's size entry carries two flags in its high bits (DangoCutouts, cutouts.py:171-199): the cutout is converted to
+// 3-channel luma (torchvision Grayscale(3): 0.2989 r + 0.587 g + 0.114 b) / mirrored horizontally (TF.hflip)
+constexpr int CUT_GREY = 1 << 30, CUT_FLIP = 1 << 29, CUT_SIZE_MASK = (1 << 24) - 1;
 struct CutoutPlan {
   const float* img;
-  const int* rects;
+  const int* rects;        // [n_cut][3] (size | flags, top, left)
   int B, H, W, n_cut, cs;
   float mul, add;          // affine applied to the image first ((img + 1) / 2: 0.5, 0.5)
   float mean[3], std[3];   // Normalize applied to the cutouts

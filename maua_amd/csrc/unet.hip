@@ -1999,8 +1999,9 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
     MAUA_REQUIRE(n->gd_rect_steps == n_steps, "maua_ddim_guided_loop: maua_unet_set_clip_guide was given another number of steps");
     MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: CLIP guides 3-channel images");
     for (size_t i = 0; i < n->gd_rects_host.size(); i += 3)
-      MAUA_REQUIRE(n->gd_rects_host[i] > 0 && n->gd_rects_host[i + 1] >= 0 && n->gd_rects_host[i + 2] >= 0 &&
-                       n->gd_rects_host[i + 1] + n->gd_rects_host[i] <= H && n->gd_rects_host[i + 2] + n->gd_rects_host[i] <= W,
+      MAUA_REQUIRE((n->gd_rects_host[i] & CUT_SIZE_MASK) > 0 && n->gd_rects_host[i + 1] >= 0 && n->gd_rects_host[i + 2] >= 0 &&
+                       n->gd_rects_host[i + 1] + (n->gd_rects_host[i] & CUT_SIZE_MASK) <= H &&
+                       n->gd_rects_host[i + 2] + (n->gd_rects_host[i] & CUT_SIZE_MASK) <= W,
                    "maua_ddim_guided_loop: a cutout leaves the image");
     if (int rc = clip_prepare_guide(clip, B, H, W, clip_group_size(clip, B, n->gd_cutn))) return rc;
   } else {

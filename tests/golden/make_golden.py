@@ -32,7 +32,8 @@ sys.path.insert(0, str(REPO))
 
 ABSENT = {"librosa", "madmom", "torchaudio", "openunmix", "torchcubicspline", "torchtyping", "torch_geometric",
           "kornia", "cv2", "resampy", "soundfile", "ffmpeg", "decord", "npy_append_array", "fire", "numba",
-          "matplotlib", "sklearn", "joblib", "resize_right", "medpy", "torchvision", "PIL", "glumpy", "pycuda"}
+          "matplotlib", "sklearn", "joblib", "resize_right", "medpy", "torchvision", "PIL", "glumpy", "pycuda", "clip", "lpips",
+          "gdown"}
 
 
 class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -600,6 +601,25 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("loss.py", "spherical_dist_loss", "maua_amd.grad", "spherical_dist_loss"),
     ("prompt.py", "TextPrompt.__init__", "maua_amd.grad", "TextPrompt.__init__"),
     ("prompt.py", "ImagePrompt.__init__", "maua_amd.grad", "ImagePrompt.__init__"),
+    # round 6, second half: the image-prompt grad modules and their perceptors
+    ("grad.py", "ColorMatchGrads.__init__", "maua_amd.grad", "ColorMatchGrads.__init__"),
+    ("grad.py", "ColorMatchGrads.histogram", "maua_amd.grad", "ColorMatchGrads.histogram"),
+    ("grad.py", "ColorMatchGrads.set_targets", "maua_amd.grad", "ColorMatchGrads.set_targets"),
+    ("grad.py", "ColorMatchGrads.forward", "maua_amd.grad", "ColorMatchGrads.forward"),
+    ("grad.py", "VGGGrads.__init__", "maua_amd.grad", "VGGGrads.__init__"),
+    ("grad.py", "VGGGrads.set_targets", "maua_amd.grad", "VGGGrads.set_targets"),
+    ("grad.py", "VGGGrads.forward", "maua_amd.grad", "VGGGrads.forward"),
+    ("grad.py", "LPIPSGrads.__init__", "maua_amd.grad", "LPIPSGrads.__init__"),
+    ("grad.py", "LPIPSGrads.set_targets", "maua_amd.grad", "LPIPSGrads.set_targets"),
+    ("grad.py", "LPIPSGrads.forward", "maua_amd.grad", "LPIPSGrads.forward"),
+    ("grad.py", "LossGrads.__init__", "maua_amd.grad", "LossGrads.__init__"),
+    ("ops/cutouts.py", "DangoCutouts.__init__", "maua_amd.grad", "DangoCutouts.__init__"),
+    ("ops/cutouts.py", "DangoCutouts.forward", "maua_amd.grad", "DangoCutouts.forward"),
+    ("perceptors/__init__.py", "Perceptor.__init__", "maua_amd.perceptors", "Perceptor.__init__"),
+    ("perceptors/__init__.py", "Perceptor.get_target_embeddings", "maua_amd.perceptors", "Perceptor.get_target_embeddings"),
+    ("perceptors/__init__.py", "Perceptor.get_loss", "maua_amd.perceptors", "Perceptor.get_loss"),
+    ("perceptors/__init__.py", "load_perceptor", "maua_amd.perceptors", "load_perceptor"),
+    ("perceptors/vgg_kbc.py", "KBCPerceptor.__init__", "maua_amd.perceptors", "KBCPerceptor.__init__"),
 ]
 
 
@@ -1123,6 +1143,123 @@ def golden_cutouts():
         else:   # (the full-size case: rectangles only - what the sampler draws per step at 256^2 / 224)
             out[f"cut{k}_sum"] = cuts.double().sum((1, 2, 3)).float()
     save("g33_cutouts", **out)
+
+
+def golden_grads():
+    """g34: the image-prompt grad modules' in-tree pieces, computed by the reference's own functions.
+    (a) maua/grad.py:27-47 differentiable_histogram (values on and between the edges, with and without weights, one value outside).
+    (b) maua/grad.py:50-70 ColorMatchGrads.histogram / set_targets / forward with oracle.grads.rgb_to_hsv standing in for the absent
+        ``kornia`` - pins the clamp / weighting / histogram / mse / autograd chain around it.
+    (c) maua/loss.py:33-80 scaled_mse_loss, feature_loss, gram_matrix.
+    (d) maua/perceptors/__init__.py:10-91: the reference's Perceptor hooks + get_loss around the restated vgg19.features (torchvision is
+        absent; seeded random weights from oracle.grads.init_vgg_params): the Gram embeddings the hooks store, the loss, and
+        torch.autograd.grad back to the image exactly as VGGGrads.forward (grad.py:90-93) asks for it.  ``torch.nested_tensor`` (gone from
+        this torch) is replaced by the identity on the list for the duration.
+    (e) maua/ops/cutouts.py:101-206 DangoCutouts(skip_augs=True): torchvision's Grayscale / hflip and resize_right replaced by the
+        oracle's restatements; pins the rectangle draws and their order, the overview / inner-crop / grey schedule over t.
+    (f) maua/ops/image.py:214-240 resample(x, 256) on a 256 x 256 image (LPIPSGrads' pre-step): the identity."""
+    import maua.grad as RG
+    import maua.loss as RL
+    import maua.ops.cutouts as RC
+    import maua.ops.image as RI
+    import maua.perceptors as RP
+    from oracle import clip as OC
+    from oracle import grads as OG
+    g = torch.Generator().manual_seed(34)
+    out = {}
+    # (a)
+    x = torch.rand(2, 300, generator=g)
+    x[0, :8] = torch.tensor([0.0, 1.0, 1 / 254, 2 / 254, 0.5, 253 / 254, 1.002, 0.99999])
+    w = torch.rand(2, 300, generator=g)
+    out.update(hist_x=x, hist_w=w, hist_out_w=RG.differentiable_histogram(x, w, 255), hist_out=RG.differentiable_histogram(x, None, 255),
+               hist_out_17=RG.differentiable_histogram(x, w, 17))
+    # (b)
+    RG.rgb_to_hsv = OG.rgb_to_hsv
+    img = torch.rand(2, 3, 24, 20, generator=g) * 2.2 - 1.1
+    style = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
+    for sw in (True, False):
+        m = RG.ColorMatchGrads(scale=3.0, saturation_weighting=sw)
+        m.register_buffer("target", m.histogram(style))                    # set_targets :65-69 for one StylePrompt
+        with torch.enable_grad():
+            xi = img.clone().requires_grad_()
+            grad = m.forward(xi, None)
+        out[f"cm_hist_{int(sw)}"] = m.histogram(img)
+        out[f"cm_target_{int(sw)}"] = m.target
+        out[f"cm_grad_{int(sw)}"] = grad
+    out.update(cm_img=img, cm_style=style)
+    # (c)
+    a, b = torch.randn(2, 6, 5, 7, generator=g), torch.randn(12, 12, generator=g)
+    gm = RL.gram_matrix(a)
+    out.update(loss_a=a, loss_b=b, gram_a=gm, scaled_mse=RL.scaled_mse_loss(gm, b), feature_loss=RL.feature_loss(gm, b))
+    # (d)
+    p = OG.init_vgg_params(OG.VGG19_CFG, 29, generator=torch.Generator().manual_seed(3400))
+    layers, i, cin = [], 0, 3
+    for v in OG.VGG19_CFG:
+        if i > 29:
+            break
+        if v == "M":
+            layers.append(torch.nn.MaxPool2d(2)); i += 1
+        else:
+            conv = torch.nn.Conv2d(cin, v, 3, padding=1, padding_mode="replicate" if i == 0 else "zeros")
+            conv.weight.data.copy_(p[f"{i}.weight"]); conv.bias.data.copy_(p[f"{i}.bias"])
+            layers += [conv, torch.nn.ReLU(inplace=True)]; cin = v; i += 2
+    per = RP.Perceptor(content_strength=0, content_layers=[], style_strength=2.5, style_layers=list(OG.KBC_STYLE_LAYERS))
+    per.net = torch.nn.Sequential(*layers).eval().requires_grad_(False)
+    per.preprocess = lambda t: OG.normalize_img(t, OG.IMAGENET_MEAN, OG.IMAGENET_STD)
+    per.register_layer_hooks()
+    torch.nested_tensor = lambda embs, device=None: list(embs)
+    try:
+        vimg = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+        vstyle = torch.rand(1, 3, 32, 32, generator=g)
+        targets = [t.clone() for t in per.forward(vstyle)]                 # what get_target_embeddings' forward leaves in the hooks
+        with torch.enable_grad():
+            xi = vimg.clone().requires_grad_()
+            loss = per.get_loss(xi.add(1).div(2), targets)
+            grad = torch.autograd.grad(loss, xi)[0]
+    finally:
+        del torch.nested_tensor
+    out.update(vgg_seed=np.int64(3400), vgg_img=vimg, vgg_style=vstyle, vgg_loss=loss.detach(), vgg_grad=grad, vgg_strength=np.float32(2.5))
+    for k, t in enumerate(targets):
+        if t.numel() <= 128 * 128:
+            out[f"vgg_target{k}"] = t
+        else:
+            out[f"vgg_target{k}_diag"] = t.diagonal().clone()
+            out[f"vgg_target{k}_sum"] = t.double().sum().float()
+    # (e)
+    seen = []
+
+    def spy_resize(cutout, out_shape):
+        seen.append(tuple(cutout.shape[-2:]))
+        assert list(out_shape[:2]) == [1, 3] and cutout.shape[0] == 1     # (resize_right applies a full-length out_shape to every dimension:
+        return OC.resize(cutout, tuple(out_shape[-2:]))                    #  with one image per call only the two spatial ones change)
+
+    class _Gray:
+        def __init__(self, n):
+            assert n == 3
+
+        def __call__(self, t):
+            return OG.grayscale3(t)
+    RC.resize = spy_resize
+    RC.T.Grayscale = _Gray
+    RC.TF.hflip = lambda t: t.flip(-1)
+    for k, (H, W, cs, t, seed) in enumerate(((40, 40, 32, 900, 1), (48, 36, 32, 100, 2), (36, 44, 32, 650, 3), (256, 256, 224, 981, 4))):
+        dimg = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(340 + k))    # (re-drawn by the tests for the full-size case)
+        dc = RC.DangoCutouts(cs, skip_augs=True)
+        torch.manual_seed(seed)
+        seen.clear()
+        cuts = dc(dimg, t)
+        out[f"dango{k}_cfg"] = np.array([H, W, cs, t, seed, dc.cut_overview[999 - t], dc.cut_innercut[999 - t]], dtype=np.int64)
+        out[f"dango{k}_grey_p"] = np.float32(dc.cut_icgray_p[999 - t])
+        out[f"dango{k}_sizes"] = np.array(seen, dtype=np.int64)
+        if H <= 64:
+            out[f"dango{k}_img"] = dimg
+            out[f"dango{k}_out"] = cuts
+        else:
+            out[f"dango{k}_sum"] = cuts.double().sum((1, 2, 3)).float()
+    # (f)
+    rx = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    out["resample256_maxdiff"] = (RI.resample(rx, 256) - rx).abs().max()
+    save("g34_grads", **out)
 
 
 if __name__ == "__main__":
