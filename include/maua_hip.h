@@ -604,6 +604,9 @@ int maua_layer_norm_vjp(maua_ctx* ctx, const void* x, const float* stats, const 
 int maua_colormatch_hist(maua_ctx* ctx, const float* img, int B, int H, int W, int nbins, int sat_weighting, float* hist);
 int maua_colormatch_grad(maua_ctx* ctx, const float* img, int B, int H, int W, int nbins, int sat_weighting, const float* target,
                          int target_per_sample, float scale, float* grad, float* loss);
+/* the conditioning's sum over its grad modules (guided.py:258-266 `if torch.isnan(sub).any(): sub = zeros; img_grad += sub`) without
+ * the host round trip: acc = (first ? 0 : acc) + (sub holds a NaN ? 0 : sub) over n device floats */
+int maua_grad_accumulate(maua_ctx* ctx, const float* sub, float* acc, long n, int first);
 /* VGG perceptors (csrc/perceptor.hip).  plan: n_ops entries, > 0 = Conv2d(3x3, pad 1) to that many channels (multiples of 64) + ReLU,
  * 0 = MaxPool2d(2) - torchvision's vgg19 / vgg16 `features` cut after the last tap; replicate_first: the first convolution pads by
  * replication (vgg_kbc.py:40); the network sees ((img * in_mul + in_add) - mean) / std (VGGGrads: img.add(1).div(2) + ImageNet

@@ -201,6 +201,20 @@ __global__ __launch_bounds__(256) void cm_grad_kernel(const float* __restrict__ 
   for (int i = 0; i < 3; i++) o[(long)i * HW] = h.live[i] ? 0.5f * dc[i] : 0.f;
 }
 
+// ---- the conditioning's sum over grad modules (guided.py:258-266): acc (+)= sub, or nothing when sub holds a NaN
+__global__ __launch_bounds__(256) void nan_flag_kernel(const float* __restrict__ x, long n, int* __restrict__ flag) {
+  bool bad = false;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) bad |= (x[i] != x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ __launch_bounds__(256) void screened_add_kernel(const float* __restrict__ sub, const int* __restrict__ flag, float* __restrict__ acc,
+                                                          long n, int first) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = *flag ? 0.f : sub[i];
+  acc[i] = first ? v : acc[i] + v;
+}
+
 int run_hist(maua_ctx* ctx, const float* img, int B, long HW, int nbins, int sat_weighting, unsigned long long** fix_out, float** gr_out) {
   const size_t fix_bytes = ((size_t)B * nbins * 8 + 255) / 256 * 256;
   if (int rc = scratch_reserve(ctx, fix_bytes + (size_t)B * nbins * 4)) return rc;
@@ -247,6 +261,21 @@ int maua_colormatch_grad(maua_ctx* ctx, const float* img, int B, int H, int W, i
   MAUA_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(cm_grad_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, ctx->stream, img, HW, nbins,
                      (float)(1.0 / (nbins - 1)), sat_weighting, gr, grad);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// GradientGuidedConditioning's loop over its grad modules (guided.py:258-266): acc = (first ? 0 : acc) + (sub holds a NaN ? 0 : sub),
+// n floats, no host round trip (the reference's `if torch.isnan(sub).any()` synchronises every step)
+int maua_grad_accumulate(maua_ctx* ctx, const float* sub, float* acc, long n, int first) {
+  MAUA_REQUIRE(ctx && sub && acc && n >= 0, "maua_grad_accumulate: bad argument");
+  if (n == 0) return MAUA_OK;
+  if (int rc = scratch_reserve(ctx, 256)) return rc;
+  int* flag = (int*)ctx->scratch;
+  MAUA_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->stream));
+  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(nan_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sub, n, flag);
+  hipLaunchKernelGGL(screened_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sub, (const int*)flag, acc, n, first);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

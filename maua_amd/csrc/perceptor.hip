@@ -24,6 +24,7 @@
 // streaming kernels.  A 256 x 256 image costs 94 GFLOP forward + backward through vgg19 - 4 % of one UNet evaluation.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -139,6 +140,69 @@ __global__ __launch_bounds__(256) void vgg_conv0_vjp_kernel(const T* __restrict_
   grad[o + 2 * HW] = acc[2] * f2;
 }
 
+// the same for Co == 64 at memory speed: 8 lanes share an input pixel, each owning 8 channels (one 16-byte load per tap and
+// pixel: a wave reads 8 pixels x 128 contiguous bytes), 24 multiply-adds per tap and lane, then a 3-step lane reduction
+template <typename T> __device__ __forceinline__ void load8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float v[8]) {
+  const u32x4 q = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(q[i] << 16); v[2 * i + 1] = __uint_as_float(q[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void vgg_conv0_vjp64_kernel(const T* __restrict__ g, const float* __restrict__ w0, float* __restrict__ grad, int B,
+                                                              int H, int W, int pad, float f0, float f1, float f2) {
+  __shared__ float wsh[27 * 64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) wsh[i] = w0[i];
+  __syncthreads();
+  const long HW = (long)H * W;
+  const int cpart = threadIdx.x & 7;
+  const long idx = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool live = idx < (long)B * HW;
+  const long id = live ? idx : 0;
+  const int x = (int)(id % W);
+  const int y = (int)((id / W) % H);
+  const int b = (int)(id / HW);
+  float acc[3] = {0.f, 0.f, 0.f};
+  const int vy0 = (pad == 1 && y == 0) ? -1 : y, vy1 = (pad == 1 && y == H - 1) ? H : y;
+  const int vx0 = (pad == 1 && x == 0) ? -1 : x, vx1 = (pad == 1 && x == W - 1) ? W : x;
+  for (int vy = vy0; vy <= vy1; vy++)
+    for (int vx = vx0; vx <= vx1; vx++)
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++) {
+        const int py = vy - (ky - 1);
+        if (py < 0 || py >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+          const int px = vx - (kx - 1);
+          if (px < 0 || px >= W) continue;
+          float gv[8];
+          load8<T>(g + (((long)b * H + py) * W + px) * 64 + cpart * 8, gv);
+          const float* wr = wsh + (ky * 3 + kx) * 64 + cpart * 8;
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            acc[0] = fmaf(gv[j], wr[j], acc[0]);
+            acc[1] = fmaf(gv[j], wr[9 * 64 + j], acc[1]);
+            acc[2] = fmaf(gv[j], wr[18 * 64 + j], acc[2]);
+          }
+        }
+      }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc[0] += __shfl_xor(acc[0], o); acc[1] += __shfl_xor(acc[1], o); acc[2] += __shfl_xor(acc[2], o);
+  }
+  if (live && cpart == 0) {
+    const long o = (long)b * 3 * HW + (long)y * W + x;
+    grad[o] = acc[0] * f0;
+    grad[o + HW] = acc[1] * f1;
+    grad[o + 2 * HW] = acc[2] * f2;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- MaxPool2d(2) and its adjoint
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C) {
@@ -209,18 +273,36 @@ __global__ __launch_bounds__(256) void maxpool2_vjp_kernel(const T* __restrict__
 }
 
 // out = act > 0 ? g + hg : 0   (either gradient may be NULL)
+template <typename T> __device__ __forceinline__ void store8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float v[8]) {
+  u32x4 q;
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = q;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float v[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// (8 elements per thread, 16-byte accesses; n is a multiple of 64 channels)
 template <typename T>
 __global__ __launch_bounds__(256) void mask_add_kernel(const T* __restrict__ g, const T* __restrict__ hg, const T* __restrict__ act, T* __restrict__ out,
                                                        long n) {
-  constexpr int E = 16 / (int)sizeof(T);
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * E;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
   if (i >= n) return;
+  float a[8], v[8], h[8];
+  load8<T>(act + i, a);
 #pragma unroll
-  for (int e = 0; e < E; e++) {
-    const float a = Elem<T>::load(act + i + e);
-    const float v = (g ? Elem<T>::load(g + i + e) : 0.f) + (hg ? Elem<T>::load(hg + i + e) : 0.f);
-    Elem<T>::store(out + i + e, a > 0.f ? v : 0.f);
+  for (int e = 0; e < 8; e++) v[e] = 0.f;
+  if (g) load8<T>(g + i, v);
+  if (hg) {
+    load8<T>(hg + i, h);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] += h[e];
   }
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = a[e] > 0.f ? v[e] : 0.f;
+  store8<T>(out + i, v);
 }
 
 // NHWC T -> planar f32 [B][C][HW]
@@ -293,33 +375,51 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
   return t;
 }
 
-// one workgroup per image: D = G - T, Q = sum D^2, A = sum |D| + 1e-8, loss[b] += strength Q / A / numel,
-// Sym = dG + dG^T with dG = strength (2 D A - Q sign D) / A^2 / numel, stored in the network dtype (the head GEMM's W operand)
-template <typename T>
-__global__ __launch_bounds__(1024) void style_dgram_kernel(const float* __restrict__ G, const float* __restrict__ Tg, long t_bstride, int C,
-                                                           float strength, T* __restrict__ Sym, float* __restrict__ loss) {
-  __shared__ float red[16];
-  const int b = blockIdx.x;
-  const long CC = (long)C * C;
+// D = G - T per image in two launches: (1) Q = sum D^2 and A0 = sum |D| as STYLE_CHUNKS partial sums per image (fixed order),
+// (2) loss[b] += strength Q / A / numel (A = A0 + 1e-8) and Sym = dG + dG^T with dG = strength (2 D A - Q sign D) / A^2 / numel,
+// stored in the network dtype (the head GEMM's W operand)
+constexpr int STYLE_CHUNKS = 64;
+__global__ __launch_bounds__(256) void style_dsum_kernel(const float* __restrict__ G, const float* __restrict__ Tg, long t_bstride, long CC,
+                                                         float* __restrict__ part) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, ch = blockIdx.x;
   const float* g = G + (long)b * CC;
   const float* t = Tg + (long)b * t_bstride;
+  const long per = (CC + STYLE_CHUNKS - 1) / STYLE_CHUNKS, i0 = ch * per, i1 = std::min<long>(i0 + per, CC);
   float q = 0.f, a = 0.f;
-  for (long i = threadIdx.x; i < CC; i += 1024) {
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
     const float d = g[i] - t[i];
     q += d * d;
     a += fabsf(d);
   }
   const float Q = block_sum_1024(q, red);
-  const float A = block_sum_1024(a, red) + 1e-8f;
+  const float A = block_sum_1024(a, red);
+  if (threadIdx.x == 0) {
+    part[((long)b * STYLE_CHUNKS + ch) * 2] = Q;
+    part[((long)b * STYLE_CHUNKS + ch) * 2 + 1] = A;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void style_dgram_kernel(const float* __restrict__ G, const float* __restrict__ Tg, long t_bstride, int C,
+                                                          float strength, const float* __restrict__ part, T* __restrict__ Sym,
+                                                          float* __restrict__ loss) {
+  const int b = blockIdx.y;
+  const long CC = (long)C * C;
+  const float* g = G + (long)b * CC;
+  const float* t = Tg + (long)b * t_bstride;
+  float Q = 0.f, A = 0.f;
+  for (int c = 0; c < STYLE_CHUNKS; c++) { Q += part[((long)b * STYLE_CHUNKS + c) * 2]; A += part[((long)b * STYLE_CHUNKS + c) * 2 + 1]; }
+  A += 1e-8f;
   const float k = strength / (float)CC;
-  for (long i = threadIdx.x; i < CC; i += 1024) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < CC) {
     const int r = (int)(i / C), c = (int)(i - (long)r * C);
     const float d1 = g[i] - t[i], d2 = g[(long)c * C + r] - t[(long)c * C + r];
     const float s1 = d1 > 0.f ? 1.f : d1 < 0.f ? -1.f : 0.f, s2 = d2 > 0.f ? 1.f : d2 < 0.f ? -1.f : 0.f;
-    const float v = k * ((2.f * d1 * A - Q * s1) + (2.f * d2 * A - Q * s2)) / (A * A);
-    Elem<T>::store(Sym + (long)b * CC + i, v);
+    Elem<T>::store(Sym + (long)b * CC + i, k * ((2.f * d1 * A - Q * s1) + (2.f * d2 * A - Q * s2)) / (A * A));
   }
-  if (loss && threadIdx.x == 0) loss[b] += k * Q / A;
+  if (loss && blockIdx.x == 0 && threadIdx.x == 0) loss[b] += k * Q / A;
 }
 
 // ---------------------------------------------------------------------------------------------- lpips head: one wave per pixel
@@ -398,6 +498,7 @@ struct maua_vgg {
   std::vector<POp> ops;
   std::vector<PConv> convs;
   int pad0 = 0;
+  int use_dma = 1;                 // bf16 convolutions on modconv_dma.hip where the shape allows (MAUA_VGG_NO_DMA=1: the generic kernel)
   float in_mul = 1.f, in_add = 0.f, mean[3] = {0, 0, 0}, istd[3] = {1, 1, 1};
   float* ones = nullptr;
   int ones_b = 0;
@@ -409,6 +510,7 @@ struct maua_vgg {
   float* gram = nullptr;           // [B][512][512]
   void* sym = nullptr;             // [B][512][512] network dtype
   float* loss_dev = nullptr;       // [B]
+  float* part = nullptr;           // [B][STYLE_CHUNKS][2]
   int loss_cap = 0;
 };
 
@@ -422,6 +524,7 @@ void free_ws(maua_vgg* n) {
   { void* p = n->gram; f(p); n->gram = nullptr; }
   f(n->sym);
   { void* p = n->loss_dev; f(p); n->loss_dev = nullptr; n->loss_cap = 0; }
+  { void* p = n->part; f(p); n->part = nullptr; }
   n->cap_key = 0;
   n->B = n->H = n->W = 0;
 }
@@ -454,7 +557,8 @@ int ensure_ws(maua_vgg* n, int B, int H, int W) {
     }
     if (hipMalloc(&n->ga, widest * n->esize) != hipSuccess || hipMalloc(&n->gb, widest * n->esize) != hipSuccess ||
         hipMalloc((void**)&n->fbuf, fb) != hipSuccess || hipMalloc((void**)&n->gram, (size_t)B * mc * mc * 4) != hipSuccess ||
-        hipMalloc(&n->sym, (size_t)B * mc * mc * n->esize) != hipSuccess || hipMalloc((void**)&n->loss_dev, (size_t)B * 4) != hipSuccess)
+        hipMalloc(&n->sym, (size_t)B * mc * mc * n->esize) != hipSuccess || hipMalloc((void**)&n->loss_dev, (size_t)B * 4) != hipSuccess ||
+        hipMalloc((void**)&n->part, (size_t)B * STYLE_CHUNKS * 2 * 4) != hipSuccess)
       return fail("maua_vgg: out of device memory (workspaces)");
     n->fbuf_bytes = fb;
     n->cap_key = key;
@@ -479,6 +583,12 @@ int run_conv(maua_vgg* n, const PConv& c, bool transposed, const void* x, void* 
   a.noise = nullptr; a.bias = transposed ? c.zero_bias : c.bias; a.y = y;
   a.B = B; a.H = h; a.W = w; a.Ci = Ci; a.Co = Co; a.up = 1;
   a.act = transposed ? MAUA_ACT_LINEAR : MAUA_ACT_LRELU; a.alpha = transposed ? 1.f : 0.f; a.gain = 1.f; a.clamp = -1.f;
+  // bf16: the LDS-direct kernel where its tiles fit (8 x 32 pixels; 128 / 256-channel N tiles, or the 64-channel narrow form)
+  if (n->dtype == MAUA_BF16 && n->use_dma &&
+      (dma_conv_supported(MAUA_BF16, Ci, Co, 1, h, w) || dma_conv_narrow_supported(MAUA_BF16, Ci, Co, h, w))) {
+    a.s = nullptr;
+    return launch_modconv_dma(n->ctx->stream, a);
+  }
   return launch_modconv3x3(n->ctx->stream, n->dtype, a);
 }
 
@@ -535,12 +645,16 @@ int backward_t(maua_vgg* n, float* grad) {
     const long ne = (long)B * h * w * o.C;
     if (o.kind == 0) {
       T* gpre = (g == bufa) ? bufb : bufa;
-      VGG_LAUNCH(mask_add_kernel<T>, (ne + E - 1) / E, (const T*)g, (const T*)(o.hg_set ? o.hg : nullptr), (const T*)o.act, gpre, ne);
+      VGG_LAUNCH(mask_add_kernel<T>, (ne + 7) / 8, (const T*)g, (const T*)(o.hg_set ? o.hg : nullptr), (const T*)o.act, gpre, ne);
       const PConv& c = n->convs[o.conv];
       if (i == 0) {
         const long total = (long)B * H * W;
-        hipLaunchKernelGGL(vgg_conv0_vjp_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)27 * c.Co * 4, st, (const T*)gpre,
-                           c.w0, grad, B, H, W, c.Co, n->pad0, n->in_mul * n->istd[0], n->in_mul * n->istd[1], n->in_mul * n->istd[2]);
+        if (c.Co == 64)
+          hipLaunchKernelGGL(vgg_conv0_vjp64_kernel<T>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, (const T*)gpre, c.w0, grad, B, H, W,
+                             n->pad0, n->in_mul * n->istd[0], n->in_mul * n->istd[1], n->in_mul * n->istd[2]);
+        else
+          hipLaunchKernelGGL(vgg_conv0_vjp_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)27 * c.Co * 4, st, (const T*)gpre,
+                             c.w0, grad, B, H, W, c.Co, n->pad0, n->in_mul * n->istd[0], n->in_mul * n->istd[1], n->in_mul * n->istd[2]);
         MAUA_HIP_CHECK(hipGetLastError());
       } else {
         T* gprev = (gpre == bufa) ? bufb : bufa;
@@ -593,8 +707,12 @@ int style_grad_t(maua_vgg* n, const float* img, int B, int H, int W, const int* 
     const int C = o.C;
     const long hw = (long)(H >> o.shift) * (W >> o.shift);
     if (int rc = gram_t<T>(n, taps[k], n->gram)) return rc;
-    hipLaunchKernelGGL(style_dgram_kernel<T>, dim3(B), dim3(1024), 0, st, (const float*)n->gram, targets[k], t_bstride ? t_bstride[k] : 0L, C,
-                       strength, (T*)n->sym, n->loss_dev);
+    const long CC = (long)C * C;
+    hipLaunchKernelGGL(style_dsum_kernel, dim3(STYLE_CHUNKS, B), dim3(256), 0, st, (const float*)n->gram, targets[k], t_bstride ? t_bstride[k] : 0L,
+                       CC, n->part);
+    MAUA_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(style_dgram_kernel<T>, dim3((unsigned)((CC + 255) / 256), B), dim3(256), 0, st, (const float*)n->gram, targets[k],
+                       t_bstride ? t_bstride[k] : 0L, C, strength, (const float*)n->part, (T*)n->sym, n->loss_dev);
     MAUA_HIP_CHECK(hipGetLastError());
     for (int b = 0; b < B; b++) {          // d loss / d F_b = F_b (dG + dG^T): [hw][C] x [C][C]^T
       GemmArgs g{};
@@ -655,6 +773,7 @@ int maua_vgg_create(maua_ctx* ctx, int dtype, const int* plan, int n_ops, int re
   maua_vgg* n = new maua_vgg();
   n->ctx = ctx; n->dtype = dtype; n->esize = dtype == MAUA_BF16 ? 2 : 4;
   n->pad0 = replicate_first ? 1 : 0; n->in_mul = in_mul; n->in_add = in_add;
+  if (const char* e = getenv("MAUA_VGG_NO_DMA")) n->use_dma = !(e[0] == '1');
   for (int i = 0; i < 3; i++) { n->mean[i] = mean[i]; n->istd[i] = 1.f / std3[i]; }
   int cin = 3, shift = 0;
   for (int i = 0; i < n_ops; i++) {
