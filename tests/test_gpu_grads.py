@@ -206,6 +206,33 @@ def test_lpipsgrads_module_at_the_sampler_size():
         m.forward(img[:, :, :128, :128], None)
 
 
+def test_full_size_style_and_perceptual_gradients_against_the_oracle():
+    """The sampler's size (256 x 256, one image - what the reference's modules are defined for) in the bench's arithmetic (bf16 tensors,
+    the LDS-direct convolutions where their tiles fit): VGGGrads and LPIPSGrads against torch.autograd on the float32 oracle - losses
+    within 2 %, gradient cosine >= 0.99; the same call twice gives the same bits."""
+    from maua_amd.grad import ContentPrompt, LPIPSGrads, StylePrompt, VGGGrads
+    gen = torch.Generator().manual_seed(21)
+    img = torch.rand(1, 3, 256, 256, generator=gen) * 2 - 1
+    style, content = torch.rand(1, 3, 256, 256, generator=gen), torch.rand(1, 3, 256, 256, generator=gen)
+    p19 = OG.init_vgg_params(OG.VGG19_CFG, 29, generator=gen)
+    vg = VGGGrads(scale=40.0, state_dict=p19)
+    vg.set_targets([StylePrompt(img=style)])
+    grad, loss = vg.forward(img, None, return_loss=True)
+    want, want_loss = OG.vgg_grads(p19, img, OG.kbc_style_embeddings(p19, style), 40.0)
+    print("256^2 bf16 VGGGrads: cosine", cos(grad, want), "loss", float(loss[0]), float(want_loss[0]))
+    assert cos(grad, want) >= 0.99 and rel(loss, want_loss) <= 0.02
+    assert torch.equal(grad, vg.forward(img, None))
+    p16 = OG.init_vgg_params(OG.VGG16_CFG, 29, generator=gen)
+    lins = OG.init_lpips_lins(gen)
+    lp = LPIPSGrads(scale=7.0, state_dict=p16, lin_state_dict={f"lin{k}.model.1.weight": w.reshape(1, -1, 1, 1) for k, w in enumerate(lins)})
+    lp.set_targets([ContentPrompt(img=content)])
+    grad, dist = lp.forward(img, None, return_loss=True)
+    want, want_d = OG.lpips_grads(p16, lins, img, content * 2 - 1, 7.0)
+    print("256^2 bf16 LPIPSGrads: cosine", cos(grad, want), "distance", float(dist[0]), float(want_d[0]))
+    assert cos(grad, want) >= 0.99 and rel(dist, want_d) <= 0.02
+    assert torch.equal(grad, lp.forward(img, None))
+
+
 # ------------------------------------------------------------------------------------------------ DangoCutouts
 def test_dango_cutouts_match_the_reference_fixture(golden):
     """DangoCutouts(skip_augs=True).forward on the device under the fixture's seed against the REFERENCE's outputs (g34; overview
