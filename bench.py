@@ -543,7 +543,8 @@ def extra_diffusion(batch=32, steps=100, size=256, clip_batch=8, full_arms=False
     # ---- image prompts, the other prompt kind of configs[3]'s sentence (get_diffusion_model's list, maua/diffusion/image.py:92-97):
     # VGGGrads (style: Gram matrices of five vgg19 layers), ColorMatchGrads (hue histogram) and LPIPSGrads (content: vgg16 + lpips
     # heads) as the grad modules of the default "fast" conditioning - every loss AND its gradient inside the library (round 6:
-    # csrc/perceptor.hip, colormatch.hip); three modules = not the captured loop: the sampler runs step by step, all `steps` timed
+    # csrc/perceptor.hip, colormatch.hip), the module LIST evaluated and summed inside the captured guided loop (maua_unet_set_guides,
+    # csrc/guides.hip): one hipGraph for the whole loop like the other arms, all `steps` timed
     def image_prompt_leg(ib):
         from maua_amd.grad import ColorMatchGrads, ContentPrompt, LPIPSGrads, StylePrompt, VGGGrads
         from maua_amd.perceptors import VGG16_CFG, VGG19_CFG
@@ -553,7 +554,7 @@ def extra_diffusion(batch=32, steps=100, size=256, clip_batch=8, full_arms=False
         gd = GuidedDiffusion(mods, timesteps=steps, model=model, diffusion=diffusion, secondary_model=secondary)
         pr = [StylePrompt(img=torch.rand(1, 3, size, size, generator=gr)), ContentPrompt(img=torch.rand(1, 3, size, size, generator=gr))]
         x0, nz = (torch.randn(ib, 3, size, size, generator=gr).cuda() for _ in range(2))
-        gd.run(x0, pr, n - 1, 3, noise=nz)                       # workspaces, targets (untimed, 3 steps)
+        gd.run(x0, pr, n - 1, n, noise=nz)                       # workspaces, targets, capture + first replay (untimed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = gd.run(x0, pr, n - 1, n, noise=nz)
@@ -573,15 +574,15 @@ def extra_diffusion(batch=32, steps=100, size=256, clip_batch=8, full_arms=False
         gf_p = vgg_gf(VGG19_CFG, 29) + vgg_gf(VGG16_CFG, 29)
         tfi = (gf + gf_sec + gf_p) * ib * steps / dt / 1e3
         return {"value": ib / dt, "unit": "samples/s", "guidance": "image prompts: VGGGrads (style) + ColorMatchGrads + LPIPSGrads (content)",
-                "batch": ib, "seconds_per_batch": dt, "ms_per_step": dt / steps * 1e3, "steps_timed": steps, "hipgraph": False,
+                "batch": ib, "seconds_per_batch": dt, "ms_per_step": dt / steps * 1e3, "steps_timed": steps, "hipgraph": model.guided_graph_active(),
                 "finite": bool(torch.isfinite(out).all()),
                 "perceptors": "vgg19.features[:30] and vgg16.features[:30] + lpips heads, random init, bf16 (no checkpoints in the image)",
                 "gflop_per_sample_step": {"unet_forward": gf, "secondary_forward_and_vjp": gf_sec, "vgg_forward_and_input_gradient": gf_p},
                 "roofline": {"bound": "mfma", "achieved": tfi, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": tfi / MFMA_BF16_PEAK_TF},
                 "over_unguided_rate": (ib / dt) / (batch / best_u),
-                "note": "step by step (three grad modules: not the captured loop); the unguided arm it is compared with is a hipGraph at batch %d" % batch}
+                "note": "the three modules' gradients are summed per step inside the captured loop (guided.py:258-266)"}
     try:
-        image_arm = image_prompt_leg(min(batch, 16))
+        image_arm = image_prompt_leg(batch)
     except Exception as e:
         image_arm = {"error": repr(e)[:300]}
     tf = (gf + gf_sec) * batch * steps / best / 1e3

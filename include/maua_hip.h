@@ -638,6 +638,27 @@ int maua_vgg_style_grad(maua_vgg* net, const float* img, int B, int H, int W, co
 int maua_vgg_lpips_grad(maua_vgg* net, const float* img, int B, int H, int W, const int* taps, int n_taps, const float* const* targets,
                         const long* target_bstride, const float* const* lins, float scale, float* grad, float* dist);
 
+/* grad modules as library objects, so that the guided loop can evaluate a LIST of them per step (guided.py:258-266 sums the modules'
+ * gradients; get_diffusion_model hands the sampler up to four, maua/diffusion/image.py:92-97).  kind: MAUA_GUIDE_STYLE = VGGGrads
+ * (arguments of maua_vgg_style_grad: net, taps, targets = Gram matrices, target_bstride, scale = strength), MAUA_GUIDE_LPIPS =
+ * LPIPSGrads (arguments of maua_vgg_lpips_grad, lins), MAUA_GUIDE_COLORMATCH = ColorMatchGrads (targets[0] = the target histogram
+ * [nbins] - target_bstride[0] == nbins: one per sample -, nbins, sat_weighting, scale; net / taps / lins unused).  The target tensors
+ * stay the caller's: device pointers that must outlive the guide; updating them IN PLACE re-targets the guide, also inside an already
+ * captured loop.  maua_guide_grad: the module as an operator, grad = d loss / d img of img device f32 [B][3][H][W]. */
+#define MAUA_GUIDE_STYLE 0
+#define MAUA_GUIDE_LPIPS 1
+#define MAUA_GUIDE_COLORMATCH 2
+typedef struct maua_guide maua_guide;
+int maua_guide_create(maua_ctx* ctx, int kind, maua_vgg* net, const int* taps, int n_taps, const float* const* targets,
+                      const long* target_bstride, const float* const* lins, float scale, int nbins, int sat_weighting, maua_guide** out);
+void maua_guide_destroy(maua_guide* guide);
+int maua_guide_grad(maua_guide* guide, const float* img, int B, int H, int W, float* grad);
+/* the guided loop with THESE grad modules: the following maua_ddim_guided_loop calls on `net` evaluate every guide of the list on the
+ * step's image estimate and sum the results (a module whose gradient holds a NaN is skipped, guided.py:262-265) - after CLIPGrads when
+ * maua_unet_set_clip_guide is active as well, instead of the image-MSE module otherwise (its target / mse_k arguments are then
+ * ignored).  n_guides == 0: back to the default.  The whole step stays inside the one captured hipGraph. */
+int maua_unet_set_guides(maua_unet* net, maua_guide* const* guides, int n_guides);
+
 /* ---- build-owned counter RNG: Philox4x32-10, identical on every device / rank and in the oracle twin (oracle/rng.py,
  * pinned to the published known-answer vectors).  No reference counterpart: the reference's random-init generator and noise planes
  * come from torch's host generator (inference/stylegan2.py:216-227, selfsupervised/noise.py:42-53); the benchmark's synthetic

@@ -215,21 +215,63 @@ __global__ __launch_bounds__(256) void screened_add_kernel(const float* __restri
   acc[i] = first ? v : acc[i] + v;
 }
 
-int run_hist(maua_ctx* ctx, const float* img, int B, long HW, int nbins, int sat_weighting, unsigned long long** fix_out, float** gr_out) {
-  const size_t fix_bytes = ((size_t)B * nbins * 8 + 255) / 256 * 256;
-  if (int rc = scratch_reserve(ctx, fix_bytes + (size_t)B * nbins * 4)) return rc;
-  unsigned long long* fix = (unsigned long long*)ctx->scratch;
-  *fix_out = fix;
-  *gr_out = (float*)((char*)ctx->scratch + fix_bytes);
-  MAUA_HIP_CHECK(hipMemsetAsync(fix, 0, (size_t)B * nbins * 8, ctx->stream));
+// (zeroing by kernel, not by a memset node: these calls are also captured into the guided loop's hipGraph, where replays of small
+//  memset nodes were seen misbehaving on ROCm 7.0.2 - unet.hip)
+__global__ __launch_bounds__(256) void zero_u32_kernel(uint32_t* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+int hist_into(hipStream_t st, const float* img, int B, long HW, int nbins, int sat_weighting, unsigned long long* fix) {
+  const long words = (long)B * nbins * 2;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, (uint32_t*)fix, words);
   const float delta = (float)(1.0 / (nbins - 1));
   const int blocks = (int)std::min<long>((HW + 255) / 256, 1024);
-  hipLaunchKernelGGL(cm_hist_kernel, dim3(blocks, B), dim3(256), 0, ctx->stream, img, HW, nbins, delta, sat_weighting, fix);
+  hipLaunchKernelGGL(cm_hist_kernel, dim3(blocks, B), dim3(256), 0, st, img, HW, nbins, delta, sat_weighting, fix);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }
 
+int run_hist(maua_ctx* ctx, const float* img, int B, long HW, int nbins, int sat_weighting, unsigned long long** fix_out, float** gr_out) {
+  const size_t fix_bytes = colormatch_fix_bytes(B, nbins);
+  if (int rc = scratch_reserve(ctx, fix_bytes + (size_t)B * nbins * 4)) return rc;
+  unsigned long long* fix = (unsigned long long*)ctx->scratch;
+  *fix_out = fix;
+  *gr_out = (float*)((char*)ctx->scratch + fix_bytes);
+  return hist_into(ctx->stream, img, B, HW, nbins, sat_weighting, fix);
+}
+
 }  // namespace
+
+namespace maua {
+size_t colormatch_fix_bytes(int B, int nbins) { return ((size_t)B * nbins * 8 + 255) / 256 * 256; }
+
+// ColorMatchGrads.forward on caller-owned workspaces (fix: colormatch_fix_bytes, gr: B * nbins floats) - nothing is allocated
+int colormatch_grad_into(hipStream_t st, const float* img, int B, int H, int W, int nbins, int sat_weighting, const float* target,
+                         int target_per_sample, float scale, unsigned long long* fix, float* gr, float* grad, float* loss) {
+  const long HW = (long)H * W;
+  if (int rc = hist_into(st, img, B, HW, nbins, sat_weighting, fix)) return rc;
+  const float coef = scale / ((float)B * (float)nbins);      // mse_loss: the mean over [B, nbins]
+  hipLaunchKernelGGL(cm_final_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long*)fix, nbins, target,
+                     target_per_sample ? (long)nbins : 0L, coef, (float*)nullptr, gr, loss);
+  MAUA_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(cm_grad_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, img, HW, nbins, (float)(1.0 / (nbins - 1)),
+                     sat_weighting, (const float*)gr, grad);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// acc = (first ? 0 : acc) + (sub holds a NaN ? 0 : sub); flag: one device int of the caller's
+int screened_accumulate(hipStream_t st, const float* sub, float* acc, long n, int first, int* flag) {
+  if (n == 0) return MAUA_OK;
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(256), 0, st, (uint32_t*)flag, 1L);
+  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(nan_flag_kernel, dim3(blocks), dim3(256), 0, st, sub, n, flag);
+  hipLaunchKernelGGL(screened_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sub, (const int*)flag, acc, n, first);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+}  // namespace maua
 
 extern "C" {
 
@@ -251,18 +293,10 @@ int maua_colormatch_grad(maua_ctx* ctx, const float* img, int B, int H, int W, i
   MAUA_REQUIRE(ctx && img && target && grad, "maua_colormatch_grad: NULL argument");
   MAUA_REQUIRE(B >= 0 && H > 0 && W > 0 && nbins >= 2 && nbins <= MAX_BINS, "maua_colormatch_grad: bad shape (2 <= bins <= 1024)");
   if (B == 0) return MAUA_OK;
-  const long HW = (long)H * W;
-  unsigned long long* fix;
-  float* gr;
-  if (int rc = run_hist(ctx, img, B, HW, nbins, sat_weighting, &fix, &gr)) return rc;
-  const float coef = scale / ((float)B * (float)nbins);      // mse_loss: the mean over [B, nbins]
-  hipLaunchKernelGGL(cm_final_kernel, dim3(B), dim3(256), 0, ctx->stream, fix, nbins, target, target_per_sample ? (long)nbins : 0L, coef,
-                     (float*)nullptr, gr, loss);
-  MAUA_HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(cm_grad_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, ctx->stream, img, HW, nbins,
-                     (float)(1.0 / (nbins - 1)), sat_weighting, gr, grad);
-  MAUA_HIP_CHECK(hipGetLastError());
-  return MAUA_OK;
+  const size_t fix_bytes = colormatch_fix_bytes(B, nbins);
+  if (int rc = scratch_reserve(ctx, fix_bytes + (size_t)B * nbins * 4)) return rc;
+  return colormatch_grad_into(ctx->stream, img, B, H, W, nbins, sat_weighting, target, target_per_sample, scale,
+                              (unsigned long long*)ctx->scratch, (float*)((char*)ctx->scratch + fix_bytes), grad, loss);
 }
 
 // GradientGuidedConditioning's loop over its grad modules (guided.py:258-266): acc = (first ? 0 : acc) + (sub holds a NaN ? 0 : sub),
@@ -271,13 +305,7 @@ int maua_grad_accumulate(maua_ctx* ctx, const float* sub, float* acc, long n, in
   MAUA_REQUIRE(ctx && sub && acc && n >= 0, "maua_grad_accumulate: bad argument");
   if (n == 0) return MAUA_OK;
   if (int rc = scratch_reserve(ctx, 256)) return rc;
-  int* flag = (int*)ctx->scratch;
-  MAUA_HIP_CHECK(hipMemsetAsync(flag, 0, 4, ctx->stream));
-  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(nan_flag_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sub, n, flag);
-  hipLaunchKernelGGL(screened_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, sub, (const int*)flag, acc, n, first);
-  MAUA_HIP_CHECK(hipGetLastError());
-  return MAUA_OK;
+  return screened_accumulate(ctx->stream, sub, acc, n, first, (int*)ctx->scratch);
 }
 
 }  // extern "C"

@@ -333,6 +333,20 @@ int launch_cutouts_forward(hipStream_t stream, int dtype, const CutoutPlan& p, v
 int launch_cutouts_vjp(hipStream_t stream, int dtype, const CutoutPlan& p, void* tables, const void* d_out, float* th, float* grad,
                        int accumulate);
 
+// colormatch.hip: ColorMatchGrads.forward on caller-owned workspaces (nothing allocated: capturable), the conditioning's NaN-screened sum
+size_t colormatch_fix_bytes(int B, int nbins);
+int colormatch_grad_into(hipStream_t st, const float* img, int B, int H, int W, int nbins, int sat_weighting, const float* target,
+                         int target_per_sample, float scale, unsigned long long* fix, float* gr, float* grad, float* loss);
+int screened_accumulate(hipStream_t st, const float* sub, float* acc, long n, int first, int* flag);
+// perceptor.hip
+maua_ctx* vgg_ctx(maua_vgg* n);
+// guides.hip: a grad module of the guided loop (maua_guide_*): evaluates d loss / d img into `out` on the context's stream;
+// guide_prepare allocates for a batch shape (never inside a capture)
+int guide_prepare(maua_guide* g, int B, int H, int W);
+int guide_eval(maua_guide* g, const float* img, int B, int H, int W, float* out);
+maua_ctx* guide_ctx(maua_guide* g);
+unsigned long long guide_uid(maua_guide* g);
+
 // secondary.hip: the context a secondary diffusion model was created on
 maua_ctx* secondary_ctx(maua_secondary* n);
 // (uid, epoch) of a secondary model's device buffers: whoever caches pointers into them (a captured graph) compares both before reuse

@@ -479,6 +479,11 @@ __global__ __launch_bounds__(256) void lpips_norm_kernel(const T* __restrict__ F
   for (int c = lane; c < C; c += 64) out[pix * C + c] = Elem<T>::load(F + pix * C + c) / re;
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 // dist[b] += mul * sum_p val[b][p]  (one workgroup per image, fixed order)
 __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ val, long HW, float mul, float* __restrict__ dist) {
   __shared__ float red[16];
@@ -700,7 +705,7 @@ int style_grad_t(maua_vgg* n, const float* img, int B, int H, int W, const int* 
                  const long* t_bstride, float strength, float* grad, float* loss) {
   hipStream_t st = n->ctx->stream;
   if (int rc = forward_t<T>(n, img, B, H, W)) return rc;
-  MAUA_HIP_CHECK(hipMemsetAsync(n->loss_dev, 0, (size_t)B * 4, st));
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, n->loss_dev, (long)B);   // (no memset node: capturable)
   for (int k = 0; k < n_taps; k++) {
     if (int rc = check_tap(n, taps[k], "maua_vgg_style_grad")) return rc;
     POp& o = n->ops[taps[k]];
@@ -734,7 +739,7 @@ int lpips_grad_t(maua_vgg* n, const float* img, int B, int H, int W, const int* 
                  const long* t_bstride, const float* const* lins, float scale, float* grad, float* dist) {
   hipStream_t st = n->ctx->stream;
   if (int rc = forward_t<T>(n, img, B, H, W)) return rc;
-  MAUA_HIP_CHECK(hipMemsetAsync(n->loss_dev, 0, (size_t)B * 4, st));
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, n->loss_dev, (long)B);   // (no memset node: capturable)
   for (int k = 0; k < n_taps; k++) {
     if (int rc = check_tap(n, taps[k], "maua_vgg_lpips_grad")) return rc;
     POp& o = n->ops[taps[k]];
@@ -762,6 +767,10 @@ int check_image(const maua_vgg* n, int B, int H, int W, const char* who) {
 }
 
 }  // namespace
+
+namespace maua {
+maua_ctx* vgg_ctx(maua_vgg* n) { return n ? n->ctx : nullptr; }
+}
 
 extern "C" {
 

@@ -762,6 +762,9 @@ struct maua_unet {
   size_t gd_key = 0;
   unsigned long long gd_sec_uid = 0, gd_sec_epoch = 0;   // the secondary model (and its buffers' generation) gd_exec points into
   // text-prompt guidance (maua_unet_set_clip_guide): CLIPGrads instead of the image-MSE module in the guided loop
+  std::vector<maua_guide*> gd_guides;   // maua_unet_set_guides: grad modules evaluated (after CLIPGrads, if set) and summed per step
+  std::vector<unsigned long long> gd_guide_uids;
+  int* gd_gflag = nullptr;           // the NaN screen's flag of the guides' sum
   maua_clip* gd_clip = nullptr;
   int* gd_rects = nullptr;           // device [n_steps][batches][cutn][3] (+ [n_steps][batches][cutn] float multiplicities behind them)
   float* gd_mult = nullptr;          // NULL: every cutout counts once
@@ -1463,7 +1466,7 @@ void maua_unet_destroy(maua_unet* n) {
   if (n->cap_side) hipStreamDestroy(n->cap_side);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_join) hipEventDestroy(n->ev_join);
-  for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag, (void*)n->gd_rects})
+  for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag, (void*)n->gd_rects, (void*)n->gd_gflag})
     if (p) hipFree(p);
   for (void* p : n->owned) hipFree(p);
   if (n->arena.base) hipFree(n->arena.base);
@@ -2004,24 +2007,32 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
                        n->gd_rects_host[i + 2] + (n->gd_rects_host[i] & CUT_SIZE_MASK) <= W,
                    "maua_ddim_guided_loop: a cutout leaves the image");
     if (int rc = clip_prepare_guide(clip, B, H, W, clip_group_size(clip, B, n->gd_cutn))) return rc;
-  } else {
+  } else if (n->gd_guides.empty()) {
     MAUA_REQUIRE(target, "maua_ddim_guided_loop: target is NULL");
+  }
+  const bool guides = !n->gd_guides.empty();
+  if (guides) {
+    MAUA_REQUIRE(n->in_ch == 3, "maua_ddim_guided_loop: the grad modules guide 3-channel images");
+    for (maua_guide* g : n->gd_guides) {
+      MAUA_REQUIRE(guide_ctx(g) == n->ctx, "maua_ddim_guided_loop: a grad module lives on another context");
+      if (int rc = guide_prepare(g, B, H, W)) return rc;
+    }
   }
   if (int rc = prepare_sampler(n, B, H, W, model_t, coef, n_steps)) return rc;
   const size_t tb = (size_t)B * chw, tab = (size_t)n_steps * B * 7 + B;
-  if (n->gd_cap < 9 * tb || n->gd_tab_cap < tab || !n->gd_flag || n->gd_flags < n_steps) {
+  if (n->gd_cap < 10 * tb || n->gd_tab_cap < tab || !n->gd_flag || n->gd_flags < n_steps) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     for (void* p : {(void*)n->gd_buf, (void*)n->gd_tab, (void*)n->gd_flag})
       if (p) hipFree(p);
     n->gd_buf = nullptr; n->gd_tab = nullptr; n->gd_flag = nullptr; n->gd_cap = n->gd_tab_cap = 0;
-    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_buf, 9 * tb * 4));
+    MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_buf, 10 * tb * 4));
     MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_tab, tab * 4));
     MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_flag, (size_t)n_steps * 4));
-    n->gd_cap = 9 * tb; n->gd_tab_cap = tab; n->gd_flags = n_steps;
+    n->gd_cap = 10 * tb; n->gd_tab_cap = tab; n->gd_flags = n_steps;
     drop_sampler_graphs(n);
   }
   float *bx = n->gd_buf, *bv = bx + tb, *bp = bv + tb, *be = bp + tb, *bimg = be + tb, *bg = bimg + tb, *bjv = bg + tb,
-        *bgrad = bjv + tb, *btgt = bgrad + tb;
+        *bgrad = bjv + tb, *btgt = bgrad + tb, *bsub = btgt + tb;
   float *t_ct = n->gd_tab, *t_img = t_ct + (size_t)n_steps * B, *t_grad = t_img + (size_t)n_steps * B * 2,
         *t_pred = t_grad + (size_t)n_steps * B * 2, *t_k = t_pred + (size_t)n_steps * B * 2;
   {
@@ -2043,14 +2054,22 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   }
   MAUA_HIP_CHECK(hipMemsetAsync(n->gd_flag, 0, (size_t)n_steps * 4, st));
   MAUA_HIP_CHECK(hipMemcpyAsync(bx, x, tb * 4, hipMemcpyDeviceToDevice, st));
-  if (!clip) MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
-  // the grad module of step s on the context's current stream: bimg -> bg
+  if (!clip && !guides) MAUA_HIP_CHECK(hipMemcpyAsync(btgt, target, (target_bstride ? tb : (size_t)chw) * 4, hipMemcpyDeviceToDevice, st));
+  // the grad module(s) of step s on the context's current stream: bimg -> bg
   auto guide_grad = [&](int s) -> int {
+    int rc = MAUA_OK;
     if (clip)
-      return clip_guide_grad(clip, bimg, B, H, W, n->gd_rects + (size_t)s * n->gd_batches * n->gd_cutn * 3,
-                             n->gd_mult ? n->gd_mult + (size_t)s * n->gd_batches * n->gd_cutn : nullptr, n->gd_cutn, n->gd_cutn_total,
-                             n->gd_batches, n->gd_clip_scale, n->gd_clip_clamp, bg);
-    return mse_guide_grad(n->ctx, bimg, btgt, target_bstride ? chw : 0, t_k, B, chw, bg, n->gd_flag + s, false);
+      rc = clip_guide_grad(clip, bimg, B, H, W, n->gd_rects + (size_t)s * n->gd_batches * n->gd_cutn * 3,
+                           n->gd_mult ? n->gd_mult + (size_t)s * n->gd_batches * n->gd_cutn : nullptr, n->gd_cutn, n->gd_cutn_total,
+                           n->gd_batches, n->gd_clip_scale, n->gd_clip_clamp, bg);
+    else if (!guides)
+      return mse_guide_grad(n->ctx, bimg, btgt, target_bstride ? chw : 0, t_k, B, chw, bg, n->gd_flag + s, false);
+    // guided.py:258-266: img_grad += sub_grad per module, a module whose gradient holds a NaN skipped
+    for (size_t k = 0; k < n->gd_guides.size() && !rc; k++) {
+      rc = guide_eval(n->gd_guides[k], bimg, B, H, W, bsub);
+      if (!rc) rc = screened_accumulate(n->ctx->stream, bsub, bg, (long)tb, !clip && k == 0, n->gd_gflag);
+    }
+    return rc;
   };
   const long tstride = target_bstride ? chw : 0;
   if (n->gd_fork && !n->ev_fork) {
@@ -2222,6 +2241,21 @@ int maua_unet_set_clip_guide(maua_unet* n, maua_clip* clip, const int* rects, co
   MAUA_HIP_CHECK(hipStreamSynchronize(st));
   n->gd_clip = clip; n->gd_rect_steps = n_steps; n->gd_cutn = cutn; n->gd_batches = batches; n->gd_clip_scale = scale;
   n->gd_clip_clamp = clamp_gradient; n->gd_mult = mult_dev; n->gd_cutn_total = cutn_total;
+  return MAUA_OK;
+}
+
+// a list of grad modules (guides.hip) as the guided loop's conditioning: evaluated after CLIPGrads (if set) and summed
+int maua_unet_set_guides(maua_unet* n, maua_guide* const* guides, int n_guides) {
+  MAUA_REQUIRE(n && n_guides >= 0 && (n_guides == 0 || guides), "maua_unet_set_guides: bad arguments");
+  std::vector<unsigned long long> uids;
+  for (int k = 0; k < n_guides; k++) {
+    MAUA_REQUIRE(guides[k], "maua_unet_set_guides: NULL guide");
+    uids.push_back(guide_uid(guides[k]));
+  }
+  if (uids != n->gd_guide_uids) n->gd_guide_gen++;   // (a captured loop bakes the list into its launches)
+  n->gd_guide_uids = uids;
+  n->gd_guides.assign(guides, guides + n_guides);
+  if (n_guides && !n->gd_gflag) MAUA_HIP_CHECK(hipMalloc((void**)&n->gd_gflag, 256));
   return MAUA_OK;
 }
 

@@ -534,6 +534,11 @@ class SpacedDiffusion:
         x = L.dev_tensor(x, torch.float32)
         B, _, H, W = x.shape
         spec = gm.graph_spec() if hasattr(gm, "graph_spec") else None
+        # the other modules of the list as library objects (VGGGrads, LPIPSGrads, ColorMatchGrads), evaluated and summed per step
+        guides = [m.graph_guide(B, H, W) for m in conditioning.grad_modules[(1 if spec is not None else 0):] if hasattr(m, "graph_guide")]
+        if any(g is None for g in guides):
+            raise ValueError("ddim_guided_loop: a grad module has no target yet (set_targets first)")
+        L.check(L.lib().maua_unet_set_guides(model._handle(), (C.c_void_p * max(len(guides), 1))(*[g.h for g in guides]), len(guides)))
         if spec is not None:
             # text-prompt guidance (CLIPGrads, maua/grad.py:96-165): the cutout rectangles of every step and cutout batch are drawn
             # here, in the order the step-by-step path draws them (per step: grad.py:149's t[[0]] = that step's model timestep)
@@ -552,6 +557,9 @@ class SpacedDiffusion:
             # loops (tests, previews) are captured
             if n_steps * spec["batches"] > 64:
                 use_graph = False
+        elif guides:
+            L.check(L.lib().maua_unet_set_clip_guide(model._handle(), None, None, None, 0, 0, 0, C.c_float(0.0), C.c_float(0.0)))
+            tgt, tstride, mse_k = None, 0, 0.0
         else:
             L.check(L.lib().maua_unet_set_clip_guide(model._handle(), None, None, None, 0, 0, 0, C.c_float(0.0), C.c_float(0.0)))
             tgt = L.dev_tensor(gm.target, torch.float32)
@@ -843,12 +851,18 @@ class GradientGuidedConditioning(torch.nn.Module):
         """True when the whole guided step is library work (speed "fast" or "regular", exactly one grad module the library has: the
         image-MSE module with a target, or CLIPGrads with one perceptor): the sampler loop then runs as one hipGraph
         (SpacedDiffusion.ddim_guided_loop)."""
-        if self.speed == "hyper" or len(self.grad_modules) != 1:
+        if self.speed == "hyper" or not self.grad_modules:
             return False
-        gm = self.grad_modules[0]
-        if hasattr(gm, "graph_spec"):      # CLIPGrads (maua_amd/grad.py): one perceptor, targets set
-            return gm.graph_spec() is not None
-        return isinstance(gm, MSEGuide) and gm.target is not None
+        mods = self.grad_modules
+        if len(mods) == 1 and isinstance(mods[0], MSEGuide):
+            return mods[0].target is not None
+        # CLIPGrads (one perceptor, targets set) first, then modules the library holds as guide objects (VGGGrads, LPIPSGrads,
+        # ColorMatchGrads: maua_unet_set_guides) - summed in the list's order, like the step-by-step path sums them
+        rest = mods[1:] if hasattr(mods[0], "graph_spec") else mods
+        if hasattr(mods[0], "graph_spec") and mods[0].graph_spec() is None:
+            return False
+        return all(hasattr(gm, "graph_guide") and not hasattr(gm, "graph_spec") for gm in rest) and \
+            all(getattr(gm, "graph_ready", lambda: True)() for gm in rest)
 
     def forward(self, x, t, kw={}):
         ot = t.clone()

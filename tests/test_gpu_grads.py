@@ -359,3 +359,65 @@ def test_image_prompt_grad_modules_guide_the_sampler():
     est = torch.rand(2, 3, 256, 256, generator=gen) * 2 - 1
     parts = [gm(est, torch.tensor([500.0, 500.0])) for gm in mods]
     assert all(bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 for g in parts)
+
+
+def test_guided_loop_with_a_module_list_as_one_graph_equals_the_step_by_step_loop():
+    """The sampler's grad-module LIST inside the library (maua_unet_set_guides: guided.py:258-266's sum over modules, each module a
+    maua_guide): [VGGGrads, ColorMatchGrads] with the default "fast" conditioning on a small UNet - the captured loop, the same loop launch
+    by launch and the Python step-by-step path give identical bits; re-targeting (set_targets with another style image: the guides'
+    target tensors are updated in place) goes through the SAME capture; CLIPGrads + a module list; speed "regular"."""
+    from maua_amd.clip import CLIPImageModel, VisionTransformer
+    from maua_amd.diffusion import GuidedDiffusion, SecondaryDiffusionImageNet2, SpacedDiffusion, UNetModel, space_timesteps
+    from maua_amd.grad import CLIPGrads, ColorMatchGrads, EmbeddingPrompt, StylePrompt, VGGGrads
+    from oracle import diffusion as OD
+    gen = torch.Generator().manual_seed(31)
+    cfg = OD.unet_config(image_size=64, model_channels=32, num_res_blocks=1, attention_resolutions=(16, 8), channel_mult=(1, 2, 2), num_head_channels=32)
+    net = UNetModel(image_size=64, in_channels=3, model_channels=32, out_channels=cfg["out_channels"], num_res_blocks=1,
+                    attention_resolutions=cfg["attention_ds"], channel_mult=(1, 2, 2), num_head_channels=32, use_scale_shift_norm=True,
+                    resblock_updown=True, dtype=torch.float32)
+    net.load_state_dict(OD.init_unet_params(cfg, torch.Generator().manual_seed(0)))
+    sd = SpacedDiffusion(space_timesteps(1000, "ddim20"), OD.linear_betas(1000), rescale_timesteps=True)
+    sec = SecondaryDiffusionImageNet2(dtype=torch.float32, exact=True)
+    sec.load_state_dict(OD.secondary_random_params(1))
+    s1, s2 = (StylePrompt(img=torch.rand(1, 3, 64, 64, generator=gen)) for _ in range(2))
+    vg = VGGGrads(scale=3000.0, allow_random_init=True, dtype=torch.float32)
+    cm = ColorMatchGrads(scale=3e5)
+    img, nz = torch.randn(2, 3, 64, 64, generator=gen), torch.randn(2, 3, 64, 64, generator=gen)
+    gd = GuidedDiffusion([vg, cm], timesteps=20, model=net, diffusion=sd, secondary_model=sec)
+    assert gd.conditioning.speed == "fast"
+    res = {}
+    for prompt, name in ((s1, "a"), (s2, "b")):
+        gd.use_graph = True
+        res[name] = gd.forward(img, [prompt], 0.3, t_end=0.8, noise=nz)
+        assert gd.conditioning.graphable() and net.guided_graph_active(), "the guided loop with a module list did not capture into a hipGraph"
+        gd.use_graph = False
+        assert torch.equal(res[name], gd.forward(img, [prompt], 0.3, t_end=0.8, noise=nz)), name
+    assert not torch.equal(res["a"], res["b"])
+    plain = GuidedDiffusion([], timesteps=20, model=net, diffusion=sd).forward(img, [], 0.3, t_end=0.8, noise=nz)
+    assert rel(res["a"], plain) > 1e-4
+    # the loop inside the library launch by launch (use_graph = 0 of the C entry point) = the captured one
+    x = sd.q_sample(img, torch.tensor([6, 6]), nz)
+    gd.conditioning.set_targets([s1.to("cuda")], nz)
+    eager = sd.ddim_guided_loop(net, gd.conditioning, x.clone(), 6, 10, use_graph=False)[1]
+    assert torch.equal(eager, res["a"])
+    # speed "regular": the modules' gradient through the UNet itself
+    gr = GuidedDiffusion([vg, cm], timesteps=20, model=net, diffusion=sd, speed="regular")
+    gr.use_graph = True
+    a = gr.forward(img, [s1], 0.3, t_end=0.6, noise=nz)
+    gr.use_graph = False
+    assert torch.equal(a, gr.forward(img, [s1], 0.3, t_end=0.6, noise=nz)) and bool(torch.isfinite(a).all())
+    # CLIPGrads first, then the list
+    p = OC.init_vit_params(dict(input_resolution=32, patch_size=8, width=64, layers=2, heads=2, output_dim=32), torch.Generator().manual_seed(2))
+    vt = VisionTransformer(32, 8, 64, 2, 2, 32, dtype=torch.float32)
+    vt.load_state_dict(p, strict=True)
+    cg = CLIPGrads(scale=200.0, cutout_kwargs=dict(cutn=8), cutout_batches=2, clip_models=[CLIPImageModel(vt)])
+    gc = GuidedDiffusion([cg, vg, cm], timesteps=20, model=net, diffusion=sd, secondary_model=sec)
+    prompts = [EmbeddingPrompt(torch.randn(32, generator=gen)), s1]
+    gc.use_graph = True
+    torch.manual_seed(5)
+    c1 = gc.forward(img, prompts, 0.3, t_end=0.6, noise=nz)
+    assert net.guided_graph_active()
+    gc.use_graph = False
+    torch.manual_seed(5)
+    c2 = gc.forward(img, prompts, 0.3, t_end=0.6, noise=nz)
+    assert torch.equal(c1, c2) and rel(c1, a) > 1e-4
