@@ -153,6 +153,11 @@ int maua_resize2d(maua_ctx* ctx, const void* x, void* y, int N, int C, int H, in
  * `radius` (taps [2*radius+1], device): the lanczos pre-filter of maua/ops/image.py:226-236 resample. */
 int maua_conv1d_reflect(maua_ctx* ctx, const float* x, float* y, const float* taps, int radius, int axis, long planes,
                         int H, int W);
+/* the adjoints of the two steps of `resample` (maua/ops/image.py:214-240) - what autograd gives a loss taken on a resampled image
+ * (LPIPSGrads, maua/grad.py:191-192): gy -> gx through the reflect-padded 1-D correlation / through the bicubic interpolation
+ * (gy device f32 [N][C][out_h][out_w] -> gx [N][C][H][W]; align_corners as maua_resize2d's mode 2 / 0) */
+int maua_conv1d_reflect_vjp(maua_ctx* ctx, const float* gy, float* gx, const float* taps, int radius, int axis, long planes, int H, int W);
+int maua_resize2d_bicubic_vjp(maua_ctx* ctx, const float* gy, float* gx, int N, int C, int H, int W, int out_h, int out_w, int align_corners);
 int maua_synth_set_option(maua_synth* net, const char* key, int value);
 /* the load_state_dict of the inference modules (inference/stylegan2.py:195-436 parameter / buffer names).
  * name: the reference state_dict key ("bs.3.conv0.weight", "bs.0.const", "bs.2.torgb.affine.bias",

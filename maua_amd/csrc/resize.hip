@@ -146,6 +146,81 @@ __global__ __launch_bounds__(256) void conv1d_planar_kernel(const float* __restr
   y[idx] = acc;
 }
 
+// adjoint of conv1d_planar_kernel: gx[i] = sum over (j, k) with reflect(j + k) == i of taps[k + radius] gy[j].  The padded positions that
+// reflect onto i are m = i, m = -i (i >= 1) and m = 2 (n - 1) - i (i <= n - 2) (radius < n: one reflection at most)
+__global__ __launch_bounds__(256) void conv1d_planar_vjp_kernel(const float* __restrict__ gy, float* __restrict__ gx, const float* __restrict__ taps,
+                                                                int radius, int axis, int H, int W, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int xx = (int)(idx % W);
+  const long r = idx / W;
+  const int yy = (int)(r % H);
+  const float* pl = gy + (r / H) * H * W;
+  const int n = axis == 0 ? H : W, i = axis == 0 ? yy : xx;
+  const long stride = axis == 0 ? W : 1;
+  const float* line = pl + (axis == 0 ? (long)xx : (long)yy * W);
+  const int ms[3] = {i, -i, 2 * (n - 1) - i};
+  const bool ok[3] = {true, i >= 1, i <= n - 2 && n > 1};
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    if (!ok[c]) continue;
+    for (int k = -radius; k <= radius; k++) {
+      const int j = ms[c] - k;
+      if (j >= 0 && j < n) acc += taps[k + radius] * line[(long)j * stride];
+    }
+  }
+  gx[idx] = acc;
+}
+
+// one axis of the bicubic adjoint: src [planes][rows][n_out] -> dst [planes][rows][n_in] (axis 1) or src [planes][n_out][cols] ->
+// dst [planes][n_in][cols] (axis 0; `rows` is then the column count): dst[i] = sum_o w(o -> i) src[o] over the outputs whose clamped taps hit i
+__global__ __launch_bounds__(256) void bicubic_axis_vjp_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_out_rows, int n_out_or_cols,
+                                                               int n_in, int axis, int align, long total) {
+  // axis 1: src [planes][R = n_out_rows][n_out = n_out_or_cols], dst [planes][R][n_in]
+  // axis 0: src [planes][n_out = n_out_rows][Cc = n_out_or_cols], dst [planes][n_in][Cc]
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int i, n_out;
+  const float* line;
+  long stride;
+  if (axis == 1) {
+    n_out = n_out_or_cols;
+    i = (int)(idx % n_in);
+    const long row = idx / n_in;                      // plane * R + r
+    line = src + row * n_out;
+    stride = 1;
+  } else {
+    n_out = n_out_rows;
+    const int cols = n_out_or_cols;
+    const int x = (int)(idx % cols);
+    const long q = idx / cols;
+    i = (int)(q % n_in);
+    line = src + (q / n_in) * (long)n_out * cols + x;
+    stride = cols;
+  }
+  const float sc = align ? (n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f) : (float)n_in / (float)n_out;
+  int lo = 0, hi = n_out - 1;
+  if (sc > 0.f) {
+    lo = max(0, (int)floorf(((float)i - 3.f) / sc) - 1);
+    hi = min(n_out - 1, (int)ceilf(((float)i + 3.f) / sc) + 1);
+  }
+  float acc = 0.f;
+  for (int o = lo; o <= hi; o++) {
+    const float sp = align ? (n_out > 1 ? o * sc : 0.f) : (o + 0.5f) * sc - 0.5f;
+    const float f = floorf(sp);
+    float c[4];
+    cubic_coeffs(sp - f, c);
+    const int i0 = (int)f - 1;
+    float w = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (min(max(i0 + k, 0), n_in - 1) == i) w += c[k];
+    if (w != 0.f) acc += w * line[(long)o * stride];
+  }
+  dst[idx] = acc;
+}
+
 // Per-sample affine warp of NHWC features with bilinear sampling and reflection padding — what kornia's translate /
 // rotate / scale (wrappers/stylegan2.py:153-194; kornia = warp_affine -> F.affine_grid + F.grid_sample(bilinear,
 // padding_mode="reflection", align_corners=True)) do to a layer's output.  minv [B][6] maps OUTPUT pixel (x, y) to the
@@ -262,6 +337,38 @@ int maua_conv1d_reflect(maua_ctx* ctx, const float* x, float* y, const float* ta
   MAUA_REQUIRE(radius >= 0 && radius < (axis == 0 ? H : W), "maua_conv1d_reflect: reflect padding must be smaller than the image");
   hipLaunchKernelGGL(conv1d_planar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, x, y, taps,
                      radius, axis, H, W, total);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// ---- adjoints (the gradient of a loss through `resample`, maua/ops/image.py:214-240: what autograd gives LPIPSGrads, grad.py:191-192)
+int maua_conv1d_reflect_vjp(maua_ctx* ctx, const float* gy, float* gx, const float* taps, int radius, int axis, long planes, int H, int W) {
+  MAUA_REQUIRE(ctx, "maua_conv1d_reflect_vjp: ctx is NULL");
+  const long total = planes * H * W;
+  if (total == 0) return MAUA_OK;
+  MAUA_REQUIRE(gy && gx && taps && gy != gx, "maua_conv1d_reflect_vjp: NULL or aliased argument");
+  MAUA_REQUIRE(axis == 0 || axis == 1, "maua_conv1d_reflect_vjp: axis must be 0 (rows) or 1 (columns)");
+  MAUA_REQUIRE(radius >= 0 && radius < (axis == 0 ? H : W), "maua_conv1d_reflect_vjp: reflect padding must be smaller than the image");
+  hipLaunchKernelGGL(conv1d_planar_vjp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, gy, gx, taps, radius, axis,
+                     H, W, total);
+  MAUA_HIP_CHECK(hipGetLastError());
+  return MAUA_OK;
+}
+
+// gy [N][C][out_h][out_w] -> gx [N][C][H][W]: the adjoint of maua_resize2d's bicubic modes (0: align_corners False, 2: True), as two
+// 1-D gather passes (columns, then rows) over the outputs whose four clamped taps touch an input sample - no atomics
+int maua_resize2d_bicubic_vjp(maua_ctx* ctx, const float* gy, float* gx, int N, int C, int H, int W, int out_h, int out_w, int align_corners) {
+  MAUA_REQUIRE(ctx, "maua_resize2d_bicubic_vjp: ctx is NULL");
+  const long planes = (long)N * C;
+  if (planes * H * W == 0) return MAUA_OK;
+  MAUA_REQUIRE(gy && gx && out_h > 0 && out_w > 0, "maua_resize2d_bicubic_vjp: bad argument");
+  if (int rc = scratch_reserve(ctx, (size_t)planes * out_h * W * 4)) return rc;
+  float* tmp = (float*)ctx->scratch;
+  const long t1 = planes * out_h * W, t2 = planes * H * W;
+  hipLaunchKernelGGL(bicubic_axis_vjp_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, ctx->stream, gy, tmp, out_h, out_w, W, 1,
+                     align_corners, t1);
+  hipLaunchKernelGGL(bicubic_axis_vjp_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)tmp, gx, out_h, W, H, 0,
+                     align_corners, t2);
   MAUA_HIP_CHECK(hipGetLastError());
   return MAUA_OK;
 }

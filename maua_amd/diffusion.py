@@ -847,7 +847,7 @@ class GradientGuidedConditioning(torch.nn.Module):
         a_c, s_c = torch.cos(cosine_t * math.pi / 2), torch.sin(cosine_t * math.pi / 2)
         return torch.stack([cosine_t, sigma, 1 - sigma, -(sigma * a_c + 1 - sigma), sigma * s_c], 1).float().contiguous()
 
-    def graphable(self):
+    def graphable(self, shape=None):
         """True when the whole guided step is library work (speed "fast" or "regular", exactly one grad module the library has: the
         image-MSE module with a target, or CLIPGrads with one perceptor): the sampler loop then runs as one hipGraph
         (SpacedDiffusion.ddim_guided_loop)."""
@@ -862,7 +862,7 @@ class GradientGuidedConditioning(torch.nn.Module):
         if hasattr(mods[0], "graph_spec") and mods[0].graph_spec() is None:
             return False
         return all(hasattr(gm, "graph_guide") and not hasattr(gm, "graph_spec") for gm in rest) and \
-            all(getattr(gm, "graph_ready", lambda: True)() for gm in rest)
+            all(gm.graph_ready(shape) for gm in rest)
 
     def forward(self, x, t, kw={}):
         ot = t.clone()
@@ -1010,7 +1010,7 @@ class GuidedDiffusion(torch.nn.Module):
             if per_sample and (len(prompts) != img.shape[0] or not self.conditioning.per_sample_prompts()):
                 raise ValueError("per_sample needs one prompt per sample and grad modules with set_targets_per_sample")
             self.conditioning.set_targets([p.to(img) for p in prompts], noise, per_sample)
-            if self.sampler == "ddim" and self.ddim_eta == 0 and self.use_graph and self.conditioning.graphable():
+            if self.sampler == "ddim" and self.ddim_eta == 0 and self.use_graph and self.conditioning.graphable(x.shape):
                 return self.diffusion.ddim_guided_loop(self.model, self.conditioning, x, start_step, n_steps)[1]
         out = None
         for _ in range(n_steps):   # guided.py:302-311, :333-337

@@ -362,3 +362,33 @@ def resample(input, size, align_corners=True):
     L.check(lib.maua_resize2d(ctx, L.ptr(x), L.ptr(out), n, c, h, w, dh, dw, 2 if align_corners else 0, 0, 0, 3,
                               C.c_float(0.0), L.dtype_id(x)))
     return out
+
+
+def resample_size(h, w, size):
+    """The (dh, dw) ``resample(x, size)`` produces for an h x w input (image.py:217-223)."""
+    if isinstance(size, (int, float)):
+        short, long = (w, h) if w <= h else (h, w)
+        new_short, new_long = round(size), round(size * long / short)
+        dw, dh = (new_short, new_long) if w <= h else (new_long, new_short)
+        return dh, dw
+    dh, dw = (int(s) for s in size)
+    return dh, dw
+
+
+def resample_vjp(grad_out, in_shape, align_corners=True):
+    """(d resample(x, size) / d x)^T grad_out for x of shape ``in_shape`` = (n, c, h, w) and grad_out [n, c, dh, dw]: the bicubic
+    interpolation's adjoint, then the adjoints of the lanczos pre-filters in reverse order - what ``torch.autograd.grad`` walks back
+    through image.py:225-240 (LPIPSGrads, maua/grad.py:191-192).  There is no autograd here."""
+    g = L.dev_tensor(grad_out, torch.float32)
+    n, c, h, w = (int(v) for v in in_shape)
+    dh, dw = g.shape[-2:]
+    lib, ctx = L.lib(), L.ctx(g.device)
+    x = torch.empty((n, c, h, w), dtype=torch.float32, device=g.device)
+    L.check(lib.maua_resize2d_bicubic_vjp(ctx, L.ptr(g), L.ptr(x), n, c, h, w, dh, dw, int(bool(align_corners))))
+    for axis, (d, s) in reversed(list(enumerate(((dh, h), (dw, w))))):
+        if d < s:
+            taps = L.dev_tensor(_lanczos_taps(d / s, 2), torch.float32)
+            y = torch.empty_like(x)
+            L.check(lib.maua_conv1d_reflect_vjp(ctx, L.ptr(x), L.ptr(y), L.ptr(taps), (taps.numel() - 1) // 2, axis, C.c_long(n * c), h, w))
+            x = y
+    return x

@@ -191,9 +191,54 @@ def test_lpips_distance_and_gradient_match_the_oracle(dt):
         assert cos(grad, want_grad) >= 0.97 and rel(d, want_d) <= 0.03
 
 
+def test_resample_adjoint_matches_autograd_on_the_oracle():
+    """maua_amd.ops.resample_vjp - the adjoints of the bicubic interpolation and of the reflect-padded lanczos pre-filters - against
+    torch.autograd through oracle.ops.resample (the restatement of maua/ops/image.py:214-240, pinned by the reference-generated resample
+    fixture): shrinking both axes, one axis, up-sampling (no pre-filter), explicit sizes, align_corners False; the forward alongside."""
+    from maua_amd.ops import resample, resample_size, resample_vjp
+    from oracle import ops as OO
+    gen = torch.Generator().manual_seed(17)
+    for (h, w, size, ac) in ((64, 64, 32, True), (96, 64, 48, True), (40, 56, 64, True), (48, 80, (32, 80), True), (64, 48, (80, 24), True),
+                             (33, 47, (20, 61), False), (512, 512, 256, True)):
+        x = torch.rand(2, 3, h, w, generator=gen) * 2 - 1
+        dh, dw = resample_size(h, w, size)
+        d = torch.randn(2, 3, dh, dw, generator=gen)
+        with torch.enable_grad():
+            xx = x.clone().requires_grad_()
+            ref = OO.resample(xx, size, align_corners=ac)
+            want = torch.autograd.grad(ref, xx, d)[0]
+        assert tuple(ref.shape[-2:]) == (dh, dw)
+        assert rel(resample(x, size, align_corners=ac), ref) <= 2e-5, (h, w, size)
+        got = resample_vjp(d, x.shape, align_corners=ac)
+        assert rel(got, want) <= 2e-5, (h, w, size, rel(got, want))
+
+
+def test_lpipsgrads_at_other_sizes_resample_like_the_reference():
+    """LPIPSGrads.forward with an image that is not 256 pixels on its short side (the reference's default checkpoint samples at 512^2):
+    resample(img, 256) -> lpips -> the gradient back through resample's adjoint, exact-f32 mode against torch.autograd on the oracle's
+    chain (maua/grad.py:189-193)."""
+    from maua_amd.grad import ContentPrompt, LPIPSGrads
+    from oracle import ops as OO
+    gen = torch.Generator().manual_seed(18)
+    p = OG.init_vgg_params(OG.VGG16_CFG, 29, generator=gen)
+    lins = OG.init_lpips_lins(gen)
+    m = LPIPSGrads(scale=4.0, dtype=torch.float32, state_dict=p, lin_state_dict={f"lin{k}.model.1.weight": w.reshape(1, -1, 1, 1) for k, w in enumerate(lins)})
+    for (h, w) in ((384, 384), (128, 192)):
+        img = torch.rand(1, 3, h, w, generator=gen) * 2 - 1
+        content = torch.rand(1, 3, h, w, generator=gen)
+        m.set_targets([ContentPrompt(img=content)])
+        grad, dist = m.forward(img, None, return_loss=True)
+        with torch.enable_grad():
+            x = img.clone().requires_grad_()
+            d = OG.lpips_distance(p, lins, OO.resample(x, 256), OO.resample(content * 2 - 1, 256))
+            want = torch.autograd.grad(d.sum() * 4.0, x)[0]
+        ok, why = close_up_to_pool_ties(grad, want)
+        assert rel(dist, d) <= 1e-4 and ok, ((h, w), rel(dist, d), why)
+
+
 def test_lpipsgrads_module_at_the_sampler_size():
     """LPIPSGrads at 256 x 256 (where the reference's resample(x, 256) is the identity, g34) with a random-init network: finite, zero
-    without a target, other sizes refused by name."""
+    without a target."""
     from maua_amd.grad import ContentPrompt, LPIPSGrads
     m = LPIPSGrads(scale=10.0, allow_random_init=True)
     gen = torch.Generator().manual_seed(12)
@@ -202,8 +247,8 @@ def test_lpipsgrads_module_at_the_sampler_size():
     m.set_targets([ContentPrompt(img=torch.rand(1, 3, 256, 256, generator=gen))])
     grad, dist = m.forward(img, None, return_loss=True)
     assert tuple(grad.shape) == (2, 3, 256, 256) and bool(torch.isfinite(grad).all()) and float(grad.abs().max()) > 0 and float(dist.min()) > 0
-    with pytest.raises(NotImplementedError):
-        m.forward(img[:, :, :128, :128], None)
+    with pytest.raises(NotImplementedError):       # 100 x 130 resamples to 256 x 333: not a multiple of the perceptor's 16
+        m.forward(torch.rand(1, 3, 100, 130) * 2 - 1, None)
 
 
 def test_full_size_style_and_perceptual_gradients_against_the_oracle():
