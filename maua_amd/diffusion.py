@@ -1034,6 +1034,29 @@ class GuidedDiffusion(torch.nn.Module):
 
 
 # ------------------------------------------------------------------- audio-onset-switched prompts (configs[3])
+def get_diffusion_model(diffusion="guided", timesteps: int = 50, sampler: str = "plms", guidance_speed: str = "fast", clip_scale: float = 0.0,
+                        lpips_scale: float = 0.0, style_scale: float = 0.0, color_match_scale: float = 0.0, cfg_scale: float = 5.0, image=None,
+                        guided_kwargs=None):
+    """maua/diffusion/image.py:76-125 for the guided-diffusion processor: the grad-module list (CLIPGrads, LPIPSGrads, VGGGrads,
+    ColorMatchGrads - each only when its scale is positive, in that order) around ``GuidedDiffusion``.  ``guided_kwargs`` (a dict) reach its
+    constructor (``allow_random_init`` / ready ``model`` + ``diffusion`` objects: there are no checkpoints in the image; the perceptors
+    follow ``allow_random_init``).  The latent / stable / glide processors are other networks and not part of this build."""
+    if isinstance(diffusion, GuidedDiffusion):
+        return diffusion
+    if diffusion != "guided":
+        raise NotImplementedError(f'get_diffusion_model("{diffusion}"): only the "guided" processor (maua/diffusion/processors/guided.py) is built')
+    from .grad import CLIPGrads, ColorMatchGrads, LPIPSGrads, VGGGrads
+    guided_kwargs = dict(guided_kwargs or {})
+    rnd = dict(allow_random_init=True) if guided_kwargs.get("allow_random_init") else {}
+    grad_modules = (
+        ([CLIPGrads(scale=clip_scale, **rnd)] if clip_scale > 0 else [])
+        + ([LPIPSGrads(scale=lpips_scale, **rnd)] if lpips_scale > 0 else [])
+        + ([VGGGrads(scale=style_scale, **rnd)] if style_scale > 0 else [])
+        + ([ColorMatchGrads(scale=color_match_scale)] if color_match_scale > 0 else [])
+    )
+    return GuidedDiffusion(grad_modules=grad_modules, sampler=sampler, timesteps=timesteps, speed=guidance_speed, **guided_kwargs)
+
+
 def onset_prompt_schedule(audio, sr, fps, n_prompts, percentile=90):
     """Per video frame, which prompt is active: the prompt index advances at every onset PEAK of the clip (frames where
     the hop-aligned onset envelope - the same bit-exact path the StyleGAN2 render uses, audio.onsets - is a local maximum

@@ -620,6 +620,7 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("perceptors/__init__.py", "Perceptor.get_loss", "maua_amd.perceptors", "Perceptor.get_loss"),
     ("perceptors/__init__.py", "load_perceptor", "maua_amd.perceptors", "load_perceptor"),
     ("perceptors/vgg_kbc.py", "KBCPerceptor.__init__", "maua_amd.perceptors", "KBCPerceptor.__init__"),
+    ("diffusion/image.py", "get_diffusion_model", "maua_amd.diffusion", "get_diffusion_model"),
 ]
 
 

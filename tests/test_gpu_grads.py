@@ -395,6 +395,16 @@ def test_image_prompt_grad_modules_guide_the_sampler():
     loss_p = vg.forward(plain, None, return_loss=True)[1].sum()
     print("style loss unguided / guided:", float(loss_p), float(loss_g))
     assert float(loss_g) < float(loss_p)
+    # get_diffusion_model (maua/diffusion/image.py:76-125): the same list assembled from the scales, in the reference's order
+    from maua_amd.diffusion import get_diffusion_model
+    gm = get_diffusion_model("guided", timesteps=20, sampler="ddim", style_scale=2000.0, color_match_scale=2e5,
+                             guided_kwargs=dict(model=net, diffusion=sd, allow_random_init=True))
+    assert [type(m).__name__ for m in gm.conditioning.grad_modules] == ["VGGGrads", "ColorMatchGrads"] and gm.conditioning.speed == "fast"
+    out = gm.forward(img, [style], 0.3, t_end=0.6, noise=nz)
+    assert bool(torch.isfinite(out).all()) and net.guided_graph_active()
+    assert get_diffusion_model(gm) is gm
+    with pytest.raises(NotImplementedError):
+        get_diffusion_model("stable")
     # (b)
     style256 = StylePrompt(img=torch.rand(1, 3, 256, 256, generator=gen))
     content = ContentPrompt(img=torch.rand(1, 3, 256, 256, generator=gen))
