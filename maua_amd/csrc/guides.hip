@@ -30,12 +30,14 @@ struct maua_guide {
   unsigned long long* fix = nullptr;
   float* gr = nullptr;
   int cm_cap = 0;                     // samples the workspaces hold
+  unsigned long long cm_epoch = 0;
 };
 
 namespace maua {
 
 maua_ctx* guide_ctx(maua_guide* g) { return g ? g->ctx : nullptr; }
 unsigned long long guide_uid(maua_guide* g) { return g ? g->uid : 0; }
+unsigned long long guide_epoch(maua_guide* g) { return !g ? 0 : g->kind == MAUA_GUIDE_COLORMATCH ? g->cm_epoch : vgg_epoch(g->vgg); }
 
 int guide_prepare(maua_guide* g, int B, int H, int W) {
   if (g->kind != MAUA_GUIDE_COLORMATCH) return MAUA_OK;   // (the perceptors size their workspaces in their first eager evaluation)
@@ -43,7 +45,7 @@ int guide_prepare(maua_guide* g, int B, int H, int W) {
   MAUA_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
   if (g->fix) hipFree(g->fix);
   if (g->gr) hipFree(g->gr);
-  g->fix = nullptr; g->gr = nullptr; g->cm_cap = 0;
+  g->fix = nullptr; g->gr = nullptr; g->cm_cap = 0; g->cm_epoch++;
   MAUA_HIP_CHECK(hipMalloc((void**)&g->fix, colormatch_fix_bytes(B, g->nbins)));
   MAUA_HIP_CHECK(hipMalloc((void**)&g->gr, (size_t)B * g->nbins * 4));
   g->cm_cap = B;

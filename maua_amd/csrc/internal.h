@@ -340,12 +340,14 @@ int colormatch_grad_into(hipStream_t st, const float* img, int B, int H, int W, 
 int screened_accumulate(hipStream_t st, const float* sub, float* acc, long n, int first, int* flag);
 // perceptor.hip
 maua_ctx* vgg_ctx(maua_vgg* n);
+unsigned long long vgg_epoch(maua_vgg* n);   // generation of the network's device buffers (a captured graph compares it before reuse)
 // guides.hip: a grad module of the guided loop (maua_guide_*): evaluates d loss / d img into `out` on the context's stream;
 // guide_prepare allocates for a batch shape (never inside a capture)
 int guide_prepare(maua_guide* g, int B, int H, int W);
 int guide_eval(maua_guide* g, const float* img, int B, int H, int W, float* out);
 maua_ctx* guide_ctx(maua_guide* g);
 unsigned long long guide_uid(maua_guide* g);
+unsigned long long guide_epoch(maua_guide* g);   // generation of the device buffers a guide's launches point into
 
 // secondary.hip: the context a secondary diffusion model was created on
 maua_ctx* secondary_ctx(maua_secondary* n);

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict_
 
 struct maua_vgg {
   maua_ctx* ctx = nullptr;
+  unsigned long long epoch = 0;    // moves whenever a workspace is freed or reallocated: a captured graph that points into them is stale
   int dtype = MAUA_BF16;
   size_t esize = 2;
   std::vector<POp> ops;
@@ -532,6 +533,7 @@ void free_ws(maua_vgg* n) {
   { void* p = n->part; f(p); n->part = nullptr; }
   n->cap_key = 0;
   n->B = n->H = n->W = 0;
+  n->epoch++;
 }
 
 int max_c(const maua_vgg* n) {
@@ -572,6 +574,7 @@ int ensure_ws(maua_vgg* n, int B, int H, int W) {
   if (B > n->ones_b) {
     MAUA_HIP_CHECK(hipStreamSynchronize(st));
     if (n->ones) hipFree(n->ones);
+    n->epoch++;
     std::vector<float> h((size_t)B * 512, 1.f);
     MAUA_HIP_CHECK(hipMalloc((void**)&n->ones, h.size() * 4));
     MAUA_HIP_CHECK(hipMemcpy(n->ones, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -770,6 +773,7 @@ int check_image(const maua_vgg* n, int B, int H, int W, const char* who) {
 
 namespace maua {
 maua_ctx* vgg_ctx(maua_vgg* n) { return n ? n->ctx : nullptr; }
+unsigned long long vgg_epoch(maua_vgg* n) { return n ? n->epoch : 0; }
 }
 
 extern "C" {

@@ -763,7 +763,7 @@ struct maua_unet {
   unsigned long long gd_sec_uid = 0, gd_sec_epoch = 0;   // the secondary model (and its buffers' generation) gd_exec points into
   // text-prompt guidance (maua_unet_set_clip_guide): CLIPGrads instead of the image-MSE module in the guided loop
   std::vector<maua_guide*> gd_guides;   // maua_unet_set_guides: grad modules evaluated (after CLIPGrads, if set) and summed per step
-  std::vector<unsigned long long> gd_guide_uids;
+  std::vector<unsigned long long> gd_guide_uids, gd_guide_epochs;   // (epochs: as of the capture)
   int* gd_gflag = nullptr;           // the NaN screen's flag of the guides' sum
   maua_clip* gd_clip = nullptr;
   int* gd_rects = nullptr;           // device [n_steps][batches][cutn][3] (+ [n_steps][batches][cutn] float multiplicities behind them)
@@ -2143,8 +2143,10 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
   auto sec_matches = [&]() {
     secondary_stamp(sec, &sec_uid, &sec_epoch);
     clip_stamp(clip, &clip_uid, &clip_ep);
+    bool guides_same = n->gd_guide_epochs.size() == n->gd_guides.size();
+    for (size_t k = 0; guides_same && k < n->gd_guides.size(); k++) guides_same = guide_epoch(n->gd_guides[k]) == n->gd_guide_epochs[k];
     return sec_uid == n->gd_sec_uid && sec_epoch == n->gd_sec_epoch && clip_uid == n->gd_clip_uid && clip_ep == n->gd_clip_epoch &&
-           n->gd_guide_gen == n->gd_guide_gen_seen;
+           n->gd_guide_gen == n->gd_guide_gen_seen && guides_same;
   };
   if (use_graph && !n->gd_failed) {
     if (!n->gd_exec || n->gd_key != key || !sec_matches()) {
@@ -2181,6 +2183,8 @@ int maua_ddim_guided_loop(maua_unet* n, maua_secondary* sec, float* x, int B, in
         secondary_stamp(sec, &n->gd_sec_uid, &n->gd_sec_epoch);   // (after the eager step: that is what sized the workspaces)
         clip_stamp(clip, &n->gd_clip_uid, &n->gd_clip_epoch);
         n->gd_guide_gen_seen = n->gd_guide_gen;
+        n->gd_guide_epochs.clear();
+        for (maua_guide* g : n->gd_guides) n->gd_guide_epochs.push_back(guide_epoch(g));
       }
     }
   }

@@ -455,6 +455,12 @@ def test_guided_loop_with_a_module_list_as_one_graph_equals_the_step_by_step_loo
     gd.conditioning.set_targets([s1.to("cuda")], nz)
     eager = sd.ddim_guided_loop(net, gd.conditioning, x.clone(), 6, 10, use_graph=False)[1]
     assert torch.equal(eager, res["a"])
+    # a larger call on the same perceptor in between reallocates its workspaces: the captured loop notices (buffer generation) and is
+    # recaptured instead of replaying launches that point into freed memory
+    vg.forward(torch.rand(5, 3, 64, 64, generator=gen) * 2 - 1, None)
+    cm.forward(torch.rand(5, 3, 64, 64, generator=gen) * 2 - 1, None)
+    gd.use_graph = True
+    assert torch.equal(gd.forward(img, [s1], 0.3, t_end=0.8, noise=nz), res["a"]) and net.guided_graph_active()
     # speed "regular": the modules' gradient through the UNet itself
     gr = GuidedDiffusion([vg, cm], timesteps=20, model=net, diffusion=sd, speed="regular")
     gr.use_graph = True
