@@ -52,9 +52,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   const int n0 = blockIdx.y * GBN;
   const int q = tid & 3, row0 = tid >> 2;  // staging role: 16-byte piece q of A row row0 and W rows row0, row0 + 64
   const int K = g.K0 + g.K1, stages = K / KC;
-  const T* a0 = reinterpret_cast<const T*>(g.a0);
+  const T* a0 = reinterpret_cast<const T*>(g.a0) + (long)blockIdx.z * g.a_bstride;
   const T* a1 = reinterpret_cast<const T*>(g.a1);
-  const T* w = reinterpret_cast<const T*>(g.w);
+  const T* w = reinterpret_cast<const T*>(g.w) + (long)blockIdx.z * g.w_bstride;
+  g.c = reinterpret_cast<char*>(g.c) + (long)blockIdx.z * g.c_bstride * (g.c_f32 ? 4 : (long)sizeof(T));
   const long am = m0 + row0;
   const bool a_ok = am < g.M;
   const bool w_ok0 = n0 + row0 < g.N, w_ok1 = n0 + row0 + 64 < g.N;
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
   const int n0 = blockIdx.y * WBN;
   const int q = tid & 7, row0 = tid >> 3;  // staging role: 16-byte piece q of rows row0 + 32 i (i < 4), A and W alike
   const int K = g.K0 + g.K1, stages = K / KC;
-  const T* a0 = reinterpret_cast<const T*>(g.a0);
+  const T* a0 = reinterpret_cast<const T*>(g.a0) + (long)blockIdx.z * g.a_bstride;
   const T* a1 = reinterpret_cast<const T*>(g.a1);
-  const T* w = reinterpret_cast<const T*>(g.w);
+  const T* w = reinterpret_cast<const T*>(g.w) + (long)blockIdx.z * g.w_bstride;
+  g.c = reinterpret_cast<char*>(g.c) + (long)blockIdx.z * g.c_bstride * (long)sizeof(T);
   u32x4 areg[4], breg[4];
 #define GEMMW_LOAD(S)                                                                                        \
   {                                                                                                          \
@@ -282,14 +284,16 @@ int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
                "gemm_nt: K parts must be multiples of 64 bytes");
   MAUA_REQUIRE(g.N % 32 == 0 && g.N > 0 && g.lda0 % 4 == 0 && g.ldc % 4 == 0, "gemm_nt: N must be a multiple of 32");
   if (g.M == 0) return MAUA_OK;
-  if (g.prefer_dma && gemm_dma_supported(dtype, g)) return launch_gemm_dma(stream, g);
+  const unsigned nb = g.batch > 1 ? (unsigned)g.batch : 1u;
+  MAUA_REQUIRE(nb == 1 || (!g.a1 && g.K1 == 0 && !g.res && !g.bias && nb <= 65535), "gemm_nt: a batched launch takes one A source, no bias, no residual");
+  if (nb == 1 && g.prefer_dma && gemm_dma_supported(dtype, g)) return launch_gemm_dma(stream, g);
   MAUA_REQUIRE(g.epi == 0, "gemm_nt: the QuickGELU epilogue forms exist on the LDS-direct kernel only (callers check gemm_dma_supported)");
   const int kcw = dtype == MAUA_BF16 ? 64 : 32;   // channels per 128-byte chunk
   const int epc = dtype == MAUA_BF16 ? 8 : 4;
   if (!g.c_f32 && g.K0 % kcw == 0 && g.K1 % kcw == 0 && g.M >= 128 && g.ldc % epc == 0 && (!g.res || g.ldr % epc == 0) &&
       g.lda0 % epc == 0 && (g.K1 == 0 || g.lda1 % epc == 0)) {
     const size_t smem = std::max<size_t>((size_t)2 * WBM * WRS, (size_t)WBM * (WBN * (dtype == MAUA_BF16 ? 2 : 4) + 16));
-    dim3 gridw((unsigned)((g.M + WBM - 1) / WBM), (unsigned)((g.N + WBN - 1) / WBN));
+    dim3 gridw((unsigned)((g.M + WBM - 1) / WBM), (unsigned)((g.N + WBN - 1) / WBN), nb);
     if (dtype == MAUA_BF16) {
       MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt128_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(gemm_nt128_kernel<bf16_t>, gridw, dim3(256), smem, stream, g);
@@ -300,7 +304,7 @@ int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
     MAUA_HIP_CHECK(hipGetLastError());
     return MAUA_OK;
   }
-  dim3 grid((unsigned)((g.M + GBM - 1) / GBM), (unsigned)((g.N + GBN - 1) / GBN));
+  dim3 grid((unsigned)((g.M + GBM - 1) / GBM), (unsigned)((g.N + GBN - 1) / GBN), nb);
   if (dtype == MAUA_BF16)
     hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, dim3(256), 0, stream, g);
   else

@@ -253,6 +253,11 @@ struct GemmArgs {
   int epi;              // 0; 1: c2 <- QuickGELU(c) as well; 2: c <- c * QuickGELU'(aux)
   void* c2; long ldc2;
   const void* aux; long ldaux;
+  // register-staged kernels only (gemm.hip): `batch` independent products in one launch (grid z) - a0 / w / c of product b at
+  // + b * a_bstride / w_bstride / c_bstride ELEMENTS (0 batch = 1 product; a1, res, bias unsupported with batch > 1).  The style head's
+  // per-image d loss / d F = F_b (dG_b + dG_b^T) (perceptor.hip)
+  int batch;
+  long a_bstride, w_bstride, c_bstride;
 };
 int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g);
 // gemm_dma.hip: 256 x 128 tiles on LDS-direct loads (see there); launch_gemm_nt routes when g.prefer_dma

@@ -722,12 +722,13 @@ int style_grad_t(maua_vgg* n, const float* img, int B, int H, int W, const int* 
     hipLaunchKernelGGL(style_dgram_kernel<T>, dim3((unsigned)((CC + 255) / 256), B), dim3(256), 0, st, (const float*)n->gram, targets[k],
                        t_bstride ? t_bstride[k] : 0L, C, strength, (const float*)n->part, (T*)n->sym, n->loss_dev);
     MAUA_HIP_CHECK(hipGetLastError());
-    for (int b = 0; b < B; b++) {          // d loss / d F_b = F_b (dG + dG^T): [hw][C] x [C][C]^T
+    {                                      // d loss / d F_b = F_b (dG_b + dG_b^T): [hw][C] x [C][C]^T, all images in one launch
       GemmArgs g{};
-      g.a0 = (const char*)o.act + (size_t)b * hw * C * n->esize; g.lda0 = C; g.K0 = C;
-      g.w = (const char*)n->sym + (size_t)b * C * C * n->esize;
-      g.c = (char*)o.hg + (size_t)b * hw * C * n->esize; g.ldc = C;
+      g.a0 = o.act; g.lda0 = C; g.K0 = C;
+      g.w = n->sym;
+      g.c = o.hg; g.ldc = C;
       g.M = hw; g.N = C;
+      g.batch = B; g.a_bstride = hw * C; g.w_bstride = (long)C * C; g.c_bstride = hw * C;
       if (int rc = launch_gemm_nt(st, n->dtype, g)) return rc;
     }
     o.hg_set = true;
