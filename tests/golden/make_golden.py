@@ -621,6 +621,8 @@ SIGNATURES = [  # (reference file under maua/, qualified name there, our module,
     ("perceptors/__init__.py", "load_perceptor", "maua_amd.perceptors", "load_perceptor"),
     ("perceptors/vgg_kbc.py", "KBCPerceptor.__init__", "maua_amd.perceptors", "KBCPerceptor.__init__"),
     ("diffusion/image.py", "get_diffusion_model", "maua_amd.diffusion", "get_diffusion_model"),
+    ("ops/cutouts.py", "Cutouts.__init__", "maua_amd.grad", "Cutouts.__init__"),
+    ("ops/cutouts.py", "Cutouts.forward", "maua_amd.grad", "Cutouts.forward"),
 ]
 
 
@@ -1257,6 +1259,30 @@ def golden_grads():
             out[f"dango{k}_out"] = cuts
         else:
             out[f"dango{k}_sum"] = cuts.double().sum((1, 2, 3)).float()
+    # (g) cutouts.py:53-98 Cutouts(skip_augs=True) ("normal"): torchvision's Pad replaced by F.pad; the draws (normal_ + two randint per crop)
+    class _Pad:
+        def __init__(self, n, fill=0):
+            self.n, self.fill = n, fill
+
+        def __call__(self, t):
+            return torch.nn.functional.pad(t, (self.n,) * 4, value=self.fill)
+    RC.T.Pad = _Pad
+
+    def spy2(cutout, out_shape):
+        base = cutout._base if cutout._base is not None else cutout
+        W_ = base.shape[-1]
+        off = cutout.storage_offset() - base.storage_offset()
+        seen.append((cutout.shape[-1], (off // W_) % base.shape[-2], off % W_))
+        return OC.resize(cutout, tuple(out_shape[-2:]))
+    RC.resize = spy2
+    for k, (S, cs, cutn, seed) in enumerate(((32, 32, 8, 11), (40, 32, 12, 12))):
+        nimg = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(350 + k))
+        torch.manual_seed(seed)
+        seen.clear()
+        cuts = RC.Cutouts(cs, cutn, skip_augs=True)(nimg, None)
+        out[f"normal{k}_cfg"] = np.array([S, cs, cutn, seed], dtype=np.int64)
+        out[f"normal{k}_rects"] = np.array([(s_ if s_ else S + 2 * (S // 4), y_, x_) for s_, y_, x_ in seen], dtype=np.int64)
+        out[f"normal{k}_out"] = cuts
     # (f)
     rx = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     out["resample256_maxdiff"] = (RI.resample(rx, 256) - rx).abs().max()

@@ -13,6 +13,12 @@ from oracle import grads as OG
 pytestmark = pytest.mark.gpu
 
 
+def golden_load(name):
+    from pathlib import Path
+    z = np.load(Path(__file__).parent / "golden" / f"{name}.npz")
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
 def rel(a, b):
     a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
     return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
@@ -332,6 +338,47 @@ def test_flagged_cutouts_and_their_vjp_match_autograd_on_the_oracle():
         s = (C.c_float * 3)(*OC.CLIP_STD)
         L.check(L.lib().maua_cutouts_vjp(L.ctx(), L.ptr(dd), 2, S, S, r.ctypes.data_as(C.c_void_p), len(r), cs, C.c_float(0.5), s, L.ptr(gi)))
         assert rel(gi, want) <= 1e-5, (S, rel(gi, want))
+
+
+def test_normal_cutouts_and_clipgrads_with_them():
+    """Cutouts(skip_augs=True) ("normal") on the device against the REFERENCE's outputs (g34), and CLIPGrads(cutouts="normal") - the image
+    padded with -1 (zero after (img + 1) / 2), the library's gradient on the padded image, cropped - against torch.autograd on the
+    oracle's chain."""
+    from maua_amd.clip import CLIPImageModel, VisionTransformer
+    from maua_amd.grad import CLIPGrads, Cutouts, EmbeddingPrompt
+    g = golden_load("g34_grads")
+    for k in range(2):
+        S, cs, cutn, seed = (int(v) for v in g[f"normal{k}_cfg"])
+        img = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(350 + k))
+        torch.manual_seed(seed)
+        out = Cutouts(cs, cutn, skip_augs=True)(img, None)
+        assert rel(out, g[f"normal{k}_out"]) <= 1e-5, k
+    cfg = dict(input_resolution=32, patch_size=8, width=64, layers=2, heads=2, output_dim=32)
+    p = OC.init_vit_params(cfg, torch.Generator().manual_seed(2))
+    vt = VisionTransformer(32, 8, 64, 2, 2, 32, dtype=torch.float32)
+    vt.load_state_dict(p, strict=True)
+    gen = torch.Generator().manual_seed(19)
+    emb = torch.randn(1, 32, generator=gen)
+    m = CLIPGrads(scale=90.0, cutouts="normal", cutout_kwargs=dict(cutn=8, skip_augs=True), cutout_batches=2, clip_models=[CLIPImageModel(vt)])
+    m.set_targets([EmbeddingPrompt(emb[0], 1.0)])
+    B, S = 2, 40
+    img = torch.rand(B, 3, S, S, generator=gen) * 2 - 1
+    torch.manual_seed(23)
+    grad = m.forward(img, torch.tensor([400.0] * B))
+    torch.manual_seed(23)
+    pad = S // 4
+    rects = [m.cutouts[0].rects(S + 2 * pad, S + 2 * pad) for _ in range(2)]
+    want = torch.zeros_like(img)
+    w = OC.normalise_weights(torch.tensor([1.0]))
+    for r in rects:
+        with torch.enable_grad():
+            x = img.clone().requires_grad_()
+            cuts = OC.cutouts_from_rects(torch.nn.functional.pad(x.add(1).div(2), (pad,) * 4), r, 32)
+            e = OC.encode_image(p, cfg, OC.normalize(cuts)).float()
+            dists = OC.spherical_dist_loss(e.unsqueeze(1), emb.unsqueeze(0))
+            loss = dists.view((-1, B, dists.shape[-1])).mul(w).sum(2).mean(0)
+            want += torch.autograd.grad(loss.sum() * 90.0, x)[0] / 2
+    assert rel(grad, want) <= 5e-4, rel(grad, want)
 
 
 def test_clipgrads_with_dango_cutouts_matches_autograd_on_the_oracle():

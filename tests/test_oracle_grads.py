@@ -89,6 +89,24 @@ def test_dango_cutouts_match_the_reference(golden):
             assert out.shape == want.shape and float((out - want).abs().max()) <= 1e-6, k
 
 
+def test_normal_cutouts_draws_match_the_reference(golden):
+    """Cutouts(skip_augs=True) ("normal", cutouts.py:53-98) under a seed: the product's host-side draw takes the reference's crops of the
+    zero-padded image from torch's global generator; the oracle's resize of them equals the reference's outputs."""
+    from maua_amd.grad import Cutouts
+    g = golden("g34_grads")
+    for k in range(2):
+        S, cs, cutn, seed = (int(v) for v in g[f"normal{k}_cfg"])
+        cu = Cutouts(cs, cutn, skip_augs=True)
+        p = cu.pad_of(S)
+        torch.manual_seed(seed)
+        rects = cu.rects(S + 2 * p, S + 2 * p)
+        assert np.array_equal(np.asarray(rects), g[f"normal{k}_rects"].numpy()), k
+        img = torch.rand(1, 3, S, S, generator=torch.Generator().manual_seed(350 + k))
+        padded = torch.nn.functional.pad(img, (p,) * 4)
+        out = OC.cutouts_from_rects(padded, rects, cs)
+        assert float((out - g[f"normal{k}_out"]).abs().max()) <= 1e-6, k
+
+
 def test_resample_is_the_identity_at_256(golden):
     assert float(golden("g34_grads")["resample256_maxdiff"]) == 0.0
 
