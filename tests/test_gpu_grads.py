@@ -284,6 +284,38 @@ def test_full_size_style_and_perceptual_gradients_against_the_oracle():
     assert torch.equal(grad, lp.forward(img, None))
 
 
+def test_grad_module_properties_at_the_sampler_size():
+    """Size-independent properties at 256 x 256, batch 4, bf16 networks: at its own target every module's loss and gradient vanish;
+    the gradient is linear in ``scale``; samples of a batch do not interact (each sample's gradient equals the one-image call's) except
+    through ColorMatchGrads' mean over the batch (mse_loss over [B, bins]: a sample's gradient scales with 1 / B)."""
+    from maua_amd.grad import ColorMatchGrads, ContentPrompt, LPIPSGrads, StylePrompt, VGGGrads
+    gen = torch.Generator().manual_seed(41)
+    style = torch.rand(1, 3, 256, 256, generator=gen)
+    img = torch.rand(4, 3, 256, 256, generator=gen) * 2 - 1
+    at_target = torch.cat([style * 2 - 1, img[1:]])
+    vg = VGGGrads(scale=30.0, allow_random_init=True, generator=gen)
+    lp = LPIPSGrads(scale=5.0, allow_random_init=True, generator=gen)
+    cm = ColorMatchGrads(scale=1e4)
+    for m in (vg, lp, cm):
+        m.set_targets([StylePrompt(img=style), ContentPrompt(img=style)])
+    for m, name in ((vg, "vgg"), (lp, "lpips")):
+        g, loss = m.forward(at_target, None, return_loss=True)
+        ref = float(g[1:].abs().max())
+        assert float(loss[0]) <= 1e-6 * float(loss[1:].mean()) and float(g[0].abs().max()) <= 1e-3 * ref, name
+        one = m.forward(at_target[2:3], None)
+        assert torch.equal(one[0], g[2]), name                       # samples do not interact
+        s0 = m.scale
+        m.scale = 2 * s0
+        if name == "vgg":
+            m.perceptor.style_strength = 2 * s0
+        g2 = m.forward(at_target, None)
+        assert rel(g2, 2 * g) <= 1e-6, name
+    g = cm.forward(at_target, None)
+    assert float(g[0].abs().max()) <= 1e-3 * float(g[1:].abs().max())
+    one = cm.forward(at_target[2:3], None)
+    assert rel(one[0], 4 * g[2]) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ DangoCutouts
 def test_dango_cutouts_match_the_reference_fixture(golden):
     """DangoCutouts(skip_augs=True).forward on the device under the fixture's seed against the REFERENCE's outputs (g34; overview
