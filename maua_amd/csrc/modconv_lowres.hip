@@ -233,6 +233,16 @@ LowresGeom lowres_geom(int esize, int B, int H, int W, int Ci, int Co, int up, i
   g.ksplit = g.stages_total;
   for (int k = want; k <= g.stages_total; k++)
     if (g.stages_total % k == 0) { g.ksplit = k; break; }
+  if (want_override) {
+    // The diffusion UNet's plain convolutions only: at large batches that many slices are thousands of two-stage workgroups and a
+    // partial-sum plane each (36 planes at 8^2: 300 MB written and read again at batch 32) - take the fewest slices that still give
+    // ~8 workgroups per CU.  This makes the slice count a function of the batch; the UNet's routing already is (LDS-direct or gather
+    // kernel by workgroup count, unet.hip), its samples are equal across batch sizes to rounding, not to the bit
+    // (test_full_size_unet_samples_across_batch_sizes).  The synthesis network's layers (no override) keep the shape-only rule above.
+    const long mn = (long)((g.M + LBM - 1) / LBM) * (g.CoV / LBN);
+    for (int k = 1; k < g.ksplit; k++)
+      if (g.stages_total % k == 0 && mn * k >= 2048) { g.ksplit = k; break; }
+  }
   return g;
 }
 
