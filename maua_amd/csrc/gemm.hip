@@ -15,6 +15,8 @@
 // or 4 x v_mfma_f32_32x32x2_f32 (exact-f32 parity mode) from identical 16-byte LDS fragments; rows of 64 + 16 bytes keep
 // the ds_read_b128 fragment reads bank-conflict-free.  These GEMMs are ~3 % of the UNet's FLOPs (the 3x3 convolutions
 // are the rest), so the tile is sized for simplicity and edge handling (any M, N % 32 == 0), not for the MFMA roof.
+#include <cstdlib>
+
 #include "common.h"
 #include "internal.h"
 
@@ -146,8 +148,16 @@ __global__ __launch_bounds__(256) void gemm_nt128_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const long m0 = (long)blockIdx.x * WBM;
-  const int n0 = blockIdx.y * WBN;
+  long mt = blockIdx.x;
+  int nt = blockIdx.y;
+  if (g.remap_nt) {   // (see GemmArgs.remap_nt)
+    const long L = blockIdx.x, j = L >> 3;
+    nt = (int)(j % g.remap_nt);
+    mt = (j / g.remap_nt) * 8 + (L & 7);
+    if (mt * WBM >= g.M) return;
+  }
+  const long m0 = mt * WBM;
+  const int n0 = nt * WBN;
   const int q = tid & 7, row0 = tid >> 3;  // staging role: 16-byte piece q of rows row0 + 32 i (i < 4), A and W alike
   const int K = g.K0 + g.K1, stages = K / KC;
   const T* a0 = reinterpret_cast<const T*>(g.a0) + (long)blockIdx.z * g.a_bstride;
@@ -294,12 +304,18 @@ int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g) {
       g.lda0 % epc == 0 && (g.K1 == 0 || g.lda1 % epc == 0)) {
     const size_t smem = std::max<size_t>((size_t)2 * WBM * WRS, (size_t)WBM * (WBN * (dtype == MAUA_BF16 ? 2 : 4) + 16));
     dim3 gridw((unsigned)((g.M + WBM - 1) / WBM), (unsigned)((g.N + WBN - 1) / WBN), nb);
+    GemmArgs gr = g;
+    static const bool xcd_off = getenv("MAUA_GEMM_XCD_OFF") != nullptr;
+    if (nb == 1 && gridw.y >= 2 && gridw.y <= 8 && gridw.x >= 64 && !xcd_off) {   // few N tiles over many rows: keep an M tile's N tiles on one XCD
+      gr.remap_nt = (int)gridw.y;
+      gridw = dim3((gridw.x + 7) / 8 * 8 * gridw.y, 1, 1);
+    }
     if (dtype == MAUA_BF16) {
       MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt128_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(gemm_nt128_kernel<bf16_t>, gridw, dim3(256), smem, stream, g);
+      hipLaunchKernelGGL(gemm_nt128_kernel<bf16_t>, gridw, dim3(256), smem, stream, gr);
     } else {
       MAUA_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_nt128_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(gemm_nt128_kernel<float>, gridw, dim3(256), smem, stream, g);
+      hipLaunchKernelGGL(gemm_nt128_kernel<float>, gridw, dim3(256), smem, stream, gr);
     }
     MAUA_HIP_CHECK(hipGetLastError());
     return MAUA_OK;

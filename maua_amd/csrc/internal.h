@@ -258,6 +258,10 @@ struct GemmArgs {
   // per-image d loss / d F = F_b (dG_b + dG_b^T) (perceptor.hip)
   int batch;
   long a_bstride, w_bstride, c_bstride;
+  // set by launch_gemm_nt (128 x 128 kernel): > 0 = the launch is one-dimensional and block L computes N tile (L / 8) % remap_nt of
+  // M tile ((L / 8) / remap_nt) * 8 + L % 8 - the N tiles of one M tile run back to back on ONE XCD (block b runs on XCD b % 8), so the
+  // second and later reads of its A rows hit that XCD's L2 instead of HBM
+  int remap_nt;
 };
 int launch_gemm_nt(hipStream_t stream, int dtype, const GemmArgs& g);
 // gemm_dma.hip: 256 x 128 tiles on LDS-direct loads (see there); launch_gemm_nt routes when g.prefer_dma
