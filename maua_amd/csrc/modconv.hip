@@ -1000,12 +1000,20 @@ __global__ __launch_bounds__(256) void torgb_kernel(RgbArgs a, int lp_log2) {
         xv[0] = __uint_as_float(v.x); xv[1] = __uint_as_float(v.y);
         xv[2] = __uint_as_float(v.z); xv[3] = __uint_as_float(v.w);
       }
-      const float* w0 = wm + pc * EPC;
+      // the lane's EPC weights of each row as 16-byte LDS reads (scalar reads at a 32-byte lane stride conflicted: lds_conf 0.65)
+      float wv[3][EPC];
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int q4 = 0; q4 < EPC / 4; q4++) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(wm + c * a.C + pc * EPC + q4 * 4);
+          wv[c][q4 * 4] = t[0]; wv[c][q4 * 4 + 1] = t[1]; wv[c][q4 * 4 + 2] = t[2]; wv[c][q4 * 4 + 3] = t[3];
+        }
 #pragma unroll
       for (int e = 0; e < EPC; e++) {
-        r0 += xv[e] * w0[e];
-        r1 += xv[e] * w0[a.C + e];
-        r2 += xv[e] * w0[2 * a.C + e];
+        r0 += xv[e] * wv[0][e];
+        r1 += xv[e] * wv[1][e];
+        r2 += xv[e] * wv[2][e];
       }
     }
     for (int o = LP >> 1; o > 0; o >>= 1) {
