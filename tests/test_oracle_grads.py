@@ -123,3 +123,21 @@ def test_lpips_oracle_properties():
     assert dab > 0 and abs(dab - dba) <= 1e-6 * dab
     grad, d = OG.lpips_grads(p, lins, a, b, 2.0)
     assert grad.shape == a.shape and float(grad.abs().max()) > 0 and abs(float(d) - dab) <= 1e-6 * dab
+
+
+def test_host_side_plans_of_the_perceptors_and_resample_sizes():
+    """Host logic of the image-prompt modules that needs no device: torchvision's features indices -> the library's plan (convolution +
+    ReLU = one entry, indexed by the ReLU), the weight-key -> convolution map, and resample's output size (image.py:217-223) against the
+    oracle's resample."""
+    from maua_amd.ops import resample_size
+    from maua_amd.perceptors import LPIPS_TAPS, VGG16_CFG, VGG19_CFG, features_plan
+    from oracle import ops as OO
+    plan, idx, convs = features_plan(VGG19_CFG, 29)
+    assert plan == [64, 64, 0, 128, 128, 0, 256, 256, 256, 256, 0, 512, 512, 512, 512, 0, 512] and idx[-1] == 29
+    assert [idx.index(t) for t in OG.KBC_STYLE_LAYERS] == [0, 3, 6, 11, 16] and convs["28"] == 12 and len(convs) == 13
+    ops, oidx = OG.vgg_plan(OG.VGG19_CFG, 29)
+    assert idx == oidx and [0 if k == "pool" else c for k, c in ops] == plan
+    plan16, idx16, _ = features_plan(VGG16_CFG, 29)
+    assert all(t in idx16 for t in LPIPS_TAPS) and plan16.count(0) == 4
+    for (h, w, size) in ((512, 512, 256), (384, 640, 256), (100, 130, 256), (48, 80, (32, 80))):
+        assert tuple(OO.resample(torch.zeros(1, 1, h, w), size).shape[-2:]) == resample_size(h, w, size)
